@@ -1,0 +1,136 @@
+"""Seeded synthetic gene clusters (the shapes BASELINE.json's configs name).
+
+No reference code is involved: this produces the *input* of the hot path, either as
+reference-shaped records ``(gene_sequences, idx, clusterpresab)`` (the tuple
+/root/reference/panfeed/input.py:468 yields) for parity tests, or as allele pools +
+per-sequence allele ids for the device-side expansion bench.py uses at full size.
+
+Per cluster c: rng = PCG64(0x9E3779B9 ^ c); gene length ~ lognormal(ln mean_len, 0.5)
+clipped to [min_len, max_len]; 1 + Poisson(7) alleles = ancestral uniform-ACGT sequence
+with allele-specific 1 % substitutions and allele-specific random flanks; allele weights
+~ 2^-i; cluster frequency 0.99 (60 % "core") or U(0.02, 0.9); 1 % of present samples
+carry a paralog copy; strand +-1 (affects coordinates only); `n_rate` of the sequences
+get one 'N'.
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from .classes import Seqinfo
+
+_CODE2ASCII = np.frombuffer(b"ACGT", dtype=np.uint8)
+_COMP = bytes.maketrans(b"ACGTN", b"TGCAN")
+
+
+@dataclass
+class SynthCluster:
+    index: int                 # global cluster ordinal (processing order)
+    idx: str                   # cluster name
+    names: list                # all sample names, CSV column order
+    alleles: list              # list of uint8 code arrays (0..3), flanks included
+    up: int                    # upstream flank actually included (Seqinfo.offset)
+    seq_sample: np.ndarray     # per sequence (iteration order): index into names
+    seq_allele: np.ndarray
+    seq_strand: np.ndarray
+    seq_npos: np.ndarray       # position of a single 'N', or -1
+    present: np.ndarray        # bool[S], CSV column order
+    _strs: dict = field(default_factory=dict, repr=False)
+
+    @property
+    def n_seqs(self):
+        return len(self.seq_sample)
+
+    def n_instances(self, k, canon=True):
+        lens = np.array([len(a) for a in self.alleles], dtype=np.int64)[self.seq_allele]
+        n = np.maximum(lens - k + 1, 0).sum()
+        return int(n if canon else 2 * n)
+
+    def seq_string(self, q):
+        a = int(self.seq_allele[q])
+        s = self._strs.get(a)
+        if s is None:
+            s = _CODE2ASCII[self.alleles[a]].tobytes()
+            self._strs[a] = s
+        p = int(self.seq_npos[q])
+        if p >= 0:
+            s = s[:p] + b"N" + s[p + 1:]
+        return s.decode()
+
+    def record(self):
+        """(gene_sequences, idx, clusterpresab) exactly as input.py:366-468 lays it out."""
+        names = self.names
+        sorted_names = sorted(names)
+        col = {x: i for i, x in enumerate(sorted_names)}
+        presab = np.zeros(len(names), dtype=np.int64)
+        gs = {}
+        for q in range(self.n_seqs):
+            name = names[int(self.seq_sample[q])]
+            seq = self.seq_string(q)
+            comp = seq.encode().translate(_COMP).decode()
+            lst = gs.setdefault(name, [])
+            strand = int(self.seq_strand[q])
+            start = 1000 + 37 * q
+            lst.append(Seqinfo(seq, comp, f"{name}_{self.index:05d}_{len(lst)}", f"{name}_contig1",
+                               start, start + len(seq) - 1, strand, self.up))
+        for i, name in enumerate(names):
+            if self.present[i]:
+                presab[col[name]] = 1
+                gs.setdefault(name, [])
+        # present strains first (CSV order) -- a dict keeps first-insertion order, so re-create
+        ordered = {}
+        for i, name in enumerate(names):
+            if self.present[i]:
+                ordered[name] = gs[name]
+        for name in sorted_names:      # `absent` is a pandas Index.difference -> sorted (input.py:373,465)
+            if name not in ordered:
+                ordered[name] = []
+        return ordered, self.idx, presab
+
+
+def sample_names(n, shuffle_seed=None):
+    names = [f"s{i:05d}" for i in range(n)]
+    if shuffle_seed is not None:
+        np.random.Generator(np.random.PCG64(shuffle_seed)).shuffle(names)
+    return names
+
+
+def generate_cluster(c, names, flank=0, mean_len=900, min_len=150, max_len=6000, n_rate=0.001,
+                     paralog_rate=0.01, sub_rate=0.01, mean_alleles=7.0, seed=0x9E3779B9):
+    rng = np.random.Generator(np.random.PCG64(seed ^ c))
+    S = len(names)
+    L = int(np.clip(np.rint(rng.lognormal(np.log(mean_len), 0.5)), min_len, max_len))
+    H = 1 + int(rng.poisson(mean_alleles))
+    anc = rng.integers(0, 4, size=L, dtype=np.uint8)
+    alleles = []
+    for i in range(H):
+        a = anc.copy()
+        if i > 0:
+            mut = rng.random(L) < sub_rate
+            a[mut] = (a[mut] + rng.integers(1, 4, size=int(mut.sum()), dtype=np.uint8)) & 3
+        if flank:
+            a = np.concatenate([rng.integers(0, 4, size=flank, dtype=np.uint8), a,
+                                rng.integers(0, 4, size=flank, dtype=np.uint8)])
+        alleles.append(a)
+    w = 0.5 ** np.arange(H)
+    w /= w.sum()
+    p = 0.99 if rng.random() < 0.6 else rng.uniform(0.02, 0.9)
+    present = rng.random(S) < p
+    if not present.any():
+        present[int(rng.integers(0, S))] = True
+    pres_idx = np.flatnonzero(present)
+    copies = 1 + (rng.random(len(pres_idx)) < paralog_rate).astype(np.int64)
+    seq_sample = np.repeat(pres_idx, copies).astype(np.int32)
+    nseq = len(seq_sample)
+    seq_allele = rng.choice(H, size=nseq, p=w).astype(np.int32)
+    seq_strand = np.where(rng.random(nseq) < 0.5, 1, -1).astype(np.int8)
+    seq_npos = np.full(nseq, -1, dtype=np.int32)
+    has_n = rng.random(nseq) < n_rate
+    for q in np.flatnonzero(has_n):
+        seq_npos[q] = int(rng.integers(0, len(alleles[seq_allele[q]])))
+    return SynthCluster(c, f"group_{c:06d}", list(names), alleles, flank, seq_sample, seq_allele,
+                        seq_strand, seq_npos, present)
+
+
+def generate(n_clusters, n_samples, first=0, shuffle_columns=None, **kw):
+    names = sample_names(n_samples, shuffle_columns)
+    return [generate_cluster(first + i, names, **kw) for i in range(n_clusters)]
