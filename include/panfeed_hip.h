@@ -1,0 +1,196 @@
+/*
+ * panfeed_hip.h -- C ABI of libpanfeed_hip.so: panfeed's per-gene-cluster k-mer extraction and
+ * presence/absence pattern hashing hot path on MI355X (gfx950).
+ *
+ * The reference has no FFI: the path sits behind two Python callables,
+ *   cluster_cutter  /root/reference/panfeed/panfeed.py:23-113
+ *   pattern_hasher  /root/reference/panfeed/panfeed.py:132-235
+ * bound with functools.partial at /root/reference/panfeed/__main__.py:277-297 and called at
+ * :352-356 (serial) / :47,:81 (worker, writer).  This header is what a binding for those two call
+ * sites talks to (ctypes stub: INTEGRATION.md; in-repo mirror: panfeed_amd/panfeed.py).
+ *
+ * Conventions: every function returns 0 on success or a negative pf_status; the message of the
+ * last failure on the calling thread is pf_last_error().  No C++ exception crosses the ABI.  All
+ * pointers are plain host pointers unless a field says "device".  One pf_ctx per GPU, used from
+ * one host thread at a time.
+ */
+#ifndef PANFEED_HIP_H
+#define PANFEED_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pf_ctx pf_ctx;
+
+enum pf_status {
+    PF_OK = 0,
+    PF_ERR_ARG = -1,      /* bad argument / unsupported option */
+    PF_ERR_OOM = -2,      /* host or device allocation failed */
+    PF_ERR_HIP = -3,      /* a HIP runtime call failed */
+    PF_ERR_CAPACITY = -4, /* a fixed-capacity table overflowed (pattern table / output arena) */
+    PF_ERR_STATE = -5     /* call order violated */
+};
+
+#define PF_MAX_K 63 /* 2 bits/base in at most two 63-bit key words */
+
+/* Options of one run = the arguments functools.partial freezes at __main__.py:277-297. */
+typedef struct {
+    uint32_t klength;          /* -k ; 1..PF_MAX_K */
+    uint32_t canon;            /* canon == True  (panfeed.py:69); 0 = --non-canonical */
+    uint32_t consider_missing; /* consider_missing_cluster (panfeed.py:17-19, 193-196, 220-222) */
+    uint32_t patfilt;          /* the value handed to pattern_hasher: the same-as-cluster filter
+                                  runs when it is 0 (panfeed.py:202-204) */
+    uint32_t multiple_files;   /* patterns set reset per cluster (panfeed.py:165) */
+    uint32_t max_strains;      /* upper bound of len(cluster.keys()) and len(clusterpresab) */
+    /* MAF filter (panfeed.py:190-200) as exact float64 semantics precomputed by the caller:
+       a k-mer with `count` ones among `n` non-missing strains is kept iff
+       maf_lo[n] <= count <= maf_hi[n]; arrays of max_strains+1 entries. */
+    const uint32_t* maf_lo;
+    const uint32_t* maf_hi;
+    uint64_t pattern_capacity; /* slots of the run-global pattern table; 0 = default (2^24) */
+    uint32_t max_items;        /* clusters in flight per internal sub-batch; 0 = default */
+    uint32_t reserved;
+} pf_opts;
+
+/*
+ * One batch of gene clusters = the records iter_gene_clusters yields
+ * (/root/reference/panfeed/input.py:455-468), already packed by the caller.
+ *
+ * A "segment" is a maximal run of A/C/G/T inside one Seqinfo.sequence (non-ACGT bases split a
+ * sequence; the windows that contain one are the caller's slow path and come back in as
+ * `extra_*` rows).  Packing: 2 bits per base (A=0 C=1 G=2 T=3), 32 bases per uint64 word, the first
+ * base in bits 63:62; every segment starts on a 16-byte boundary; the buffer carries 16 bytes
+ * of padding after the last segment.
+ *
+ * Inside a cluster the segments are sorted by seg_sample (stable).  A window starting at base
+ * `pos` of a segment is instance number  seg_ord_base + pos  of the cluster in the reference's
+ * iteration order (panfeed.py:54-64); in non-canonical mode the forward k-mer is instance
+ * 2*(seg_ord_base+pos) and the reverse complement 2*(seg_ord_base+pos)+1 (panfeed.py:82-88).
+ */
+typedef struct {
+    uint32_t n_clusters;
+    uint32_t n_segs;
+    uint64_t n_words;               /* uint64 words in `packed`, padding included */
+    uint32_t on_device;             /* 1: every array below is a device pointer (bench / tests) */
+    uint32_t reserved;
+    const uint64_t* packed;
+    const uint64_t* seg_word_off;   /* [n_segs]   word offset of the segment (even) */
+    const uint32_t* seg_len;        /* [n_segs]   bases */
+    const uint32_t* seg_sample;     /* [n_segs]   column in sorted(cluster.keys()) order (panfeed.py:47-49) */
+    const uint32_t* seg_ord_base;   /* [n_segs] */
+    const uint32_t* cluster_seg_off;  /* [n_clusters+1] */
+    const uint32_t* cluster_nstrains; /* [n_clusters] len(cluster.keys()) */
+    const uint32_t* cluster_npresab;  /* [n_clusters] len(clusterpresab) */
+    const uint32_t* cluster_presab;   /* [n_clusters * W] clusterpresab as bits, W = ceil(max_strains/32) */
+    const uint64_t* cluster_ordinal;  /* [n_clusters] position in the run's processing order */
+    /* slow-path rows (k-mers containing a non-ACGT base), grouped by cluster, any order inside: */
+    uint32_t n_extra;
+    uint32_t reserved2;
+    const uint32_t* extra_cluster;  /* [n_extra] batch-local cluster index, non-decreasing */
+    const uint32_t* extra_ord;      /* [n_extra] first-occurrence instance number */
+    const uint32_t* extra_bits;     /* [n_extra * W] presence bits */
+    /* strand bits for positional rows (panfeed.py:69-75 used_strand; canonical mode only):
+       seg_strand_off[s] = index of the first uint64 of segment s in the strand-bit stream, or
+       0xFFFFFFFF to skip the segment; window pos -> bit (pos & 63) of word (pos >> 6);
+       bit = 1 when the reverse complement is the canonical k-mer.  NULL = none wanted. */
+    const uint32_t* seg_strand_off;
+    uint64_t n_strand_words;
+} pf_batch;
+
+/* Result of pf_submit, valid until the next pf_submit / pf_destroy on the context. */
+typedef struct {
+    uint64_t n_instances;      /* trip count of panfeed.py:64 (x2 non-canonical), slow path excluded */
+    uint64_t n_unique;         /* unique k-mers over all clusters (len(cluster_dict) summed) */
+    uint64_t n_kept;           /* rows of kmers_to_hashes.tsv minus the per-cluster rows */
+    uint64_t n_new_patterns;   /* rows this batch adds to hashes_to_patterns.tsv */
+    uint32_t W;                /* uint32 words per presence row */
+    uint32_t key_words;        /* 1 (k <= 31) or 2 */
+    /* per cluster (batch order) */
+    const uint64_t* cluster_kmer_off;  /* [n_clusters] first kept k-mer in kmer_* */
+    const uint32_t* cluster_kmer_cnt;  /* [n_clusters] */
+    const uint32_t* cluster_pattern;   /* [n_clusters] pattern id of the cluster row (panfeed.py:175-187) */
+    const uint32_t* cluster_unique;    /* [n_clusters] len(cluster_dict) */
+    /* per kept k-mer, in dict insertion order inside each cluster (panfeed.py:189) */
+    const uint64_t* kmer_key;          /* [n_kept_total * key_words]; bit 63 of word 0 set: slow-path row,
+                                          low 32 bits = index into the batch's extra_* arrays */
+    const uint32_t* kmer_pattern;      /* [n_kept_total] pattern id */
+    /* patterns first seen in this batch, sorted by first_seen = the order of hashes_to_patterns.tsv */
+    const uint32_t* new_pattern_id;    /* [n_new_patterns] */
+    /* run-global pattern pool, indexed by pattern id */
+    uint64_t n_patterns;
+    const uint8_t* pattern_md5;        /* [n_patterns * 16] md5 of the int64 / float64 image */
+    const uint32_t* pattern_bits;      /* [n_patterns * W] */
+    const uint32_t* pattern_nan;       /* [n_patterns * W] NaN positions (consider_missing), else NULL */
+    const uint32_t* pattern_n;         /* [n_patterns] vector length; bit 31 set: int64 image (cluster row) */
+    const uint64_t* pattern_first_seen;/* [n_patterns] cluster_ordinal << 32 | rank inside the cluster */
+    const uint64_t* strand_bits;       /* [n_strand_words] or NULL */
+} pf_result;
+
+/* device-side timing of the last pf_submit, milliseconds (hipEvent on the context's stream) */
+typedef struct {
+    float total_ms;
+    float scan_ms;     /* kmer_scan_kernel launches */
+    float rows_ms;     /* rows_kernel */
+    float emit_ms;     /* emit_kernel + pattern row/md5 kernels */
+    uint32_t scan_launches;
+    uint32_t n_items;  /* (cluster, key-partition) work items scanned, retries included */
+    uint32_t n_retried;/* clusters whose table overflowed and were re-run with more partitions */
+    uint32_t reserved;
+    uint64_t scan_packed_bytes; /* packed sequence bytes the scan kernels were asked to read */
+} pf_timing;
+
+const char* pf_last_error(void);
+const char* pf_version(void);
+
+/* Number of visible HIP devices, or a negative pf_status. */
+int pf_device_count(void);
+
+int pf_create(pf_ctx** out, int device, const pf_opts* opts);
+void pf_destroy(pf_ctx* ctx);
+
+/* Forget the run-global patterns (a new run on the same context). */
+int pf_reset_patterns(pf_ctx* ctx);
+
+/* Run cluster_cutter + pattern_hasher over one batch.  Results stay on the device until
+ * pf_fetch; `res` (may be NULL) receives the counters only. */
+int pf_submit(pf_ctx* ctx, const pf_batch* batch, pf_result* counters);
+
+/* Copy the arrays of the last batch's result to host memory owned by the context. */
+int pf_fetch(pf_ctx* ctx, pf_result* res);
+
+int pf_get_timing(pf_ctx* ctx, pf_timing* t);
+
+/* Multi-GPU (one process per GPU): first-seen bookkeeping for the run-global pattern dedup.
+ * pf_export_patterns: (md5[16], first_seen) of every pattern this rank holds;
+ * the driver all-gathers them (RCCL) and keeps, per digest, the rank with the lowest first_seen. */
+int pf_export_patterns(pf_ctx* ctx, uint64_t* n, const uint8_t** md5, const uint64_t** first_seen);
+
+/* Device buffers for callers that keep batches resident (bench.py, tests): plain hipMalloc /
+ * hipMemcpy / hipFree on the context's device. */
+int pf_dev_alloc(pf_ctx* ctx, uint64_t bytes, void** dptr);
+int pf_dev_free(pf_ctx* ctx, void* dptr);
+int pf_dev_upload(pf_ctx* ctx, void* dptr, const void* src, uint64_t bytes);
+int pf_dev_download(pf_ctx* ctx, void* dst, const void* dptr, uint64_t bytes);
+
+/* Synthetic-input helper (bench.py): expand allele pools into per-sample packed segments on the
+ * device.  seg i becomes a copy of allele seg_allele[i]: words
+ * [allele_word_off[a], allele_word_off[a] + ceil16(len)) -> packed[seg_word_off[i] ...].
+ * All pointers are device pointers. */
+int pf_synth_expand(pf_ctx* ctx, const uint64_t* allele_words, const uint64_t* allele_word_off,
+                    const uint32_t* seg_allele, const uint64_t* seg_word_off, const uint32_t* seg_len,
+                    uint32_t n_segs, uint64_t* packed);
+
+/* Host helper: pack ASCII A/C/G/T (upper case) to the layout above.  dst must hold
+ * 2*ceil(len/64) words; returns the number of words written. */
+uint64_t pf_pack_acgt(const char* seq, uint32_t len, uint64_t* dst);
+
+/* Host helper: md5 + base64 of a digest -- panfeed.py:175-176 -- for writers. */
+void pf_b64_digest(const uint8_t md5[16], char out[24]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,103 @@
+"""ctypes binding of libpanfeed_hip.so (include/panfeed_hip.h).
+
+The library is the product: there is no CPU fallback.  Loading fails loudly when the shared
+object is missing (build it with ``python -c 'import __graft_entry__ as g; g.build()'``), and
+every entry point raises ``PanfeedHipError`` with the library's message on a non-zero status.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpanfeed_hip.so")
+
+
+class PanfeedHipError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"libpanfeed_hip: status {status}: {message}")
+        self.status = status
+
+
+class Opts(C.Structure):
+    _fields_ = [("klength", C.c_uint32), ("canon", C.c_uint32), ("consider_missing", C.c_uint32),
+                ("patfilt", C.c_uint32), ("multiple_files", C.c_uint32), ("max_strains", C.c_uint32),
+                ("maf_lo", C.POINTER(C.c_uint32)), ("maf_hi", C.POINTER(C.c_uint32)),
+                ("pattern_capacity", C.c_uint64), ("max_items", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class Batch(C.Structure):
+    _fields_ = [("n_clusters", C.c_uint32), ("n_segs", C.c_uint32), ("n_words", C.c_uint64),
+                ("on_device", C.c_uint32), ("reserved", C.c_uint32),
+                ("packed", C.c_void_p), ("seg_word_off", C.c_void_p), ("seg_len", C.c_void_p),
+                ("seg_sample", C.c_void_p), ("seg_ord_base", C.c_void_p), ("cluster_seg_off", C.c_void_p),
+                ("cluster_nstrains", C.c_void_p), ("cluster_npresab", C.c_void_p), ("cluster_presab", C.c_void_p),
+                ("cluster_ordinal", C.c_void_p),
+                ("n_extra", C.c_uint32), ("reserved2", C.c_uint32),
+                ("extra_cluster", C.c_void_p), ("extra_ord", C.c_void_p), ("extra_bits", C.c_void_p),
+                ("seg_strand_off", C.c_void_p), ("n_strand_words", C.c_uint64)]
+
+
+class Result(C.Structure):
+    _fields_ = [("n_instances", C.c_uint64), ("n_unique", C.c_uint64), ("n_kept", C.c_uint64),
+                ("n_new_patterns", C.c_uint64), ("W", C.c_uint32), ("key_words", C.c_uint32),
+                ("cluster_kmer_off", C.POINTER(C.c_uint64)), ("cluster_kmer_cnt", C.POINTER(C.c_uint32)),
+                ("cluster_pattern", C.POINTER(C.c_uint32)), ("cluster_unique", C.POINTER(C.c_uint32)),
+                ("kmer_key", C.POINTER(C.c_uint64)), ("kmer_pattern", C.POINTER(C.c_uint32)),
+                ("new_pattern_id", C.POINTER(C.c_uint32)), ("n_patterns", C.c_uint64),
+                ("pattern_md5", C.POINTER(C.c_uint8)), ("pattern_bits", C.POINTER(C.c_uint32)),
+                ("pattern_nan", C.POINTER(C.c_uint32)), ("pattern_n", C.POINTER(C.c_uint32)),
+                ("pattern_first_seen", C.POINTER(C.c_uint64)), ("strand_bits", C.POINTER(C.c_uint64))]
+
+
+class Timing(C.Structure):
+    _fields_ = [("total_ms", C.c_float), ("scan_ms", C.c_float), ("rows_ms", C.c_float), ("emit_ms", C.c_float),
+                ("scan_launches", C.c_uint32), ("n_items", C.c_uint32), ("n_retried", C.c_uint32),
+                ("reserved", C.c_uint32), ("scan_packed_bytes", C.c_uint64)]
+
+
+# every symbol include/panfeed_hip.h declares
+EXPORTS = ["pf_last_error", "pf_version", "pf_device_count", "pf_create", "pf_destroy", "pf_reset_patterns",
+           "pf_submit", "pf_fetch", "pf_get_timing", "pf_export_patterns", "pf_dev_alloc", "pf_dev_free",
+           "pf_dev_upload", "pf_dev_download", "pf_synth_expand", "pf_pack_acgt", "pf_b64_digest"]
+
+_lib = None
+
+
+def load():
+    """dlopen the HIP library; raises if it is not built -- never falls back to anything else."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build the HIP extension first "
+                          "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        getattr(L, name)  # AttributeError here means header and library disagree
+    L.pf_last_error.restype = C.c_char_p
+    L.pf_version.restype = C.c_char_p
+    L.pf_device_count.restype = C.c_int
+    L.pf_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(Opts)]
+    L.pf_destroy.argtypes = [C.c_void_p]
+    L.pf_destroy.restype = None
+    L.pf_reset_patterns.argtypes = [C.c_void_p]
+    L.pf_submit.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(Result)]
+    L.pf_fetch.argtypes = [C.c_void_p, C.POINTER(Result)]
+    L.pf_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
+    L.pf_export_patterns.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.POINTER(C.c_uint8)),
+                                     C.POINTER(C.POINTER(C.c_uint64))]
+    L.pf_dev_alloc.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
+    L.pf_dev_free.argtypes = [C.c_void_p, C.c_void_p]
+    L.pf_dev_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+    L.pf_dev_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+    L.pf_synth_expand.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_uint32, C.c_void_p]
+    L.pf_pack_acgt.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p]
+    L.pf_pack_acgt.restype = C.c_uint64
+    L.pf_b64_digest.argtypes = [C.c_void_p, C.c_char_p]
+    L.pf_b64_digest.restype = None
+    _lib = L
+    return L
+
+
+def check(status):
+    if status != 0:
+        raise PanfeedHipError(status, load().pf_last_error().decode(errors="replace"))

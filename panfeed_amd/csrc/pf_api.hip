@@ -1,0 +1,854 @@
+// pf_api.hip -- C ABI (include/panfeed_hip.h) over the kernels in pf_kernels.h.
+//
+// Host orchestration of one batch (pf_submit):
+//   per-cluster instance counts -> work items (cluster x key partition, plus one prebuilt item per cluster
+//   for slow-path rows) -> sub-batches of <= max_items items, each: scan -> rows -> base -> emit -> pattern
+//   rows; clusters whose LDS table overflowed are re-run with 4x the partitions; MD5 of new patterns last.
+// Everything is stream-ordered on one HIP stream; the only host syncs are the instance-count read-back, the
+// overflow read-back per pass and the final counter read-back.
+#include "pf_kernels.h"
+#include "../../include/panfeed_hip.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(e_ == hipErrorOutOfMemory ? PF_ERR_OOM : PF_ERR_HIP, "%s failed: %s (%s:%d)", \
+                        #expr, hipGetErrorString(e_), __FILE__, __LINE__);                             \
+    } while (0)
+#define PFCHK(expr)             \
+    do {                        \
+        int r_ = (expr);        \
+        if (r_ != PF_OK) return r_; \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return PF_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(PF_ERR_OOM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        }
+        cap = want;
+        return PF_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct Item {
+    uint32_t cluster, part, nparts, nslots, slice, sib0, nsib, extra_first, is_extra;
+};
+
+struct Arena {
+    DevBuf key, pid, first;
+    uint64_t cap = 0;        // entries
+    uint64_t base = 0;       // global index of entry 0
+    uint64_t used = 0;
+};
+
+struct EvPair { hipEvent_t a, b; int cat; };
+
+}  // namespace
+
+struct pf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    pf_opts o{};
+    int KW = 1;
+    uint32_t NS = 0, W = 0, max_items = 0;
+    std::vector<uint32_t> maf_lo, maf_hi;
+    DevBuf d_maf_lo, d_maf_hi;
+    // pattern table + pool
+    pf::PatternTable pt{};
+    DevBuf pt_lo, pt_val, pt_first, pt_counters, pat_bits, pat_nan, pat_n, pat_md5;
+    uint32_t n_patterns = 0;       // patterns allocated after the last submit
+    uint32_t pid0 = 0;             // first pattern id of the last submit
+    // scratch slices
+    DevBuf tab_key, tab_ord, chunkbits, chunkmask, slot_hash, sorted_pair, kept_prefix;
+    // uploaded batch (when the caller passes host pointers)
+    DevBuf b_packed, b_seg_word_off, b_seg_len, b_seg_sample, b_seg_ord, b_cl_seg_off, b_cl_nstr, b_cl_npres,
+        b_cl_presab, b_cl_ordinal, b_extra_ord, b_extra_bits, b_seg_strand_off;
+    // per batch device arrays
+    DevBuf cl_ninst, cl_words, cl_overflow, cl_kmer_off, cl_kmer_cnt, cl_unique, cl_pattern, cl_first, cursor;
+    DevBuf strand_bits;
+    DevBuf it_cluster, it_part, it_nparts, it_nslots, it_slice, it_sib0, it_nsib, it_extra_first, it_count,
+        it_unique, it_kept, work_scan, work_extra, sub_cluster, sub_item0, sub_nitems;
+    std::vector<Arena*> arenas;
+    // last batch bookkeeping
+    bool have_batch = false;
+    uint32_t n_clusters = 0;
+    uint64_t n_strand_words = 0;
+    std::vector<uint32_t> cluster_arena;   // arena index per cluster
+    pf_result counters{};
+    pf_timing timing{};
+    std::vector<EvPair> events;
+    std::vector<hipEvent_t> ev_pool;
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+    // host result storage
+    std::vector<uint64_t> h_kmer_off, h_kmer_key, h_first_seen, h_strand;
+    std::vector<uint32_t> h_kmer_cnt, h_cl_pattern, h_cl_unique, h_kmer_pid, h_new_pid, h_pat_bits, h_pat_nan, h_pat_n;
+    std::vector<uint8_t> h_pat_md5;
+};
+
+namespace {
+
+int get_event(pf_ctx* c, hipEvent_t* ev) {
+    if (!c->ev_pool.empty()) { *ev = c->ev_pool.back(); c->ev_pool.pop_back(); return PF_OK; }
+    HIPCHK(hipEventCreate(ev));
+    return PF_OK;
+}
+int mark_begin(pf_ctx* c, int cat) {
+    EvPair e; e.cat = cat;
+    PFCHK(get_event(c, &e.a));
+    PFCHK(get_event(c, &e.b));
+    HIPCHK(hipEventRecord(e.a, c->stream));
+    c->events.push_back(e);
+    return PF_OK;
+}
+int mark_end(pf_ctx* c) {
+    HIPCHK(hipEventRecord(c->events.back().b, c->stream));
+    return PF_OK;
+}
+
+template <class T>
+int upload(pf_ctx* c, DevBuf& b, const T* src, size_t n, const T** out) {
+    PFCHK(b.ensure(std::max<size_t>(n, 1) * sizeof(T)));
+    if (n) HIPCHK(hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    *out = b.as<T>();
+    return PF_OK;
+}
+template <class T>
+int upload_vec(pf_ctx* c, DevBuf& b, const std::vector<T>& v) {
+    const T* dummy;
+    return upload(c, b, v.data(), v.size(), &dummy);
+}
+
+int fill_u64(pf_ctx* c, void* p, uint64_t v, uint64_t n) {
+    if (!n) return PF_OK;
+    uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(pf::fill_u64_kernel, dim3(blocks), dim3(256), 0, c->stream, (uint64_t*)p, v, n);
+    HIPCHK(hipGetLastError());
+    return PF_OK;
+}
+
+int reset_patterns(pf_ctx* c) {
+    PFCHK(fill_u64(c, c->pt_lo.p, pf::EMPTY64, c->pt.cap));
+    PFCHK(fill_u64(c, c->pt_val.p, pf::EMPTY64, c->pt.cap));
+    PFCHK(fill_u64(c, c->pt_first.p, pf::EMPTY64, c->pt.pool));
+    HIPCHK(hipMemsetAsync(c->pt_counters.p, 0, 16, c->stream));
+    c->n_patterns = 0;
+    c->pid0 = 0;
+    c->h_pat_bits.clear(); c->h_pat_nan.clear(); c->h_pat_n.clear(); c->h_pat_md5.clear(); c->h_first_seen.clear();
+    return PF_OK;
+}
+
+template <int KW, bool CANON>
+int launch_scan_t(pf_ctx* c, const pf::ScanParams& sp, uint32_t n) {
+    static bool attr_done = false;
+    auto kern = pf::kmer_scan_kernel<KW, CANON>;
+    const uint32_t lds = c->NS * (8u * KW + 8u) + pf::MISC_WORDS * 4;
+    if (!attr_done) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(n), dim3(pf::SCAN_THREADS), lds, c->stream, sp);
+    HIPCHK(hipGetLastError());
+    return PF_OK;
+}
+int launch_scan(pf_ctx* c, const pf::ScanParams& sp, uint32_t n) {
+    if (c->KW == 1) return c->o.canon ? launch_scan_t<1, true>(c, sp, n) : launch_scan_t<1, false>(c, sp, n);
+    return c->o.canon ? launch_scan_t<2, true>(c, sp, n) : launch_scan_t<2, false>(c, sp, n);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pf_last_error(void) { return g_err.c_str(); }
+const char* pf_version(void) { return "panfeed_hip 0.1 (gfx950)"; }
+
+int pf_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(PF_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+void pf_destroy(pf_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->d_maf_lo, &c->d_maf_hi, &c->pt_lo, &c->pt_val, &c->pt_first, &c->pt_counters, &c->pat_bits,
+                      &c->pat_nan, &c->pat_n, &c->pat_md5, &c->tab_key, &c->tab_ord, &c->chunkbits, &c->chunkmask,
+                      &c->slot_hash, &c->sorted_pair, &c->kept_prefix, &c->b_packed, &c->b_seg_word_off, &c->b_seg_len,
+                      &c->b_seg_sample, &c->b_seg_ord, &c->b_cl_seg_off, &c->b_cl_nstr, &c->b_cl_npres, &c->b_cl_presab,
+                      &c->b_cl_ordinal, &c->b_extra_ord, &c->b_extra_bits, &c->b_seg_strand_off, &c->cl_ninst,
+                      &c->cl_words, &c->cl_overflow, &c->cl_kmer_off, &c->cl_kmer_cnt, &c->cl_unique, &c->cl_pattern,
+                      &c->cl_first, &c->cursor, &c->strand_bits, &c->it_cluster, &c->it_part, &c->it_nparts,
+                      &c->it_nslots, &c->it_slice, &c->it_sib0, &c->it_nsib, &c->it_extra_first, &c->it_count,
+                      &c->it_unique, &c->it_kept, &c->work_scan, &c->work_extra, &c->sub_cluster, &c->sub_item0,
+                      &c->sub_nitems};
+    for (DevBuf* b : bufs) b->release();
+    for (Arena* a : c->arenas) { a->key.release(); a->pid.release(); a->first.release(); delete a; }
+    for (auto& e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
+    if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int pf_create(pf_ctx** out, int device, const pf_opts* o) {
+    if (!out || !o) return fail(PF_ERR_ARG, "pf_create: null argument");
+    *out = nullptr;
+    if (o->klength < 1 || o->klength > PF_MAX_K)
+        return fail(PF_ERR_ARG, "klength %u unsupported (1..%d)", o->klength, PF_MAX_K);
+    if (o->max_strains < 1 || o->max_strains > pf::MAX_CHUNKS * 32)
+        return fail(PF_ERR_ARG, "max_strains %u unsupported (1..%u)", o->max_strains, pf::MAX_CHUNKS * 32);
+    if (!o->maf_lo || !o->maf_hi) return fail(PF_ERR_ARG, "maf_lo / maf_hi tables are required");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(PF_ERR_ARG, "device %d not present (%d devices)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(PF_ERR_ARG, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+
+    pf_ctx* c = new pf_ctx();
+    c->device = device;
+    c->o = *o;
+    c->KW = o->klength <= 31 ? 1 : 2;
+    c->NS = pf::nslots_max(c->KW);
+    c->W = (o->max_strains + 31) / 32;
+    c->max_items = o->max_items ? o->max_items : 2048;
+    c->maf_lo.assign(o->maf_lo, o->maf_lo + o->max_strains + 1);
+    c->maf_hi.assign(o->maf_hi, o->maf_hi + o->max_strains + 1);
+    c->o.maf_lo = c->maf_lo.data();
+    c->o.maf_hi = c->maf_hi.data();
+    int rc = PF_OK;
+    auto guard = [&](int r) { if (r != PF_OK && rc == PF_OK) rc = r; return r == PF_OK; };
+    do {
+        hipError_t e = hipStreamCreate(&c->stream);
+        if (e != hipSuccess) { rc = fail(PF_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); break; }
+        if (hipEventCreate(&c->ev_t0) != hipSuccess || hipEventCreate(&c->ev_t1) != hipSuccess) {
+            rc = fail(PF_ERR_HIP, "hipEventCreate failed"); break;
+        }
+        if (!guard(upload_vec(c, c->d_maf_lo, c->maf_lo))) break;
+        if (!guard(upload_vec(c, c->d_maf_hi, c->maf_hi))) break;
+        uint64_t cap = o->pattern_capacity ? o->pattern_capacity : (1ull << 24);
+        uint64_t p2 = 1024;
+        while (p2 < cap) p2 <<= 1;
+        c->pt.cap = p2;
+        c->pt.pool = (uint32_t)std::min<uint64_t>(p2 / 2, 0x7FFFFFF0ull);
+        const size_t W = c->W;
+        if (!guard(c->pt_lo.ensure(p2 * 8)) || !guard(c->pt_val.ensure(p2 * 8)) ||
+            !guard(c->pt_first.ensure((size_t)c->pt.pool * 8)) || !guard(c->pt_counters.ensure(16)) ||
+            !guard(c->pat_bits.ensure((size_t)c->pt.pool * W * 4)) || !guard(c->pat_n.ensure((size_t)c->pt.pool * 4)) ||
+            !guard(c->pat_md5.ensure((size_t)c->pt.pool * 16)))
+            break;
+        if (o->consider_missing && !guard(c->pat_nan.ensure((size_t)c->pt.pool * W * 4))) break;
+        c->pt.lo = c->pt_lo.as<uint64_t>();
+        c->pt.val = c->pt_val.as<uint64_t>();
+        c->pt.first_seen = c->pt_first.as<uint64_t>();
+        c->pt.counters = c->pt_counters.as<uint32_t>();
+        if (!guard(reset_patterns(c))) break;
+        // scratch slices
+        const size_t NS = c->NS, S = c->max_items;
+        if (!guard(c->tab_key.ensure(S * NS * 8 * c->KW)) || !guard(c->tab_ord.ensure(S * NS * 4)) ||
+            !guard(c->chunkbits.ensure(S * NS * W * 4)) || !guard(c->chunkmask.ensure(S * 8 * 4)) ||
+            !guard(c->slot_hash.ensure(S * NS * 16)) || !guard(c->sorted_pair.ensure(S * NS * 8)) ||
+            !guard(c->kept_prefix.ensure(S * (NS + 1) * 4)) || !guard(c->cursor.ensure(64)))
+            break;
+        e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { rc = fail(PF_ERR_HIP, "pf_create sync: %s", hipGetErrorString(e)); break; }
+    } while (0);
+    if (rc != PF_OK) { std::string keep = g_err; pf_destroy(c); g_err = keep; return rc; }
+    *out = c;
+    return PF_OK;
+}
+
+int pf_reset_patterns(pf_ctx* c) {
+    if (!c) return fail(PF_ERR_ARG, "null context");
+    HIPCHK(hipSetDevice(c->device));
+    PFCHK(reset_patterns(c));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PF_OK;
+}
+
+int pf_dev_alloc(pf_ctx* c, uint64_t bytes, void** dptr) {
+    if (!c || !dptr) return fail(PF_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMalloc(dptr, bytes ? bytes : 16));
+    return PF_OK;
+}
+int pf_dev_free(pf_ctx* c, void* dptr) {
+    if (!c) return fail(PF_ERR_ARG, "null context");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipFree(dptr));
+    return PF_OK;
+}
+int pf_dev_upload(pf_ctx* c, void* dptr, const void* src, uint64_t bytes) {
+    if (!c) return fail(PF_ERR_ARG, "null context");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpy(dptr, src, bytes, hipMemcpyHostToDevice));
+    return PF_OK;
+}
+int pf_dev_download(pf_ctx* c, void* dst, const void* dptr, uint64_t bytes) {
+    if (!c) return fail(PF_ERR_ARG, "null context");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(dst, dptr, bytes, hipMemcpyDeviceToHost));
+    return PF_OK;
+}
+
+int pf_synth_expand(pf_ctx* c, const uint64_t* allele_words, const uint64_t* allele_word_off,
+                    const uint32_t* seg_allele, const uint64_t* seg_word_off, const uint32_t* seg_len,
+                    uint32_t n_segs, uint64_t* packed) {
+    if (!c) return fail(PF_ERR_ARG, "null context");
+    HIPCHK(hipSetDevice(c->device));
+    if (!n_segs) return PF_OK;
+    hipLaunchKernelGGL(pf::synth_expand_kernel, dim3(2048), dim3(256), 0, c->stream, allele_words, allele_word_off,
+                       seg_allele, seg_word_off, seg_len, n_segs, packed);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PF_OK;
+}
+
+uint64_t pf_pack_acgt(const char* seq, uint32_t len, uint64_t* dst) {
+    const uint64_t nw = 2ull * ((len + 63) / 64);
+    for (uint64_t i = 0; i < nw; i++) dst[i] = 0;
+    for (uint32_t i = 0; i < len; i++) {
+        uint64_t code;
+        switch (seq[i]) {
+            case 'A': code = 0; break;
+            case 'C': code = 1; break;
+            case 'G': code = 2; break;
+            default: code = 3; break;
+        }
+        dst[i >> 5] |= code << (62 - 2 * (i & 31));
+    }
+    return nw;
+}
+
+void pf_b64_digest(const uint8_t d[16], char out[24]) {
+    static const char* T = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+    int o = 0;
+    for (int i = 0; i < 15; i += 3) {
+        uint32_t v = ((uint32_t)d[i] << 16) | ((uint32_t)d[i + 1] << 8) | d[i + 2];
+        out[o++] = T[(v >> 18) & 63]; out[o++] = T[(v >> 12) & 63]; out[o++] = T[(v >> 6) & 63]; out[o++] = T[v & 63];
+    }
+    uint32_t v = (uint32_t)d[15] << 16;
+    out[o++] = T[(v >> 18) & 63]; out[o++] = T[(v >> 12) & 63]; out[o++] = '='; out[o++] = '=';
+}
+
+// ---------------------------------------------------------------------------------------------
+int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
+    if (!c || !b) return fail(PF_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    c->have_batch = false;
+    const uint32_t C = b->n_clusters, NSEG = b->n_segs, W = c->W, NS = c->NS, KW = (uint32_t)c->KW;
+    if (b->n_segs && (!b->packed || !b->seg_word_off || !b->seg_len || !b->seg_sample || !b->seg_ord_base))
+        return fail(PF_ERR_ARG, "segment arrays missing");
+    if (C && (!b->cluster_seg_off || !b->cluster_nstrains || !b->cluster_npresab || !b->cluster_presab ||
+              !b->cluster_ordinal))
+        return fail(PF_ERR_ARG, "cluster arrays missing");
+    if (b->n_extra && (!b->extra_cluster || !b->extra_ord || !b->extra_bits))
+        return fail(PF_ERR_ARG, "extra arrays missing");
+    for (auto& e : c->events) { c->ev_pool.push_back(e.a); c->ev_pool.push_back(e.b); }
+    c->events.clear();
+    c->timing = pf_timing{};
+    HIPCHK(hipEventRecord(c->ev_t0, c->stream));
+
+    // ---- batch arrays on the device
+    pf_batch d = *b;
+    std::vector<uint32_t> h_extra_cluster;
+    if (!b->on_device) {
+        PFCHK(upload(c, c->b_packed, b->packed, (size_t)b->n_words, &d.packed));
+        PFCHK(upload(c, c->b_seg_word_off, b->seg_word_off, NSEG, &d.seg_word_off));
+        PFCHK(upload(c, c->b_seg_len, b->seg_len, NSEG, &d.seg_len));
+        PFCHK(upload(c, c->b_seg_sample, b->seg_sample, NSEG, &d.seg_sample));
+        PFCHK(upload(c, c->b_seg_ord, b->seg_ord_base, NSEG, &d.seg_ord_base));
+        PFCHK(upload(c, c->b_cl_seg_off, b->cluster_seg_off, (size_t)C + 1, &d.cluster_seg_off));
+        PFCHK(upload(c, c->b_cl_nstr, b->cluster_nstrains, C, &d.cluster_nstrains));
+        PFCHK(upload(c, c->b_cl_npres, b->cluster_npresab, C, &d.cluster_npresab));
+        PFCHK(upload(c, c->b_cl_presab, b->cluster_presab, (size_t)C * W, &d.cluster_presab));
+        PFCHK(upload(c, c->b_cl_ordinal, b->cluster_ordinal, C, &d.cluster_ordinal));
+        PFCHK(upload(c, c->b_extra_ord, b->extra_ord, b->n_extra, &d.extra_ord));
+        PFCHK(upload(c, c->b_extra_bits, b->extra_bits, (size_t)b->n_extra * W, &d.extra_bits));
+        if (b->seg_strand_off) PFCHK(upload(c, c->b_seg_strand_off, b->seg_strand_off, NSEG, &d.seg_strand_off));
+        if (b->n_extra) h_extra_cluster.assign(b->extra_cluster, b->extra_cluster + b->n_extra);
+        // validate what the kernels index with (host copies are at hand)
+        for (uint32_t i = 0; i < C; i++) {
+            if (b->cluster_seg_off[i] > b->cluster_seg_off[i + 1] || b->cluster_seg_off[i + 1] > NSEG)
+                return fail(PF_ERR_ARG, "cluster_seg_off not monotone / out of range at %u", i);
+            if (b->cluster_nstrains[i] > c->o.max_strains || b->cluster_npresab[i] > c->o.max_strains)
+                return fail(PF_ERR_ARG, "cluster %u has more strains than max_strains", i);
+        }
+        for (uint32_t s = 0; s < NSEG; s++) {
+            const uint64_t nw = 2ull * ((b->seg_len[s] + 63) / 64);
+            if ((b->seg_word_off[s] & 1) || b->seg_word_off[s] + nw + 2 > b->n_words)
+                return fail(PF_ERR_ARG, "segment %u: misaligned or outside packed[] (needs 2 words of tail padding)", s);
+        }
+        for (uint32_t i = 0; i < C; i++)
+            for (uint32_t s = b->cluster_seg_off[i]; s < b->cluster_seg_off[i + 1]; s++) {
+                if (b->seg_sample[s] >= b->cluster_nstrains[i])
+                    return fail(PF_ERR_ARG, "segment %u: sample column %u >= n_strains %u", s, b->seg_sample[s],
+                                b->cluster_nstrains[i]);
+                if (s > b->cluster_seg_off[i] && b->seg_sample[s] < b->seg_sample[s - 1])
+                    return fail(PF_ERR_ARG, "segments of cluster %u are not sorted by sample", i);
+            }
+    } else if (b->n_extra) {
+        h_extra_cluster.resize(b->n_extra);
+        HIPCHK(hipMemcpy(h_extra_cluster.data(), b->extra_cluster, (size_t)b->n_extra * 4, hipMemcpyDeviceToHost));
+    }
+    for (uint32_t e = 0; e < b->n_extra; e++) {
+        if (h_extra_cluster[e] >= C || (e && h_extra_cluster[e] < h_extra_cluster[e - 1]))
+            return fail(PF_ERR_ARG, "extra_cluster must be non-decreasing and < n_clusters");
+    }
+
+    // ---- per-cluster instance counts
+    PFCHK(c->cl_ninst.ensure((size_t)std::max(C, 1u) * 8));
+    PFCHK(c->cl_words.ensure((size_t)std::max(C, 1u) * 8));
+    std::vector<uint64_t> ninst(C), words(C);
+    if (C) {
+        hipLaunchKernelGGL(pf::cluster_ninst_kernel, dim3((C + 255) / 256), dim3(256), 0, c->stream, d.cluster_seg_off,
+                           d.seg_len, c->o.klength, C, c->cl_ninst.as<uint64_t>(), c->cl_words.as<uint64_t>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(ninst.data(), c->cl_ninst.p, (size_t)C * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(words.data(), c->cl_words.p, (size_t)C * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    const uint64_t mult = c->o.canon ? 1 : 2;
+    uint64_t total_inst = 0;
+    for (uint32_t i = 0; i < C; i++) {
+        if (ninst[i] * mult >= 0xFFFFFFF0ull) return fail(PF_ERR_ARG, "cluster %u has too many k-mer instances", i);
+        total_inst += ninst[i] * mult;
+    }
+
+    // ---- per batch outputs
+    const size_t C1 = std::max(C, 1u);
+    PFCHK(c->cl_overflow.ensure(C1 * 4));
+    PFCHK(c->cl_kmer_off.ensure(C1 * 8));
+    PFCHK(c->cl_kmer_cnt.ensure(C1 * 4));
+    PFCHK(c->cl_unique.ensure(C1 * 4));
+    PFCHK(c->cl_pattern.ensure(C1 * 4));
+    PFCHK(c->cl_first.ensure(C1 * 8));
+    HIPCHK(hipMemsetAsync(c->cl_overflow.p, 0, C1 * 4, c->stream));
+    HIPCHK(hipMemsetAsync(c->cl_kmer_cnt.p, 0, C1 * 4, c->stream));
+    HIPCHK(hipMemsetAsync(c->cl_unique.p, 0, C1 * 4, c->stream));
+    HIPCHK(hipMemsetAsync(c->cl_pattern.p, 0xFF, C1 * 4, c->stream));
+    HIPCHK(hipMemsetAsync(c->cursor.p, 0, 64, c->stream));
+    c->n_strand_words = (b->seg_strand_off && c->o.canon) ? b->n_strand_words : 0;
+    if (c->n_strand_words) {
+        PFCHK(c->strand_bits.ensure((size_t)c->n_strand_words * 8));
+        HIPCHK(hipMemsetAsync(c->strand_bits.p, 0, (size_t)c->n_strand_words * 8, c->stream));
+    }
+    c->pid0 = c->n_patterns;
+    c->cluster_arena.assign(C, 0);
+
+    // extras per cluster
+    std::vector<uint32_t> ex_first(C + 1, 0);
+    for (uint32_t e = 0; e < b->n_extra; e++) ex_first[h_extra_cluster[e] + 1]++;
+    for (uint32_t i = 0; i < C; i++) ex_first[i + 1] += ex_first[i];
+
+    std::vector<uint32_t> todo(C), nparts(C, 1);
+    std::iota(todo.begin(), todo.end(), 0u);
+    uint32_t pass = 0;
+    const uint32_t lim_full = pf::insert_limit(NS);
+    uint64_t arena_base = 0;
+
+    while (!todo.empty()) {
+        // ---- items of this pass
+        std::vector<Item> items;
+        struct Sub { uint32_t item0, nitems, cl0, ncl; };
+        std::vector<Sub> subs;
+        std::vector<uint32_t> sub_cluster, sub_item0, sub_nitems;
+        uint64_t arena_cap = 0;
+        Sub cur{0, 0, 0, 0};
+        for (uint32_t ci : todo) {
+            const uint32_t np = nparts[ci];
+            const uint32_t nex = ex_first[ci + 1] - ex_first[ci];
+            const uint32_t nex_items = (nex + lim_full - 1) / lim_full;
+            const uint32_t nit = np + nex_items;
+            if (nit > c->max_items)
+                return fail(PF_ERR_CAPACITY, "cluster %u needs %u work items; raise max_items (%u)", ci, nit, c->max_items);
+            if (cur.nitems + nit > c->max_items) {
+                subs.push_back(cur);
+                cur = Sub{(uint32_t)items.size(), 0, (uint32_t)sub_cluster.size(), 0};
+            }
+            const uint32_t sib0 = (uint32_t)items.size();
+            // table size: a cluster that cannot overflow a small table gets one (less flush traffic)
+            uint32_t ns = NS;
+            const uint64_t inst = ninst[ci] * mult;
+            if (np == 1 && NS > 4096 + pf::INSERT_SLACK && inst <= pf::insert_limit(4096)) ns = 4096;
+            for (uint32_t q = 0; q < np; q++)
+                items.push_back(Item{ci, q, np, ns, cur.nitems + q, sib0, nit, 0, 0});
+            for (uint32_t q = 0; q < nex_items; q++) {
+                const uint32_t first = ex_first[ci] + q * lim_full;
+                const uint32_t cnt = std::min(lim_full, ex_first[ci + 1] - first);
+                items.push_back(Item{ci, 0, 1, cnt, cur.nitems + np + q, sib0, nit, first, 1});
+            }
+            for (uint32_t q = 0; q < np; q++) arena_cap += std::min<uint64_t>(pf::insert_limit(ns), inst);
+            arena_cap += nex;
+            sub_cluster.push_back(ci);
+            sub_item0.push_back(sib0);
+            sub_nitems.push_back(nit);
+            cur.nitems += nit;
+            cur.ncl++;
+            c->cluster_arena[ci] = pass;
+        }
+        if (cur.nitems) subs.push_back(cur);
+
+        // ---- arena of this pass
+        while (c->arenas.size() <= pass) c->arenas.push_back(new Arena());
+        Arena* ar = c->arenas[pass];
+        ar->cap = std::max<uint64_t>(arena_cap, 1);
+        ar->base = arena_base;
+        PFCHK(ar->key.ensure((size_t)ar->cap * 8 * KW));
+        PFCHK(ar->pid.ensure((size_t)ar->cap * 4));
+        PFCHK(ar->first.ensure((size_t)ar->cap * 8));
+
+        // ---- item arrays
+        const size_t NI = items.size();
+        std::vector<uint32_t> v_cluster(NI), v_part(NI), v_nparts(NI), v_nslots(NI), v_slice(NI), v_sib0(NI), v_nsib(NI),
+            v_exfirst(NI), w_scan, w_extra;
+        for (size_t i = 0; i < NI; i++) {
+            v_cluster[i] = items[i].cluster; v_part[i] = items[i].part; v_nparts[i] = items[i].nparts;
+            v_nslots[i] = items[i].nslots; v_slice[i] = items[i].slice; v_sib0[i] = items[i].sib0;
+            v_nsib[i] = items[i].nsib; v_exfirst[i] = items[i].extra_first;
+        }
+        PFCHK(upload_vec(c, c->it_cluster, v_cluster));
+        PFCHK(upload_vec(c, c->it_part, v_part));
+        PFCHK(upload_vec(c, c->it_nparts, v_nparts));
+        PFCHK(upload_vec(c, c->it_nslots, v_nslots));
+        PFCHK(upload_vec(c, c->it_slice, v_slice));
+        PFCHK(upload_vec(c, c->it_sib0, v_sib0));
+        PFCHK(upload_vec(c, c->it_nsib, v_nsib));
+        PFCHK(upload_vec(c, c->it_extra_first, v_exfirst));
+        PFCHK(upload_vec(c, c->sub_cluster, sub_cluster));
+        PFCHK(upload_vec(c, c->sub_item0, sub_item0));
+        PFCHK(upload_vec(c, c->sub_nitems, sub_nitems));
+        PFCHK(c->it_count.ensure(std::max<size_t>(NI, 1) * 4));
+        PFCHK(c->it_unique.ensure(std::max<size_t>(NI, 1) * 4));
+        PFCHK(c->it_kept.ensure(std::max<size_t>(NI, 1) * 4));
+        // work lists per sub-batch, concatenated
+        std::vector<uint32_t> scan_off(subs.size() + 1, 0), extra_off(subs.size() + 1, 0);
+        for (size_t s = 0; s < subs.size(); s++) {
+            for (uint32_t i = subs[s].item0; i < subs[s].item0 + subs[s].nitems; i++)
+                (items[i].is_extra ? w_extra : w_scan).push_back(i);
+            scan_off[s + 1] = (uint32_t)w_scan.size();
+            extra_off[s + 1] = (uint32_t)w_extra.size();
+        }
+        PFCHK(upload_vec(c, c->work_scan, w_scan));
+        PFCHK(upload_vec(c, c->work_extra, w_extra));
+        // the cursor's next free index restarts at this arena's base
+        {
+            uint64_t cur0 = arena_base;
+            HIPCHK(hipMemcpyAsync(c->cursor.p, &cur0, 8, hipMemcpyHostToDevice, c->stream));
+        }
+
+        for (size_t s = 0; s < subs.size(); s++) {
+            const Sub& sb = subs[s];
+            const uint32_t n_scan = scan_off[s + 1] - scan_off[s], n_extra_items = extra_off[s + 1] - extra_off[s];
+            if (n_extra_items) {
+                pf::ExtraParams ep{};
+                ep.extra_ord = d.extra_ord; ep.extra_bits = d.extra_bits;
+                ep.item_first = c->it_extra_first.as<uint32_t>(); ep.item_nslots = c->it_nslots.as<uint32_t>();
+                ep.item_scratch = c->it_slice.as<uint32_t>();
+                ep.tab_key = c->tab_key.as<uint64_t>(); ep.tab_ord = c->tab_ord.as<uint32_t>();
+                ep.chunkbits = c->chunkbits.as<uint32_t>(); ep.chunkmask = c->chunkmask.as<uint32_t>();
+                ep.item_count = c->it_count.as<uint32_t>();
+                ep.work = c->work_extra.as<uint32_t>() + extra_off[s];
+                ep.W = W; ep.NS = NS; ep.KW = KW;
+                PFCHK(mark_begin(c, 2));
+                hipLaunchKernelGGL(pf::extra_fill_kernel, dim3(n_extra_items), dim3(256), 0, c->stream, ep);
+                HIPCHK(hipGetLastError());
+                PFCHK(mark_end(c));
+            }
+            if (n_scan) {
+                pf::ScanParams sp{};
+                sp.packed = d.packed; sp.seg_word_off = d.seg_word_off; sp.seg_len = d.seg_len;
+                sp.seg_sample = d.seg_sample; sp.seg_ord_base = d.seg_ord_base;
+                sp.cluster_seg_off = d.cluster_seg_off; sp.cluster_nstrains = d.cluster_nstrains;
+                sp.seg_strand_off = c->n_strand_words ? d.seg_strand_off : nullptr;
+                sp.strand_bits = c->n_strand_words ? c->strand_bits.as<uint64_t>() : nullptr;
+                sp.item_cluster = c->it_cluster.as<uint32_t>(); sp.item_part = c->it_part.as<uint32_t>();
+                sp.item_nparts = c->it_nparts.as<uint32_t>(); sp.item_nslots = c->it_nslots.as<uint32_t>();
+                sp.item_scratch = c->it_slice.as<uint32_t>();
+                sp.tab_key = c->tab_key.as<uint64_t>(); sp.tab_ord = c->tab_ord.as<uint32_t>();
+                sp.chunkbits = c->chunkbits.as<uint32_t>(); sp.chunkmask = c->chunkmask.as<uint32_t>();
+                sp.item_count = c->it_count.as<uint32_t>(); sp.cluster_overflow = c->cl_overflow.as<uint32_t>();
+                sp.work = c->work_scan.as<uint32_t>() + scan_off[s];
+                sp.k = c->o.klength; sp.W = W; sp.NS = NS;
+                PFCHK(mark_begin(c, 0));
+                PFCHK(launch_scan(c, sp, n_scan));
+                PFCHK(mark_end(c));
+                c->timing.scan_launches++;
+            }
+            pf::RowsParams rp{};
+            rp.item_cluster = c->it_cluster.as<uint32_t>(); rp.item_nslots = c->it_nslots.as<uint32_t>();
+            rp.item_scratch = c->it_slice.as<uint32_t>(); rp.item_count = c->it_count.as<uint32_t>();
+            rp.cluster_overflow = c->cl_overflow.as<uint32_t>();
+            rp.cluster_nstrains = d.cluster_nstrains; rp.cluster_npresab = d.cluster_npresab;
+            rp.cluster_presab = d.cluster_presab; rp.cluster_ordinal = d.cluster_ordinal;
+            rp.maf_lo = c->d_maf_lo.as<uint32_t>(); rp.maf_hi = c->d_maf_hi.as<uint32_t>();
+            rp.tab_ord = c->tab_ord.as<uint32_t>(); rp.chunkbits = c->chunkbits.as<uint32_t>();
+            rp.chunkmask = c->chunkmask.as<uint32_t>();
+            rp.slot_hash = c->slot_hash.as<uint4>(); rp.sorted_pair = c->sorted_pair.as<uint64_t>();
+            rp.kept_prefix = c->kept_prefix.as<uint32_t>();
+            rp.item_unique = c->it_unique.as<uint32_t>(); rp.item_kept = c->it_kept.as<uint32_t>();
+            rp.item0 = sb.item0; rp.W = W; rp.NS = NS;
+            rp.consider_missing = c->o.consider_missing; rp.patfilt = c->o.patfilt; rp.multiple_files = c->o.multiple_files;
+            PFCHK(mark_begin(c, 1));
+            hipLaunchKernelGGL(pf::rows_kernel, dim3(sb.nitems), dim3(pf::ROWS_THREADS), 0, c->stream, rp);
+            HIPCHK(hipGetLastError());
+            PFCHK(mark_end(c));
+
+            pf::BaseParams bp{};
+            bp.sub_cluster = c->sub_cluster.as<uint32_t>() + sb.cl0;
+            bp.cluster_item0 = c->sub_item0.as<uint32_t>() + sb.cl0;
+            bp.cluster_nitems = c->sub_nitems.as<uint32_t>() + sb.cl0;
+            bp.item_kept = c->it_kept.as<uint32_t>(); bp.item_unique = c->it_unique.as<uint32_t>();
+            bp.cluster_overflow = c->cl_overflow.as<uint32_t>();
+            bp.cluster_kmer_off = c->cl_kmer_off.as<uint64_t>(); bp.cluster_kmer_cnt = c->cl_kmer_cnt.as<uint32_t>();
+            bp.cluster_unique = c->cl_unique.as<uint32_t>(); bp.cursor = c->cursor.as<uint64_t>();
+            bp.n = sb.ncl;
+            PFCHK(mark_begin(c, 2));
+            hipLaunchKernelGGL(pf::cluster_base_kernel, dim3(1), dim3(1024), 0, c->stream, bp);
+            HIPCHK(hipGetLastError());
+
+            pf::EmitParams em{};
+            em.item_cluster = c->it_cluster.as<uint32_t>(); em.item_scratch = c->it_slice.as<uint32_t>();
+            em.item_unique = c->it_unique.as<uint32_t>(); em.item_sib0 = c->it_sib0.as<uint32_t>();
+            em.item_nsib = c->it_nsib.as<uint32_t>(); em.cluster_overflow = c->cl_overflow.as<uint32_t>();
+            em.cluster_nstrains = d.cluster_nstrains; em.cluster_npresab = d.cluster_npresab;
+            em.cluster_presab = d.cluster_presab; em.cluster_ordinal = d.cluster_ordinal;
+            em.cluster_kmer_off = c->cl_kmer_off.as<uint64_t>();
+            em.tab_key = c->tab_key.as<uint64_t>(); em.slot_hash = c->slot_hash.as<uint4>();
+            em.sorted_pair = c->sorted_pair.as<uint64_t>(); em.kept_prefix = c->kept_prefix.as<uint32_t>();
+            em.out_key = ar->key.as<uint64_t>(); em.out_pid = ar->pid.as<uint32_t>(); em.out_first = ar->first.as<uint64_t>();
+            em.cluster_pattern = c->cl_pattern.as<uint32_t>(); em.cluster_first = c->cl_first.as<uint64_t>();
+            em.pt = c->pt; em.out_base = ar->base; em.out_cap = ar->cap;
+            em.item0 = sb.item0; em.W = W; em.NS = NS; em.KW = KW;
+            em.consider_missing = c->o.consider_missing; em.multiple_files = c->o.multiple_files;
+            hipLaunchKernelGGL(pf::emit_kernel, dim3(sb.nitems), dim3(256), 0, c->stream, em);
+            HIPCHK(hipGetLastError());
+
+            pf::PatRowsParams pr{};
+            pr.item_cluster = em.item_cluster; pr.item_scratch = em.item_scratch; pr.item_unique = em.item_unique;
+            pr.item_sib0 = em.item_sib0; pr.item_nsib = em.item_nsib; pr.cluster_overflow = em.cluster_overflow;
+            pr.cluster_nstrains = d.cluster_nstrains; pr.cluster_npresab = d.cluster_npresab;
+            pr.cluster_presab = d.cluster_presab; pr.cluster_kmer_off = em.cluster_kmer_off;
+            pr.sorted_pair = em.sorted_pair; pr.kept_prefix = em.kept_prefix;
+            pr.chunkbits = c->chunkbits.as<uint32_t>(); pr.chunkmask = c->chunkmask.as<uint32_t>();
+            pr.out_pid = em.out_pid; pr.out_first = em.out_first;
+            pr.cluster_pattern = em.cluster_pattern; pr.cluster_first = em.cluster_first;
+            pr.pat_first_seen = c->pt.first_seen;
+            pr.pat_bits = c->pat_bits.as<uint32_t>();
+            pr.pat_nan = c->o.consider_missing ? c->pat_nan.as<uint32_t>() : nullptr;
+            pr.pat_n = c->pat_n.as<uint32_t>();
+            pr.out_base = ar->base; pr.out_cap = ar->cap; pr.pool = c->pt.pool;
+            pr.item0 = sb.item0; pr.W = W; pr.NS = NS; pr.consider_missing = c->o.consider_missing;
+            hipLaunchKernelGGL(pf::pattern_rows_kernel, dim3(sb.nitems), dim3(256), 0, c->stream, pr);
+            HIPCHK(hipGetLastError());
+            PFCHK(mark_end(c));
+        }
+        c->timing.n_items += (uint32_t)NI;
+        for (uint32_t ci : todo) c->timing.scan_packed_bytes += words[ci] * 8 * nparts[ci];
+
+        // ---- who overflowed?
+        std::vector<uint32_t> ovf(C);
+        uint64_t cur3[3];
+        HIPCHK(hipMemcpyAsync(ovf.data(), c->cl_overflow.p, (size_t)C * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(cur3, c->cursor.p, 24, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        ar->used = cur3[0] - ar->base;
+        if (ar->used > ar->cap) return fail(PF_ERR_CAPACITY, "output arena overflow (%llu > %llu)",
+                                            (unsigned long long)ar->used, (unsigned long long)ar->cap);
+        arena_base += ar->cap;
+        std::vector<uint32_t> next;
+        for (uint32_t ci : todo)
+            if (ovf[ci]) {
+                next.push_back(ci);
+                nparts[ci] = nparts[ci] * 4;
+                if (nparts[ci] > 65536) return fail(PF_ERR_CAPACITY, "cluster %u does not fit 65536 key partitions", ci);
+            }
+        if (!next.empty()) {
+            c->timing.n_retried += (uint32_t)next.size();
+            HIPCHK(hipMemsetAsync(c->cl_overflow.p, 0, C1 * 4, c->stream));
+        }
+        todo.swap(next);
+        pass++;
+    }
+
+    // ---- MD5 of the patterns this batch created
+    uint32_t cnt2[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(cnt2, c->pt_counters.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (cnt2[1] || cnt2[0] > c->pt.pool)
+        return fail(PF_ERR_CAPACITY, "pattern table full (%u patterns, pool %u): raise pattern_capacity", cnt2[0], c->pt.pool);
+    const uint32_t pid1 = cnt2[0];
+    if (pid1 > c->pid0) {
+        pf::Md5Params mp{};
+        mp.pat_bits = c->pat_bits.as<uint32_t>();
+        mp.pat_nan = c->o.consider_missing ? c->pat_nan.as<uint32_t>() : nullptr;
+        mp.pat_n = c->pat_n.as<uint32_t>(); mp.pat_md5 = c->pat_md5.as<uint8_t>();
+        mp.pid0 = c->pid0; mp.pid1 = pid1; mp.W = W;
+        PFCHK(mark_begin(c, 2));
+        hipLaunchKernelGGL(pf::md5_kernel, dim3((pid1 - c->pid0 + 255) / 256), dim3(256), 0, c->stream, mp);
+        HIPCHK(hipGetLastError());
+        PFCHK(mark_end(c));
+    }
+    c->n_patterns = pid1;
+    uint64_t cur3[3];
+    HIPCHK(hipMemcpyAsync(cur3, c->cursor.p, 24, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipEventRecord(c->ev_t1, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+
+    // ---- timing
+    HIPCHK(hipEventElapsedTime(&c->timing.total_ms, c->ev_t0, c->ev_t1));
+    for (auto& e : c->events) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
+        if (e.cat == 0) c->timing.scan_ms += ms;
+        else if (e.cat == 1) c->timing.rows_ms += ms;
+        else c->timing.emit_ms += ms;
+    }
+
+    c->n_clusters = C;
+    c->counters = pf_result{};
+    c->counters.n_instances = total_inst;
+    c->counters.n_unique = cur3[1];
+    c->counters.n_kept = cur3[2];
+    c->counters.n_new_patterns = pid1 - c->pid0;
+    c->counters.n_patterns = pid1;
+    c->counters.W = W;
+    c->counters.key_words = KW;
+    c->have_batch = true;
+    if (counters) *counters = c->counters;
+    return PF_OK;
+}
+
+int pf_get_timing(pf_ctx* c, pf_timing* t) {
+    if (!c || !t) return fail(PF_ERR_ARG, "null argument");
+    *t = c->timing;
+    return PF_OK;
+}
+
+int pf_fetch(pf_ctx* c, pf_result* res) {
+    if (!c || !res) return fail(PF_ERR_ARG, "null argument");
+    if (!c->have_batch) return fail(PF_ERR_STATE, "pf_fetch without a successful pf_submit");
+    HIPCHK(hipSetDevice(c->device));
+    const uint32_t C = c->n_clusters, W = c->W, KW = (uint32_t)c->KW;
+    c->h_kmer_off.resize(C); c->h_kmer_cnt.resize(C); c->h_cl_pattern.resize(C); c->h_cl_unique.resize(C);
+    if (C) {
+        HIPCHK(hipMemcpy(c->h_kmer_off.data(), c->cl_kmer_off.p, (size_t)C * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(c->h_kmer_cnt.data(), c->cl_kmer_cnt.p, (size_t)C * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(c->h_cl_pattern.data(), c->cl_pattern.p, (size_t)C * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(c->h_cl_unique.data(), c->cl_unique.p, (size_t)C * 4, hipMemcpyDeviceToHost));
+    }
+    // concatenate the used prefixes of the arenas; remap cluster offsets
+    uint64_t total = 0;
+    std::vector<uint64_t> host_base(c->arenas.size(), 0);
+    for (size_t a = 0; a < c->arenas.size(); a++) { host_base[a] = total; total += c->arenas[a]->used; }
+    c->h_kmer_key.resize((size_t)total * KW);
+    c->h_kmer_pid.resize((size_t)total);
+    for (size_t a = 0; a < c->arenas.size(); a++) {
+        Arena* ar = c->arenas[a];
+        if (!ar->used) continue;
+        HIPCHK(hipMemcpy(c->h_kmer_key.data() + host_base[a] * KW, ar->key.p, (size_t)ar->used * 8 * KW, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(c->h_kmer_pid.data() + host_base[a], ar->pid.p, (size_t)ar->used * 4, hipMemcpyDeviceToHost));
+    }
+    for (uint32_t i = 0; i < C; i++) {
+        const uint32_t a = c->cluster_arena[i];
+        if (c->h_kmer_cnt[i]) c->h_kmer_off[i] = c->h_kmer_off[i] - c->arenas[a]->base + host_base[a];
+        else c->h_kmer_off[i] = 0;
+    }
+    // pattern pool: extend the host mirror by the patterns of this batch
+    const uint32_t p0 = c->pid0, p1 = c->n_patterns;
+    c->h_pat_bits.resize((size_t)p1 * W); c->h_pat_n.resize(p1); c->h_pat_md5.resize((size_t)p1 * 16);
+    c->h_first_seen.resize(p1);
+    if (c->o.consider_missing) c->h_pat_nan.resize((size_t)p1 * W);
+    if (p1 > p0) {
+        const size_t n = p1 - p0;
+        HIPCHK(hipMemcpy(c->h_pat_bits.data() + (size_t)p0 * W, c->pat_bits.as<uint32_t>() + (size_t)p0 * W, n * W * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(c->h_pat_n.data() + p0, c->pat_n.as<uint32_t>() + p0, n * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(c->h_pat_md5.data() + (size_t)p0 * 16, c->pat_md5.as<uint8_t>() + (size_t)p0 * 16, n * 16, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(c->h_first_seen.data() + p0, c->pt.first_seen + p0, n * 8, hipMemcpyDeviceToHost));
+        if (c->o.consider_missing)
+            HIPCHK(hipMemcpy(c->h_pat_nan.data() + (size_t)p0 * W, c->pat_nan.as<uint32_t>() + (size_t)p0 * W, n * W * 4, hipMemcpyDeviceToHost));
+    }
+    c->h_new_pid.resize(p1 - p0);
+    std::iota(c->h_new_pid.begin(), c->h_new_pid.end(), p0);
+    std::sort(c->h_new_pid.begin(), c->h_new_pid.end(),
+              [&](uint32_t x, uint32_t y) { return c->h_first_seen[x] < c->h_first_seen[y]; });
+    c->h_strand.resize((size_t)c->n_strand_words);
+    if (c->n_strand_words)
+        HIPCHK(hipMemcpy(c->h_strand.data(), c->strand_bits.p, (size_t)c->n_strand_words * 8, hipMemcpyDeviceToHost));
+
+    *res = c->counters;
+    res->cluster_kmer_off = c->h_kmer_off.data();
+    res->cluster_kmer_cnt = c->h_kmer_cnt.data();
+    res->cluster_pattern = c->h_cl_pattern.data();
+    res->cluster_unique = c->h_cl_unique.data();
+    res->kmer_key = c->h_kmer_key.data();
+    res->kmer_pattern = c->h_kmer_pid.data();
+    res->new_pattern_id = c->h_new_pid.data();
+    res->n_patterns = p1;
+    res->pattern_md5 = c->h_pat_md5.data();
+    res->pattern_bits = c->h_pat_bits.data();
+    res->pattern_nan = c->o.consider_missing ? c->h_pat_nan.data() : nullptr;
+    res->pattern_n = c->h_pat_n.data();
+    res->pattern_first_seen = c->h_first_seen.data();
+    res->strand_bits = c->n_strand_words ? c->h_strand.data() : nullptr;
+    return PF_OK;
+}
+
+int pf_export_patterns(pf_ctx* c, uint64_t* n, const uint8_t** md5, const uint64_t** first_seen) {
+    if (!c || !n || !md5 || !first_seen) return fail(PF_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    const uint32_t p1 = c->n_patterns;
+    c->h_pat_md5.resize((size_t)p1 * 16);
+    c->h_first_seen.resize(p1);
+    if (p1) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipMemcpy(c->h_pat_md5.data(), c->pat_md5.p, (size_t)p1 * 16, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(c->h_first_seen.data(), c->pt.first_seen, (size_t)p1 * 8, hipMemcpyDeviceToHost));
+    }
+    *n = p1;
+    *md5 = c->h_pat_md5.data();
+    *first_seen = c->h_first_seen.data();
+    return PF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,940 @@
+// pf_kernels.h -- HIP kernels of the panfeed hot path for gfx950 (MI355X, wave64, 160 KiB LDS/CU).
+//
+// Pipeline per sub-batch of gene clusters (DESIGN.md has the full picture):
+//   kmer_scan_kernel   one 1024-thread workgroup per (cluster, key partition): slides the k window over
+//                      the 2-bit packed segments, canonicalises (panfeed.py:65-75), and groups k-mers in
+//                      an LDS hash table {key, first-occurrence ordinal, 32-sample presence word};
+//                      samples are swept in chunks of 32 columns, each chunk's words flushed coalesced.
+//   rows_kernel        per item: popcount / MAF + same-as-cluster filter (panfeed.py:190-204), 128-bit row
+//                      hash, LDS bitonic sort by first-occurrence ordinal (dict insertion order, :189).
+//   cluster_base_kernel  output offsets per cluster.
+//   emit_kernel        per item: merged rank over the cluster's partitions, run-global pattern table
+//                      (first-seen rule, panfeed.py:179-187, 210-223), k-mer -> pattern id output.
+//   pattern_rows_kernel  representative rows of new patterns -> pattern pool.
+//   md5_kernel         MD5 of the int64 / float64 image of each new pattern (panfeed.py:175, 206).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pf {
+
+constexpr uint32_t SCAN_THREADS = 1024;
+constexpr uint32_t SCAN_WAVES = SCAN_THREADS / 64;
+constexpr uint32_t LDS_BYTES = 163840;           // 160 KiB, whole CU
+constexpr uint32_t MISC_WORDS = 512;             // counters + chunk offsets (<= 257 chunks + 1)
+constexpr uint32_t MAX_CHUNKS = 256;             // 32 samples each -> max_strains <= 8192
+constexpr uint32_t INSERT_SLACK = 2176;          // > 2*SCAN_THREADS: inserts that can land after the limit trips
+                                                 // (every wave re-checks the flag before each 64-window unit; a
+                                                 // unit inserts at most 2 keys per lane in non-canonical mode)
+constexpr uint64_t EMPTY64 = ~0ull;
+constexpr uint32_t NO_ORD = 0xFFFFFFFFu;
+constexpr uint64_t KEY_EXTRA_FLAG = 1ull << 63;  // tab_key of a slow-path row
+
+__host__ __device__ constexpr uint32_t nslots_max(int kw) {
+    // keys (8*kw) + ord (4) + bits (4) per slot, MISC_WORDS*4 bytes aside, multiple of 64
+    return ((LDS_BYTES - MISC_WORDS * 4) / (8u * kw + 8u)) / 64u * 64u;
+}
+__host__ __device__ inline uint32_t insert_limit(uint32_t ns) {
+    uint32_t a = ns - INSERT_SLACK, b = (uint32_t)(((uint64_t)ns * 4) / 5);
+    return a < b ? a : b;
+}
+
+template <int KW>
+struct Key {
+    uint64_t w[KW];
+};
+
+// ---------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+__device__ __forceinline__ uint32_t mix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    return h;
+}
+template <int KW>
+__device__ __forceinline__ uint32_t key_hash(const Key<KW>& k) {
+    uint32_t h = (uint32_t)k.w[0] * 0x9E3779B1u ^ (uint32_t)(k.w[0] >> 32) * 0x85EBCA77u;
+    if (KW == 2) {
+        h = rotl32(h, 13) ^ ((uint32_t)k.w[1] * 0xC2B2AE3Du);
+        h = rotl32(h, 13) ^ ((uint32_t)(k.w[1] >> 32) * 0x27D4EB2Fu);
+    }
+    return mix32(h);
+}
+// swap the two bits of every 2-bit group
+__device__ __forceinline__ uint64_t pairswap(uint64_t x) {
+    return ((x & 0x5555555555555555ull) << 1) | ((x >> 1) & 0x5555555555555555ull);
+}
+// reverse the order of the 32 two-bit groups of x
+__device__ __forceinline__ uint64_t rev_groups(uint64_t x) { return pairswap(__brevll(x)); }
+
+// murmur3_x86_128 block / finalisation (Appleby, public domain algorithm) on 32-bit words
+struct H128 {
+    uint32_t h1, h2, h3, h4;
+};
+__device__ __forceinline__ void mm3_block(H128& s, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t k4) {
+    const uint32_t c1 = 0x239b961b, c2 = 0xab0e9789, c3 = 0x38b34ae5, c4 = 0xa1e38b93;
+    k1 *= c1; k1 = rotl32(k1, 15); k1 *= c2; s.h1 ^= k1;
+    s.h1 = rotl32(s.h1, 19); s.h1 += s.h2; s.h1 = s.h1 * 5 + 0x561ccd1b;
+    k2 *= c2; k2 = rotl32(k2, 16); k2 *= c3; s.h2 ^= k2;
+    s.h2 = rotl32(s.h2, 17); s.h2 += s.h3; s.h2 = s.h2 * 5 + 0x0bcaa747;
+    k3 *= c3; k3 = rotl32(k3, 17); k3 *= c4; s.h3 ^= k3;
+    s.h3 = rotl32(s.h3, 15); s.h3 += s.h4; s.h3 = s.h3 * 5 + 0x96cd1c35;
+    k4 *= c4; k4 = rotl32(k4, 18); k4 *= c1; s.h4 ^= k4;
+    s.h4 = rotl32(s.h4, 13); s.h4 += s.h1; s.h4 = s.h4 * 5 + 0x32ac3b17;
+}
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85ebca6b; h ^= h >> 13; h *= 0xc2b2ae35; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ void mm3_final(H128& s, uint32_t len) {
+    s.h1 ^= len; s.h2 ^= len; s.h3 ^= len; s.h4 ^= len;
+    s.h1 += s.h2; s.h1 += s.h3; s.h1 += s.h4; s.h2 += s.h1; s.h3 += s.h1; s.h4 += s.h1;
+    s.h1 = fmix32(s.h1); s.h2 = fmix32(s.h2); s.h3 = fmix32(s.h3); s.h4 = fmix32(s.h4);
+    s.h1 += s.h2; s.h1 += s.h3; s.h1 += s.h4; s.h2 += s.h1; s.h3 += s.h1; s.h4 += s.h1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kmer_scan_kernel
+// ---------------------------------------------------------------------------------------------
+struct ScanParams {
+    const uint64_t* packed;
+    const uint64_t* seg_word_off;
+    const uint32_t* seg_len;
+    const uint32_t* seg_sample;
+    const uint32_t* seg_ord_base;
+    const uint32_t* cluster_seg_off;
+    const uint32_t* cluster_nstrains;
+    const uint32_t* seg_strand_off;   // may be null
+    uint64_t* strand_bits;            // may be null
+    // per item (item = work[blockIdx.x])
+    const uint32_t* item_cluster;     // batch-local cluster index
+    const uint32_t* item_part;
+    const uint32_t* item_nparts;
+    const uint32_t* item_nslots;
+    const uint32_t* item_scratch;     // scratch slice of the item
+    // scratch, indexed by slice
+    uint64_t* tab_key;                // [slice][KW][NS]
+    uint32_t* tab_ord;                // [slice][NS]
+    uint32_t* chunkbits;              // [slice][W][NS]
+    uint32_t* chunkmask;              // [slice][8]  bit ch set: chunk ch was flushed
+    uint32_t* item_count;             // [item] unique keys in the item's table
+    uint32_t* cluster_overflow;       // [cluster] |= 1 when any partition overflowed
+    const uint32_t* work;             // [gridDim.x] item ids of this launch
+    uint32_t k;
+    uint32_t W;
+    uint32_t NS;                      // slots per scratch slice (= nslots_max(KW))
+};
+
+// lower bound of `v` in seg_sample[a..b)
+__device__ __forceinline__ uint32_t seg_lower_bound(const uint32_t* seg_sample, uint32_t a, uint32_t b, uint32_t v) {
+    while (a < b) {
+        uint32_t m = (a + b) >> 1;
+        if (seg_sample[m] < v) a = m + 1; else b = m;
+    }
+    return a;
+}
+
+// insert-or-find `key` in the LDS table, then fold (ordinal, sample bit) into the slot
+template <int KW>
+__device__ __forceinline__ void table_update(uint64_t* keys, uint32_t* ord, uint32_t* bits, uint32_t* misc,
+                                             uint32_t NS, uint32_t ns, uint32_t limit, bool active,
+                                             const Key<KW>& key, uint32_t home, uint32_t myord, uint32_t bit) {
+    uint32_t slot = home;
+    bool inserted = false;
+    while (active) {
+        if (KW == 1) {
+            uint64_t cur = __hip_atomic_load(&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (cur == EMPTY64) {
+                cur = atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)EMPTY64,
+                                (unsigned long long)key.w[0]);
+                if (cur == EMPTY64) { inserted = true; cur = key.w[0]; }
+            }
+            if (cur == key.w[0]) break;
+            slot = slot + 1 == ns ? 0 : slot + 1;
+        } else {
+            // word 0 is claimed by CAS, word 1 published right after; a reader that sees word 0 match but
+            // word 1 still EMPTY re-reads the same slot on its next iteration.
+            uint64_t cur = __hip_atomic_load(&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            bool claimed = false;
+            if (cur == EMPTY64) {
+                cur = atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)EMPTY64,
+                                (unsigned long long)key.w[0]);
+                if (cur == EMPTY64) {
+                    __hip_atomic_store(&keys[NS + slot], key.w[KW - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    inserted = true; claimed = true;
+                }
+            }
+            if (claimed) break;
+            if (cur == key.w[0]) {
+                uint64_t c1 = __hip_atomic_load(&keys[NS + slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (c1 == key.w[KW - 1]) break;
+                if (c1 == EMPTY64) continue;   // not published yet: look again
+            }
+            slot = slot + 1 == ns ? 0 : slot + 1;
+        }
+    }
+    if (active) {
+        atomicMin(&ord[slot], myord);
+        atomicOr(&bits[slot], bit);
+        if (inserted) {
+            uint32_t c = atomicAdd(&misc[0], 1u);
+            if (c + 1 > limit) misc[1] = 1;   // overflow: the cluster is re-run with more partitions
+        }
+    }
+}
+
+template <int KW, bool CANON>
+__global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t NS = p.NS;
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);          // [KW][NS]
+    uint32_t* ord = reinterpret_cast<uint32_t*>(keys + (size_t)KW * NS);
+    uint32_t* bits = ord + NS;
+    uint32_t* misc = bits + NS;                                   // [0] count [1] overflow [2..] chunk offsets
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t item = p.work[blockIdx.x];
+    const uint32_t c = p.item_cluster[item];
+    const uint32_t part = p.item_part[item], nparts = p.item_nparts[item];
+    const uint32_t ns = p.item_nslots[item];
+    const uint32_t slice = p.item_scratch[item];
+    const uint32_t seg0 = p.cluster_seg_off[c], seg1 = p.cluster_seg_off[c + 1];
+    const uint32_t nstr = p.cluster_nstrains[c];
+    const uint32_t nchunks = (nstr + 31) >> 5;
+    const uint32_t k = p.k;
+    const uint32_t limit = insert_limit(ns);
+
+    for (uint32_t i = tid; i < ns; i += SCAN_THREADS) {
+        keys[i] = EMPTY64;
+        if (KW == 2) keys[NS + i] = EMPTY64;
+        ord[i] = NO_ORD;
+        bits[i] = 0;
+    }
+    if (tid < 2) misc[tid] = 0;
+    for (uint32_t ch = tid; ch <= nchunks; ch += SCAN_THREADS)
+        misc[2 + ch] = seg_lower_bound(p.seg_sample, seg0, seg1, ch << 5);
+    __syncthreads();
+
+    uint32_t mask_word = 0;   // thread t < 8 accumulates chunkmask word t
+    bool overflow = false;
+
+    for (uint32_t ch = 0; ch < nchunks; ch++) {
+        const uint32_t a = misc[2 + ch], b = misc[3 + ch];
+        if (a == b) continue;                       // no segment in these 32 columns (uniform)
+        uint32_t unit_prefix = 0;
+        for (uint32_t s = a; s < b; s++) {
+            const uint32_t len = p.seg_len[s];
+            const uint32_t ninst = len >= k ? len - k + 1 : 0;
+            const uint32_t nunits = (ninst + 63) >> 6;
+            const uint32_t u0 = (wave + SCAN_WAVES - (unit_prefix & (SCAN_WAVES - 1))) & (SCAN_WAVES - 1);
+            unit_prefix += nunits;
+            if (u0 >= nunits) continue;
+            const uint64_t* wp = p.packed + p.seg_word_off[s];
+            const uint32_t bit = 1u << (p.seg_sample[s] & 31);
+            const uint32_t ordb = p.seg_ord_base[s];
+            const uint32_t soff = (CANON && p.seg_strand_off) ? p.seg_strand_off[s] : 0xFFFFFFFFu;
+            for (uint32_t u = u0; u < nunits; u += SCAN_WAVES) {
+                // table past its limit: stop inserting (the cluster is re-run with more key partitions)
+                if (__hip_atomic_load(&misc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                const uint32_t pos = (u << 6) + lane;
+                const bool valid = pos < ninst;
+                const uint32_t sh = (lane & 31) << 1;
+                const uint64_t* q = wp + 2 * (size_t)u + (lane >> 5);
+                Key<KW> fwd, rc;
+                if (KW == 1) {
+                    const uint64_t w0 = q[0], w1 = q[1];
+                    const uint64_t x = (w0 << sh) | ((w1 >> 1) >> (63 - sh));
+                    fwd.w[0] = x >> (64 - 2 * k);
+                    rc.w[0] = rev_groups(~x) & ((1ull << (2 * k)) - 1);   // low 2k bits of the reversed complement
+                } else {
+                    const uint64_t w0 = q[0], w1 = q[1], w2 = q[2];
+                    const uint64_t x0 = (w0 << sh) | ((w1 >> 1) >> (63 - sh));
+                    const uint64_t x1 = (w1 << sh) | ((w2 >> 1) >> (63 - sh));
+                    // V = top 2k bits of (x0:x1), right aligned in 128 bits, 32 <= k <= 63
+                    const uint32_t r = 128 - 2 * k;                       // 2..64
+                    uint64_t vhi, vlo;
+                    if (r == 64) { vhi = 0; vlo = x0; }
+                    else { vhi = x0 >> r; vlo = (x0 << (64 - r)) | (x1 >> r); }
+                    // reverse complement of the 128-bit window, then keep its low 2k bits
+                    const uint64_t r0 = rev_groups(~x1), r1 = rev_groups(~x0);   // (r0:r1) = reversed (x0:x1)
+                    // the window's bases sit in the TOP 2k bits of (x0:x1) -> in the LOW 2k bits of (r0:r1)
+                    uint64_t chi = r0, clo = r1;
+                    const uint32_t kb = 2 * k;                             // 64..126
+                    chi = kb == 64 ? 0 : (chi & ((1ull << (kb - 64)) - 1));
+                    // split 126-bit values into two 63-bit words
+                    fwd.w[0] = (vhi << 1) | (vlo >> 63); fwd.w[1] = vlo & 0x7FFFFFFFFFFFFFFFull;
+                    rc.w[0] = (chi << 1) | (clo >> 63);  rc.w[1] = clo & 0x7FFFFFFFFFFFFFFFull;
+                }
+                bool rc_smaller;
+                if (KW == 1) rc_smaller = rc.w[0] < fwd.w[0];
+                else rc_smaller = rc.w[0] < fwd.w[0] || (rc.w[0] == fwd.w[0] && rc.w[1] < fwd.w[1]);
+
+                if (CANON) {
+                    if (soff != 0xFFFFFFFFu && part == 0) {
+                        const uint64_t bal = __ballot(valid && rc_smaller);
+                        if (lane == 0) p.strand_bits[(size_t)soff + u] = bal;
+                    }
+                    Key<KW> key = rc_smaller ? rc : fwd;          // specseq <= revspecseq -> forward (panfeed.py:70)
+                    const uint32_t h = key_hash<KW>(key);
+                    const bool mine = nparts == 1 || (((h & 0xFFFFu) * nparts) >> 16) == part;
+                    table_update<KW>(keys, ord, bits, misc, NS, ns, limit, valid && mine, key,
+                                     __umulhi(h, ns), ordb + pos, bit);
+                } else {
+                    // forward then reverse complement, both inserted (panfeed.py:82-88)
+                    uint32_t h = key_hash<KW>(fwd);
+                    bool mine = nparts == 1 || (((h & 0xFFFFu) * nparts) >> 16) == part;
+                    table_update<KW>(keys, ord, bits, misc, NS, ns, limit, valid && mine, fwd,
+                                     __umulhi(h, ns), 2 * (ordb + pos), bit);
+                    h = key_hash<KW>(rc);
+                    mine = nparts == 1 || (((h & 0xFFFFu) * nparts) >> 16) == part;
+                    table_update<KW>(keys, ord, bits, misc, NS, ns, limit, valid && mine, rc,
+                                     __umulhi(h, ns), 2 * (ordb + pos) + 1, bit);
+                }
+            }
+        }
+        __syncthreads();
+        if (misc[1]) { overflow = true; break; }   // uniform: written before the barrier or not at all
+        uint32_t* dst = p.chunkbits + ((size_t)slice * p.W + ch) * NS;
+        for (uint32_t i = tid; i < ns; i += SCAN_THREADS) {
+            dst[i] = bits[i];
+            bits[i] = 0;
+        }
+        if (tid == (ch >> 5)) mask_word |= 1u << (ch & 31);
+        __syncthreads();
+    }
+
+    if (overflow) {
+        if (tid == 0) { atomicOr(&p.cluster_overflow[c], 1u); p.item_count[item] = 0; }
+        return;
+    }
+    for (uint32_t i = tid; i < ns; i += SCAN_THREADS) {
+        p.tab_key[((size_t)slice * KW) * NS + i] = keys[i];
+        if (KW == 2) p.tab_key[((size_t)slice * KW + 1) * NS + i] = keys[NS + i];
+        p.tab_ord[(size_t)slice * NS + i] = ord[i];
+    }
+    if (tid < 8) p.chunkmask[slice * 8 + tid] = mask_word;
+    if (tid == 0) {
+        p.item_count[item] = misc[0];
+        if (misc[1]) atomicOr(&p.cluster_overflow[c], 1u);   // tripped inside the last chunk
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// slow-path rows -> a prebuilt table in an item's scratch slice (same layout the scan kernel leaves)
+// ---------------------------------------------------------------------------------------------
+struct ExtraParams {
+    const uint32_t* extra_ord;
+    const uint32_t* extra_bits;    // [n_extra][W]
+    const uint32_t* item_first;    // [n] first extra row of the item
+    const uint32_t* item_nslots;   // [n] rows of the item
+    const uint32_t* item_scratch;
+    uint64_t* tab_key; uint32_t* tab_ord; uint32_t* chunkbits; uint32_t* chunkmask; uint32_t* item_count;
+    const uint32_t* work;          // [gridDim.x] item ids of this launch
+    uint32_t W, NS, KW;
+};
+__global__ void extra_fill_kernel(ExtraParams p) {
+    const uint32_t item = p.work[blockIdx.x];
+    const uint32_t first = p.item_first[item], n = p.item_nslots[item], slice = p.item_scratch[item];
+    for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
+        p.tab_key[((size_t)slice * p.KW) * p.NS + e] = KEY_EXTRA_FLAG | (uint64_t)(first + e);
+        if (p.KW == 2) p.tab_key[((size_t)slice * p.KW + 1) * p.NS + e] = 0;
+        p.tab_ord[(size_t)slice * p.NS + e] = p.extra_ord[first + e];
+        for (uint32_t w = 0; w < p.W; w++)
+            p.chunkbits[((size_t)slice * p.W + w) * p.NS + e] = p.extra_bits[(size_t)(first + e) * p.W + w];
+    }
+    if (threadIdx.x < 8) p.chunkmask[slice * 8 + threadIdx.x] = 0xFFFFFFFFu;
+    if (threadIdx.x == 0) p.item_count[item] = n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// rows_kernel
+// ---------------------------------------------------------------------------------------------
+struct RowsParams {
+    const uint32_t* item_cluster; const uint32_t* item_nslots; const uint32_t* item_scratch;
+    const uint32_t* item_count;
+    const uint32_t* cluster_overflow;
+    const uint32_t* cluster_nstrains; const uint32_t* cluster_npresab; const uint32_t* cluster_presab;
+    const uint64_t* cluster_ordinal;
+    const uint32_t* maf_lo; const uint32_t* maf_hi;
+    const uint32_t* tab_ord; const uint32_t* chunkbits; const uint32_t* chunkmask;
+    uint4* slot_hash;        // [slice][NS]
+    uint64_t* sorted_pair;   // [slice][NS]  ord << 32 | slot, ascending
+    uint32_t* kept_prefix;   // [slice][NS+1] exclusive prefix of keep flags in sorted order
+    uint32_t* item_unique;   // [item]
+    uint32_t* item_kept;     // [item]
+    uint32_t item0, W, NS;
+    uint32_t consider_missing, patfilt, multiple_files;
+};
+
+constexpr uint32_t ROWS_THREADS = 1024;
+constexpr uint32_t SORT_MAX = 8192;   // >= insert_limit(nslots_max(1)) + slack, power of two
+
+// exclusive scan of one value per thread over the block; returns the exclusive prefix, *total = sum
+__device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t* wave_tot /*[17]*/, uint32_t* total) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    uint32_t x = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t y = __shfl_up(x, d);
+        if ((int)lane >= d) x += y;
+    }
+    if (lane == 63) wave_tot[wave] = x;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t w = 0; w < nw; w++) { uint32_t t = wave_tot[w]; wave_tot[w] = run; run += t; }
+        wave_tot[nw] = run;
+    }
+    __syncthreads();
+    uint32_t ex = wave_tot[wave] + x - v;
+    *total = wave_tot[nw];
+    __syncthreads();
+    return ex;
+}
+
+__global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
+    __shared__ uint64_t pairs[SORT_MAX];          // 64 KiB
+    __shared__ uint8_t keepf[16384];              // keep flag per slot (NS <= 10112)
+    __shared__ uint32_t cmask[8];
+    __shared__ uint32_t wave_tot[ROWS_THREADS / 64 + 1];
+    __shared__ uint32_t sh_cnt, sh_npres;
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t item = p.item0 + blockIdx.x;
+    const uint32_t c = p.item_cluster[item];
+    const uint32_t slice = p.item_scratch[item];
+    const uint32_t NS = p.NS, W = p.W;
+    if (p.cluster_overflow[c]) {
+        if (tid == 0) { p.item_unique[item] = 0; p.item_kept[item] = 0; }
+        return;
+    }
+    const uint32_t ns = p.item_nslots[item];
+    const uint32_t U = p.item_count[item];
+    const uint32_t nstr = p.cluster_nstrains[c], npres = p.cluster_npresab[c];
+    const uint32_t nchunks = (nstr + 31) >> 5;
+    const uint32_t* presab = p.cluster_presab + (size_t)c * W;
+
+    if (tid < 8) cmask[tid] = p.chunkmask[slice * 8 + tid];
+    if (tid == 0) {
+        sh_cnt = 0;
+        uint32_t np = 0;
+        for (uint32_t w = 0; w < W; w++) np += __popc(presab[w]);
+        sh_npres = np;
+    }
+    for (uint32_t i = tid; i < SORT_MAX; i += ROWS_THREADS) pairs[i] = EMPTY64;
+    __syncthreads();
+    const uint32_t npresent = sh_npres;
+    // denominators of panfeed.py:191 / :196
+    const uint32_t n_eff = p.consider_missing ? npresent : nstr;
+    const uint32_t lo = p.maf_lo[n_eff], hi = p.maf_hi[n_eff];
+    // tuple(vec) == tuple(clusterpresab) can only hold for equal lengths and a NaN-free vector (panfeed.py:203)
+    const bool same_possible = !p.patfilt && nstr == npres && (!p.consider_missing || npresent == nstr);
+    // the NaN mask of the float image is a function of the cluster: fold (n, kind, cluster-specific salt) in
+    const uint64_t ordinal = p.cluster_ordinal[c];
+
+    const uint32_t* ordp = p.tab_ord + (size_t)slice * NS;
+    const uint32_t* cb = p.chunkbits + (size_t)slice * W * NS;
+    for (uint32_t i = tid; i < ns; i += ROWS_THREADS) {
+        const uint32_t o = ordp[i];
+        if (o == NO_ORD) continue;
+        H128 s;
+        s.h1 = 0x9747b28cu ^ nstr; s.h2 = 0x1b873593u; s.h3 = 0xe6546b64u; s.h4 = 0x85ebca6bu;
+        if (p.multiple_files) { s.h2 ^= (uint32_t)ordinal; s.h3 ^= (uint32_t)(ordinal >> 32); }
+        uint32_t cnt = 0;
+        bool eq = true;
+        for (uint32_t ch = 0; ch < nchunks; ch += 4) {
+            uint32_t wv[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t cc = ch + j;
+                uint32_t w = 0;
+                if (cc < nchunks && ((cmask[cc >> 5] >> (cc & 31)) & 1)) w = cb[(size_t)cc * NS + i];
+                if (cc < nchunks) { cnt += __popc(w); eq = eq && (w == presab[cc]); }
+                wv[j] = w;
+            }
+            mm3_block(s, wv[0], wv[1], wv[2], wv[3]);
+        }
+        if (p.consider_missing) {
+            // NaN where clusterpresab == 0 (panfeed.py:19): the image depends on presab too
+            for (uint32_t ch = 0; ch < nchunks; ch += 4) {
+                uint32_t wv[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) wv[j] = (ch + j < nchunks) ? ~presab[ch + j] : 0;
+                mm3_block(s, wv[0], wv[1], wv[2], wv[3]);
+            }
+        }
+        mm3_final(s, nchunks * 4);
+        bool keep = cnt >= lo && cnt <= hi;                 // panfeed.py:197-200 (host-tabulated float64)
+        if (same_possible && eq) keep = false;              // panfeed.py:202-204
+        keepf[i] = keep ? 1 : 0;
+        p.slot_hash[(size_t)slice * NS + i] = make_uint4(s.h1, s.h2, s.h3, s.h4);
+        const uint32_t at = atomicAdd(&sh_cnt, 1u);
+        if (at < SORT_MAX) pairs[at] = ((uint64_t)o << 32) | i;
+    }
+    __syncthreads();
+    const uint32_t found = sh_cnt;   // == U unless the table overflowed (then the cluster is skipped anyway)
+    uint32_t M = 64;
+    while (M < found && M < SORT_MAX) M <<= 1;
+    // bitonic sort of pairs[0..M) ascending (EMPTY64 pads sort to the end)
+    for (uint32_t k2 = 2; k2 <= M; k2 <<= 1) {
+        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < (M >> 1); t += ROWS_THREADS) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const uint32_t l = i | j;
+                const bool up = (i & k2) == 0;
+                const uint64_t a = pairs[i], b = pairs[l];
+                if ((a > b) == up) { pairs[i] = b; pairs[l] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    const uint32_t n = found < SORT_MAX ? found : SORT_MAX;
+    // keep-prefix in sorted order: thread t owns positions [t*PER, t*PER+PER)
+    constexpr uint32_t PER = SORT_MAX / ROWS_THREADS;
+    uint32_t loc[PER];
+    uint32_t sum = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < PER; j++) {
+        const uint32_t r = tid * PER + j;
+        uint32_t kf = 0;
+        if (r < n) kf = keepf[(uint32_t)pairs[r]];
+        loc[j] = sum;
+        sum += kf;
+    }
+    uint32_t total;
+    const uint32_t base = block_exscan(sum, wave_tot, &total);
+    uint64_t* sp = p.sorted_pair + (size_t)slice * NS;
+    uint32_t* kp = p.kept_prefix + (size_t)slice * (NS + 1);
+#pragma unroll
+    for (uint32_t j = 0; j < PER; j++) {
+        const uint32_t r = tid * PER + j;
+        if (r < n) { sp[r] = pairs[r]; kp[r] = base + loc[j]; }
+    }
+    if (tid == 0) {
+        kp[n] = total;
+        p.item_unique[item] = n;
+        p.item_kept[item] = total;
+    }
+    (void)U;
+}
+
+// ---------------------------------------------------------------------------------------------
+// cluster_base_kernel: cluster_kmer_off / cluster_kmer_cnt for the clusters of one sub-batch
+// ---------------------------------------------------------------------------------------------
+struct BaseParams {
+    const uint32_t* sub_cluster;       // [n] batch-local cluster ids of this sub-batch
+    const uint32_t* cluster_item0;     // [n] first item (absolute) of the cluster in this pass
+    const uint32_t* cluster_nitems;    // [n]
+    const uint32_t* item_kept; const uint32_t* item_unique;
+    const uint32_t* cluster_overflow;
+    uint64_t* cluster_kmer_off; uint32_t* cluster_kmer_cnt; uint32_t* cluster_unique;
+    uint64_t* cursor;                  // [0] next free output index  [1] total unique  [2] total kept
+    uint32_t n;
+};
+__global__ __launch_bounds__(1024) void cluster_base_kernel(BaseParams p) {
+    __shared__ uint32_t wave_tot[17];
+    __shared__ uint64_t sh_base;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) sh_base = p.cursor[0];
+    __syncthreads();
+    uint64_t uniq_sum = 0;
+    for (uint32_t start = 0; start < p.n; start += 1024) {
+        const uint32_t i = start + tid;
+        uint32_t kept = 0, uniq = 0, c = 0;
+        bool live = false;
+        if (i < p.n) {
+            c = p.sub_cluster[i];
+            live = !p.cluster_overflow[c];
+            if (live) {
+                const uint32_t i0 = p.cluster_item0[i], ni = p.cluster_nitems[i];
+                for (uint32_t q = 0; q < ni; q++) { kept += p.item_kept[i0 + q]; uniq += p.item_unique[i0 + q]; }
+            }
+        }
+        uint32_t total;
+        const uint32_t ex = block_exscan(kept, wave_tot, &total);
+        if (i < p.n && live) {
+            p.cluster_kmer_off[c] = sh_base + ex;
+            p.cluster_kmer_cnt[c] = kept;
+            p.cluster_unique[c] = uniq;
+            uniq_sum += uniq;
+        }
+        __syncthreads();
+        if (tid == 0) sh_base += total;
+        __syncthreads();
+    }
+    // totals
+    for (int d = 32; d > 0; d >>= 1) uniq_sum += __shfl_down(uniq_sum, d);
+    if ((tid & 63) == 0 && uniq_sum) atomicAdd((unsigned long long*)&p.cursor[1], (unsigned long long)uniq_sum);
+    __syncthreads();
+    if (tid == 0) {
+        p.cursor[2] += sh_base - p.cursor[0];
+        p.cursor[0] = sh_base;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// run-global pattern table
+// ---------------------------------------------------------------------------------------------
+struct PatternTable {
+    uint64_t* lo;          // [cap] 64 bits of the row hash, EMPTY64 = free; claimed by CAS
+    uint64_t* val;         // [cap] (32 more hash bits) << 32 | pattern id, EMPTY64 until published
+    uint64_t* first_seen;  // [pool] by pattern id, atomicMin
+    uint32_t* counters;    // [0] patterns allocated  [1] error flag
+    uint64_t cap;          // power of two
+    uint32_t pool;         // pattern ids available
+};
+
+__device__ __forceinline__ uint32_t pattern_insert(const PatternTable& t, uint4 h, uint64_t first_seen) {
+    uint64_t lo = ((uint64_t)h.x << 32) | h.y;
+    if (lo == EMPTY64) lo = EMPTY64 - 1;
+    const uint32_t hi32 = h.z;
+    uint64_t slot = (((uint64_t)h.w << 32) | h.z) & (t.cap - 1);
+    uint32_t pid = 0xFFFFFFFFu;
+    for (uint64_t probes = 0; probes < t.cap; ) {
+        uint64_t cur = __hip_atomic_load(&t.lo[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == EMPTY64) {
+            cur = atomicCAS((unsigned long long*)&t.lo[slot], (unsigned long long)EMPTY64, (unsigned long long)lo);
+            if (cur == EMPTY64) {
+                const uint32_t id = atomicAdd(&t.counters[0], 1u);
+                if (id >= t.pool) { t.counters[1] = 1; pid = 0xFFFFFFFFu; }
+                else pid = id;
+                // publish even on failure so that readers never spin forever
+                __hip_atomic_store(&t.val[slot], ((uint64_t)hi32 << 32) | pid, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        if (cur == lo) {
+            const uint64_t v = __hip_atomic_load(&t.val[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v == EMPTY64) continue;                    // claimed, not yet published: look again
+            if ((uint32_t)(v >> 32) == hi32) { pid = (uint32_t)v; break; }
+        }
+        slot = (slot + 1) & (t.cap - 1);
+        probes++;
+    }
+    if (pid == 0xFFFFFFFFu) { t.counters[1] = 1; return pid; }
+    atomicMin((unsigned long long*)&t.first_seen[pid], (unsigned long long)first_seen);
+    return pid;
+}
+
+// ---------------------------------------------------------------------------------------------
+// emit_kernel
+// ---------------------------------------------------------------------------------------------
+struct EmitParams {
+    const uint32_t* item_cluster; const uint32_t* item_scratch; const uint32_t* item_unique;
+    const uint32_t* item_sib0;       // [item] first item of the same cluster (absolute)
+    const uint32_t* item_nsib;       // [item] items of that cluster
+    const uint32_t* cluster_overflow;
+    const uint32_t* cluster_nstrains; const uint32_t* cluster_npresab; const uint32_t* cluster_presab;
+    const uint64_t* cluster_ordinal;
+    const uint64_t* cluster_kmer_off;
+    const uint64_t* tab_key; const uint4* slot_hash; const uint64_t* sorted_pair; const uint32_t* kept_prefix;
+    uint64_t* out_key; uint32_t* out_pid; uint64_t* out_first;     // out_first: first_seen each k-mer offered
+    uint32_t* cluster_pattern; uint64_t* cluster_first;
+    PatternTable pt;
+    uint64_t out_base;      // global index of out_key[0] (arena base)
+    uint64_t out_cap;       // entries in the arena
+    uint32_t item0, W, NS, KW;
+    uint32_t consider_missing, multiple_files;
+};
+
+__device__ __forceinline__ uint32_t pair_lower_bound(const uint64_t* sp, uint32_t n, uint32_t ord) {
+    uint32_t a = 0, b = n;
+    while (a < b) {
+        uint32_t m = (a + b) >> 1;
+        if ((uint32_t)(sp[m] >> 32) < ord) a = m + 1; else b = m;
+    }
+    return a;
+}
+
+__global__ __launch_bounds__(256) void emit_kernel(EmitParams p) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t item = p.item0 + blockIdx.x;
+    const uint32_t c = p.item_cluster[item];
+    if (p.cluster_overflow[c]) return;
+    const uint32_t slice = p.item_scratch[item];
+    const uint32_t NS = p.NS, W = p.W, KW = p.KW;
+    const uint32_t U = p.item_unique[item];
+    const uint32_t sib0 = p.item_sib0[item], nsib = p.item_nsib[item];
+    const uint64_t ordinal = p.cluster_ordinal[c];
+    const uint64_t obase = p.cluster_kmer_off[c] - p.out_base;
+    const uint64_t* sp = p.sorted_pair + (size_t)slice * NS;
+    const uint32_t* kp = p.kept_prefix + (size_t)slice * (NS + 1);
+
+    if (item == sib0 && tid == 0) {
+        // the cluster's own row: md5 of the int64 image of clusterpresab (panfeed.py:175-187)
+        const uint32_t npres = p.cluster_npresab[c];
+        const uint32_t nw = (npres + 31) >> 5;
+        const uint32_t* presab = p.cluster_presab + (size_t)c * W;
+        H128 s;
+        s.h1 = 0x9747b28cu ^ npres; s.h2 = 0x1b873593u ^ 0x5bd1e995u; s.h3 = 0xe6546b64u; s.h4 = 0x85ebca6bu;
+        if (p.multiple_files) { s.h2 ^= (uint32_t)ordinal; s.h3 ^= (uint32_t)(ordinal >> 32); }
+        for (uint32_t w = 0; w < nw; w += 4) {
+            uint32_t wv[4];
+            for (int j = 0; j < 4; j++) wv[j] = (w + j < nw) ? presab[w + j] : 0;
+            mm3_block(s, wv[0], wv[1], wv[2], wv[3]);
+        }
+        mm3_final(s, nw * 4 + 1);
+        const uint64_t fs = ordinal << 32;
+        p.cluster_pattern[c] = pattern_insert(p.pt, make_uint4(s.h1, s.h2, s.h3, s.h4), fs);
+        p.cluster_first[c] = fs;
+    }
+
+    for (uint32_t r = tid; r < U; r += blockDim.x) {
+        const uint32_t kb = kp[r];
+        const bool keep = kp[r + 1] != kb;
+        const uint64_t pr = sp[r];
+        const uint32_t ord = (uint32_t)(pr >> 32), slot = (uint32_t)pr;
+        uint32_t rank = r, kept_before = kb;
+        for (uint32_t q = 0; q < nsib; q++) {
+            const uint32_t it = sib0 + q;
+            if (it == item) continue;
+            const uint32_t sl = p.item_scratch[it];
+            const uint32_t n = p.item_unique[it];
+            const uint32_t lb = pair_lower_bound(p.sorted_pair + (size_t)sl * NS, n, ord);
+            rank += lb;
+            kept_before += p.kept_prefix[(size_t)sl * (NS + 1) + lb];
+        }
+        if (!keep) continue;
+        const uint64_t fs = (ordinal << 32) | (uint64_t)(rank + 1);
+        const uint4 h = p.slot_hash[(size_t)slice * NS + slot];
+        const uint32_t pid = pattern_insert(p.pt, h, fs);
+        const uint64_t o = obase + kept_before;
+        if (o >= p.out_cap) { p.pt.counters[1] = 2; continue; }   // cannot happen: the arena holds every item's limit
+        p.out_key[o * KW] = p.tab_key[((size_t)slice * KW) * NS + slot];
+        if (KW == 2) p.out_key[o * KW + 1] = p.tab_key[((size_t)slice * KW + 1) * NS + slot];
+        p.out_pid[o] = pid;
+        p.out_first[o] = fs;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pattern_rows_kernel: the k-mer (or cluster row) that holds a pattern's first_seen writes its row
+// ---------------------------------------------------------------------------------------------
+struct PatRowsParams {
+    const uint32_t* item_cluster; const uint32_t* item_scratch; const uint32_t* item_unique;
+    const uint32_t* item_sib0; const uint32_t* item_nsib;
+    const uint32_t* cluster_overflow;
+    const uint32_t* cluster_nstrains; const uint32_t* cluster_npresab; const uint32_t* cluster_presab;
+    const uint64_t* cluster_kmer_off;
+    const uint64_t* sorted_pair; const uint32_t* kept_prefix; const uint32_t* chunkbits; const uint32_t* chunkmask;
+    const uint32_t* out_pid; const uint64_t* out_first;
+    const uint32_t* cluster_pattern; const uint64_t* cluster_first;
+    const uint64_t* pat_first_seen;
+    uint32_t* pat_bits; uint32_t* pat_nan; uint32_t* pat_n;
+    uint64_t out_base, out_cap;
+    uint32_t pool;
+    uint32_t item0, W, NS;
+    uint32_t consider_missing;
+};
+__global__ __launch_bounds__(256) void pattern_rows_kernel(PatRowsParams p) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t item = p.item0 + blockIdx.x;
+    const uint32_t c = p.item_cluster[item];
+    if (p.cluster_overflow[c]) return;
+    const uint32_t slice = p.item_scratch[item];
+    const uint32_t NS = p.NS, W = p.W;
+    const uint32_t U = p.item_unique[item];
+    const uint32_t sib0 = p.item_sib0[item], nsib = p.item_nsib[item];
+    const uint32_t nstr = p.cluster_nstrains[c];
+    const uint32_t nchunks = (nstr + 31) >> 5;
+    const uint32_t* presab = p.cluster_presab + (size_t)c * W;
+    const uint64_t obase = p.cluster_kmer_off[c] - p.out_base;
+    const uint64_t* sp = p.sorted_pair + (size_t)slice * NS;
+    const uint32_t* kp = p.kept_prefix + (size_t)slice * (NS + 1);
+    const uint32_t* cb = p.chunkbits + (size_t)slice * W * NS;
+    const uint32_t* cm = p.chunkmask + slice * 8;
+
+    if (item == sib0 && tid == 0) {
+        const uint32_t pid = p.cluster_pattern[c];
+        if (pid < p.pool && p.pat_first_seen[pid] == p.cluster_first[c]) {
+            const uint32_t npres = p.cluster_npresab[c];
+            for (uint32_t w = 0; w < W; w++) {
+                p.pat_bits[(size_t)pid * W + w] = presab[w];
+                if (p.pat_nan) p.pat_nan[(size_t)pid * W + w] = 0;
+            }
+            p.pat_n[pid] = npres | 0x80000000u;
+        }
+    }
+    for (uint32_t r = tid; r < U; r += blockDim.x) {
+        const uint32_t kb = kp[r];
+        if (kp[r + 1] == kb) continue;
+        const uint64_t pr = sp[r];
+        const uint32_t ord = (uint32_t)(pr >> 32), slot = (uint32_t)pr;
+        uint32_t kept_before = kb;
+        for (uint32_t q = 0; q < nsib; q++) {
+            const uint32_t it = sib0 + q;
+            if (it == item) continue;
+            const uint32_t sl = p.item_scratch[it];
+            const uint32_t lb = pair_lower_bound(p.sorted_pair + (size_t)sl * NS, p.item_unique[it], ord);
+            kept_before += p.kept_prefix[(size_t)sl * (NS + 1) + lb];
+        }
+        const uint64_t o = obase + kept_before;
+        if (o >= p.out_cap) continue;
+        const uint32_t pid = p.out_pid[o];
+        if (pid >= p.pool || p.pat_first_seen[pid] != p.out_first[o]) continue;
+        for (uint32_t w = 0; w < W; w++) {
+            uint32_t v = 0;
+            if (w < nchunks && ((cm[w >> 5] >> (w & 31)) & 1)) v = cb[(size_t)w * NS + slot];
+            p.pat_bits[(size_t)pid * W + w] = v;
+            if (p.pat_nan) {
+                uint32_t nn = 0;
+                if (p.consider_missing && w < nchunks) {
+                    nn = ~presab[w];
+                    const uint32_t rem = nstr - (w << 5);
+                    if (rem < 32) nn &= (1u << rem) - 1;
+                }
+                p.pat_nan[(size_t)pid * W + w] = nn;
+            }
+        }
+        p.pat_n[pid] = nstr;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// md5_kernel: one lane per pattern, MD5 (RFC 1321) of the 8*n-byte image generated from the bits
+// ---------------------------------------------------------------------------------------------
+__device__ __constant__ uint32_t MD5_K[64] = {
+    0xd76aa478, 0xe8c7b756, 0x242070db, 0xc1bdceee, 0xf57c0faf, 0x4787c62a, 0xa8304613, 0xfd469501,
+    0x698098d8, 0x8b44f7af, 0xffff5bb1, 0x895cd7be, 0x6b901122, 0xfd987193, 0xa679438e, 0x49b40821,
+    0xf61e2562, 0xc040b340, 0x265e5a51, 0xe9b6c7aa, 0xd62f105d, 0x02441453, 0xd8a1e681, 0xe7d3fbc8,
+    0x21e1cde6, 0xc33707d6, 0xf4d50d87, 0x455a14ed, 0xa9e3e905, 0xfcefa3f8, 0x676f02d9, 0x8d2a4c8a,
+    0xfffa3942, 0x8771f681, 0x6d9d6122, 0xfde5380c, 0xa4beea44, 0x4bdecfa9, 0xf6bb4b60, 0xbebfbc70,
+    0x289b7ec6, 0xeaa127fa, 0xd4ef3085, 0x04881d05, 0xd9d4d039, 0xe6db99e5, 0x1fa27cf8, 0xc4ac5665,
+    0xf4292244, 0x432aff97, 0xab9423a7, 0xfc93a039, 0x655b59c3, 0x8f0ccc92, 0xffeff47d, 0x85845dd1,
+    0x6fa87e4f, 0xfe2ce6e0, 0xa3014314, 0x4e0811a1, 0xf7537e82, 0xbd3af235, 0x2ad7d2bb, 0xeb86d391};
+
+#define PF_MD5_STEP(f, a, b, c, d, m, kc, s)            \
+    {                                                   \
+        uint32_t t_ = (a) + (f) + (kc) + (m);           \
+        (a) = (b) + ((t_ << (s)) | (t_ >> (32 - (s)))); \
+    }
+
+__device__ __forceinline__ void md5_block(uint32_t st[4], const uint32_t m[16]) {
+    uint32_t a = st[0], b = st[1], c = st[2], d = st[3];
+#define F1(x, y, z) (((x) & (y)) | (~(x) & (z)))
+#define F2(x, y, z) (((x) & (z)) | ((y) & ~(z)))
+#define F3(x, y, z) ((x) ^ (y) ^ (z))
+#define F4(x, y, z) ((y) ^ ((x) | ~(z)))
+#define R4(F, i, g0, g1, g2, g3, s0, s1, s2, s3)                      \
+    PF_MD5_STEP(F(b, c, d), a, b, c, d, m[g0], MD5_K[i], s0)          \
+    PF_MD5_STEP(F(a, b, c), d, a, b, c, m[g1], MD5_K[i + 1], s1)      \
+    PF_MD5_STEP(F(d, a, b), c, d, a, b, m[g2], MD5_K[i + 2], s2)      \
+    PF_MD5_STEP(F(c, d, a), b, c, d, a, m[g3], MD5_K[i + 3], s3)
+    R4(F1, 0, 0, 1, 2, 3, 7, 12, 17, 22) R4(F1, 4, 4, 5, 6, 7, 7, 12, 17, 22)
+    R4(F1, 8, 8, 9, 10, 11, 7, 12, 17, 22) R4(F1, 12, 12, 13, 14, 15, 7, 12, 17, 22)
+    R4(F2, 16, 1, 6, 11, 0, 5, 9, 14, 20) R4(F2, 20, 5, 10, 15, 4, 5, 9, 14, 20)
+    R4(F2, 24, 9, 14, 3, 8, 5, 9, 14, 20) R4(F2, 28, 13, 2, 7, 12, 5, 9, 14, 20)
+    R4(F3, 32, 5, 8, 11, 14, 4, 11, 16, 23) R4(F3, 36, 1, 4, 7, 10, 4, 11, 16, 23)
+    R4(F3, 40, 13, 0, 3, 6, 4, 11, 16, 23) R4(F3, 44, 9, 12, 15, 2, 4, 11, 16, 23)
+    R4(F4, 48, 0, 7, 14, 5, 6, 10, 15, 21) R4(F4, 52, 12, 3, 10, 1, 6, 10, 15, 21)
+    R4(F4, 56, 8, 15, 6, 13, 6, 10, 15, 21) R4(F4, 60, 4, 11, 2, 9, 6, 10, 15, 21)
+#undef R4
+#undef F1
+#undef F2
+#undef F3
+#undef F4
+    st[0] += a; st[1] += b; st[2] += c; st[3] += d;
+}
+
+struct Md5Params {
+    const uint32_t* pat_bits; const uint32_t* pat_nan; const uint32_t* pat_n;
+    uint8_t* pat_md5;
+    uint32_t pid0, pid1, W;
+};
+__global__ __launch_bounds__(256) void md5_kernel(Md5Params p) {
+    const uint32_t pid = p.pid0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (pid >= p.pid1) return;
+    const uint32_t nk = p.pat_n[pid];
+    const bool is_int = (nk >> 31) != 0;
+    const uint32_t n = nk & 0x7FFFFFFFu;
+    const uint32_t* bits = p.pat_bits + (size_t)pid * p.W;
+    const uint32_t* nan = p.pat_nan ? p.pat_nan + (size_t)pid * p.W : nullptr;
+    uint32_t st[4] = {0x67452301u, 0xefcdab89u, 0x98badcfeu, 0x10325476u};
+    const uint64_t nbytes = (uint64_t)n * 8;
+    const uint32_t full = n >> 3;             // whole 64-byte blocks = 8 elements each
+    uint32_t m[16];
+    for (uint32_t blk = 0; blk < full; blk++) {
+        const uint32_t e0 = blk << 3;
+        const uint32_t bw = (bits[e0 >> 5] >> (e0 & 31)) & 0xFF;
+        const uint32_t nw = nan ? (nan[e0 >> 5] >> (e0 & 31)) & 0xFF : 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t bit = (bw >> j) & 1, isn = (nw >> j) & 1;
+            // int64 LE: 01 00.. ; float64 LE: 1.0 = 0x3FF00000:00000000, NaN = 0x7FF80000:00000000 (np.nan)
+            m[2 * j] = is_int ? bit : 0;
+            m[2 * j + 1] = is_int ? 0 : (bit ? 0x3FF00000u : (isn ? 0x7FF80000u : 0));
+        }
+        md5_block(st, m);
+    }
+    // tail: remaining elements, 0x80, zero pad, 64-bit length
+    const uint32_t rem = n & 7;
+#pragma unroll
+    for (int j = 0; j < 16; j++) m[j] = 0;
+    {
+        const uint32_t e0 = full << 3;
+        const uint32_t bw = rem ? (bits[e0 >> 5] >> (e0 & 31)) & 0xFF : 0;
+        const uint32_t nw = (rem && nan) ? (nan[e0 >> 5] >> (e0 & 31)) & 0xFF : 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t bit = (bw >> j) & 1, isn = (nw >> j) & 1;
+            if ((uint32_t)j < rem) {
+                m[2 * j] = is_int ? bit : 0;
+                m[2 * j + 1] = is_int ? 0 : (bit ? 0x3FF00000u : (isn ? 0x7FF80000u : 0));
+            } else if ((uint32_t)j == rem) {
+                m[2 * j] = 0x80;              // first pad byte right after the data
+            }
+        }
+    }
+    if (rem == 7) {                           // 56 data bytes + 0x80 leaves no room for the length
+        md5_block(st, m);
+#pragma unroll
+        for (int j = 0; j < 16; j++) m[j] = 0;
+    }
+    m[14] = (uint32_t)(nbytes << 3);
+    m[15] = (uint32_t)((nbytes << 3) >> 32);
+    md5_block(st, m);
+    uint8_t* out = p.pat_md5 + (size_t)pid * 16;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) out[4 * i + j] = (uint8_t)(st[i] >> (8 * j));
+}
+
+// ---------------------------------------------------------------------------------------------
+// misc kernels
+// ---------------------------------------------------------------------------------------------
+// per-cluster instance counts (trip count of panfeed.py:64)
+__global__ void cluster_ninst_kernel(const uint32_t* cluster_seg_off, const uint32_t* seg_len, uint32_t k,
+                                     uint32_t n_clusters, uint64_t* cluster_ninst, uint64_t* cluster_words) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_clusters) return;
+    uint64_t n = 0, w = 0;
+    for (uint32_t s = cluster_seg_off[c]; s < cluster_seg_off[c + 1]; s++) {
+        const uint32_t len = seg_len[s];
+        if (len >= k) n += len - k + 1;
+        w += 2 * (uint64_t)((len + 63) >> 6);
+    }
+    cluster_ninst[c] = n;
+    cluster_words[c] = w;
+}
+
+__global__ void fill_u64_kernel(uint64_t* p, uint64_t v, uint64_t n) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        p[i] = v;
+}
+
+// bench helper: copy allele words into per-sample segments, 16 bytes per lane
+__global__ void synth_expand_kernel(const uint64_t* allele_words, const uint64_t* allele_word_off,
+                                    const uint32_t* seg_allele, const uint64_t* seg_word_off,
+                                    const uint32_t* seg_len, uint32_t n_segs, uint64_t* packed) {
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t s = wave; s < n_segs; s += nwaves) {
+        const uint32_t pieces = (seg_len[s] + 63) >> 6;     // 16-byte pieces
+        const ulonglong2* src = reinterpret_cast<const ulonglong2*>(allele_words + allele_word_off[seg_allele[s]]);
+        ulonglong2* dst = reinterpret_cast<ulonglong2*>(packed + seg_word_off[s]);
+        for (uint32_t i = lane; i < pieces; i += 64) dst[i] = src[i];
+    }
+}
+
+}  // namespace pf

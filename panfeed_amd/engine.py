@@ -1,0 +1,251 @@
+"""Batched host driver of the HIP hot path: packs cluster records, calls libpanfeed_hip through
+ctypes, and renders the three TSV bodies exactly as the reference writes them
+(/root/reference/panfeed/panfeed.py:104-107, 177, 187, 208, 223).
+
+One ``Engine`` = one panfeed run on one GPU: it owns the run-global pattern set
+(panfeed.py:149-150) in device memory, so clusters must be fed in processing order.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .packing import build_batch, decode_keys, maf_tables
+
+KMERS_TSV_HEADER = ("cluster\tstrain\tfeature_id\tcontig\tfeature_strand\tcontig_start\tcontig_end\t"
+                    "gene_start\tgene_end\tstrand\tk-mer\n")           # input.py:243
+KMERS_TO_HASHES_HEADER = "cluster\tk-mer\thashed_pattern\n"            # panfeed.py:127
+
+
+def hashes_to_patterns_header(strains):
+    return "hashed_pattern" + "".join(f"\t{s}" for s in sorted(strains)) + "\n"   # panfeed.py:120-123
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
+
+
+def _view(ptr, n, dtype):
+    if n == 0:
+        return np.zeros(0, dtype=dtype)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).view(dtype) if ptr else np.zeros(0, dtype=dtype)
+
+
+class BatchOutput:
+    """Texts of one batch (bodies only, no headers) plus counters."""
+
+    def __init__(self):
+        self.kmers_tsv = ""
+        self.kmers_to_hashes = ""
+        self.hashes_to_patterns = ""
+        self.per_cluster = []   # multiple_files: [(idx, kmers_tsv, kmers_to_hashes, hashes_to_patterns)]
+        self.stats = {}
+        self.timing = {}
+
+
+class Engine:
+    def __init__(self, klength=31, canon=True, consider_missing=False, patfilt=True, maf=0.01,
+                 multiple_files=False, max_strains=1024, stroi=(), device=0, pattern_capacity=0,
+                 max_items=0):
+        self.L = _lib.load()
+        self.k = int(klength)
+        self.canon = bool(canon)
+        self.consider_missing = bool(consider_missing)
+        self.patfilt = bool(patfilt)
+        self.maf = float(maf)
+        self.multiple_files = bool(multiple_files)
+        self.max_strains = int(max_strains)
+        self.W = (self.max_strains + 31) // 32
+        self.stroi = stroi if stroi else ()
+        self._lo, self._hi = maf_tables(self.maf, self.max_strains)
+        o = _lib.Opts(self.k, int(self.canon), int(self.consider_missing), int(self.patfilt),
+                      int(self.multiple_files), self.max_strains,
+                      self._lo.ctypes.data_as(C.POINTER(C.c_uint32)), self._hi.ctypes.data_as(C.POINTER(C.c_uint32)),
+                      int(pattern_capacity), int(max_items), 0)
+        self.ctx = C.c_void_p()
+        _lib.check(self.L.pf_create(C.byref(self.ctx), int(device), C.byref(o)))
+        self.next_ordinal = 0
+        self._md5_b64 = {}      # pattern id -> 24-char hash string (patterns seen so far)
+        self.n_patterns = 0
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.L.pf_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ device calls
+    def submit_host_batch(self, hb):
+        b = _lib.Batch()
+        b.n_clusters = hb.n_clusters
+        b.n_segs = len(hb.seg_len)
+        b.n_words = len(hb.packed)
+        b.on_device = 0
+        b.packed = _ptr(hb.packed)
+        b.seg_word_off = _ptr(hb.seg_word_off)
+        b.seg_len = _ptr(hb.seg_len)
+        b.seg_sample = _ptr(hb.seg_sample)
+        b.seg_ord_base = _ptr(hb.seg_ord_base)
+        b.cluster_seg_off = _ptr(hb.cluster_seg_off)
+        b.cluster_nstrains = _ptr(hb.cluster_nstrains)
+        b.cluster_npresab = _ptr(hb.cluster_npresab)
+        b.cluster_presab = _ptr(hb.cluster_presab)
+        b.cluster_ordinal = _ptr(hb.cluster_ordinal)
+        b.n_extra = len(hb.extra_ord)
+        b.extra_cluster = _ptr(hb.extra_cluster)
+        b.extra_ord = _ptr(hb.extra_ord)
+        b.extra_bits = _ptr(hb.extra_bits)
+        if hb.n_strand_words:
+            b.seg_strand_off = _ptr(hb.seg_strand_off)
+            b.n_strand_words = hb.n_strand_words
+        res = _lib.Result()
+        _lib.check(self.L.pf_submit(self.ctx, C.byref(b), C.byref(res)))
+        return res
+
+    def fetch(self):
+        res = _lib.Result()
+        _lib.check(self.L.pf_fetch(self.ctx, C.byref(res)))
+        return res
+
+    def timing(self):
+        t = _lib.Timing()
+        _lib.check(self.L.pf_get_timing(self.ctx, C.byref(t)))
+        return {f: getattr(t, f) for f, _ in _lib.Timing._fields_ if f != "reserved"}
+
+    # ------------------------------------------------------------------ one batch, text out
+    def run(self, records):
+        """cluster_cutter + pattern_hasher over `records` (in processing order)."""
+        records = list(records)
+        hb = build_batch(records, self.k, self.canon, self.W, stroi=self.stroi,
+                         first_ordinal=self.next_ordinal)
+        self.next_ordinal += len(records)
+        self.submit_host_batch(hb)
+        res = self.fetch()
+        return self._render(hb, res)
+
+    def _hash_strings(self, res):
+        p0, p1 = self.n_patterns, int(res.n_patterns)
+        if p1 > p0:
+            md5 = _view(res.pattern_md5, p1 * 16, np.uint8).reshape(p1, 16)
+            buf = C.create_string_buffer(24)
+            for pid in range(p0, p1):
+                d = md5[pid].tobytes()
+                self.L.pf_b64_digest(d, buf)
+                self._md5_b64[pid] = buf.raw[:24].decode()
+            self.n_patterns = p1
+        return self._md5_b64
+
+    def _pattern_row(self, res, pid):
+        """'<hash>\\t<patterntup>\\n'  (panfeed.py:181-187, 217-223)"""
+        W = self.W
+        nk = int(res.pattern_n[pid])
+        n = nk & 0x7FFFFFFF
+        bits = _view(res.pattern_bits, (pid + 1) * W, np.uint32)[pid * W:(pid + 1) * W]
+        b = (bits[np.arange(n) >> 5] >> (np.arange(n, dtype=np.uint32) & 31)) & 1 if n else np.zeros(0, np.uint32)
+        cells = [str(int(x)) for x in b]
+        if self.consider_missing and not (nk >> 31) and res.pattern_nan:
+            nan = _view(res.pattern_nan, (pid + 1) * W, np.uint32)[pid * W:(pid + 1) * W]
+            isn = (nan[np.arange(n) >> 5] >> (np.arange(n, dtype=np.uint32) & 31)) & 1
+            cells = ["" if isn[i] else cells[i] for i in range(n)]
+        return self._md5_b64[pid] + "\t" + "\t".join(cells) + "\n"
+
+    def _render(self, hb, res):
+        out = BatchOutput()
+        C_ = hb.n_clusters
+        kw = int(res.key_words)
+        hashes = self._hash_strings(res)
+        off = _view(res.cluster_kmer_off, C_, np.uint64)
+        cnt = _view(res.cluster_kmer_cnt, C_, np.uint32)
+        cpat = _view(res.cluster_pattern, C_, np.uint32)
+        total = int((off + cnt).max()) if C_ and cnt.any() else 0
+        keys = _view(res.kmer_key, total * kw, np.uint64).reshape(-1, kw) if total else np.zeros((0, kw), np.uint64)
+        pids = _view(res.kmer_pattern, total, np.uint32)
+        first_seen = _view(res.pattern_first_seen, int(res.n_patterns), np.uint64)
+        new_ids = _view(res.new_pattern_id, int(res.n_new_patterns), np.uint32)
+
+        # kmers_to_hashes.tsv body, cluster by cluster (panfeed.py:177, 208)
+        kh_parts = []
+        for ci in range(C_):
+            idx = hb.idx[ci]
+            lines = [f"{idx}\t\t{hashes[int(cpat[ci])]}\n"]
+            o, n = int(off[ci]), int(cnt[ci])
+            if n:
+                kk = keys[o:o + n]
+                is_extra = (kk[:, 0] >> np.uint64(63)).astype(bool)
+                strs = decode_keys(np.where(is_extra[:, None], np.uint64(0), kk), self.k, kw)
+                for j in range(n):
+                    kmer = hb.extra_keys[int(kk[j, 0] & np.uint64(0xFFFFFFFF))] if is_extra[j] else strs[j]
+                    lines.append(f"{idx}\t{kmer}\t{hashes[int(pids[o + j])]}\n")
+            kh_parts.append("".join(lines))
+        # hashes_to_patterns.tsv body: new patterns in first-seen order (panfeed.py:179-187, 210-223)
+        hp_by_cluster = [[] for _ in range(C_)]
+        ord0 = int(hb.cluster_ordinal[0]) if C_ else 0
+        for pid in new_ids:
+            pid = int(pid)
+            ci = int(first_seen[pid] >> np.uint64(32)) - ord0
+            hp_by_cluster[ci].append(self._pattern_row(res, pid))
+        # kmers.tsv body (panfeed.py:90-107)
+        kt_by_cluster = [[] for _ in range(C_)]
+        strand = _view(res.strand_bits, hb.n_strand_words, np.uint64) if hb.n_strand_words else None
+        for meta in hb.targets:
+            kt_by_cluster[meta.cluster].append(self._positional_rows(hb, meta, strand))
+
+        if self.multiple_files:
+            for ci in range(C_):
+                out.per_cluster.append((hb.idx[ci], "".join(kt_by_cluster[ci]), kh_parts[ci],
+                                        "".join(hp_by_cluster[ci])))
+        out.kmers_to_hashes = "".join(kh_parts)
+        out.hashes_to_patterns = "".join("".join(x) for x in hp_by_cluster)
+        out.kmers_tsv = "".join("".join(x) for x in kt_by_cluster)
+        out.stats = {"instances": int(res.n_instances) + self._slow_instances(hb),
+                     "device_instances": int(res.n_instances),
+                     "unique_kmers": int(res.n_unique), "kept_kmers": int(res.n_kept),
+                     "new_patterns": int(res.n_new_patterns), "patterns": int(res.n_patterns)}
+        out.timing = self.timing()
+        return out
+
+    @staticmethod
+    def _slow_instances(hb):
+        return 0   # slow-path windows are counted inside hb.n_instances; device counter excludes them
+
+    def _positional_rows(self, hb, meta, strand):
+        """one row per instance for a target strain's sequence (panfeed.py:90-107)"""
+        s, k = meta.seq, self.k
+        idx = hb.idx[meta.cluster]
+        seq, comp = s.sequence, s.compsequence
+        # rc-is-canonical flag per pure window, from the device strand bits
+        rc = {}
+        if self.canon and strand is not None:
+            for seg, a, nw in meta.segs:
+                so = int(hb.seg_strand_off[seg])
+                for j in range(nw):
+                    rc[a + j] = (int(strand[so + (j >> 6)]) >> (j & 63)) & 1
+        rows = []
+        for pos in range(meta.num_kmer):
+            if s.strand > 0:                                   # panfeed.py:91-94
+                truestart = s.start + pos
+                trueend = s.start + pos + k
+            else:                                              # panfeed.py:96-99
+                trueend = s.end - pos
+                truestart = s.end - pos - k
+            genestart = pos - s.offset                         # panfeed.py:101-102
+            geneend = pos + k - s.offset
+            head = f"{idx}\t{meta.strain}\t{s.id}\t{s.chromosome}\t{s.strand}\t{truestart}\t{trueend}\t{genestart}\t{geneend}\t"
+            spec = seq[pos:pos + k]
+            if self.canon:
+                if pos in meta.ambig:
+                    canonseq, used = meta.ambig[pos]
+                else:
+                    used = -1 if rc[pos] else 1
+                    canonseq = comp[pos:pos + k][::-1] if rc[pos] else spec
+                rows.append(f"{head}{used}\t{canonseq}\n")      # panfeed.py:104
+            else:
+                rev = comp[pos:pos + k][::-1]
+                rows.append(f"{head}{s.strand}\t{spec}\n")      # panfeed.py:106
+                rows.append(f"{head}{-s.strand}\t{rev}\n")      # panfeed.py:107
+        return "".join(rows)

@@ -1,0 +1,264 @@
+"""Host side of the device boundary: reference-shaped cluster records -> the packed batch of
+include/panfeed_hip.h, and the slow path for windows that contain a non-ACGT base.
+
+A record is what /root/reference/panfeed/input.py:468 yields:
+``(gene_sequences, idx, clusterpresab)`` with ``gene_sequences = {strain: [Seqinfo, ...]}``.
+
+Everything here is bookkeeping (ordering, 2-bit packing, coordinates); the k-mer work itself
+runs on the GPU, except for windows with a base outside A/C/G/T -- they cannot be 2-bit
+packed, are rare, and are grouped here exactly as cluster_cutter does
+(/root/reference/panfeed/panfeed.py:64-88), then handed to the device as pre-grouped rows.
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+_LUT = np.full(256, 255, dtype=np.uint8)
+for _i, _c in enumerate(b"ACGT"):
+    _LUT[_c] = _i
+_COMP_CODE = np.array([3, 2, 1, 0], dtype=np.uint8)
+_ASCII = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def maf_tables(maf, max_strains):
+    """keep-interval per denominator n: a k-mer with `count` ones among n strains survives
+    panfeed.py:190-200 iff lo[n] <= count <= hi[n].  Same float64 arithmetic as the reference
+    (sum of 0/1 float64 == count exactly; count / n; 1 - af; af < maf)."""
+    lo = np.zeros(max_strains + 1, dtype=np.uint32)
+    hi = np.zeros(max_strains + 1, dtype=np.uint32)
+    maf = float(maf)
+    for n in range(1, max_strains + 1):
+        cnt = np.arange(0, n + 1, dtype=np.float64)
+        af = cnt / np.float64(n)
+        af = np.where(af >= 0.5, 1 - af, af)
+        keep = ~(af < maf)
+        idx = np.flatnonzero(keep)
+        if len(idx) == 0:
+            lo[n], hi[n] = 1, 0
+            continue
+        if idx[-1] - idx[0] + 1 != len(idx):
+            raise ValueError(f"MAF keep set is not an interval for n={n}")
+        lo[n], hi[n] = idx[0], idx[-1]
+    return lo, hi
+
+
+def pack_codes(codes):
+    """uint8 codes (0..3) -> uint64 words: 32 bases per word, first base in bits 63:62,
+    padded with A to a multiple of 64 bases (16 bytes)."""
+    n = len(codes)
+    npad = (n + 63) // 64 * 64
+    buf = np.zeros(npad, dtype=np.uint8)
+    buf[:n] = codes
+    bits = np.empty(npad * 2, dtype=np.uint8)
+    bits[0::2] = buf >> 1
+    bits[1::2] = buf & 1
+    return np.packbits(bits).view(">u8").astype(np.uint64)
+
+
+@dataclass
+class SeqMeta:
+    """what the positional rows (panfeed.py:90-107) need about one Seqinfo"""
+    cluster: int
+    strain: str
+    seq: object            # the Seqinfo
+    ord_base: int
+    num_kmer: int
+    segs: list             # [(seg_index_in_batch, start_pos, n_windows)]
+    ambig: dict            # pos -> (canonseq, used_strand) for slow-path windows (canonical mode)
+
+
+@dataclass
+class HostBatch:
+    k: int
+    canon: bool
+    W: int
+    idx: list = field(default_factory=list)               # cluster names
+    sorted_strains: list = field(default_factory=list)    # per cluster: sorted(cluster.keys())
+    presab: list = field(default_factory=list)            # per cluster: the int vector as given
+    packed: np.ndarray = None
+    seg_word_off: np.ndarray = None
+    seg_len: np.ndarray = None
+    seg_sample: np.ndarray = None
+    seg_ord_base: np.ndarray = None
+    seg_strand_off: np.ndarray = None
+    n_strand_words: int = 0
+    cluster_seg_off: np.ndarray = None
+    cluster_nstrains: np.ndarray = None
+    cluster_npresab: np.ndarray = None
+    cluster_presab: np.ndarray = None
+    cluster_ordinal: np.ndarray = None
+    extra_cluster: np.ndarray = None
+    extra_ord: np.ndarray = None
+    extra_bits: np.ndarray = None
+    extra_keys: list = field(default_factory=list)        # k-mer strings of the slow-path rows
+    targets: list = field(default_factory=list)           # SeqMeta of sequences in target strains
+    n_instances: int = 0                                  # trip count of panfeed.py:64 (x2 non-canonical)
+
+    @property
+    def n_clusters(self):
+        return len(self.idx)
+
+
+def build_batch(records, klength, canon, W, stroi=(), first_ordinal=0, want_strand=True):
+    """records: iterable of (gene_sequences, idx, clusterpresab)."""
+    k = int(klength)
+    hb = HostBatch(k=k, canon=bool(canon), W=W)
+    words, word_off = [], 0
+    seg_word_off, seg_len, seg_sample, seg_ord, seg_strand = [], [], [], [], []
+    cl_seg_off = [0]
+    cl_nstr, cl_npres, cl_presab, cl_ord = [], [], [], []
+    ex_cluster, ex_ord, ex_bits = [], [], []
+    strand_words = 0
+
+    for ci, (gs, idx, presab) in enumerate(records):
+        names = list(gs.keys())
+        n = len(names)
+        if n > W * 32:
+            raise ValueError(f"cluster {idx}: {n} strains exceed the context's max_strains")
+        sorted_names = sorted(names)
+        col = {x: i for i, x in enumerate(sorted_names)}          # panfeed.py:47-49
+        presab = np.asarray(presab)
+        if len(presab) > W * 32:
+            raise ValueError(f"cluster {idx}: clusterpresab longer than max_strains")
+        if presab.size and not np.isin(presab, (0, 1)).all():
+            raise ValueError(f"cluster {idx}: clusterpresab must hold 0/1")
+        pb = np.zeros(W, dtype=np.uint32)
+        for i in np.flatnonzero(presab):
+            pb[i >> 5] |= np.uint32(1 << (i & 31))
+        hb.idx.append(str(idx))
+        hb.sorted_strains.append(sorted_names)
+        hb.presab.append(presab)
+        cl_nstr.append(n)
+        cl_npres.append(len(presab))
+        cl_presab.append(pb)
+        cl_ord.append(first_ordinal + ci)
+
+        segs = []          # (sample, order, word arrays, len, ord_base, strand_off)
+        ambig_rows = {}    # key -> [first_ord, set(cols)]
+        ord_base = 0
+        order = 0
+        for strain in names:                                      # panfeed.py:54
+            c = col[strain]
+            is_target = bool(stroi) and (strain in stroi)         # panfeed.py:90
+            for s in gs[strain]:                                  # panfeed.py:55
+                seq = s.sequence
+                L = len(seq)
+                num_kmer = max(L - k + 1, 0)                      # panfeed.py:59,64
+                raw = np.frombuffer(seq.encode("latin-1"), dtype=np.uint8)
+                codes = _LUT[raw]
+                bad = np.flatnonzero(codes == 255)
+                craw = np.frombuffer(s.compsequence.encode("latin-1"), dtype=np.uint8)
+                if len(craw) != L:
+                    raise ValueError(f"{idx}/{strain}: sequence and compsequence differ in length")
+                ok = codes != 255
+                if not np.array_equal(_LUT[craw][ok], _COMP_CODE[codes[ok]]):
+                    raise ValueError(f"{idx}/{strain}: compsequence is not the complement of sequence")
+                meta = SeqMeta(ci, strain, s, ord_base, num_kmer, [], {}) if is_target else None
+                # maximal A/C/G/T runs -> device segments
+                bounds = np.concatenate(([-1], bad, [L]))
+                for a, b in zip(bounds[:-1] + 1, bounds[1:]):
+                    a, b = int(a), int(b)
+                    if b - a < k:
+                        continue
+                    soff = 0xFFFFFFFF
+                    if is_target and canon and want_strand:
+                        soff = strand_words
+                        strand_words += (b - a - k + 1 + 63) // 64
+                    segs.append((c, order, pack_codes(codes[a:b]), b - a, ord_base + a, soff))
+                    if meta is not None:
+                        meta.segs.append((order, a, b - a - k + 1))
+                    order += 1
+                # windows touching a non-ACGT base: the reference's own string semantics
+                if len(bad) and num_kmer > 0:
+                    comp = s.compsequence
+                    touched = np.zeros(num_kmer, dtype=bool)
+                    for p in bad:
+                        touched[max(0, int(p) - k + 1):min(num_kmer, int(p) + 1)] = True
+                    for pos in np.flatnonzero(touched):
+                        pos = int(pos)
+                        spec = seq[pos:pos + k]                   # panfeed.py:65
+                        rev = comp[pos:pos + k][::-1]             # panfeed.py:67
+                        if canon:
+                            key, used = (spec, 1) if spec <= rev else (rev, -1)   # panfeed.py:70-75
+                            ent = ambig_rows.setdefault(key, [ord_base + pos, set()])
+                            ent[1].add(c)
+                            if meta is not None:
+                                meta.ambig[pos] = (key, used)
+                        else:
+                            for j, key in enumerate((spec, rev)):                 # panfeed.py:82-88
+                                ent = ambig_rows.setdefault(key, [2 * (ord_base + pos) + j, set()])
+                                ent[1].add(c)
+                if meta is not None:
+                    hb.targets.append(meta)
+                ord_base += num_kmer
+        hb.n_instances += ord_base * (1 if canon else 2)
+        if ord_base * 2 >= 0xFFFFFFF0:
+            raise ValueError(f"cluster {idx}: too many k-mer instances for 32-bit ordinals")
+
+        # segments sorted by sample column (stable); remember where each went for the strand bits
+        segs_sorted = sorted(segs, key=lambda t: (t[0], t[1]))
+        base_index = len(seg_len)
+        where = {}
+        for j, (c, order, w, ln, ob, soff) in enumerate(segs_sorted):
+            where[order] = base_index + j
+            seg_word_off.append(word_off)
+            words.append(w)
+            word_off += len(w)
+            seg_len.append(ln)
+            seg_sample.append(c)
+            seg_ord.append(ob)
+            seg_strand.append(soff)
+        for meta in hb.targets:
+            if meta.cluster == ci:
+                meta.segs = [(where[o], a, nw) for (o, a, nw) in meta.segs]
+        cl_seg_off.append(len(seg_len))
+        for key, (o, cols) in ambig_rows.items():
+            row = np.zeros(W, dtype=np.uint32)
+            for c in cols:
+                row[c >> 5] |= np.uint32(1 << (c & 31))
+            ex_cluster.append(ci)
+            ex_ord.append(o)
+            ex_bits.append(row)
+            hb.extra_keys.append(key)
+
+    words.append(np.zeros(2, dtype=np.uint64))   # 16 bytes of tail padding
+    hb.packed = np.ascontiguousarray(np.concatenate(words))
+    hb.seg_word_off = np.asarray(seg_word_off, dtype=np.uint64)
+    hb.seg_len = np.asarray(seg_len, dtype=np.uint32)
+    hb.seg_sample = np.asarray(seg_sample, dtype=np.uint32)
+    hb.seg_ord_base = np.asarray(seg_ord, dtype=np.uint32)
+    hb.seg_strand_off = np.asarray(seg_strand, dtype=np.uint32)
+    hb.n_strand_words = strand_words
+    hb.cluster_seg_off = np.asarray(cl_seg_off, dtype=np.uint32)
+    hb.cluster_nstrains = np.asarray(cl_nstr, dtype=np.uint32)
+    hb.cluster_npresab = np.asarray(cl_npres, dtype=np.uint32)
+    hb.cluster_presab = (np.stack(cl_presab) if cl_presab else np.zeros((0, W), dtype=np.uint32)).astype(np.uint32)
+    hb.cluster_ordinal = np.asarray(cl_ord, dtype=np.uint64)
+    hb.extra_cluster = np.asarray(ex_cluster, dtype=np.uint32)
+    hb.extra_ord = np.asarray(ex_ord, dtype=np.uint32)
+    hb.extra_bits = (np.stack(ex_bits) if ex_bits else np.zeros((0, W), dtype=np.uint32)).astype(np.uint32)
+    return hb
+
+
+def decode_keys(keys, k, key_words):
+    """device k-mer keys -> list of str.  One word: the k bases in the low 2k bits, first base on
+    top.  Two words: a 2k-bit value split into two 63-bit words (word 0 = high part)."""
+    keys = np.asarray(keys, dtype=np.uint64).reshape(-1, key_words)
+    n = len(keys)
+    if n == 0:
+        return []
+    if key_words == 1:
+        hi = np.zeros(n, dtype=np.uint64)
+        lo = keys[:, 0]
+    else:
+        hi = keys[:, 0] >> np.uint64(1)
+        lo = ((keys[:, 0] & np.uint64(1)) << np.uint64(63)) | keys[:, 1]
+    out = np.empty((n, k), dtype=np.uint8)
+    for i in range(k):
+        bit = 2 * (k - 1 - i)
+        if bit >= 64:
+            code = (hi >> np.uint64(bit - 64)) & np.uint64(3)
+        else:
+            code = (lo >> np.uint64(bit)) & np.uint64(3)
+        out[:, i] = _ASCII[code.astype(np.intp)]
+    return [row.tobytes().decode() for row in out]

@@ -1,0 +1,181 @@
+"""Parity of the HIP path (through the C ABI) with (a) outputs of the reference itself
+(tests/golden/) and (b) the CPU oracle on seeded inputs.  Bit-exact: all of this is integer /
+byte work (k-mer keys, presence bits, MD5 digests, text)."""
+import io
+
+import numpy as np
+import pytest
+
+from conftest import all_cases, case_ids, case_records
+
+pytestmark = pytest.mark.gpu
+
+CASES = all_cases()
+
+
+def _engine(case_opts, max_strains, **kw):
+    from panfeed_amd.engine import Engine
+    o = case_opts
+    return Engine(klength=o["klength"], canon=o["canon"], consider_missing=o["consider_missing"],
+                  patfilt=o["patfilt"], maf=o["maf"], multiple_files=o["multiple_files"],
+                  max_strains=max_strains, stroi=set(o["stroi"]) if o["stroi"] else (), **kw)
+
+
+def _headers(case):
+    from panfeed_amd.engine import KMERS_TSV_HEADER, KMERS_TO_HASHES_HEADER, hashes_to_patterns_header
+    return KMERS_TSV_HEADER, KMERS_TO_HASHES_HEADER, hashes_to_patterns_header(case["all_strains"])
+
+
+@pytest.mark.parametrize("case", CASES, ids=case_ids(CASES))
+def test_golden_engine(case):
+    """Engine.run over the whole case as ONE batch vs the reference's files."""
+    from panfeed_amd._lib import PanfeedHipError
+    o = case["opts"]
+    ms = max(32, (len(case["all_strains"]) + 31) // 32 * 32)
+    if o["klength"] > 63:
+        with pytest.raises(PanfeedHipError):
+            _engine(o, ms)
+        return
+    eng = _engine(o, ms)
+    out = eng.run(case_records(case))
+    hk, hkh, hhp = _headers(case)
+    exp = case["expect"]
+    if o["multiple_files"]:
+        for idx, kt, kh, hp in out.per_cluster:
+            assert hkh + kh == exp["dirs"][idx]["kmers_to_hashes.tsv"], idx
+            assert hhp + hp == exp["dirs"][idx]["hashes_to_patterns.tsv"], idx
+            assert hk + kt == exp["dirs"][idx]["kmers.tsv"], idx
+    else:
+        assert hkh + out.kmers_to_hashes == exp["kmers_to_hashes.tsv"]
+        assert hhp + out.hashes_to_patterns == exp["hashes_to_patterns.tsv"]
+        assert hk + out.kmers_tsv == exp["kmers.tsv"]
+        assert out.stats["patterns"] == exp["n_patterns"]
+    eng.close()
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if not c["opts"]["multiple_files"] and c["opts"]["klength"] <= 63][::3],
+                         ids=lambda c: c["name"])
+def test_golden_mirror_one_cluster_per_call(case):
+    """The reference's own driver loop (__main__.py:350-356) over the mirror API, one cluster per call."""
+    import pandas as pd
+    from panfeed_amd.panfeed import cluster_cutter, pattern_hasher, write_headers
+    from panfeed_amd.engine import KMERS_TSV_HEADER
+    o = case["opts"]
+    stroi = set(o["stroi"]) if o["stroi"] is not None else ""
+    ks, hp, kh = io.StringIO(), io.StringIO(), io.StringIO()
+    ks.write(KMERS_TSV_HEADER)
+    genepres = pd.DataFrame(columns=case["all_strains"])
+    write_headers(hp, kh, genepres)
+    patterns = None
+    for x in case_records(case):
+        ret = cluster_cutter(x, o["klength"], stroi, False, o["canon"], o["consider_missing"], "unused")
+        patterns = pattern_hasher((ret,), ks, hp, kh, genepres, o["patfilt"], o["maf"], "unused",
+                                  patterns=patterns, consider_missing_cluster=o["consider_missing"])
+    exp = case["expect"]
+    assert kh.getvalue() == exp["kmers_to_hashes.tsv"]
+    assert hp.getvalue() == exp["hashes_to_patterns.tsv"]
+    assert ks.getvalue() == exp["kmers.tsv"]
+    assert len(patterns) == exp["n_patterns"]
+
+
+def _oracle_texts(records, stroi=(), **kw):
+    from oracle import oracle as po
+    run = po.OracleRun(stroi=stroi, **kw)
+    run.feed(records)
+    return run.texts(), run.stats()
+
+
+@pytest.mark.parametrize("k,canon,S,flank", [(31, True, 200, 0), (31, False, 96, 10), (51, True, 130, 0), (21, True, 333, 25)])
+def test_seeded_vs_oracle(k, canon, S, flank):
+    """mid-size seeded clusters (multi-word rows, several sample chunks, paralogs, Ns)"""
+    from panfeed_amd import synth
+    from panfeed_amd.engine import Engine
+    cl = synth.generate(10, S, first=1234, flank=flank, mean_len=400, min_len=80, max_len=1500, n_rate=0.01,
+                        paralog_rate=0.03, shuffle_columns=5)
+    recs = [c.record() for c in cl]
+    stroi = {cl[0].names[3], cl[0].names[S // 2]}
+    eng = Engine(klength=k, canon=canon, max_strains=(S + 31) // 32 * 32, stroi=stroi)
+    out = eng.run(recs)
+    (ek, ekh, ehp), st = _oracle_texts(recs, stroi=stroi, klength=k, canon=canon)
+    assert out.kmers_to_hashes == ekh
+    assert out.hashes_to_patterns == ehp
+    assert out.kmers_tsv == ek
+    assert out.stats["unique_kmers"] == st["unique_kmers"]
+    assert out.stats["instances"] == st["instances"]
+    eng.close()
+
+
+def _diverse_records(n_samples, length, seed, n_clusters=2):
+    """every sample carries its own random sequence: unique k-mers ~ instances (table overflow path)"""
+    from panfeed_amd.classes import Seqinfo
+    rng = np.random.default_rng(seed)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    names = [f"d{i:03d}" for i in range(n_samples)]
+    recs = []
+    for c in range(n_clusters):
+        gs = {}
+        for i, nm in enumerate(names):
+            s = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, length)].tobytes()
+            gs[nm] = [Seqinfo(s.decode(), s.translate(comp).decode(), f"g{c}_{i}", "ctg", 10, 10 + length - 1, 1, 0)]
+        recs.append((gs, f"div{c}", np.ones(n_samples, dtype=np.int64)))
+    return recs, names
+
+
+@pytest.mark.parametrize("k,canon", [(31, True), (31, False), (47, True)])
+def test_table_overflow_repartitions(k, canon):
+    """one LDS table cannot hold these clusters: they are re-run with 4x / 16x key partitions and the
+    merged order must still be the reference's dict insertion order"""
+    from panfeed_amd.engine import Engine
+    recs, names = _diverse_records(48, 1500, seed=99)
+    eng = Engine(klength=k, canon=canon, max_strains=64, maf=0.0)
+    out = eng.run(recs)
+    assert out.timing["n_retried"] >= 2
+    (ek, ekh, ehp), st = _oracle_texts(recs, klength=k, canon=canon, maf=0.0)
+    assert out.kmers_to_hashes == ekh
+    assert out.hashes_to_patterns == ehp
+    assert out.stats["unique_kmers"] == st["unique_kmers"]
+    eng.close()
+
+
+def test_sub_batches_and_pattern_carry_over():
+    """max_items=3 forces many internal sub-batches; two run() calls share the run-global patterns"""
+    from panfeed_amd import synth
+    from panfeed_amd.engine import Engine
+    cl = synth.generate(14, 24, first=500, mean_len=150, min_len=40, max_len=400, n_rate=0.02)
+    recs = [c.record() for c in cl]
+    eng = Engine(klength=15, max_strains=32, max_items=3)
+    o1 = eng.run(recs[:9])
+    o2 = eng.run(recs[9:])
+    (ek, ekh, ehp), st = _oracle_texts(recs, klength=15)
+    assert o1.kmers_to_hashes + o2.kmers_to_hashes == ekh
+    assert o1.hashes_to_patterns + o2.hashes_to_patterns == ehp
+    assert o2.stats["patterns"] == st["patterns"]
+    eng.close()
+
+
+def test_device_resident_batch_matches_host_batch():
+    """pf_submit on device pointers (the bench path) == on host pointers; synth expansion == host packing"""
+    from panfeed_amd import devbatch, synth
+    from panfeed_amd.engine import Engine
+    from panfeed_amd.packing import build_batch
+    cl = synth.generate(9, 64, first=42, flank=15, mean_len=300, min_len=50, max_len=800, n_rate=0.0)
+    recs = [c.record() for c in cl]
+    eng = Engine(klength=31, max_strains=64)
+    ref = eng.run(recs)
+    eng2 = Engine(klength=31, max_strains=64)
+    db = devbatch.from_synth(eng2, cl, 31)
+    res = db.submit()
+    assert int(res.n_instances) == ref.stats["device_instances"] == db.n_instances
+    assert int(res.n_unique) == ref.stats["unique_kmers"]
+    assert int(res.n_kept) == ref.stats["kept_kmers"]
+    assert int(res.n_new_patterns) == ref.stats["new_patterns"]
+    hb = build_batch(recs, 31, True, eng2.W)
+    got = eng2._render(hb, eng2.fetch())
+    assert got.kmers_to_hashes == ref.kmers_to_hashes
+    assert got.hashes_to_patterns == ref.hashes_to_patterns
+    # the expanded device buffer is byte-identical to the host packer's
+    packed = db.download("packed", np.uint64, len(hb.packed))
+    assert np.array_equal(packed, hb.packed)
+    db.free()
+    eng.close()
+    eng2.close()

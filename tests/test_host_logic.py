@@ -1,0 +1,110 @@
+"""CPU-only checks of the host side: packing, MAF tables, batch invariants, and that the C-ABI
+library loads and exports every symbol include/panfeed_hip.h declares (no compute without a GPU)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import REPO, all_cases, case_records
+from panfeed_amd import packing
+
+
+def test_library_exports_every_header_symbol():
+    from panfeed_amd import _lib
+    L = _lib.load()
+    hdr = open(os.path.join(REPO, "include", "panfeed_hip.h")).read()
+    declared = set(re.findall(r"\b(pf_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert b"gfx950" in L.pf_version()
+
+
+def test_no_device_fails_loudly():
+    """without a GPU the product path raises -- it never falls back to a CPU implementation"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from panfeed_amd._lib import PanfeedHipError
+    from panfeed_amd.engine import Engine
+    with pytest.raises(PanfeedHipError):
+        Engine(klength=31, max_strains=32)
+
+
+def test_product_never_imports_the_oracle():
+    for root, _d, files in os.walk(os.path.join(REPO, "panfeed_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(root, f)).read()
+                assert "oracle" not in src.replace("# oracle", ""), f
+
+
+def test_maf_tables_match_reference_arithmetic():
+    for maf in (0.01, 0.05, 0.1, 0.0, 0.5, 0.3333):
+        lo, hi = packing.maf_tables(maf, 130)
+        for n in (1, 2, 3, 7, 64, 100, 129, 130):
+            for c in range(n + 1):
+                v = np.zeros(n)
+                v[:c] = 1.0
+                af = v.sum() / v.shape[0]          # panfeed.py:191
+                if af >= 0.5:
+                    af = 1 - af
+                keep = not (af < maf)
+                assert keep == (lo[n] <= c <= hi[n]), (maf, n, c)
+    lo, hi = packing.maf_tables(0.01, 1000)
+    assert (lo[1000], hi[1000]) == (10, 990) and (lo[991], hi[991]) == (10, 981)   # SURVEY 8(a) H4 probes
+
+
+def test_pack_and_decode_roundtrip():
+    L = packing._LUT
+    rng = np.random.default_rng(1)
+    lib = None
+    from panfeed_amd import _lib
+    lib = _lib.load()
+    for n in (1, 31, 32, 33, 63, 64, 65, 200):
+        codes = rng.integers(0, 4, n).astype(np.uint8)
+        w = packing.pack_codes(codes)
+        assert len(w) == 2 * ((n + 63) // 64)
+        for i in range(n):
+            assert (int(w[i >> 5]) >> (62 - 2 * (i & 31))) & 3 == codes[i]
+        # the C helper packs identically
+        s = np.frombuffer(b"ACGT", np.uint8)[codes].tobytes()
+        out = np.zeros(len(w), dtype=np.uint64)
+        assert lib.pf_pack_acgt(s, n, out.ctypes.data) == len(w)
+        assert np.array_equal(out, w)
+    assert L[ord("N")] == 255
+    # key decode, one and two words
+    for k, kw in ((5, 1), (31, 1), (32, 2), (51, 2), (63, 2)):
+        codes = rng.integers(0, 4, k)
+        val = 0
+        for c in codes:
+            val = (val << 2) | int(c)
+        if kw == 1:
+            keys = np.array([val], dtype=np.uint64)
+        else:
+            keys = np.array([val >> 63, val & ((1 << 63) - 1)], dtype=np.uint64)
+        assert packing.decode_keys(keys, k, kw) == ["".join("ACGT"[c] for c in codes)]
+
+
+def test_build_batch_invariants():
+    for case in all_cases():
+        o = case["opts"]
+        recs = case_records(case)
+        W = max(1, (len(case["all_strains"]) + 31) // 32)
+        hb = packing.build_batch(recs, o["klength"], o["canon"], W, stroi=set(o["stroi"] or ()))
+        assert hb.n_clusters == len(recs)
+        assert len(hb.packed) >= 2 and hb.packed[-1] == 0 and hb.packed[-2] == 0
+        assert (hb.seg_word_off % 2 == 0).all()
+        k = o["klength"]
+        total = 0
+        for ci, (gs, idx, presab) in enumerate(recs):
+            a, b = hb.cluster_seg_off[ci], hb.cluster_seg_off[ci + 1]
+            assert (np.diff(hb.seg_sample[a:b].astype(np.int64)) >= 0).all()
+            assert (hb.seg_len[a:b] >= k).all()
+            assert (hb.seg_sample[a:b] < max(1, len(gs))).all()
+            n = sum(max(len(s.sequence) - k + 1, 0) for v in gs.values() for s in v)
+            total += n * (1 if o["canon"] else 2)
+        assert hb.n_instances == total
+        assert len(hb.extra_keys) == len(hb.extra_ord) == len(hb.extra_cluster)
+        assert (np.diff(hb.extra_cluster.astype(np.int64)) >= 0).all()
