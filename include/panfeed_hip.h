@@ -167,6 +167,11 @@ int pf_get_timing(pf_ctx* ctx, pf_timing* t);
  * pf_export_patterns: (md5[16], first_seen) of every pattern this rank holds;
  * the driver all-gathers them (RCCL) and keeps, per digest, the rank with the lowest first_seen. */
 int pf_export_patterns(pf_ctx* ctx, uint64_t* n, const uint8_t** md5, const uint64_t** first_seen);
+/* Same, device to device: copies min(count, cap) entries into caller-owned DEVICE buffers
+ * (d_md5: 16 B each, d_first_seen: 8 B each) so the all-gather can start from HBM. */
+int pf_export_patterns_dev(pf_ctx* ctx, uint64_t cap, void* d_md5, void* d_first_seen, uint64_t* n);
+/* Number of patterns in the run-global set after the last pf_submit. */
+int pf_pattern_count(pf_ctx* ctx, uint64_t* n);
 
 /* Device buffers for callers that keep batches resident (bench.py, tests): plain hipMalloc /
  * hipMemcpy / hipFree on the context's device. */

@@ -109,6 +109,10 @@ class OracleRun:
 
     def feed(self, clusters):
         """clusters: iterable of (gene_sequences, idx, clusterpresab)."""
+        self.run_prepared(self.prepare(clusters))
+
+    def prepare(self, clusters):
+        """marshal records into C structs (kept out of timed regions)"""
         clusters = list(clusters)
         keep = []  # keep ctypes buffers alive
         arr = (_Cluster * max(1, len(clusters)))()
@@ -132,7 +136,11 @@ class OracleRun:
             keep += [c_names, tgt, seqs, pa]
             arr[ci] = _Cluster(_b(idx), n, nseq, c_names, tgt, seqs, len(pa), 0,
                                pa.ctypes.data_as(C.POINTER(C.c_int64)))
-        rc = self.L.po_run_clusters(self.h, arr, len(clusters), C.byref(self.opts), int(self.threads))
+        return arr, len(clusters), keep
+
+    def run_prepared(self, prepared):
+        arr, n, keep = prepared
+        rc = self.L.po_run_clusters(self.h, arr, n, C.byref(self.opts), int(self.threads))
         if rc != 0:
             raise RuntimeError("oracle failed")
         del keep

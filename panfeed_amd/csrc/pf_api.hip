@@ -851,4 +851,24 @@ int pf_export_patterns(pf_ctx* c, uint64_t* n, const uint8_t** md5, const uint64
     return PF_OK;
 }
 
+int pf_export_patterns_dev(pf_ctx* c, uint64_t cap, void* d_md5, void* d_first_seen, uint64_t* n) {
+    if (!c || !n) return fail(PF_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    const uint64_t m = std::min<uint64_t>(cap, c->n_patterns);
+    if (m) {
+        if (!d_md5 || !d_first_seen) return fail(PF_ERR_ARG, "null destination");
+        HIPCHK(hipMemcpyAsync(d_md5, c->pat_md5.p, (size_t)m * 16, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(d_first_seen, c->pt.first_seen, (size_t)m * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    *n = m;
+    return PF_OK;
+}
+
+int pf_pattern_count(pf_ctx* c, uint64_t* n) {
+    if (!c || !n) return fail(PF_ERR_ARG, "null argument");
+    *n = c->n_patterns;
+    return PF_OK;
+}
+
 }  // extern "C"

@@ -1,0 +1,123 @@
+"""Multi-GPU: gene clusters shard across ranks (one process per GPU, contiguous ranges of the
+processing order); the only cross-rank state of the path is the run-global `patterns` set and its
+first-seen rule (/root/reference/panfeed/panfeed.py:149-150, 179-180, 210-212).
+
+Every rank dedups its own clusters on its GPU; at the end (or per super-batch) the ranks all-gather
+{md5 digest (16 B), first_seen (8 B)} of their patterns over RCCL -- an all-gather, not a ring
+all-reduce: the payload is a set union, and on xGMI it spreads over all seven links -- and each
+rank keeps a pattern row iff its first_seen is the minimum for that digest.  first_seen =
+(global cluster ordinal << 32 | rank inside the cluster) is monotone in the reference's --cores 1
+order, so the surviving rows, sorted by first_seen, are exactly hashes_to_patterns.tsv.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def shard_range(n_clusters, rank, world, weights=None):
+    """contiguous [start, stop) of the processing order for `rank`; balanced by `weights`
+    (k-mer instances per cluster) when given, else by count."""
+    if weights is None:
+        base, rem = divmod(n_clusters, world)
+        start = rank * base + min(rank, rem)
+        return start, start + base + (1 if rank < rem else 0)
+    w = np.asarray(weights, dtype=np.float64)
+    cum = np.concatenate(([0.0], np.cumsum(w)))
+    total = cum[-1]
+    cuts = [int(np.searchsorted(cum, total * r / world, side="left")) for r in range(world + 1)]
+    cuts[0], cuts[-1] = 0, n_clusters
+    for i in range(1, world + 1):
+        cuts[i] = max(cuts[i], cuts[i - 1])
+    return cuts[rank], cuts[rank + 1]
+
+
+def merge_pattern_tensors(md5, first_seen, dist=None):
+    """md5: uint8 [n,16], first_seen: int64 [n] (this rank's patterns, any device).
+    Returns (keep_mask [n] bool: this rank's row is the global first for its digest,
+             n_global: number of distinct digests over all ranks)."""
+    dev = md5.device
+    n = md5.shape[0]
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        world, rank = dist.get_world_size(), dist.get_rank()
+        counts = torch.zeros(world, dtype=torch.int64, device=dev)
+        mine = torch.tensor([n], dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(counts, mine)
+        cl = counts.tolist()
+        nmax = max(max(cl), 1)
+        pay = torch.zeros((nmax, 3), dtype=torch.int64, device=dev)
+        if n:
+            pay[:n, :2] = md5.contiguous().view(torch.int64).view(n, 2)
+            pay[:n, 2] = first_seen
+        allpay = torch.empty((world * nmax, 3), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(allpay, pay)
+        valid = (torch.arange(nmax, device=dev)[None, :] < counts[:, None]).reshape(-1)
+        owner = torch.arange(world, device=dev).repeat_interleave(nmax)[valid]
+        allpay = allpay[valid]
+    else:
+        rank = 0
+        allpay = torch.empty((n, 3), dtype=torch.int64, device=dev)
+        if n:
+            allpay[:, :2] = md5.contiguous().view(torch.int64).view(n, 2)
+            allpay[:, 2] = first_seen
+        owner = torch.zeros(n, dtype=torch.int64, device=dev)
+    m = allpay.shape[0]
+    if m == 0:
+        return torch.zeros(0, dtype=torch.bool, device=dev), 0
+    # lexicographic sort by (digest hi, digest lo): two stable passes
+    order = torch.argsort(allpay[:, 1], stable=True)
+    order = order[torch.argsort(allpay[order, 0], stable=True)]
+    sp = allpay[order]
+    new_group = torch.ones(m, dtype=torch.bool, device=dev)
+    new_group[1:] = (sp[1:, 0] != sp[:-1, 0]) | (sp[1:, 1] != sp[:-1, 1])
+    gid = torch.cumsum(new_group.to(torch.int64), 0) - 1
+    n_global = int(gid[-1].item()) + 1
+    gmin = torch.full((n_global,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=dev)
+    gmin.scatter_reduce_(0, gid, sp[:, 2], reduce="amin")
+    is_first = sp[:, 2] == gmin[gid]
+    # map back to this rank's rows (they sit at the start of its all-gather slot, in order)
+    mine_sorted = owner[order] == rank
+    keep = torch.zeros(n, dtype=torch.bool, device=dev)
+    if n:
+        # position of each of my rows inside my slot = index among my rows in gathered order
+        my_pos = torch.cumsum((owner == rank).to(torch.int64), 0) - 1
+        keep[my_pos[order][mine_sorted]] = is_first[mine_sorted]
+    return keep, n_global
+
+
+def export_patterns(engine, device):
+    """(md5 uint8 [n,16], first_seen int64 [n]) of the engine's pattern pool as torch tensors."""
+    L = engine.L
+    if device.type == "cuda":
+        n = int(engine_n_patterns(engine))
+        md5 = torch.empty((max(n, 1), 16), dtype=torch.uint8, device=device)
+        fs = torch.empty(max(n, 1), dtype=torch.int64, device=device)
+        got = C.c_uint64()
+        _lib.check(L.pf_export_patterns_dev(engine.ctx, n, C.c_void_p(md5.data_ptr()), C.c_void_p(fs.data_ptr()),
+                                            C.byref(got)))
+        return md5[:n], fs[:n]
+    n = C.c_uint64()
+    p_md5 = C.POINTER(C.c_uint8)()
+    p_fs = C.POINTER(C.c_uint64)()
+    _lib.check(L.pf_export_patterns(engine.ctx, C.byref(n), C.byref(p_md5), C.byref(p_fs)))
+    n = n.value
+    if n == 0:
+        return torch.zeros((0, 16), dtype=torch.uint8), torch.zeros(0, dtype=torch.int64)
+    md5 = torch.from_numpy(np.ctypeslib.as_array(p_md5, shape=(n * 16,)).reshape(n, 16).copy())
+    fs = torch.from_numpy(np.ctypeslib.as_array(p_fs, shape=(n,)).astype(np.int64))
+    return md5, fs
+
+
+def engine_n_patterns(engine):
+    n = C.c_uint64()
+    _lib.check(engine.L.pf_pattern_count(engine.ctx, C.byref(n)))
+    return n.value
+
+
+def merge_patterns(engine, dist, device):
+    """All-gather the engine's pattern digests and return the number of run-global unique patterns."""
+    md5, fs = export_patterns(engine, device)
+    _keep, n_global = merge_pattern_tensors(md5, fs, dist)
+    return n_global

@@ -202,16 +202,12 @@ class Engine:
         out.kmers_to_hashes = "".join(kh_parts)
         out.hashes_to_patterns = "".join("".join(x) for x in hp_by_cluster)
         out.kmers_tsv = "".join("".join(x) for x in kt_by_cluster)
-        out.stats = {"instances": int(res.n_instances) + self._slow_instances(hb),
+        out.stats = {"instances": int(hb.n_instances),
                      "device_instances": int(res.n_instances),
                      "unique_kmers": int(res.n_unique), "kept_kmers": int(res.n_kept),
                      "new_patterns": int(res.n_new_patterns), "patterns": int(res.n_patterns)}
         out.timing = self.timing()
         return out
-
-    @staticmethod
-    def _slow_instances(hb):
-        return 0   # slow-path windows are counted inside hb.n_instances; device counter excludes them
 
     def _positional_rows(self, hb, meta, strand):
         """one row per instance for a target strain's sequence (panfeed.py:90-107)"""
