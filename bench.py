@@ -58,7 +58,7 @@ def cpu_baseline(args, threads):
     """the CPU oracle on the first clusters of the same workload, ~10-30 s of CPU work"""
     from oracle import oracle as po
     from panfeed_amd import synth
-    n = args.cpu_clusters or max(8, min(args.clusters, 20 * threads))
+    n = args.cpu_clusters or max(8, min(args.clusters, 80 * threads))   # ~15-25 s at ~5e6 instances/s/thread
     cl = synth.generate(n, args.samples, first=0, flank=args.flank, n_rate=0.0)
     recs = [c.record() for c in cl]
     ninst = sum(c.n_instances(args.k) for c in cl)
@@ -185,7 +185,7 @@ def main():
             "setup_s": {"generate_and_upload": t_gen},
         }
         if world == 1 and not args.no_cpu_baseline:
-            threads = len(os.sched_getaffinity(0))
+            threads = min(len(os.sched_getaffinity(0)), 16)   # a 1-GPU box's CPU share
             out["cpu_baseline"] = cpu_baseline(args, threads)
         print(json.dumps(out), flush=True)
     for d in dbs:

@@ -21,7 +21,7 @@ namespace pf {
 constexpr uint32_t SCAN_THREADS = 1024;
 constexpr uint32_t SCAN_WAVES = SCAN_THREADS / 64;
 constexpr uint32_t LDS_BYTES = 163840;           // 160 KiB, whole CU
-constexpr uint32_t MISC_WORDS = 512;             // counters + chunk offsets (<= 257 chunks + 1)
+constexpr uint32_t MISC_WORDS = 2560;            // counters, chunk offsets, staged segment metadata (10 KiB)
 constexpr uint32_t MAX_CHUNKS = 256;             // 32 samples each -> max_strains <= 8192
 constexpr uint32_t INSERT_SLACK = 2176;          // > 2*SCAN_THREADS: inserts that can land after the limit trips
                                                  // (every wave re-checks the flag before each 64-window unit; a
@@ -185,6 +185,75 @@ __device__ __forceinline__ void table_update(uint64_t* keys, uint32_t* ord, uint
     }
 }
 
+// One 64-window unit of one segment: build forward / reverse-complement keys for this lane's window and
+// fold them into the table.  w0..w2 are the packed words at word index 2u + (lane>>5) of the segment.
+template <int KW, bool CANON>
+__device__ __forceinline__ void scan_unit(uint64_t* keys, uint32_t* ord, uint32_t* bits, uint32_t* misc,
+                                          uint32_t NS, uint32_t ns, uint32_t limit, uint32_t k, uint32_t lane,
+                                          uint32_t part, uint32_t nparts, uint64_t w0, uint64_t w1, uint64_t w2,
+                                          uint32_t u, uint32_t ninst, uint32_t ordb, uint32_t bit, uint32_t soff,
+                                          uint64_t* strand_bits) {
+    const uint32_t pos = (u << 6) + lane;
+    const bool valid = pos < ninst;
+    const uint32_t sh = (lane & 31) << 1;
+    Key<KW> fwd, rc;
+    if (KW == 1) {
+        const uint64_t x = (w0 << sh) | ((w1 >> 1) >> (63 - sh));
+        fwd.w[0] = x >> (64 - 2 * k);
+        rc.w[0] = rev_groups(~x) & ((1ull << (2 * k)) - 1);   // low 2k bits of the reversed complement
+    } else {
+        const uint64_t x0 = (w0 << sh) | ((w1 >> 1) >> (63 - sh));
+        const uint64_t x1 = (w1 << sh) | ((w2 >> 1) >> (63 - sh));
+        // V = top 2k bits of (x0:x1), right aligned in 128 bits, 32 <= k <= 63
+        const uint32_t r = 128 - 2 * k;                       // 2..64
+        uint64_t vhi, vlo;
+        if (r == 64) { vhi = 0; vlo = x0; }
+        else { vhi = x0 >> r; vlo = (x0 << (64 - r)) | (x1 >> r); }
+        // reversed complement of the 128-bit window: its low 2k bits are the k-mer's reverse complement
+        uint64_t chi = rev_groups(~x1), clo = rev_groups(~x0);
+        const uint32_t kb = 2 * k;                             // 64..126
+        chi = kb == 64 ? 0 : (chi & ((1ull << (kb - 64)) - 1));
+        // split the 2k-bit values into two 63-bit words
+        fwd.w[0] = (vhi << 1) | (vlo >> 63); fwd.w[KW - 1] = vlo & 0x7FFFFFFFFFFFFFFFull;
+        rc.w[0] = (chi << 1) | (clo >> 63);  rc.w[KW - 1] = clo & 0x7FFFFFFFFFFFFFFFull;
+    }
+    bool rc_smaller;
+    if (KW == 1) rc_smaller = rc.w[0] < fwd.w[0];
+    else rc_smaller = rc.w[0] < fwd.w[0] || (rc.w[0] == fwd.w[0] && rc.w[KW - 1] < fwd.w[KW - 1]);
+
+    if (CANON) {
+        if (soff != 0xFFFFFFFFu && part == 0) {
+            const uint64_t bal = __ballot(valid && rc_smaller);
+            if (lane == 0) strand_bits[(size_t)soff + u] = bal;
+        }
+        Key<KW> key = rc_smaller ? rc : fwd;          // specseq <= revspecseq -> forward (panfeed.py:70)
+        const uint32_t h = key_hash<KW>(key);
+        const bool mine = nparts == 1 || (((h & 0xFFFFu) * nparts) >> 16) == part;
+        table_update<KW>(keys, ord, bits, misc, NS, ns, limit, valid && mine, key, __umulhi(h, ns), ordb + pos, bit);
+    } else {
+        // forward then reverse complement, both inserted (panfeed.py:82-88)
+        uint32_t h = key_hash<KW>(fwd);
+        bool mine = nparts == 1 || (((h & 0xFFFFu) * nparts) >> 16) == part;
+        table_update<KW>(keys, ord, bits, misc, NS, ns, limit, valid && mine, fwd, __umulhi(h, ns),
+                         2 * (ordb + pos), bit);
+        h = key_hash<KW>(rc);
+        mine = nparts == 1 || (((h & 0xFFFFu) * nparts) >> 16) == part;
+        table_update<KW>(keys, ord, bits, misc, NS, ns, limit, valid && mine, rc, __umulhi(h, ns),
+                         2 * (ordb + pos) + 1, bit);
+    }
+}
+
+// misc[] layout (uint32 words)
+constexpr uint32_t M_COUNT = 0, M_OVERFLOW = 1, M_CHUNK = 2;            // chunk offsets: MAX_CHUNKS + 2 words
+constexpr uint32_t SEG_TILE = 256;                                       // segments staged per tile
+constexpr uint32_t M_WOFF = 272;                                         // [2*SEG_TILE] word offset (lo, hi)
+constexpr uint32_t M_NINST = M_WOFF + 2 * SEG_TILE;
+constexpr uint32_t M_ORDB = M_NINST + SEG_TILE;
+constexpr uint32_t M_SAMPLE = M_ORDB + SEG_TILE;
+constexpr uint32_t M_SOFF = M_SAMPLE + SEG_TILE;
+constexpr uint32_t M_UPREF = M_SOFF + SEG_TILE;                          // [SEG_TILE + 1] unit prefix
+static_assert(M_UPREF + SEG_TILE + 1 <= MISC_WORDS, "misc area too small");
+
 template <int KW, bool CANON>
 __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -192,7 +261,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem);          // [KW][NS]
     uint32_t* ord = reinterpret_cast<uint32_t*>(keys + (size_t)KW * NS);
     uint32_t* bits = ord + NS;
-    uint32_t* misc = bits + NS;                                   // [0] count [1] overflow [2..] chunk offsets
+    uint32_t* misc = bits + NS;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t item = p.work[blockIdx.x];
@@ -214,96 +283,117 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
     }
     if (tid < 2) misc[tid] = 0;
     for (uint32_t ch = tid; ch <= nchunks; ch += SCAN_THREADS)
-        misc[2 + ch] = seg_lower_bound(p.seg_sample, seg0, seg1, ch << 5);
+        misc[M_CHUNK + ch] = seg_lower_bound(p.seg_sample, seg0, seg1, ch << 5);
     __syncthreads();
 
     uint32_t mask_word = 0;   // thread t < 8 accumulates chunkmask word t
     bool overflow = false;
+    uint32_t ch = 0;          // current sample chunk (32 columns); its bits[] words are live in LDS
+    bool chunk_dirty = false; // some segment of chunk `ch` has been scanned since the last flush
 
-    for (uint32_t ch = 0; ch < nchunks; ch++) {
-        const uint32_t a = misc[2 + ch], b = misc[3 + ch];
-        if (a == b) continue;                       // no segment in these 32 columns (uniform)
-        uint32_t unit_prefix = 0;
-        for (uint32_t s = a; s < b; s++) {
-            const uint32_t len = p.seg_len[s];
-            const uint32_t ninst = len >= k ? len - k + 1 : 0;
-            const uint32_t nunits = (ninst + 63) >> 6;
-            const uint32_t u0 = (wave + SCAN_WAVES - (unit_prefix & (SCAN_WAVES - 1))) & (SCAN_WAVES - 1);
-            unit_prefix += nunits;
-            if (u0 >= nunits) continue;
-            const uint64_t* wp = p.packed + p.seg_word_off[s];
-            const uint32_t bit = 1u << (p.seg_sample[s] & 31);
-            const uint32_t ordb = p.seg_ord_base[s];
-            const uint32_t soff = (CANON && p.seg_strand_off) ? p.seg_strand_off[s] : 0xFFFFFFFFu;
-            for (uint32_t u = u0; u < nunits; u += SCAN_WAVES) {
-                // table past its limit: stop inserting (the cluster is re-run with more key partitions)
-                if (__hip_atomic_load(&misc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-                const uint32_t pos = (u << 6) + lane;
-                const bool valid = pos < ninst;
-                const uint32_t sh = (lane & 31) << 1;
-                const uint64_t* q = wp + 2 * (size_t)u + (lane >> 5);
-                Key<KW> fwd, rc;
-                if (KW == 1) {
-                    const uint64_t w0 = q[0], w1 = q[1];
-                    const uint64_t x = (w0 << sh) | ((w1 >> 1) >> (63 - sh));
-                    fwd.w[0] = x >> (64 - 2 * k);
-                    rc.w[0] = rev_groups(~x) & ((1ull << (2 * k)) - 1);   // low 2k bits of the reversed complement
-                } else {
-                    const uint64_t w0 = q[0], w1 = q[1], w2 = q[2];
-                    const uint64_t x0 = (w0 << sh) | ((w1 >> 1) >> (63 - sh));
-                    const uint64_t x1 = (w1 << sh) | ((w2 >> 1) >> (63 - sh));
-                    // V = top 2k bits of (x0:x1), right aligned in 128 bits, 32 <= k <= 63
-                    const uint32_t r = 128 - 2 * k;                       // 2..64
-                    uint64_t vhi, vlo;
-                    if (r == 64) { vhi = 0; vlo = x0; }
-                    else { vhi = x0 >> r; vlo = (x0 << (64 - r)) | (x1 >> r); }
-                    // reverse complement of the 128-bit window, then keep its low 2k bits
-                    const uint64_t r0 = rev_groups(~x1), r1 = rev_groups(~x0);   // (r0:r1) = reversed (x0:x1)
-                    // the window's bases sit in the TOP 2k bits of (x0:x1) -> in the LOW 2k bits of (r0:r1)
-                    uint64_t chi = r0, clo = r1;
-                    const uint32_t kb = 2 * k;                             // 64..126
-                    chi = kb == 64 ? 0 : (chi & ((1ull << (kb - 64)) - 1));
-                    // split 126-bit values into two 63-bit words
-                    fwd.w[0] = (vhi << 1) | (vlo >> 63); fwd.w[1] = vlo & 0x7FFFFFFFFFFFFFFFull;
-                    rc.w[0] = (chi << 1) | (clo >> 63);  rc.w[1] = clo & 0x7FFFFFFFFFFFFFFFull;
-                }
-                bool rc_smaller;
-                if (KW == 1) rc_smaller = rc.w[0] < fwd.w[0];
-                else rc_smaller = rc.w[0] < fwd.w[0] || (rc.w[0] == fwd.w[0] && rc.w[1] < fwd.w[1]);
-
-                if (CANON) {
-                    if (soff != 0xFFFFFFFFu && part == 0) {
-                        const uint64_t bal = __ballot(valid && rc_smaller);
-                        if (lane == 0) p.strand_bits[(size_t)soff + u] = bal;
-                    }
-                    Key<KW> key = rc_smaller ? rc : fwd;          // specseq <= revspecseq -> forward (panfeed.py:70)
-                    const uint32_t h = key_hash<KW>(key);
-                    const bool mine = nparts == 1 || (((h & 0xFFFFu) * nparts) >> 16) == part;
-                    table_update<KW>(keys, ord, bits, misc, NS, ns, limit, valid && mine, key,
-                                     __umulhi(h, ns), ordb + pos, bit);
-                } else {
-                    // forward then reverse complement, both inserted (panfeed.py:82-88)
-                    uint32_t h = key_hash<KW>(fwd);
-                    bool mine = nparts == 1 || (((h & 0xFFFFu) * nparts) >> 16) == part;
-                    table_update<KW>(keys, ord, bits, misc, NS, ns, limit, valid && mine, fwd,
-                                     __umulhi(h, ns), 2 * (ordb + pos), bit);
-                    h = key_hash<KW>(rc);
-                    mine = nparts == 1 || (((h & 0xFFFFu) * nparts) >> 16) == part;
-                    table_update<KW>(keys, ord, bits, misc, NS, ns, limit, valid && mine, rc,
-                                     __umulhi(h, ns), 2 * (ordb + pos) + 1, bit);
-                }
-            }
-        }
-        __syncthreads();
-        if (misc[1]) { overflow = true; break; }   // uniform: written before the barrier or not at all
+    // flush the presence words of chunk `ch` (coalesced) and clear them
+    auto flush_chunk = [&]() {
         uint32_t* dst = p.chunkbits + ((size_t)slice * p.W + ch) * NS;
         for (uint32_t i = tid; i < ns; i += SCAN_THREADS) {
             dst[i] = bits[i];
             bits[i] = 0;
         }
         if (tid == (ch >> 5)) mask_word |= 1u << (ch & 31);
+    };
+
+    for (uint32_t t0 = seg0; t0 < seg1 && !overflow; t0 += SEG_TILE) {
+        const uint32_t nseg = min(SEG_TILE, seg1 - t0);
+        // ---- stage this tile's segment metadata (coalesced), then unit prefix by wave 0
+        if (tid < nseg) {
+            const uint32_t s = t0 + tid;
+            const uint32_t len = p.seg_len[s];
+            const uint64_t wo = p.seg_word_off[s];
+            misc[M_WOFF + 2 * tid] = (uint32_t)wo;
+            misc[M_WOFF + 2 * tid + 1] = (uint32_t)(wo >> 32);
+            misc[M_NINST + tid] = len >= k ? len - k + 1 : 0;
+            misc[M_ORDB + tid] = p.seg_ord_base[s];
+            misc[M_SAMPLE + tid] = p.seg_sample[s];
+            misc[M_SOFF + tid] = (CANON && p.seg_strand_off) ? p.seg_strand_off[s] : 0xFFFFFFFFu;
+        }
         __syncthreads();
+        if (wave == 0) {
+            uint32_t v[4], sum = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t i = lane * 4 + j;
+                v[j] = i < nseg ? (misc[M_NINST + i] + 63) >> 6 : 0;
+                sum += v[j];
+            }
+            uint32_t x = sum;
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = __shfl_up(x, d);
+                if ((int)lane >= d) x += y;
+            }
+            uint32_t run = x - sum;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t i = lane * 4 + j;
+                if (i <= nseg) misc[M_UPREF + i] = run;
+                run += v[j];
+            }
+            if (lane == 63) misc[M_UPREF + SEG_TILE] = x;   // total when nseg == SEG_TILE (i == 256 not covered above)
+        }
+        __syncthreads();
+
+        // ---- walk the chunks that intersect this tile
+        uint32_t lo = 0;   // local segment index
+        while (lo < nseg) {
+            const uint32_t smp = misc[M_SAMPLE + lo];
+            const uint32_t want = smp >> 5;
+            if (want != ch) {
+                // a new chunk starts: flush the previous one first
+                if (chunk_dirty) { flush_chunk(); chunk_dirty = false; __syncthreads(); }
+                ch = want;
+            }
+            // local end of this chunk inside the tile: chunk offsets are absolute segment indices
+            const uint32_t cend = misc[M_CHUNK + ch + 1];
+            const uint32_t hi = min(nseg, cend - t0);
+            const uint32_t ubase = misc[M_UPREF + lo], uend = misc[M_UPREF + hi];
+            // ---- this wave's units: ubase + wave, + SCAN_WAVES, ... with the next unit's words prefetched
+            uint32_t g = ubase + wave;
+            if (g < uend) {
+                uint32_t s = lo;
+                while (g >= misc[M_UPREF + s + 1]) s++;
+                const uint64_t* q = p.packed + (((uint64_t)misc[M_WOFF + 2 * s + 1] << 32) | misc[M_WOFF + 2 * s]) +
+                                    2 * (size_t)(g - misc[M_UPREF + s]) + (lane >> 5);
+                uint64_t c0 = q[0], c1 = q[1], c2 = KW == 2 ? q[2] : 0;
+                while (g < uend) {
+                    // the next unit's words are requested before this unit is processed; the load is
+                    // unconditional (it re-reads the current address past the end) so that the compiler can
+                    // keep exactly one load in flight across the table work (s_waitcnt vmcnt(1), not 0)
+                    const uint32_t gn = g + SCAN_WAVES;
+                    uint32_t sn = s;
+                    const uint64_t* qn = q;
+                    if (gn < uend) {
+                        while (gn >= misc[M_UPREF + sn + 1]) sn++;
+                        qn = p.packed + (((uint64_t)misc[M_WOFF + 2 * sn + 1] << 32) | misc[M_WOFF + 2 * sn]) +
+                             2 * (size_t)(gn - misc[M_UPREF + sn]) + (lane >> 5);
+                    }
+                    const uint64_t n0 = qn[0], n1 = qn[1], n2 = KW == 2 ? qn[2] : 0;
+                    // table past its limit: stop inserting (the cluster is re-run with more key partitions)
+                    if (__hip_atomic_load(&misc[M_OVERFLOW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                    scan_unit<KW, CANON>(keys, ord, bits, misc, NS, ns, limit, k, lane, part, nparts, c0, c1, c2,
+                                         g - misc[M_UPREF + s], misc[M_NINST + s], misc[M_ORDB + s],
+                                         1u << (misc[M_SAMPLE + s] & 31), misc[M_SOFF + s], p.strand_bits);
+                    c0 = n0; c1 = n1; c2 = n2;
+                    q = qn;
+                    s = sn;
+                    g = gn;
+                }
+            }
+            chunk_dirty = true;
+            lo = hi;
+            __syncthreads();                       // the chunk part is complete in LDS
+            if (misc[M_OVERFLOW]) { overflow = true; break; }
+        }
+        // the next tile overwrites the staged metadata: everyone is past the barrier above
     }
+    if (!overflow && chunk_dirty) { flush_chunk(); __syncthreads(); }
 
     if (overflow) {
         if (tid == 0) { atomicOr(&p.cluster_overflow[c], 1u); p.item_count[item] = 0; }
@@ -315,10 +405,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
         p.tab_ord[(size_t)slice * NS + i] = ord[i];
     }
     if (tid < 8) p.chunkmask[slice * 8 + tid] = mask_word;
-    if (tid == 0) {
-        p.item_count[item] = misc[0];
-        if (misc[1]) atomicOr(&p.cluster_overflow[c], 1u);   // tripped inside the last chunk
-    }
+    if (tid == 0) p.item_count[item] = misc[M_COUNT];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -369,7 +456,7 @@ struct RowsParams {
 };
 
 constexpr uint32_t ROWS_THREADS = 1024;
-constexpr uint32_t SORT_MAX = 8192;   // >= insert_limit(nslots_max(1)) + slack, power of two
+constexpr uint32_t SORT_MAX = 8192;   // >= insert_limit(nslots_max(1)), power of two
 
 // exclusive scan of one value per thread over the block; returns the exclusive prefix, *total = sum
 __device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t* wave_tot /*[17]*/, uint32_t* total) {
