@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--max-items", type=int, default=2048)
     ap.add_argument("--cpu-clusters", type=int, default=0, help="clusters in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dedup", action="store_true", help="scan every copy of identical sequences (PF_FLAG_NO_DEDUP)")
+    ap.add_argument("--no-every-copy-leg", action="store_true", help="skip the extra scan-every-copy step")
     return ap.parse_args()
 
 
@@ -97,9 +99,9 @@ def main():
     first = rank * args.clusters
     t_gen = time.time()
     eng = Engine(klength=k, max_strains=(S + 31) // 32 * 32, device=local, max_items=args.max_items,
-                 pattern_capacity=1 << 25)
+                 pattern_capacity=1 << 25, dedup=not args.no_dedup)
     # generate + upload in slabs so the host never holds more than a slab of cluster objects
-    slab = 5000
+    slab = 25000
     dbs = []
     for s0 in range(0, args.clusters, slab):
         cl = synth.generate(min(slab, args.clusters - s0), S, first=first + s0, flank=args.flank, n_rate=0.0)
@@ -109,14 +111,20 @@ def main():
     n_inst = sum(d.n_instances for d in dbs)
     packed_bytes = sum(d.packed_bytes for d in dbs)
 
-    def step():
+    def step(eng=eng):
         from panfeed_amd import _lib
         _lib.check(eng.L.pf_reset_patterns(eng.ctx))
-        tot = {"kept": 0, "new": 0, "scan_ms": 0.0, "rows_ms": 0.0, "emit_ms": 0.0, "total_ms": 0.0,
-               "launches": 0, "items": 0, "retried": 0, "unique": 0}
+        tot = {"kept": 0, "new": 0, "scan_ms": 0.0, "rows_ms": 0.0, "emit_ms": 0.0, "total_ms": 0.0, "dedup_ms": 0.0,
+               "patrows_ms": 0.0, "md5_ms": 0.0,
+               "launches": 0, "items": 0, "retried": 0, "unique": 0, "dedup_clusters": 0, "scan_bytes": 0}
         for d in dbs:
-            res = d.submit()
+            res = d.submit(eng)
             tm = eng.timing()
+            tot["dedup_ms"] += tm["dedup_ms"]
+            tot["patrows_ms"] += tm["patrows_ms"]
+            tot["md5_ms"] += tm["md5_ms"]
+            tot["dedup_clusters"] += tm["n_dedup_clusters"]
+            tot["scan_bytes"] += tm["scan_packed_bytes"]
             tot["kept"] += int(res.n_kept)
             tot["new"] += int(res.n_new_patterns)
             tot["unique"] += int(res.n_unique)
@@ -153,11 +161,32 @@ def main():
     dt = float(tmax.item())
     tot_inst, tot_kept, tot_packed = (float(x) for x in agg.tolist())
 
+    # transparency leg (untimed for `value`): the same pass with the identical-sequence shortcut off
+    every = None
+    if world == 1 and not args.no_dedup and not args.no_every_copy_leg:
+        eng2 = Engine(klength=k, max_strains=(S + 31) // 32 * 32, device=local, max_items=args.max_items,
+                      pattern_capacity=1 << 25, dedup=False)
+        torch.cuda.synchronize()
+        t1 = time.time()
+        e = step(eng2)
+        torch.cuda.synchronize()
+        dt1 = time.time() - t1
+        assert (e["kept"], e["new"], e["unique"]) == (last["kept"], last["new"], last["unique"]), "dedup changed the result"
+        every = {"value": n_inst / dt1, "unit": "kmer_instances/s", "ms_per_step": dt1 * 1e3, "scan_ms": e["scan_ms"],
+                 "rows_ms": e["rows_ms"], "emit_ms": e["emit_ms"], "clusters_repartitioned": e["retried"],
+                 "note": "PF_FLAG_NO_DEDUP: every copy of every sequence scanned; same outputs"}
+        eng2.close()
+
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         alg = algorithmic_bytes(packed_bytes, last["kept"], last["new"], S, k)   # this rank, one step
-        scan_s = last["scan_ms"] / 1e3
-        achieved = alg / scan_s / 1e9 if scan_s > 0 else 0.0
+        kern_ms = {"cluster_dedup_kernel": last["dedup_ms"], "kmer_scan_kernel": last["scan_ms"],
+                   "rows_kernel": last["rows_ms"], "emit_kernel": last["emit_ms"],
+                   "pattern_rows_kernel": last["patrows_ms"], "md5_kernel": last["md5_ms"]}
+        dom = max(kern_ms, key=kern_ms.get)
+        dom_launches = {"cluster_dedup_kernel": len(dbs), "md5_kernel": len(dbs)}.get(dom, last["launches"])
+        dom_s = kern_ms[dom] / 1e3
+        achieved = alg / dom_s / 1e9 if dom_s > 0 else 0.0
         out = {
             "metric": "k-mer instances/s (+ unique patterns/s), k=31, 50k clusters x 1k samples",
             "value": tot_inst * args.steps / dt,
@@ -172,16 +201,17 @@ def main():
                        "instances_per_gpu": n_inst, "packed_bytes_per_gpu": packed_bytes,
                        "unique_kmers": last["unique"], "kept_kmers": last["kept"], "patterns": last["global_patterns"],
                        "sharding": f"{world} x contiguous cluster ranges" + (", RCCL all-gather of pattern digests" if world > 1 else "")},
-            "roofline": {"bound": "hbm", "kernel": "kmer_scan_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_step": alg, "kernel_ms_per_step": last["scan_ms"],
-                         "launches_per_step": last["launches"],
-                         "avg_launch_ms": last["scan_ms"] / max(1, last["launches"]),
-                         "note": "algorithmic bytes (SURVEY 8d) of the clusters a launch processes / its duration, "
-                                 "HIP events on the library's stream"},
-            "device_ms_per_step": {"scan": last["scan_ms"], "rows": last["rows_ms"], "emit_patterns_md5": last["emit_ms"],
-                                   "submit_total": last["total_ms"]},
+                         "algorithmic_bytes_per_step": alg, "kernel_ms_per_step": kern_ms[dom],
+                         "launches_per_step": dom_launches,
+                         "avg_launch_ms": kern_ms[dom] / max(1, dom_launches),
+                         "note": "dominant kernel by device time; algorithmic bytes (SURVEY 8d) of the clusters a "
+                                 "launch processes / its duration, HIP events on the library's stream"},
+            "device_ms_per_step": dict(kern_ms, submit_total=last["total_ms"]),
             "work_items": last["items"], "clusters_repartitioned": last["retried"],
+            "clusters_deduplicated": last["dedup_clusters"], "scan_packed_bytes": last["scan_bytes"],
+            "scan_every_copy": every,
             "setup_s": {"generate_and_upload": t_gen},
         }
         if world == 1 and not args.no_cpu_baseline:

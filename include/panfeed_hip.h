@@ -52,8 +52,12 @@ typedef struct {
     const uint32_t* maf_hi;
     uint64_t pattern_capacity; /* slots of the run-global pattern table; 0 = default (2^24) */
     uint32_t max_items;        /* clusters in flight per internal sub-batch; 0 = default */
-    uint32_t reserved;
+    uint32_t flags;            /* PF_FLAG_* */
 } pf_opts;
+
+/* Scan every segment even when a cluster holds identical copies of a sequence (same output, slower:
+   by default only one representative per distinct sequence is scanned). */
+#define PF_FLAG_NO_DEDUP 1u
 
 /*
  * One batch of gene clusters = the records iter_gene_clusters yields
@@ -65,6 +69,7 @@ typedef struct {
  * base in bits 63:62; every segment starts on a 16-byte boundary; the buffer carries 16 bytes
  * of padding after the last segment.
  *
+ * Padding bits inside a segment's last 16 bytes are zero.  cluster_seg_off[0] == 0.
  * Inside a cluster the segments are sorted by seg_sample (stable).  A window starting at base
  * `pos` of a segment is instance number  seg_ord_base + pos  of the cluster in the reference's
  * iteration order (panfeed.py:54-64); in non-canonical mode the forward k-mer is instance
@@ -134,12 +139,16 @@ typedef struct {
     float total_ms;
     float scan_ms;     /* kmer_scan_kernel launches */
     float rows_ms;     /* rows_kernel */
-    float emit_ms;     /* emit_kernel + pattern row/md5 kernels */
+    float emit_ms;     /* cluster_base_kernel + emit_kernel (+ extra_fill_kernel) */
     uint32_t scan_launches;
     uint32_t n_items;  /* (cluster, key-partition) work items scanned, retries included */
     uint32_t n_retried;/* clusters whose table overflowed and were re-run with more partitions */
-    uint32_t reserved;
+    uint32_t n_dedup_clusters; /* clusters scanned through distinct-sequence representatives */
     uint64_t scan_packed_bytes; /* packed sequence bytes the scan kernels were asked to read */
+    float dedup_ms;    /* cluster_dedup_kernel */
+    float patrows_ms;  /* pattern_rows_kernel (emit_ms excludes it) */
+    float md5_ms;      /* md5_kernel (emit_ms excludes it) */
+    float reserved;
 } pf_timing;
 
 const char* pf_last_error(void);

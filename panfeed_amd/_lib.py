@@ -21,7 +21,7 @@ class Opts(C.Structure):
     _fields_ = [("klength", C.c_uint32), ("canon", C.c_uint32), ("consider_missing", C.c_uint32),
                 ("patfilt", C.c_uint32), ("multiple_files", C.c_uint32), ("max_strains", C.c_uint32),
                 ("maf_lo", C.POINTER(C.c_uint32)), ("maf_hi", C.POINTER(C.c_uint32)),
-                ("pattern_capacity", C.c_uint64), ("max_items", C.c_uint32), ("reserved", C.c_uint32)]
+                ("pattern_capacity", C.c_uint64), ("max_items", C.c_uint32), ("flags", C.c_uint32)]
 
 
 class Batch(C.Structure):
@@ -51,7 +51,10 @@ class Result(C.Structure):
 class Timing(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("scan_ms", C.c_float), ("rows_ms", C.c_float), ("emit_ms", C.c_float),
                 ("scan_launches", C.c_uint32), ("n_items", C.c_uint32), ("n_retried", C.c_uint32),
-                ("reserved", C.c_uint32), ("scan_packed_bytes", C.c_uint64)]
+                ("n_dedup_clusters", C.c_uint32), ("scan_packed_bytes", C.c_uint64),
+                ("dedup_ms", C.c_float), ("patrows_ms", C.c_float), ("md5_ms", C.c_float), ("reserved", C.c_float)]
+
+FLAG_NO_DEDUP = 1
 
 
 # every symbol include/panfeed_hip.h declares

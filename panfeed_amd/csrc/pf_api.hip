@@ -97,7 +97,10 @@ struct pf_ctx {
     DevBuf b_packed, b_seg_word_off, b_seg_len, b_seg_sample, b_seg_ord, b_cl_seg_off, b_cl_nstr, b_cl_npres,
         b_cl_presab, b_cl_ordinal, b_extra_ord, b_extra_bits, b_seg_strand_off;
     // per batch device arrays
-    DevBuf cl_ninst, cl_words, cl_overflow, cl_kmer_off, cl_kmer_cnt, cl_unique, cl_pattern, cl_first, cursor;
+    DevBuf cl_ninst, cl_vinst, cl_vwords, cl_overflow, cl_kmer_off, cl_kmer_cnt, cl_unique, cl_pattern, cl_first, cursor;
+    // scan view built by cluster_dedup_kernel
+    DevBuf v_word_off, v_len, v_sample, v_ord, seg_distinct, v_nseg, v_nstr, v_mode, v_dense, extra_off, extra_dense;
+    DevBuf bm_occ, bm_keep, pre_occ, pre_keep, mrows, slot_out, it_is_extra;
     DevBuf strand_bits;
     DevBuf it_cluster, it_part, it_nparts, it_nslots, it_slice, it_sib0, it_nsib, it_extra_first, it_count,
         it_unique, it_kept, work_scan, work_extra, sub_cluster, sub_item0, sub_nitems;
@@ -211,8 +214,9 @@ void pf_destroy(pf_ctx* c) {
                       &c->pat_nan, &c->pat_n, &c->pat_md5, &c->tab_key, &c->tab_ord, &c->chunkbits, &c->chunkmask,
                       &c->slot_hash, &c->sorted_pair, &c->kept_prefix, &c->b_packed, &c->b_seg_word_off, &c->b_seg_len,
                       &c->b_seg_sample, &c->b_seg_ord, &c->b_cl_seg_off, &c->b_cl_nstr, &c->b_cl_npres, &c->b_cl_presab,
-                      &c->b_cl_ordinal, &c->b_extra_ord, &c->b_extra_bits, &c->b_seg_strand_off, &c->cl_ninst,
-                      &c->cl_words, &c->cl_overflow, &c->cl_kmer_off, &c->cl_kmer_cnt, &c->cl_unique, &c->cl_pattern,
+                      &c->b_cl_ordinal, &c->b_extra_ord, &c->b_extra_bits, &c->b_seg_strand_off, &c->cl_ninst, &c->cl_vinst, &c->cl_vwords, &c->v_word_off, &c->v_len, &c->v_sample, &c->v_ord,
+                      &c->seg_distinct, &c->v_nseg, &c->v_nstr, &c->v_mode, &c->v_dense, &c->extra_off, &c->extra_dense,
+                      &c->bm_occ, &c->bm_keep, &c->pre_occ, &c->pre_keep, &c->mrows, &c->slot_out, &c->it_is_extra, &c->cl_overflow, &c->cl_kmer_off, &c->cl_kmer_cnt, &c->cl_unique, &c->cl_pattern,
                       &c->cl_first, &c->cursor, &c->strand_bits, &c->it_cluster, &c->it_part, &c->it_nparts,
                       &c->it_nslots, &c->it_slice, &c->it_sib0, &c->it_nsib, &c->it_extra_first, &c->it_count,
                       &c->it_unique, &c->it_kept, &c->work_scan, &c->work_extra, &c->sub_cluster, &c->sub_item0,
@@ -287,7 +291,10 @@ int pf_create(pf_ctx** out, int device, const pf_opts* o) {
         if (!guard(c->tab_key.ensure(S * NS * 8 * c->KW)) || !guard(c->tab_ord.ensure(S * NS * 4)) ||
             !guard(c->chunkbits.ensure(S * NS * W * 4)) || !guard(c->chunkmask.ensure(S * 8 * 4)) ||
             !guard(c->slot_hash.ensure(S * NS * 16)) || !guard(c->sorted_pair.ensure(S * NS * 8)) ||
-            !guard(c->kept_prefix.ensure(S * (NS + 1) * 4)) || !guard(c->cursor.ensure(64)))
+            !guard(c->kept_prefix.ensure(S * (NS + 1) * 4)) || !guard(c->cursor.ensure(64)) ||
+            !guard(c->bm_occ.ensure(S * pf::DENSE_WORDS * 4)) || !guard(c->bm_keep.ensure(S * pf::DENSE_WORDS * 4)) ||
+            !guard(c->pre_occ.ensure(S * pf::DENSE_WORDS * 4)) || !guard(c->pre_keep.ensure(S * pf::DENSE_WORDS * 4)) ||
+            !guard(c->mrows.ensure(S * pf::DEDUP_MROWS * 4)) || !guard(c->slot_out.ensure(S * NS * 4)))
             break;
         e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { rc = fail(PF_ERR_HIP, "pf_create sync: %s", hipGetErrorString(e)); break; }
@@ -393,6 +400,27 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
     pf_batch d = *b;
     std::vector<uint32_t> h_extra_cluster;
     if (!b->on_device) {
+        // validate what the kernels index with (host copies are at hand)
+        for (uint32_t i = 0; i < C; i++) {
+            if (b->cluster_seg_off[i] > b->cluster_seg_off[i + 1] || b->cluster_seg_off[i + 1] > NSEG)
+                return fail(PF_ERR_ARG, "cluster_seg_off not monotone / out of range at %u", i);
+            if (b->cluster_nstrains[i] > c->o.max_strains || b->cluster_npresab[i] > c->o.max_strains)
+                return fail(PF_ERR_ARG, "cluster %u has more strains than max_strains", i);
+        }
+        if (C && b->cluster_seg_off[0] != 0) return fail(PF_ERR_ARG, "cluster_seg_off[0] must be 0");
+        for (uint32_t s = 0; s < NSEG; s++) {
+            const uint64_t nw = 2ull * ((b->seg_len[s] + 63) / 64);
+            if ((b->seg_word_off[s] & 1) || b->seg_word_off[s] + nw + 2 > b->n_words)
+                return fail(PF_ERR_ARG, "segment %u: misaligned or outside packed[] (needs 2 words of tail padding)", s);
+        }
+        for (uint32_t i = 0; i < C; i++)
+            for (uint32_t s = b->cluster_seg_off[i]; s < b->cluster_seg_off[i + 1]; s++) {
+                if (b->seg_sample[s] >= b->cluster_nstrains[i])
+                    return fail(PF_ERR_ARG, "segment %u: sample column %u >= n_strains %u", s, b->seg_sample[s],
+                                b->cluster_nstrains[i]);
+                if (s > b->cluster_seg_off[i] && b->seg_sample[s] < b->seg_sample[s - 1])
+                    return fail(PF_ERR_ARG, "segments of cluster %u are not sorted by sample", i);
+            }
         PFCHK(upload(c, c->b_packed, b->packed, (size_t)b->n_words, &d.packed));
         PFCHK(upload(c, c->b_seg_word_off, b->seg_word_off, NSEG, &d.seg_word_off));
         PFCHK(upload(c, c->b_seg_len, b->seg_len, NSEG, &d.seg_len));
@@ -407,26 +435,6 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
         PFCHK(upload(c, c->b_extra_bits, b->extra_bits, (size_t)b->n_extra * W, &d.extra_bits));
         if (b->seg_strand_off) PFCHK(upload(c, c->b_seg_strand_off, b->seg_strand_off, NSEG, &d.seg_strand_off));
         if (b->n_extra) h_extra_cluster.assign(b->extra_cluster, b->extra_cluster + b->n_extra);
-        // validate what the kernels index with (host copies are at hand)
-        for (uint32_t i = 0; i < C; i++) {
-            if (b->cluster_seg_off[i] > b->cluster_seg_off[i + 1] || b->cluster_seg_off[i + 1] > NSEG)
-                return fail(PF_ERR_ARG, "cluster_seg_off not monotone / out of range at %u", i);
-            if (b->cluster_nstrains[i] > c->o.max_strains || b->cluster_npresab[i] > c->o.max_strains)
-                return fail(PF_ERR_ARG, "cluster %u has more strains than max_strains", i);
-        }
-        for (uint32_t s = 0; s < NSEG; s++) {
-            const uint64_t nw = 2ull * ((b->seg_len[s] + 63) / 64);
-            if ((b->seg_word_off[s] & 1) || b->seg_word_off[s] + nw + 2 > b->n_words)
-                return fail(PF_ERR_ARG, "segment %u: misaligned or outside packed[] (needs 2 words of tail padding)", s);
-        }
-        for (uint32_t i = 0; i < C; i++)
-            for (uint32_t s = b->cluster_seg_off[i]; s < b->cluster_seg_off[i + 1]; s++) {
-                if (b->seg_sample[s] >= b->cluster_nstrains[i])
-                    return fail(PF_ERR_ARG, "segment %u: sample column %u >= n_strains %u", s, b->seg_sample[s],
-                                b->cluster_nstrains[i]);
-                if (s > b->cluster_seg_off[i] && b->seg_sample[s] < b->seg_sample[s - 1])
-                    return fail(PF_ERR_ARG, "segments of cluster %u are not sorted by sample", i);
-            }
     } else if (b->n_extra) {
         h_extra_cluster.resize(b->n_extra);
         HIPCHK(hipMemcpy(h_extra_cluster.data(), b->extra_cluster, (size_t)b->n_extra * 4, hipMemcpyDeviceToHost));
@@ -435,51 +443,94 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
         if (h_extra_cluster[e] >= C || (e && h_extra_cluster[e] < h_extra_cluster[e - 1]))
             return fail(PF_ERR_ARG, "extra_cluster must be non-decreasing and < n_clusters");
     }
-
-    // ---- per-cluster instance counts
-    PFCHK(c->cl_ninst.ensure((size_t)std::max(C, 1u) * 8));
-    PFCHK(c->cl_words.ensure((size_t)std::max(C, 1u) * 8));
-    std::vector<uint64_t> ninst(C), words(C);
-    if (C) {
-        hipLaunchKernelGGL(pf::cluster_ninst_kernel, dim3((C + 255) / 256), dim3(256), 0, c->stream, d.cluster_seg_off,
-                           d.seg_len, c->o.klength, C, c->cl_ninst.as<uint64_t>(), c->cl_words.as<uint64_t>());
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(ninst.data(), c->cl_ninst.p, (size_t)C * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(words.data(), c->cl_words.p, (size_t)C * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-    }
-    const uint64_t mult = c->o.canon ? 1 : 2;
-    uint64_t total_inst = 0;
-    for (uint32_t i = 0; i < C; i++) {
-        if (ninst[i] * mult >= 0xFFFFFFF0ull) return fail(PF_ERR_ARG, "cluster %u has too many k-mer instances", i);
-        total_inst += ninst[i] * mult;
-    }
+    // extras per cluster (CSR)
+    std::vector<uint32_t> ex_first(C + 1, 0);
+    for (uint32_t e = 0; e < b->n_extra; e++) ex_first[h_extra_cluster[e] + 1]++;
+    for (uint32_t i = 0; i < C; i++) ex_first[i + 1] += ex_first[i];
+    PFCHK(upload_vec(c, c->extra_off, ex_first));
 
     // ---- per batch outputs
-    const size_t C1 = std::max(C, 1u);
+    const size_t C1 = std::max(C, 1u), NSEG1 = std::max(NSEG, 1u), NEX1 = std::max(b->n_extra, 1u);
     PFCHK(c->cl_overflow.ensure(C1 * 4));
     PFCHK(c->cl_kmer_off.ensure(C1 * 8));
     PFCHK(c->cl_kmer_cnt.ensure(C1 * 4));
     PFCHK(c->cl_unique.ensure(C1 * 4));
     PFCHK(c->cl_pattern.ensure(C1 * 4));
     PFCHK(c->cl_first.ensure(C1 * 8));
+    PFCHK(c->cl_ninst.ensure(C1 * 8));
+    PFCHK(c->cl_vinst.ensure(C1 * 8));
+    PFCHK(c->cl_vwords.ensure(C1 * 8));
+    PFCHK(c->v_word_off.ensure(NSEG1 * 8));
+    PFCHK(c->v_len.ensure(NSEG1 * 4));
+    PFCHK(c->v_sample.ensure(NSEG1 * 4));
+    PFCHK(c->v_ord.ensure(NSEG1 * 4));
+    PFCHK(c->seg_distinct.ensure(NSEG1 * 4));
+    PFCHK(c->v_nseg.ensure(C1 * 4));
+    PFCHK(c->v_nstr.ensure(C1 * 4));
+    PFCHK(c->v_mode.ensure(C1 * 4));
+    PFCHK(c->v_dense.ensure(C1 * 4));
+    PFCHK(c->extra_dense.ensure(NEX1 * 4));
     HIPCHK(hipMemsetAsync(c->cl_overflow.p, 0, C1 * 4, c->stream));
     HIPCHK(hipMemsetAsync(c->cl_kmer_cnt.p, 0, C1 * 4, c->stream));
     HIPCHK(hipMemsetAsync(c->cl_unique.p, 0, C1 * 4, c->stream));
     HIPCHK(hipMemsetAsync(c->cl_pattern.p, 0xFF, C1 * 4, c->stream));
     HIPCHK(hipMemsetAsync(c->cursor.p, 0, 64, c->stream));
+
+    // ---- identical segments -> scan view (mode 1) or the caller's list as it is (mode 0)
+    std::vector<uint64_t> ninst(C), vinst(C), words(C);
+    std::vector<uint32_t> h_mode(C);
+    if (C) {
+        pf::DedupParams dp{};
+        dp.packed = d.packed; dp.seg_word_off = d.seg_word_off; dp.seg_len = d.seg_len;
+        dp.seg_sample = d.seg_sample; dp.seg_ord_base = d.seg_ord_base;
+        dp.cluster_seg_off = d.cluster_seg_off; dp.cluster_nstrains = d.cluster_nstrains;
+        dp.extra_off = c->extra_off.as<uint32_t>(); dp.extra_ord = d.extra_ord;
+        dp.v_word_off = c->v_word_off.as<uint64_t>(); dp.v_len = c->v_len.as<uint32_t>();
+        dp.v_sample = c->v_sample.as<uint32_t>(); dp.v_ord = c->v_ord.as<uint32_t>();
+        dp.seg_distinct = c->seg_distinct.as<uint32_t>();
+        dp.v_nseg = c->v_nseg.as<uint32_t>(); dp.v_nstr = c->v_nstr.as<uint32_t>();
+        dp.v_mode = c->v_mode.as<uint32_t>(); dp.v_dense = c->v_dense.as<uint32_t>();
+        dp.extra_dense = c->extra_dense.as<uint32_t>();
+        dp.k = c->o.klength; dp.W = W; dp.canon = c->o.canon;
+        dp.enable = (c->o.flags & PF_FLAG_NO_DEDUP) ? 0u : 1u;
+        PFCHK(mark_begin(c, 3));
+        hipLaunchKernelGGL(pf::cluster_dedup_kernel, dim3(C), dim3(pf::DEDUP_THREADS), 0, c->stream, dp);
+        HIPCHK(hipGetLastError());
+        PFCHK(mark_end(c));
+        hipLaunchKernelGGL(pf::cluster_ninst_kernel, dim3((C + 3) / 4), dim3(256), 0, c->stream, d.cluster_seg_off,
+                           d.seg_len, c->v_len.as<uint32_t>(), c->v_nseg.as<uint32_t>(), c->o.klength, C,
+                           c->cl_ninst.as<uint64_t>(), c->cl_vinst.as<uint64_t>(), c->cl_vwords.as<uint64_t>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(ninst.data(), c->cl_ninst.p, (size_t)C * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(vinst.data(), c->cl_vinst.p, (size_t)C * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(words.data(), c->cl_vwords.p, (size_t)C * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(h_mode.data(), c->v_mode.p, (size_t)C * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    // ---- strand bits of target-strain segments (canonical mode)
     c->n_strand_words = (b->seg_strand_off && c->o.canon) ? b->n_strand_words : 0;
-    if (c->n_strand_words) {
+    if (c->n_strand_words && NSEG) {
         PFCHK(c->strand_bits.ensure((size_t)c->n_strand_words * 8));
         HIPCHK(hipMemsetAsync(c->strand_bits.p, 0, (size_t)c->n_strand_words * 8, c->stream));
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)NSEG + 3) / 4, 4096);
+        if (KW == 1)
+            hipLaunchKernelGGL(pf::strand_bits_kernel<1>, dim3(blocks), dim3(256), 0, c->stream, d.packed, d.seg_word_off,
+                               d.seg_len, d.seg_strand_off, NSEG, c->o.klength, c->strand_bits.as<uint64_t>());
+        else
+            hipLaunchKernelGGL(pf::strand_bits_kernel<2>, dim3(blocks), dim3(256), 0, c->stream, d.packed, d.seg_word_off,
+                               d.seg_len, d.seg_strand_off, NSEG, c->o.klength, c->strand_bits.as<uint64_t>());
+        HIPCHK(hipGetLastError());
     }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const uint64_t mult = c->o.canon ? 1 : 2;
+    uint64_t total_inst = 0;
+    for (uint32_t i = 0; i < C; i++) {
+        if (ninst[i] * mult >= 0xFFFFFFF0ull) return fail(PF_ERR_ARG, "cluster %u has too many k-mer instances", i);
+        total_inst += ninst[i] * mult;
+        c->timing.n_dedup_clusters += h_mode[i];
+    }
+
     c->pid0 = c->n_patterns;
     c->cluster_arena.assign(C, 0);
-
-    // extras per cluster
-    std::vector<uint32_t> ex_first(C + 1, 0);
-    for (uint32_t e = 0; e < b->n_extra; e++) ex_first[h_extra_cluster[e] + 1]++;
-    for (uint32_t i = 0; i < C; i++) ex_first[i + 1] += ex_first[i];
 
     std::vector<uint32_t> todo(C), nparts(C, 1);
     std::iota(todo.begin(), todo.end(), 0u);
@@ -509,7 +560,7 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
             const uint32_t sib0 = (uint32_t)items.size();
             // table size: a cluster that cannot overflow a small table gets one (less flush traffic)
             uint32_t ns = NS;
-            const uint64_t inst = ninst[ci] * mult;
+            const uint64_t inst = vinst[ci] * mult;
             if (np == 1 && NS > 4096 + pf::INSERT_SLACK && inst <= pf::insert_limit(4096)) ns = 4096;
             for (uint32_t q = 0; q < np; q++)
                 items.push_back(Item{ci, q, np, ns, cur.nitems + q, sib0, nit, 0, 0});
@@ -541,11 +592,11 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
         // ---- item arrays
         const size_t NI = items.size();
         std::vector<uint32_t> v_cluster(NI), v_part(NI), v_nparts(NI), v_nslots(NI), v_slice(NI), v_sib0(NI), v_nsib(NI),
-            v_exfirst(NI), w_scan, w_extra;
+            v_exfirst(NI), v_isex(NI), w_scan, w_extra;
         for (size_t i = 0; i < NI; i++) {
             v_cluster[i] = items[i].cluster; v_part[i] = items[i].part; v_nparts[i] = items[i].nparts;
             v_nslots[i] = items[i].nslots; v_slice[i] = items[i].slice; v_sib0[i] = items[i].sib0;
-            v_nsib[i] = items[i].nsib; v_exfirst[i] = items[i].extra_first;
+            v_nsib[i] = items[i].nsib; v_exfirst[i] = items[i].extra_first; v_isex[i] = items[i].is_extra;
         }
         PFCHK(upload_vec(c, c->it_cluster, v_cluster));
         PFCHK(upload_vec(c, c->it_part, v_part));
@@ -555,17 +606,21 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
         PFCHK(upload_vec(c, c->it_sib0, v_sib0));
         PFCHK(upload_vec(c, c->it_nsib, v_nsib));
         PFCHK(upload_vec(c, c->it_extra_first, v_exfirst));
+        PFCHK(upload_vec(c, c->it_is_extra, v_isex));
         PFCHK(upload_vec(c, c->sub_cluster, sub_cluster));
         PFCHK(upload_vec(c, c->sub_item0, sub_item0));
         PFCHK(upload_vec(c, c->sub_nitems, sub_nitems));
         PFCHK(c->it_count.ensure(std::max<size_t>(NI, 1) * 4));
         PFCHK(c->it_unique.ensure(std::max<size_t>(NI, 1) * 4));
         PFCHK(c->it_kept.ensure(std::max<size_t>(NI, 1) * 4));
-        // work lists per sub-batch, concatenated
+        // work lists per sub-batch, concatenated; scan items heaviest first (the grid drains evenly)
         std::vector<uint32_t> scan_off(subs.size() + 1, 0), extra_off(subs.size() + 1, 0);
         for (size_t s = 0; s < subs.size(); s++) {
+            const size_t w0 = w_scan.size();
             for (uint32_t i = subs[s].item0; i < subs[s].item0 + subs[s].nitems; i++)
                 (items[i].is_extra ? w_extra : w_scan).push_back(i);
+            std::stable_sort(w_scan.begin() + w0, w_scan.end(),
+                             [&](uint32_t x, uint32_t y) { return vinst[items[x].cluster] > vinst[items[y].cluster]; });
             scan_off[s + 1] = (uint32_t)w_scan.size();
             extra_off[s + 1] = (uint32_t)w_extra.size();
         }
@@ -582,7 +637,7 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
             const uint32_t n_scan = scan_off[s + 1] - scan_off[s], n_extra_items = extra_off[s + 1] - extra_off[s];
             if (n_extra_items) {
                 pf::ExtraParams ep{};
-                ep.extra_ord = d.extra_ord; ep.extra_bits = d.extra_bits;
+                ep.extra_ord = c->extra_dense.as<uint32_t>(); ep.extra_bits = d.extra_bits;
                 ep.item_first = c->it_extra_first.as<uint32_t>(); ep.item_nslots = c->it_nslots.as<uint32_t>();
                 ep.item_scratch = c->it_slice.as<uint32_t>();
                 ep.tab_key = c->tab_key.as<uint64_t>(); ep.tab_ord = c->tab_ord.as<uint32_t>();
@@ -597,11 +652,10 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
             }
             if (n_scan) {
                 pf::ScanParams sp{};
-                sp.packed = d.packed; sp.seg_word_off = d.seg_word_off; sp.seg_len = d.seg_len;
-                sp.seg_sample = d.seg_sample; sp.seg_ord_base = d.seg_ord_base;
-                sp.cluster_seg_off = d.cluster_seg_off; sp.cluster_nstrains = d.cluster_nstrains;
-                sp.seg_strand_off = c->n_strand_words ? d.seg_strand_off : nullptr;
-                sp.strand_bits = c->n_strand_words ? c->strand_bits.as<uint64_t>() : nullptr;
+                sp.packed = d.packed; sp.seg_word_off = c->v_word_off.as<uint64_t>(); sp.seg_len = c->v_len.as<uint32_t>();
+                sp.seg_sample = c->v_sample.as<uint32_t>(); sp.seg_ord_base = c->v_ord.as<uint32_t>();
+                sp.cluster_seg_off = d.cluster_seg_off; sp.cluster_vnseg = c->v_nseg.as<uint32_t>();
+                sp.cluster_vnstr = c->v_nstr.as<uint32_t>();
                 sp.item_cluster = c->it_cluster.as<uint32_t>(); sp.item_part = c->it_part.as<uint32_t>();
                 sp.item_nparts = c->it_nparts.as<uint32_t>(); sp.item_nslots = c->it_nslots.as<uint32_t>();
                 sp.item_scratch = c->it_slice.as<uint32_t>();
@@ -618,7 +672,11 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
             pf::RowsParams rp{};
             rp.item_cluster = c->it_cluster.as<uint32_t>(); rp.item_nslots = c->it_nslots.as<uint32_t>();
             rp.item_scratch = c->it_slice.as<uint32_t>(); rp.item_count = c->it_count.as<uint32_t>();
+            rp.item_is_extra = c->it_is_extra.as<uint32_t>();
             rp.cluster_overflow = c->cl_overflow.as<uint32_t>();
+            rp.cluster_seg_off = d.cluster_seg_off; rp.seg_sample = d.seg_sample;
+            rp.seg_distinct = c->seg_distinct.as<uint32_t>();
+            rp.v_mode = c->v_mode.as<uint32_t>(); rp.v_nstr = c->v_nstr.as<uint32_t>(); rp.v_dense = c->v_dense.as<uint32_t>();
             rp.cluster_nstrains = d.cluster_nstrains; rp.cluster_npresab = d.cluster_npresab;
             rp.cluster_presab = d.cluster_presab; rp.cluster_ordinal = d.cluster_ordinal;
             rp.maf_lo = c->d_maf_lo.as<uint32_t>(); rp.maf_hi = c->d_maf_hi.as<uint32_t>();
@@ -626,6 +684,9 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
             rp.chunkmask = c->chunkmask.as<uint32_t>();
             rp.slot_hash = c->slot_hash.as<uint4>(); rp.sorted_pair = c->sorted_pair.as<uint64_t>();
             rp.kept_prefix = c->kept_prefix.as<uint32_t>();
+            rp.bm_occ = c->bm_occ.as<uint32_t>(); rp.bm_keep = c->bm_keep.as<uint32_t>();
+            rp.pre_occ = c->pre_occ.as<uint32_t>(); rp.pre_keep = c->pre_keep.as<uint32_t>();
+            rp.mrows = c->mrows.as<uint32_t>();
             rp.item_unique = c->it_unique.as<uint32_t>(); rp.item_kept = c->it_kept.as<uint32_t>();
             rp.item0 = sb.item0; rp.W = W; rp.NS = NS;
             rp.consider_missing = c->o.consider_missing; rp.patfilt = c->o.patfilt; rp.multiple_files = c->o.multiple_files;
@@ -649,28 +710,39 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
 
             pf::EmitParams em{};
             em.item_cluster = c->it_cluster.as<uint32_t>(); em.item_scratch = c->it_slice.as<uint32_t>();
-            em.item_unique = c->it_unique.as<uint32_t>(); em.item_sib0 = c->it_sib0.as<uint32_t>();
+            em.item_unique = c->it_unique.as<uint32_t>(); em.item_nslots = c->it_nslots.as<uint32_t>();
+            em.item_sib0 = c->it_sib0.as<uint32_t>();
             em.item_nsib = c->it_nsib.as<uint32_t>(); em.cluster_overflow = c->cl_overflow.as<uint32_t>();
+            em.v_mode = c->v_mode.as<uint32_t>(); em.v_dense = c->v_dense.as<uint32_t>();
             em.cluster_nstrains = d.cluster_nstrains; em.cluster_npresab = d.cluster_npresab;
             em.cluster_presab = d.cluster_presab; em.cluster_ordinal = d.cluster_ordinal;
             em.cluster_kmer_off = c->cl_kmer_off.as<uint64_t>();
-            em.tab_key = c->tab_key.as<uint64_t>(); em.slot_hash = c->slot_hash.as<uint4>();
+            em.tab_key = c->tab_key.as<uint64_t>(); em.tab_ord = c->tab_ord.as<uint32_t>();
+            em.slot_hash = c->slot_hash.as<uint4>();
             em.sorted_pair = c->sorted_pair.as<uint64_t>(); em.kept_prefix = c->kept_prefix.as<uint32_t>();
+            em.bm_occ = c->bm_occ.as<uint32_t>(); em.bm_keep = c->bm_keep.as<uint32_t>();
+            em.pre_occ = c->pre_occ.as<uint32_t>(); em.pre_keep = c->pre_keep.as<uint32_t>();
+            em.slot_out = c->slot_out.as<uint32_t>();
             em.out_key = ar->key.as<uint64_t>(); em.out_pid = ar->pid.as<uint32_t>(); em.out_first = ar->first.as<uint64_t>();
             em.cluster_pattern = c->cl_pattern.as<uint32_t>(); em.cluster_first = c->cl_first.as<uint64_t>();
             em.pt = c->pt; em.out_base = ar->base; em.out_cap = ar->cap;
             em.item0 = sb.item0; em.W = W; em.NS = NS; em.KW = KW;
             em.consider_missing = c->o.consider_missing; em.multiple_files = c->o.multiple_files;
-            hipLaunchKernelGGL(pf::emit_kernel, dim3(sb.nitems), dim3(256), 0, c->stream, em);
+            hipLaunchKernelGGL(pf::emit_kernel, dim3(sb.nitems), dim3(pf::EMIT_THREADS), 0, c->stream, em);
             HIPCHK(hipGetLastError());
+            PFCHK(mark_end(c));
+            PFCHK(mark_begin(c, 4));
 
             pf::PatRowsParams pr{};
             pr.item_cluster = em.item_cluster; pr.item_scratch = em.item_scratch; pr.item_unique = em.item_unique;
+            pr.item_nslots = em.item_nslots; pr.item_is_extra = c->it_is_extra.as<uint32_t>();
             pr.item_sib0 = em.item_sib0; pr.item_nsib = em.item_nsib; pr.cluster_overflow = em.cluster_overflow;
+            pr.v_mode = em.v_mode; pr.v_nstr = c->v_nstr.as<uint32_t>();
             pr.cluster_nstrains = d.cluster_nstrains; pr.cluster_npresab = d.cluster_npresab;
             pr.cluster_presab = d.cluster_presab; pr.cluster_kmer_off = em.cluster_kmer_off;
             pr.sorted_pair = em.sorted_pair; pr.kept_prefix = em.kept_prefix;
             pr.chunkbits = c->chunkbits.as<uint32_t>(); pr.chunkmask = c->chunkmask.as<uint32_t>();
+            pr.slot_out = c->slot_out.as<uint32_t>(); pr.mrows = c->mrows.as<uint32_t>();
             pr.out_pid = em.out_pid; pr.out_first = em.out_first;
             pr.cluster_pattern = em.cluster_pattern; pr.cluster_first = em.cluster_first;
             pr.pat_first_seen = c->pt.first_seen;
@@ -700,7 +772,7 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
         for (uint32_t ci : todo)
             if (ovf[ci]) {
                 next.push_back(ci);
-                nparts[ci] = nparts[ci] * 4;
+                nparts[ci] = nparts[ci] * 2;
                 if (nparts[ci] > 65536) return fail(PF_ERR_CAPACITY, "cluster %u does not fit 65536 key partitions", ci);
             }
         if (!next.empty()) {
@@ -710,6 +782,7 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
         todo.swap(next);
         pass++;
     }
+    for (size_t a = pass; a < c->arenas.size(); a++) c->arenas[a]->used = 0;   // arenas of an earlier, longer batch
 
     // ---- MD5 of the patterns this batch created
     uint32_t cnt2[2] = {0, 0};
@@ -724,7 +797,7 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
         mp.pat_nan = c->o.consider_missing ? c->pat_nan.as<uint32_t>() : nullptr;
         mp.pat_n = c->pat_n.as<uint32_t>(); mp.pat_md5 = c->pat_md5.as<uint8_t>();
         mp.pid0 = c->pid0; mp.pid1 = pid1; mp.W = W;
-        PFCHK(mark_begin(c, 2));
+        PFCHK(mark_begin(c, 5));
         hipLaunchKernelGGL(pf::md5_kernel, dim3((pid1 - c->pid0 + 255) / 256), dim3(256), 0, c->stream, mp);
         HIPCHK(hipGetLastError());
         PFCHK(mark_end(c));
@@ -742,6 +815,9 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
         HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
         if (e.cat == 0) c->timing.scan_ms += ms;
         else if (e.cat == 1) c->timing.rows_ms += ms;
+        else if (e.cat == 3) c->timing.dedup_ms += ms;
+        else if (e.cat == 4) c->timing.patrows_ms += ms;
+        else if (e.cat == 5) c->timing.md5_ms += ms;
         else c->timing.emit_ms += ms;
     }
 

@@ -1,6 +1,7 @@
 // pf_kernels.h -- HIP kernels of the panfeed hot path for gfx950 (MI355X, wave64, 160 KiB LDS/CU).
 //
 // Pipeline per sub-batch of gene clusters (DESIGN.md has the full picture):
+//   cluster_dedup_kernel  per cluster: identical segments -> one representative per distinct sequence (exact).
 //   kmer_scan_kernel   one 1024-thread workgroup per (cluster, key partition): slides the k window over
 //                      the 2-bit packed segments, canonicalises (panfeed.py:65-75), and groups k-mers in
 //                      an LDS hash table {key, first-occurrence ordinal, 32-sample presence word};
@@ -98,16 +99,18 @@ __device__ __forceinline__ void mm3_final(H128& s, uint32_t len) {
 // ---------------------------------------------------------------------------------------------
 // kmer_scan_kernel
 // ---------------------------------------------------------------------------------------------
+// The scan reads a "view" of each cluster's segments: either the caller's segments as they are
+// (mode 0) or, after cluster_dedup_kernel found identical segments, only one representative per
+// distinct sequence with the distinct index in place of the sample column (mode 1).
 struct ScanParams {
     const uint64_t* packed;
-    const uint64_t* seg_word_off;
-    const uint32_t* seg_len;
-    const uint32_t* seg_sample;
-    const uint32_t* seg_ord_base;
-    const uint32_t* cluster_seg_off;
-    const uint32_t* cluster_nstrains;
-    const uint32_t* seg_strand_off;   // may be null
-    uint64_t* strand_bits;            // may be null
+    const uint64_t* seg_word_off;     // view
+    const uint32_t* seg_len;          // view
+    const uint32_t* seg_sample;       // view: sample column (mode 0) / distinct index (mode 1)
+    const uint32_t* seg_ord_base;     // view: instance ordinal of the segment's first window
+    const uint32_t* cluster_seg_off;  // first view segment of the cluster
+    const uint32_t* cluster_vnseg;    // view segments of the cluster
+    const uint32_t* cluster_vnstr;    // columns of the view (len(cluster) / distinct sequences)
     // per item (item = work[blockIdx.x])
     const uint32_t* item_cluster;     // batch-local cluster index
     const uint32_t* item_part;
@@ -185,22 +188,16 @@ __device__ __forceinline__ void table_update(uint64_t* keys, uint32_t* ord, uint
     }
 }
 
-// One 64-window unit of one segment: build forward / reverse-complement keys for this lane's window and
-// fold them into the table.  w0..w2 are the packed words at word index 2u + (lane>>5) of the segment.
-template <int KW, bool CANON>
-__device__ __forceinline__ void scan_unit(uint64_t* keys, uint32_t* ord, uint32_t* bits, uint32_t* misc,
-                                          uint32_t NS, uint32_t ns, uint32_t limit, uint32_t k, uint32_t lane,
-                                          uint32_t part, uint32_t nparts, uint64_t w0, uint64_t w1, uint64_t w2,
-                                          uint32_t u, uint32_t ninst, uint32_t ordb, uint32_t bit, uint32_t soff,
-                                          uint64_t* strand_bits) {
-    const uint32_t pos = (u << 6) + lane;
-    const bool valid = pos < ninst;
+// forward and reverse-complement key of this lane's window; w0..w2 = packed words at index 2u + (lane>>5)
+template <int KW>
+__device__ __forceinline__ bool window_keys(uint32_t k, uint32_t lane, uint64_t w0, uint64_t w1, uint64_t w2,
+                                            Key<KW>& fwd, Key<KW>& rc) {
     const uint32_t sh = (lane & 31) << 1;
-    Key<KW> fwd, rc;
     if (KW == 1) {
         const uint64_t x = (w0 << sh) | ((w1 >> 1) >> (63 - sh));
         fwd.w[0] = x >> (64 - 2 * k);
         rc.w[0] = rev_groups(~x) & ((1ull << (2 * k)) - 1);   // low 2k bits of the reversed complement
+        return rc.w[0] < fwd.w[0];
     } else {
         const uint64_t x0 = (w0 << sh) | ((w1 >> 1) >> (63 - sh));
         const uint64_t x1 = (w1 << sh) | ((w2 >> 1) >> (63 - sh));
@@ -216,16 +213,21 @@ __device__ __forceinline__ void scan_unit(uint64_t* keys, uint32_t* ord, uint32_
         // split the 2k-bit values into two 63-bit words
         fwd.w[0] = (vhi << 1) | (vlo >> 63); fwd.w[KW - 1] = vlo & 0x7FFFFFFFFFFFFFFFull;
         rc.w[0] = (chi << 1) | (clo >> 63);  rc.w[KW - 1] = clo & 0x7FFFFFFFFFFFFFFFull;
+        return rc.w[0] < fwd.w[0] || (rc.w[0] == fwd.w[0] && rc.w[KW - 1] < fwd.w[KW - 1]);
     }
-    bool rc_smaller;
-    if (KW == 1) rc_smaller = rc.w[0] < fwd.w[0];
-    else rc_smaller = rc.w[0] < fwd.w[0] || (rc.w[0] == fwd.w[0] && rc.w[KW - 1] < fwd.w[KW - 1]);
+}
 
+// One 64-window unit of one segment: fold this lane's window into the table.
+template <int KW, bool CANON>
+__device__ __forceinline__ void scan_unit(uint64_t* keys, uint32_t* ord, uint32_t* bits, uint32_t* misc,
+                                          uint32_t NS, uint32_t ns, uint32_t limit, uint32_t k, uint32_t lane,
+                                          uint32_t part, uint32_t nparts, uint64_t w0, uint64_t w1, uint64_t w2,
+                                          uint32_t u, uint32_t ninst, uint32_t ordb, uint32_t bit) {
+    const uint32_t pos = (u << 6) + lane;
+    const bool valid = pos < ninst;
+    Key<KW> fwd, rc;
+    const bool rc_smaller = window_keys<KW>(k, lane, w0, w1, w2, fwd, rc);
     if (CANON) {
-        if (soff != 0xFFFFFFFFu && part == 0) {
-            const uint64_t bal = __ballot(valid && rc_smaller);
-            if (lane == 0) strand_bits[(size_t)soff + u] = bal;
-        }
         Key<KW> key = rc_smaller ? rc : fwd;          // specseq <= revspecseq -> forward (panfeed.py:70)
         const uint32_t h = key_hash<KW>(key);
         const bool mine = nparts == 1 || (((h & 0xFFFFu) * nparts) >> 16) == part;
@@ -250,8 +252,7 @@ constexpr uint32_t M_WOFF = 272;                                         // [2*S
 constexpr uint32_t M_NINST = M_WOFF + 2 * SEG_TILE;
 constexpr uint32_t M_ORDB = M_NINST + SEG_TILE;
 constexpr uint32_t M_SAMPLE = M_ORDB + SEG_TILE;
-constexpr uint32_t M_SOFF = M_SAMPLE + SEG_TILE;
-constexpr uint32_t M_UPREF = M_SOFF + SEG_TILE;                          // [SEG_TILE + 1] unit prefix
+constexpr uint32_t M_UPREF = M_SAMPLE + SEG_TILE;                        // [SEG_TILE + 1] unit prefix
 static_assert(M_UPREF + SEG_TILE + 1 <= MISC_WORDS, "misc area too small");
 
 template <int KW, bool CANON>
@@ -269,8 +270,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
     const uint32_t part = p.item_part[item], nparts = p.item_nparts[item];
     const uint32_t ns = p.item_nslots[item];
     const uint32_t slice = p.item_scratch[item];
-    const uint32_t seg0 = p.cluster_seg_off[c], seg1 = p.cluster_seg_off[c + 1];
-    const uint32_t nstr = p.cluster_nstrains[c];
+    const uint32_t seg0 = p.cluster_seg_off[c], seg1 = seg0 + p.cluster_vnseg[c];
+    const uint32_t nstr = p.cluster_vnstr[c];
     const uint32_t nchunks = (nstr + 31) >> 5;
     const uint32_t k = p.k;
     const uint32_t limit = insert_limit(ns);
@@ -313,7 +314,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
             misc[M_NINST + tid] = len >= k ? len - k + 1 : 0;
             misc[M_ORDB + tid] = p.seg_ord_base[s];
             misc[M_SAMPLE + tid] = p.seg_sample[s];
-            misc[M_SOFF + tid] = (CANON && p.seg_strand_off) ? p.seg_strand_off[s] : 0xFFFFFFFFu;
         }
         __syncthreads();
         if (wave == 0) {
@@ -336,15 +336,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
                 if (i <= nseg) misc[M_UPREF + i] = run;
                 run += v[j];
             }
-            if (lane == 63) misc[M_UPREF + SEG_TILE] = x;   // total when nseg == SEG_TILE (i == 256 not covered above)
+            if (lane == 63) misc[M_UPREF + SEG_TILE] = x;   // total (index 256 is not covered above)
         }
         __syncthreads();
 
         // ---- walk the chunks that intersect this tile
         uint32_t lo = 0;   // local segment index
         while (lo < nseg) {
-            const uint32_t smp = misc[M_SAMPLE + lo];
-            const uint32_t want = smp >> 5;
+            const uint32_t want = misc[M_SAMPLE + lo] >> 5;
             if (want != ch) {
                 // a new chunk starts: flush the previous one first
                 if (chunk_dirty) { flush_chunk(); chunk_dirty = false; __syncthreads(); }
@@ -353,36 +352,47 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
             // local end of this chunk inside the tile: chunk offsets are absolute segment indices
             const uint32_t cend = misc[M_CHUNK + ch + 1];
             const uint32_t hi = min(nseg, cend - t0);
-            const uint32_t ubase = misc[M_UPREF + lo], uend = misc[M_UPREF + hi];
-            // ---- this wave's units: ubase + wave, + SCAN_WAVES, ... with the next unit's words prefetched
-            uint32_t g = ubase + wave;
-            if (g < uend) {
+            const uint32_t ubase = misc[M_UPREF + lo], utot = misc[M_UPREF + hi] - ubase;
+            // ---- this wave's units: a contiguous share of [ubase, ubase+utot), so that consecutive units
+            // mostly stay inside one segment; the next unit's words are requested before this one is processed
+            const uint32_t q16 = utot / SCAN_WAVES, r16 = utot % SCAN_WAVES;
+            uint32_t g = ubase + wave * q16 + min(wave, r16);
+            const uint32_t gend = g + q16 + (wave < r16 ? 1u : 0u);
+            if (g < gend) {
                 uint32_t s = lo;
                 while (g >= misc[M_UPREF + s + 1]) s++;
+                uint32_t send = misc[M_UPREF + s + 1];      // first unit past segment s
+                uint32_t u = g - misc[M_UPREF + s];
+                uint32_t ninst = misc[M_NINST + s], ordb = misc[M_ORDB + s], bit = 1u << (misc[M_SAMPLE + s] & 31);
                 const uint64_t* q = p.packed + (((uint64_t)misc[M_WOFF + 2 * s + 1] << 32) | misc[M_WOFF + 2 * s]) +
-                                    2 * (size_t)(g - misc[M_UPREF + s]) + (lane >> 5);
+                                    2 * (size_t)u + (lane >> 5);
                 uint64_t c0 = q[0], c1 = q[1], c2 = KW == 2 ? q[2] : 0;
-                while (g < uend) {
-                    // the next unit's words are requested before this unit is processed; the load is
-                    // unconditional (it re-reads the current address past the end) so that the compiler can
-                    // keep exactly one load in flight across the table work (s_waitcnt vmcnt(1), not 0)
-                    const uint32_t gn = g + SCAN_WAVES;
-                    uint32_t sn = s;
+                while (g < gend) {
+                    // unconditional prefetch (re-reads the current address past the end) so that the compiler
+                    // keeps exactly one load in flight across the table work: s_waitcnt vmcnt(1), not 0
+                    const uint32_t gn = g + 1;
                     const uint64_t* qn = q;
-                    if (gn < uend) {
-                        while (gn >= misc[M_UPREF + sn + 1]) sn++;
-                        qn = p.packed + (((uint64_t)misc[M_WOFF + 2 * sn + 1] << 32) | misc[M_WOFF + 2 * sn]) +
-                             2 * (size_t)(gn - misc[M_UPREF + sn]) + (lane >> 5);
+                    uint32_t sn = s, sendn = send, un = u, ninstn = ninst, ordbn = ordb, bitn = bit;
+                    if (gn < gend) {
+                        if (gn < send) { qn = q + 2; un = u + 1; }
+                        else {
+                            sn = s + 1;
+                            while (gn >= misc[M_UPREF + sn + 1]) sn++;
+                            sendn = misc[M_UPREF + sn + 1];
+                            un = gn - misc[M_UPREF + sn];
+                            ninstn = misc[M_NINST + sn]; ordbn = misc[M_ORDB + sn];
+                            bitn = 1u << (misc[M_SAMPLE + sn] & 31);
+                            qn = p.packed + (((uint64_t)misc[M_WOFF + 2 * sn + 1] << 32) | misc[M_WOFF + 2 * sn]) +
+                                 2 * (size_t)un + (lane >> 5);
+                        }
                     }
                     const uint64_t n0 = qn[0], n1 = qn[1], n2 = KW == 2 ? qn[2] : 0;
                     // table past its limit: stop inserting (the cluster is re-run with more key partitions)
                     if (__hip_atomic_load(&misc[M_OVERFLOW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
                     scan_unit<KW, CANON>(keys, ord, bits, misc, NS, ns, limit, k, lane, part, nparts, c0, c1, c2,
-                                         g - misc[M_UPREF + s], misc[M_NINST + s], misc[M_ORDB + s],
-                                         1u << (misc[M_SAMPLE + s] & 31), misc[M_SOFF + s], p.strand_bits);
+                                         u, ninst, ordb, bit);
                     c0 = n0; c1 = n1; c2 = n2;
-                    q = qn;
-                    s = sn;
+                    q = qn; s = sn; send = sendn; u = un; ninst = ninstn; ordb = ordbn; bit = bitn;
                     g = gn;
                 }
             }
@@ -409,10 +419,237 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// strand_bits_kernel: used_strand of panfeed.py:69-75 for the windows of target-strain segments
+// (one wave per flagged segment; bit = 1 when the reverse complement is the canonical k-mer)
+// ---------------------------------------------------------------------------------------------
+template <int KW>
+__global__ __launch_bounds__(256) void strand_bits_kernel(const uint64_t* packed, const uint64_t* seg_word_off,
+                                                          const uint32_t* seg_len, const uint32_t* seg_strand_off,
+                                                          uint32_t n_segs, uint32_t k, uint64_t* strand_bits) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t s = wave; s < n_segs; s += nwaves) {
+        const uint32_t soff = seg_strand_off[s];
+        if (soff == 0xFFFFFFFFu) continue;
+        const uint32_t len = seg_len[s];
+        const uint32_t ninst = len >= k ? len - k + 1 : 0;
+        const uint64_t* wp = packed + seg_word_off[s];
+        for (uint32_t u = 0; u < (ninst + 63) >> 6; u++) {
+            const uint64_t* q = wp + 2 * (size_t)u + (lane >> 5);
+            Key<KW> fwd, rc;
+            const bool rc_smaller = window_keys<KW>(k, lane, q[0], q[1], KW == 2 ? q[2] : 0, fwd, rc);
+            const uint64_t bal = __ballot(((u << 6) + lane) < ninst && rc_smaller);
+            if (lane == 0) strand_bits[(size_t)soff + u] = bal;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// cluster_dedup_kernel: find identical segments inside a cluster (exact: hash, then word compare)
+// ---------------------------------------------------------------------------------------------
+// Samples that carry the same allele contribute the same k-mers at the same relative positions, so
+// only one representative per distinct sequence has to be scanned: the representative is the copy
+// with the lowest instance ordinal (its windows are the first occurrences, panfeed.py:77-79), the
+// scan sets "distinct-sequence" bits instead of sample bits, and rows_kernel expands them through
+// M[d] = set of samples that carry distinct sequence d.  Output is identical to scanning every copy.
+// A cluster stays in mode 0 (scan everything) when dedup does not pay or does not fit.
+constexpr uint32_t DEDUP_MAX_SEGS = 2048;     // segments of a cluster the LDS tables hold
+constexpr uint32_t DEDUP_TAB = 4096;          // hash table slots (power of two, 2x segments)
+constexpr uint32_t DEDUP_MAX_D = 64;          // distinct sequences (two 32-bit presence words)
+constexpr uint32_t DEDUP_MROWS = 4096;        // words of the M matrix: D * ceil4(W) <= this
+constexpr uint32_t DENSE_WORDS = 8192;        // ordinal bitmap words (262144 dense ordinals)
+
+struct DedupParams {
+    const uint64_t* packed; const uint64_t* seg_word_off; const uint32_t* seg_len;
+    const uint32_t* seg_sample; const uint32_t* seg_ord_base;
+    const uint32_t* cluster_seg_off; const uint32_t* cluster_nstrains;
+    const uint32_t* extra_off;        // [C+1] extras per cluster (CSR)
+    const uint32_t* extra_ord;        // [n_extra]
+    uint64_t* v_word_off; uint32_t* v_len; uint32_t* v_sample; uint32_t* v_ord;   // view, [n_segs]
+    uint32_t* seg_distinct;           // [n_segs] distinct index of every original segment (mode 1)
+    uint32_t* v_nseg; uint32_t* v_nstr; uint32_t* v_mode; uint32_t* v_dense;       // [C]
+    uint32_t* extra_dense;            // [n_extra] ordinal of the extra row in the cluster's (dense) numbering
+    uint32_t k, W, canon, enable;
+};
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; x ^= x >> 31;
+    return x;
+}
+
+constexpr uint32_t DEDUP_THREADS = 1024;
+
+__global__ __launch_bounds__(DEDUP_THREADS) void cluster_dedup_kernel(DedupParams p) {
+    __shared__ uint64_t s_hash[DEDUP_MAX_SEGS];
+    __shared__ uint64_t t_key[DEDUP_TAB];
+    __shared__ uint64_t t_val[DEDUP_TAB];      // min over the group of (ord_base << 32 | local index)
+    __shared__ uint32_t s_rep[DEDUP_MAX_SEGS]; // local index of the representative
+    __shared__ uint32_t s_rank[DEDUP_MAX_SEGS];// distinct index of a representative
+    __shared__ uint32_t r_list[DEDUP_MAX_D];   // representatives (local indices), unordered
+    __shared__ uint32_t r_ord0[DEDUP_MAX_D], r_ninst[DEDUP_MAX_D], r_dense[DEDUP_MAX_D];   // by distinct index
+    __shared__ uint32_t sh_bad, sh_nrep, sh_total;
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t c = blockIdx.x;
+    const uint32_t seg0 = p.cluster_seg_off[c], seg1 = p.cluster_seg_off[c + 1];
+    const uint32_t n = seg1 - seg0;
+    const uint32_t ex0 = p.extra_off[c], ex1 = p.extra_off[c + 1];
+    const uint32_t k = p.k;
+    const uint32_t mult = p.canon ? 1u : 2u;
+    const uint32_t Wp = (p.W + 3) & ~3u;
+
+    bool mode1 = p.enable && n >= 4 && n <= DEDUP_MAX_SEGS;
+    if (tid == 0) { sh_bad = 0; sh_nrep = 0; sh_total = 0; }
+    if (mode1) {
+        for (uint32_t i = tid; i < DEDUP_TAB; i += DEDUP_THREADS) { t_key[i] = EMPTY64; t_val[i] = EMPTY64; }
+    }
+    __syncthreads();
+    if (mode1) {
+        // ---- 1. 64-bit content hash per segment: 16 lanes per segment, 16 bytes per lane and step
+        const uint32_t grp = tid >> 4, gl = tid & 15, ngrp = DEDUP_THREADS >> 4;
+        for (uint32_t s = grp; s < n; s += 2 * ngrp) {
+            // two segments per group and step: their loads are issued together (more bytes in flight)
+            const uint32_t s2 = s + ngrp;
+            const bool has2 = s2 < n;
+            const uint32_t lenA = p.seg_len[seg0 + s], lenB = has2 ? p.seg_len[seg0 + s2] : 0;
+            const ulonglong2* wa = reinterpret_cast<const ulonglong2*>(p.packed + p.seg_word_off[seg0 + s]);
+            const ulonglong2* wb = reinterpret_cast<const ulonglong2*>(p.packed + p.seg_word_off[seg0 + (has2 ? s2 : s)]);
+            const uint32_t pa = (lenA + 63) >> 6, pb = (lenB + 63) >> 6;
+            uint64_t accA = 0, accB = 0;
+            for (uint32_t j = gl; j < max(pa, pb); j += 16) {
+                ulonglong2 va = make_ulonglong2(0, 0), vb = make_ulonglong2(0, 0);
+                if (j < pa) va = wa[j];
+                if (j < pb) vb = wb[j];
+                if (j < pa) accA += mix64(va.x + 0x9E3779B97F4A7C15ull * (2 * j + 1)) ^ mix64(va.y + 0xC2B2AE3D27D4EB4Full * (2 * j + 2));
+                if (j < pb) accB += mix64(vb.x + 0x9E3779B97F4A7C15ull * (2 * j + 1)) ^ mix64(vb.y + 0xC2B2AE3D27D4EB4Full * (2 * j + 2));
+            }
+            for (int d = 1; d < 16; d <<= 1) { accA += __shfl_xor(accA, d); accB += __shfl_xor(accB, d); }
+            uint64_t hA = mix64(accA ^ ((uint64_t)lenA << 40)), hB = mix64(accB ^ ((uint64_t)lenB << 40));
+            if (hA == EMPTY64) hA = EMPTY64 - 1;
+            if (hB == EMPTY64) hB = EMPTY64 - 1;
+            if (gl == 0) { s_hash[s] = hA; if (has2) s_hash[s2] = hB; }
+        }
+        __syncthreads();
+        // ---- 2. group by hash; the group's representative is the copy with the lowest ordinal
+        for (uint32_t s = tid; s < n; s += DEDUP_THREADS) {
+            const uint64_t h = s_hash[s];
+            uint32_t slot = (uint32_t)h & (DEDUP_TAB - 1);
+            for (;;) {
+                uint64_t cur = __hip_atomic_load(&t_key[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (cur == EMPTY64) {
+                    cur = atomicCAS((unsigned long long*)&t_key[slot], (unsigned long long)EMPTY64, (unsigned long long)h);
+                    if (cur == EMPTY64) cur = h;
+                }
+                if (cur == h) break;
+                slot = (slot + 1) & (DEDUP_TAB - 1);
+            }
+            atomicMin((unsigned long long*)&t_val[slot],
+                      (unsigned long long)(((uint64_t)p.seg_ord_base[seg0 + s] << 32) | s));
+            s_rep[s] = slot;     // table slot for now
+        }
+        __syncthreads();
+        for (uint32_t s = tid; s < n; s += DEDUP_THREADS) s_rep[s] = (uint32_t)t_val[s_rep[s]];
+        __syncthreads();
+        // ---- 3. verify every copy against its representative, word for word
+        for (uint32_t s = grp; s < n; s += ngrp) {
+            const uint32_t r = s_rep[s];
+            if (r == s) continue;
+            const uint32_t len = p.seg_len[seg0 + s];
+            bool diff = len != p.seg_len[seg0 + r];
+            if (!diff) {
+                const ulonglong2* a = reinterpret_cast<const ulonglong2*>(p.packed + p.seg_word_off[seg0 + s]);
+                const ulonglong2* b = reinterpret_cast<const ulonglong2*>(p.packed + p.seg_word_off[seg0 + r]);
+                const uint32_t pieces = (len + 63) >> 6;
+                for (uint32_t j = gl; j < pieces; j += 16) {
+                    const ulonglong2 x = a[j], y = b[j];
+                    diff = diff || x.x != y.x || x.y != y.y;
+                }
+            }
+            if (diff) sh_bad = 1;     // a 64-bit hash collision: give up on this cluster (mode 0), stay exact
+        }
+        __syncthreads();
+        // ---- 4. representatives -> distinct indices in ordinal order
+        for (uint32_t s = tid; s < n; s += DEDUP_THREADS)
+            if (s_rep[s] == s) {
+                const uint32_t at = atomicAdd(&sh_nrep, 1u);
+                if (at < DEDUP_MAX_D) r_list[at] = s;
+            }
+        __syncthreads();
+        const uint32_t D = sh_nrep;
+        mode1 = !sh_bad && D <= DEDUP_MAX_D && D * Wp <= DEDUP_MROWS && 2 * D <= n;
+        if (mode1) {
+            if (tid < D) {
+                const uint32_t s = r_list[tid];
+                const uint32_t o = p.seg_ord_base[seg0 + s];
+                uint32_t rank = 0;
+                for (uint32_t j = 0; j < D; j++) rank += p.seg_ord_base[seg0 + r_list[j]] < o ? 1u : 0u;
+                s_rank[s] = rank;
+                const uint32_t len = p.seg_len[seg0 + s];
+                r_ord0[rank] = o;
+                r_ninst[rank] = len >= k ? len - k + 1 : 0;
+            }
+            __syncthreads();
+            if (tid < D) {
+                // dense ordinal of this representative's first window: scanned instances before it plus the
+                // slow-path rows before it (those never fall inside a segment's ordinal range)
+                uint32_t base = 0;
+                for (uint32_t j = 0; j < tid; j++) base += r_ninst[j];
+                uint32_t xb = 0;
+                const uint32_t o0 = r_ord0[tid] * mult;
+                for (uint32_t e = ex0; e < ex1; e++) xb += p.extra_ord[e] < o0 ? 1u : 0u;
+                r_dense[tid] = base + xb;
+                if (tid == D - 1) sh_total = base + r_ninst[tid];
+            }
+            __syncthreads();
+            const uint64_t dense_bits = ((uint64_t)sh_total + (ex1 - ex0)) * mult;
+            mode1 = dense_bits <= (uint64_t)DENSE_WORDS * 32;
+            if (mode1) {
+                for (uint32_t s = tid; s < n; s += DEDUP_THREADS) p.seg_distinct[seg0 + s] = s_rank[s_rep[s]];
+                if (tid < D) {
+                    const uint32_t s = r_list[tid], d = s_rank[s];
+                    p.v_word_off[seg0 + d] = p.seg_word_off[seg0 + s];
+                    p.v_len[seg0 + d] = p.seg_len[seg0 + s];
+                    p.v_sample[seg0 + d] = d;
+                    p.v_ord[seg0 + d] = r_dense[d];
+                }
+                for (uint32_t e = ex0 + tid; e < ex1; e += DEDUP_THREADS) {
+                    // F(o) = scanned instances below o + slow-path rows below o  (monotone in the reference order)
+                    const uint32_t o = p.extra_ord[e];
+                    const uint32_t oi = o / mult;
+                    uint32_t below = 0;
+                    for (uint32_t d = 0; d < D; d++) {
+                        const uint32_t a = r_ord0[d];
+                        below += oi <= a ? 0u : min(oi - a, r_ninst[d]);
+                    }
+                    uint32_t er = 0;
+                    for (uint32_t f = ex0; f < ex1; f++) er += p.extra_ord[f] < o ? 1u : 0u;
+                    p.extra_dense[e] = (below + er) * mult;
+                }
+                if (tid == 0) {
+                    p.v_nseg[c] = D; p.v_nstr[c] = D; p.v_mode[c] = 1; p.v_dense[c] = (uint32_t)dense_bits;
+                }
+            }
+        }
+    }
+    if (!mode1) {
+        // mode 0: the view is the caller's segment list
+        for (uint32_t s = tid; s < n; s += DEDUP_THREADS) {
+            p.v_word_off[seg0 + s] = p.seg_word_off[seg0 + s];
+            p.v_len[seg0 + s] = p.seg_len[seg0 + s];
+            p.v_sample[seg0 + s] = p.seg_sample[seg0 + s];
+            p.v_ord[seg0 + s] = p.seg_ord_base[seg0 + s];
+        }
+        for (uint32_t e = ex0 + tid; e < ex1; e += DEDUP_THREADS) p.extra_dense[e] = p.extra_ord[e];
+        if (tid == 0) { p.v_nseg[c] = n; p.v_nstr[c] = p.cluster_nstrains[c]; p.v_mode[c] = 0; p.v_dense[c] = 0; }
+    }
+    (void)lane;
+}
+
+// ---------------------------------------------------------------------------------------------
 // slow-path rows -> a prebuilt table in an item's scratch slice (same layout the scan kernel leaves)
 // ---------------------------------------------------------------------------------------------
 struct ExtraParams {
-    const uint32_t* extra_ord;
+    const uint32_t* extra_ord;     // ordinals in the cluster's numbering (cluster_dedup_kernel's extra_dense)
     const uint32_t* extra_bits;    // [n_extra][W]
     const uint32_t* item_first;    // [n] first extra row of the item
     const uint32_t* item_nslots;   // [n] rows of the item
@@ -440,15 +677,22 @@ __global__ void extra_fill_kernel(ExtraParams p) {
 // ---------------------------------------------------------------------------------------------
 struct RowsParams {
     const uint32_t* item_cluster; const uint32_t* item_nslots; const uint32_t* item_scratch;
-    const uint32_t* item_count;
+    const uint32_t* item_count; const uint32_t* item_is_extra;
     const uint32_t* cluster_overflow;
+    const uint32_t* cluster_seg_off;                                   // caller's segments (for M)
+    const uint32_t* seg_sample; const uint32_t* seg_distinct;          // caller's sample column / distinct index
+    const uint32_t* v_mode; const uint32_t* v_nstr; const uint32_t* v_dense;
     const uint32_t* cluster_nstrains; const uint32_t* cluster_npresab; const uint32_t* cluster_presab;
     const uint64_t* cluster_ordinal;
     const uint32_t* maf_lo; const uint32_t* maf_hi;
     const uint32_t* tab_ord; const uint32_t* chunkbits; const uint32_t* chunkmask;
     uint4* slot_hash;        // [slice][NS]
+    // mode 0 (sorted)
     uint64_t* sorted_pair;   // [slice][NS]  ord << 32 | slot, ascending
     uint32_t* kept_prefix;   // [slice][NS+1] exclusive prefix of keep flags in sorted order
+    // mode 1 (ordinal bitmaps)
+    uint32_t* bm_occ; uint32_t* bm_keep; uint32_t* pre_occ; uint32_t* pre_keep;   // [slice][DENSE_WORDS]
+    uint32_t* mrows;         // [slice][DEDUP_MROWS]  M[d][Wp]: samples that carry distinct sequence d
     uint32_t* item_unique;   // [item]
     uint32_t* item_kept;     // [item]
     uint32_t item0, W, NS;
@@ -456,6 +700,7 @@ struct RowsParams {
 };
 
 constexpr uint32_t ROWS_THREADS = 1024;
+constexpr uint32_t AT_SLOTS = 1024, AT_LIMIT = 768;   // distinct allele masks per item held in LDS (mode 1)
 constexpr uint32_t SORT_MAX = 8192;   // >= insert_limit(nslots_max(1)), power of two
 
 // exclusive scan of one value per thread over the block; returns the exclusive prefix, *total = sum
@@ -481,11 +726,14 @@ __device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t* wave_tot 
 }
 
 __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
-    __shared__ uint64_t pairs[SORT_MAX];          // 64 KiB
-    __shared__ uint8_t keepf[16384];              // keep flag per slot (NS <= 10112)
+    // mode 0: pairs u64[8192] | keepf u8[16384]          mode 1: M u32[4096] | occ u32[8192] | keep u32[8192]
+    __shared__ __align__(16) uint32_t rsh[20480];
     __shared__ uint32_t cmask[8];
     __shared__ uint32_t wave_tot[ROWS_THREADS / 64 + 1];
-    __shared__ uint32_t sh_cnt, sh_npres;
+    __shared__ uint32_t sh_cnt, sh_npres, at_count;
+    __shared__ uint64_t at_key[AT_SLOTS];      // mode 1: distinct allele masks of the item
+    __shared__ uint4 at_hash[AT_SLOTS];
+    __shared__ uint32_t at_keep[AT_SLOTS];
 
     const uint32_t tid = threadIdx.x;
     const uint32_t item = p.item0 + blockIdx.x;
@@ -497,10 +745,19 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         return;
     }
     const uint32_t ns = p.item_nslots[item];
-    const uint32_t U = p.item_count[item];
+    const uint32_t mode = p.v_mode[c];
+    const bool expand = mode == 1 && !p.item_is_extra[item];
     const uint32_t nstr = p.cluster_nstrains[c], npres = p.cluster_npresab[c];
     const uint32_t nchunks = (nstr + 31) >> 5;
+    const uint32_t Wp = (W + 3) & ~3u;
     const uint32_t* presab = p.cluster_presab + (size_t)c * W;
+
+    uint64_t* pairs = reinterpret_cast<uint64_t*>(rsh);
+    uint8_t* keepf = reinterpret_cast<uint8_t*>(rsh + 2 * SORT_MAX);
+    uint32_t* M = rsh;
+    uint32_t* occ = rsh + DEDUP_MROWS;
+    uint32_t* keepbm = occ + DENSE_WORDS;
+    const uint32_t dense_words = mode == 1 ? (p.v_dense[c] + 31) >> 5 : 0;
 
     if (tid < 8) cmask[tid] = p.chunkmask[slice * 8 + tid];
     if (tid == 0) {
@@ -509,37 +766,63 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         for (uint32_t w = 0; w < W; w++) np += __popc(presab[w]);
         sh_npres = np;
     }
-    for (uint32_t i = tid; i < SORT_MAX; i += ROWS_THREADS) pairs[i] = EMPTY64;
+    if (mode == 0) {
+        for (uint32_t i = tid; i < SORT_MAX; i += ROWS_THREADS) pairs[i] = EMPTY64;
+    } else {
+        for (uint32_t i = tid; i < DEDUP_MROWS + 2 * DENSE_WORDS; i += ROWS_THREADS) rsh[i] = 0;
+    }
     __syncthreads();
+    if (expand) {
+        // M[d] = samples whose sequence is distinct sequence d, from the caller's segment list
+        const uint32_t s0 = p.cluster_seg_off[c], s1 = p.cluster_seg_off[c + 1];
+        for (uint32_t s = s0 + tid; s < s1; s += ROWS_THREADS) {
+            const uint32_t d = p.seg_distinct[s], smp = p.seg_sample[s];
+            atomicOr(&M[d * Wp + (smp >> 5)], 1u << (smp & 31));
+        }
+        __syncthreads();
+        const uint32_t mw = p.v_nstr[c] * Wp;
+        for (uint32_t i = tid; i < mw; i += ROWS_THREADS) p.mrows[(size_t)slice * DEDUP_MROWS + i] = M[i];
+    }
     const uint32_t npresent = sh_npres;
     // denominators of panfeed.py:191 / :196
     const uint32_t n_eff = p.consider_missing ? npresent : nstr;
     const uint32_t lo = p.maf_lo[n_eff], hi = p.maf_hi[n_eff];
     // tuple(vec) == tuple(clusterpresab) can only hold for equal lengths and a NaN-free vector (panfeed.py:203)
     const bool same_possible = !p.patfilt && nstr == npres && (!p.consider_missing || npresent == nstr);
-    // the NaN mask of the float image is a function of the cluster: fold (n, kind, cluster-specific salt) in
     const uint64_t ordinal = p.cluster_ordinal[c];
 
     const uint32_t* ordp = p.tab_ord + (size_t)slice * NS;
     const uint32_t* cb = p.chunkbits + (size_t)slice * W * NS;
-    for (uint32_t i = tid; i < ns; i += ROWS_THREADS) {
-        const uint32_t o = ordp[i];
-        if (o == NO_ORD) continue;
+    const bool f0 = (cmask[0] & 1) != 0, f1 = (cmask[0] & 2) != 0;
+
+    // presence row of one k-mer -> (128-bit row hash, keep flag).  The row comes either from the chunk words of
+    // slot i, or (mode 1) from the union of the sample sets of the distinct sequences in `amask`.
+    auto row_eval = [&](bool from_mask, uint64_t amask, uint32_t i, uint4& hout) -> bool {
         H128 s;
         s.h1 = 0x9747b28cu ^ nstr; s.h2 = 0x1b873593u; s.h3 = 0xe6546b64u; s.h4 = 0x85ebca6bu;
         if (p.multiple_files) { s.h2 ^= (uint32_t)ordinal; s.h3 ^= (uint32_t)(ordinal >> 32); }
         uint32_t cnt = 0;
         bool eq = true;
         for (uint32_t ch = 0; ch < nchunks; ch += 4) {
-            uint32_t wv[4];
+            uint32_t wv[4] = {0, 0, 0, 0};
+            if (from_mask) {
+                uint64_t t = amask;
+                while (t) {
+                    const uint32_t d = __ffsll((unsigned long long)t) - 1;
+                    t &= t - 1;
+                    const uint4 m = *reinterpret_cast<const uint4*>(&M[d * Wp + ch]);
+                    wv[0] |= m.x; wv[1] |= m.y; wv[2] |= m.z; wv[3] |= m.w;
+                }
+            } else {
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t cc = ch + j;
-                uint32_t w = 0;
-                if (cc < nchunks && ((cmask[cc >> 5] >> (cc & 31)) & 1)) w = cb[(size_t)cc * NS + i];
-                if (cc < nchunks) { cnt += __popc(w); eq = eq && (w == presab[cc]); }
-                wv[j] = w;
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t cc = ch + j;
+                    if (cc < nchunks && ((cmask[cc >> 5] >> (cc & 31)) & 1)) wv[j] = cb[(size_t)cc * NS + i];
+                }
             }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (ch + j < nchunks) { cnt += __popc(wv[j]); eq = eq && (wv[j] == presab[ch + j]); }
             mm3_block(s, wv[0], wv[1], wv[2], wv[3]);
         }
         if (p.consider_missing) {
@@ -554,19 +837,110 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         mm3_final(s, nchunks * 4);
         bool keep = cnt >= lo && cnt <= hi;                 // panfeed.py:197-200 (host-tabulated float64)
         if (same_possible && eq) keep = false;              // panfeed.py:202-204
-        keepf[i] = keep ? 1 : 0;
-        p.slot_hash[(size_t)slice * NS + i] = make_uint4(s.h1, s.h2, s.h3, s.h4);
-        const uint32_t at = atomicAdd(&sh_cnt, 1u);
-        if (at < SORT_MAX) pairs[at] = ((uint64_t)o << 32) | i;
+        hout = make_uint4(s.h1, s.h2, s.h3, s.h4);
+        return keep;
+    };
+
+    if (expand) {
+        // Few distinct sequences -> few distinct masks: evaluate each distinct mask once (LDS table), then
+        // hand the result to every slot that carries it.
+        for (uint32_t t = tid; t < AT_SLOTS; t += ROWS_THREADS) at_key[t] = 0;
+        if (tid == 0) at_count = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < ns; i += ROWS_THREADS) {
+            if (ordp[i] == NO_ORD) continue;
+            const uint64_t amask = (f0 ? (uint64_t)cb[i] : 0) | (f1 ? (uint64_t)cb[(size_t)NS + i] << 32 : 0);
+            if (!amask) continue;
+            uint32_t a = (uint32_t)mix64(amask) & (AT_SLOTS - 1);
+            for (uint32_t probes = 0; probes < AT_SLOTS; probes++) {
+                uint64_t cur = __hip_atomic_load(&at_key[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (cur == 0) {
+                    if (__hip_atomic_load(&at_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= AT_LIMIT) break;
+                    cur = atomicCAS((unsigned long long*)&at_key[a], 0ull, (unsigned long long)amask);
+                    if (cur == 0) { atomicAdd(&at_count, 1u); break; }
+                }
+                if (cur == amask) break;
+                a = (a + 1) & (AT_SLOTS - 1);
+            }
+        }
+        __syncthreads();
+        for (uint32_t t = tid; t < AT_SLOTS; t += ROWS_THREADS) {
+            const uint64_t key = at_key[t];
+            if (!key) continue;
+            uint4 h;
+            const bool keep = row_eval(true, key, 0, h);
+            at_hash[t] = h;
+            at_keep[t] = keep ? 1u : 0u;
+        }
+        __syncthreads();
+    }
+    for (uint32_t i = tid; i < ns; i += ROWS_THREADS) {
+        const uint32_t o = ordp[i];
+        if (o == NO_ORD) continue;
+        uint4 h;
+        bool keep;
+        if (expand) {
+            const uint64_t amask = (f0 ? (uint64_t)cb[i] : 0) | (f1 ? (uint64_t)cb[(size_t)NS + i] << 32 : 0);
+            bool found = false;
+            uint32_t a = (uint32_t)mix64(amask) & (AT_SLOTS - 1);
+            for (uint32_t probes = 0; amask && probes < AT_SLOTS; probes++) {
+                const uint64_t cur = at_key[a];
+                if (cur == 0) break;
+                if (cur == amask) { found = true; break; }
+                a = (a + 1) & (AT_SLOTS - 1);
+            }
+            if (found) { h = at_hash[a]; keep = at_keep[a] != 0; }
+            else keep = row_eval(true, amask, i, h);          // table was full: evaluate this slot on its own
+        } else {
+            keep = row_eval(false, 0, i, h);
+        }
+        p.slot_hash[(size_t)slice * NS + i] = h;
+        if (mode == 0) {
+            keepf[i] = keep ? 1 : 0;
+            const uint32_t at = atomicAdd(&sh_cnt, 1u);
+            if (at < SORT_MAX) pairs[at] = ((uint64_t)o << 32) | i;
+        } else if ((o >> 5) < dense_words) {
+            atomicOr(&occ[o >> 5], 1u << (o & 31));
+            if (keep) atomicOr(&keepbm[o >> 5], 1u << (o & 31));
+        }
     }
     __syncthreads();
-    const uint32_t found = sh_cnt;   // == U unless the table overflowed (then the cluster is skipped anyway)
-    uint32_t M = 64;
-    while (M < found && M < SORT_MAX) M <<= 1;
-    // bitonic sort of pairs[0..M) ascending (EMPTY64 pads sort to the end)
-    for (uint32_t k2 = 2; k2 <= M; k2 <<= 1) {
+
+    if (mode == 1) {
+        // ranks come from the ordinal bitmaps: prefix popcounts per word, stored for emit_kernel
+        constexpr uint32_t PW = DENSE_WORDS / ROWS_THREADS;   // 8 words per thread
+        uint32_t so = 0, sk = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < PW; j++) {
+            const uint32_t w = tid * PW + j;
+            so += __popc(occ[w]);
+            sk += __popc(keepbm[w]);
+        }
+        uint32_t tot_o, tot_k;
+        uint32_t bo = block_exscan(so, wave_tot, &tot_o);
+        uint32_t bk = block_exscan(sk, wave_tot, &tot_k);
+        const size_t gb = (size_t)slice * DENSE_WORDS;
+#pragma unroll
+        for (uint32_t j = 0; j < PW; j++) {
+            const uint32_t w = tid * PW + j;
+            if (w < dense_words) {
+                const uint32_t a = occ[w], b = keepbm[w];
+                p.bm_occ[gb + w] = a; p.bm_keep[gb + w] = b;
+                p.pre_occ[gb + w] = bo; p.pre_keep[gb + w] = bk;
+                bo += __popc(a); bk += __popc(b);
+            }
+        }
+        if (tid == 0) { p.item_unique[item] = tot_o; p.item_kept[item] = tot_k; }
+        return;
+    }
+
+    const uint32_t found = sh_cnt;
+    uint32_t Msz = 64;
+    while (Msz < found && Msz < SORT_MAX) Msz <<= 1;
+    // bitonic sort of pairs[0..Msz) ascending (EMPTY64 pads sort to the end)
+    for (uint32_t k2 = 2; k2 <= Msz; k2 <<= 1) {
         for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = tid; t < (M >> 1); t += ROWS_THREADS) {
+            for (uint32_t t = tid; t < (Msz >> 1); t += ROWS_THREADS) {
                 const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
                 const uint32_t l = i | j;
                 const bool up = (i & k2) == 0;
@@ -603,7 +977,6 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         p.item_unique[item] = n;
         p.item_kept[item] = total;
     }
-    (void)U;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -672,11 +1045,11 @@ struct PatternTable {
     uint32_t pool;         // pattern ids available
 };
 
-__device__ __forceinline__ uint32_t pattern_insert(const PatternTable& t, uint4 h, uint64_t first_seen) {
-    uint64_t lo = ((uint64_t)h.x << 32) | h.y;
+// identity = (lo, hi32) = 96 bits of the 128-bit row hash
+__device__ __forceinline__ uint32_t pattern_insert(const PatternTable& t, uint64_t lo, uint32_t hi32,
+                                                   uint64_t first_seen) {
     if (lo == EMPTY64) lo = EMPTY64 - 1;
-    const uint32_t hi32 = h.z;
-    uint64_t slot = (((uint64_t)h.w << 32) | h.z) & (t.cap - 1);
+    uint64_t slot = (lo ^ ((uint64_t)hi32 * 0x9E3779B97F4A7C15ull)) & (t.cap - 1);
     uint32_t pid = 0xFFFFFFFFu;
     for (uint64_t probes = 0; probes < t.cap; ) {
         uint64_t cur = __hip_atomic_load(&t.lo[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -704,19 +1077,27 @@ __device__ __forceinline__ uint32_t pattern_insert(const PatternTable& t, uint4 
     atomicMin((unsigned long long*)&t.first_seen[pid], (unsigned long long)first_seen);
     return pid;
 }
+__device__ __forceinline__ uint32_t pattern_insert(const PatternTable& t, uint4 h, uint64_t first_seen) {
+    return pattern_insert(t, ((uint64_t)h.x << 32) | h.y, h.z, first_seen);
+}
 
 // ---------------------------------------------------------------------------------------------
 // emit_kernel
 // ---------------------------------------------------------------------------------------------
 struct EmitParams {
     const uint32_t* item_cluster; const uint32_t* item_scratch; const uint32_t* item_unique;
+    const uint32_t* item_nslots;
     const uint32_t* item_sib0;       // [item] first item of the same cluster (absolute)
     const uint32_t* item_nsib;       // [item] items of that cluster
     const uint32_t* cluster_overflow;
+    const uint32_t* v_mode; const uint32_t* v_dense;
     const uint32_t* cluster_nstrains; const uint32_t* cluster_npresab; const uint32_t* cluster_presab;
     const uint64_t* cluster_ordinal;
     const uint64_t* cluster_kmer_off;
-    const uint64_t* tab_key; const uint4* slot_hash; const uint64_t* sorted_pair; const uint32_t* kept_prefix;
+    const uint64_t* tab_key; const uint32_t* tab_ord; const uint4* slot_hash;
+    const uint64_t* sorted_pair; const uint32_t* kept_prefix;                                       // mode 0
+    const uint32_t* bm_occ; const uint32_t* bm_keep; const uint32_t* pre_occ; const uint32_t* pre_keep;   // mode 1
+    uint32_t* slot_out;              // [slice][NS] mode 1: index of the slot's k-mer inside the cluster's output
     uint64_t* out_key; uint32_t* out_pid; uint64_t* out_first;     // out_first: first_seen each k-mer offered
     uint32_t* cluster_pattern; uint64_t* cluster_first;
     PatternTable pt;
@@ -735,7 +1116,19 @@ __device__ __forceinline__ uint32_t pair_lower_bound(const uint64_t* sp, uint32_
     return a;
 }
 
-__global__ __launch_bounds__(256) void emit_kernel(EmitParams p) {
+constexpr uint32_t EMIT_THREADS = 1024;
+constexpr uint32_t LT_SLOTS = 4096;      // per-cluster pattern table in LDS (mode 1)
+constexpr uint32_t LT_LIMIT = 3072;
+
+__global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
+    // mode 1: the cluster's patterns are first deduplicated in LDS so that the run-global table sees one
+    // insert per distinct pattern of the cluster instead of one per k-mer
+    __shared__ uint64_t lt_lo[LT_SLOTS];
+    __shared__ uint64_t lt_hi[LT_SLOTS];
+    __shared__ uint64_t lt_first[LT_SLOTS];
+    __shared__ uint32_t lt_pid[LT_SLOTS];
+    __shared__ uint32_t lt_count;
+
     const uint32_t tid = threadIdx.x;
     const uint32_t item = p.item0 + blockIdx.x;
     const uint32_t c = p.item_cluster[item];
@@ -746,8 +1139,7 @@ __global__ __launch_bounds__(256) void emit_kernel(EmitParams p) {
     const uint32_t sib0 = p.item_sib0[item], nsib = p.item_nsib[item];
     const uint64_t ordinal = p.cluster_ordinal[c];
     const uint64_t obase = p.cluster_kmer_off[c] - p.out_base;
-    const uint64_t* sp = p.sorted_pair + (size_t)slice * NS;
-    const uint32_t* kp = p.kept_prefix + (size_t)slice * (NS + 1);
+    const uint32_t mode = p.v_mode[c];
 
     if (item == sib0 && tid == 0) {
         // the cluster's own row: md5 of the int64 image of clusterpresab (panfeed.py:175-187)
@@ -768,31 +1160,126 @@ __global__ __launch_bounds__(256) void emit_kernel(EmitParams p) {
         p.cluster_first[c] = fs;
     }
 
-    for (uint32_t r = tid; r < U; r += blockDim.x) {
-        const uint32_t kb = kp[r];
-        const bool keep = kp[r + 1] != kb;
-        const uint64_t pr = sp[r];
-        const uint32_t ord = (uint32_t)(pr >> 32), slot = (uint32_t)pr;
-        uint32_t rank = r, kept_before = kb;
-        for (uint32_t q = 0; q < nsib; q++) {
-            const uint32_t it = sib0 + q;
-            if (it == item) continue;
-            const uint32_t sl = p.item_scratch[it];
-            const uint32_t n = p.item_unique[it];
-            const uint32_t lb = pair_lower_bound(p.sorted_pair + (size_t)sl * NS, n, ord);
-            rank += lb;
-            kept_before += p.kept_prefix[(size_t)sl * (NS + 1) + lb];
+    if (mode == 0) {
+        const uint64_t* sp = p.sorted_pair + (size_t)slice * NS;
+        const uint32_t* kp = p.kept_prefix + (size_t)slice * (NS + 1);
+        for (uint32_t r = tid; r < U; r += EMIT_THREADS) {
+            const uint32_t kb = kp[r];
+            const bool keep = kp[r + 1] != kb;
+            const uint64_t pr = sp[r];
+            const uint32_t ord = (uint32_t)(pr >> 32), slot = (uint32_t)pr;
+            uint32_t rank = r, kept_before = kb;
+            for (uint32_t q = 0; q < nsib; q++) {
+                const uint32_t it = sib0 + q;
+                if (it == item) continue;
+                const uint32_t sl = p.item_scratch[it];
+                const uint32_t n = p.item_unique[it];
+                const uint32_t lb = pair_lower_bound(p.sorted_pair + (size_t)sl * NS, n, ord);
+                rank += lb;
+                kept_before += p.kept_prefix[(size_t)sl * (NS + 1) + lb];
+            }
+            if (!keep) continue;
+            const uint64_t fs = (ordinal << 32) | (uint64_t)(rank + 1);
+            const uint4 h = p.slot_hash[(size_t)slice * NS + slot];
+            const uint32_t pid = pattern_insert(p.pt, h, fs);
+            const uint64_t o = obase + kept_before;
+            if (o >= p.out_cap) { p.pt.counters[1] = 2; continue; }   // cannot happen: the arena holds every item's limit
+            p.out_key[o * KW] = p.tab_key[((size_t)slice * KW) * NS + slot];
+            if (KW == 2) p.out_key[o * KW + 1] = p.tab_key[((size_t)slice * KW + 1) * NS + slot];
+            p.out_pid[o] = pid;
+            p.out_first[o] = fs;
         }
-        if (!keep) continue;
-        const uint64_t fs = (ordinal << 32) | (uint64_t)(rank + 1);
-        const uint4 h = p.slot_hash[(size_t)slice * NS + slot];
-        const uint32_t pid = pattern_insert(p.pt, h, fs);
-        const uint64_t o = obase + kept_before;
-        if (o >= p.out_cap) { p.pt.counters[1] = 2; continue; }   // cannot happen: the arena holds every item's limit
-        p.out_key[o * KW] = p.tab_key[((size_t)slice * KW) * NS + slot];
-        if (KW == 2) p.out_key[o * KW + 1] = p.tab_key[((size_t)slice * KW + 1) * NS + slot];
-        p.out_pid[o] = pid;
-        p.out_first[o] = fs;
+        return;
+    }
+
+    // ---------------- mode 1: ranks from the ordinal bitmaps of the cluster's items
+    const uint32_t ns = p.item_nslots[item];
+    const uint32_t dense_words = (p.v_dense[c] + 31) >> 5;
+    const uint32_t* ordp = p.tab_ord + (size_t)slice * NS;
+    const size_t gb = (size_t)slice * DENSE_WORDS;
+    uint32_t* sout = p.slot_out + (size_t)slice * NS;
+    for (uint32_t i = tid; i < LT_SLOTS; i += EMIT_THREADS) { lt_lo[i] = EMPTY64; lt_hi[i] = EMPTY64; lt_first[i] = EMPTY64; }
+    if (tid == 0) lt_count = 0;
+    __syncthreads();
+    // pass 1: rank, output index, cluster-local pattern table
+    for (uint32_t i = tid; i < ns; i += EMIT_THREADS) {
+        const uint32_t o = ordp[i];
+        uint32_t res = 0xFFFFFFFFu;
+        if (o != NO_ORD && (o >> 5) < dense_words) {
+            const uint32_t w = o >> 5, below = (1u << (o & 31)) - 1;
+            if ((p.bm_keep[gb + w] >> (o & 31)) & 1) {
+                uint32_t rank = 0, kept_before = 0;
+                for (uint32_t q = 0; q < nsib; q++) {
+                    const size_t g2 = (size_t)p.item_scratch[sib0 + q] * DENSE_WORDS + w;
+                    rank += p.pre_occ[g2] + __popc(p.bm_occ[g2] & below);
+                    kept_before += p.pre_keep[g2] + __popc(p.bm_keep[g2] & below);
+                }
+                res = kept_before;
+                const uint64_t fs = (ordinal << 32) | (uint64_t)(rank + 1);
+                const uint64_t o_idx = obase + kept_before;
+                if (o_idx < p.out_cap) p.out_first[o_idx] = fs;
+                const uint4 h = p.slot_hash[(size_t)slice * NS + i];
+                uint64_t lo = ((uint64_t)h.x << 32) | h.y, hi = ((uint64_t)h.z << 32) | h.w;
+                if (lo == EMPTY64) lo--;
+                if (hi == EMPTY64) hi--;
+                uint32_t ls = (uint32_t)(lo ^ (hi >> 7)) & (LT_SLOTS - 1);
+                for (uint32_t probes = 0; probes < LT_SLOTS; ) {
+                    uint64_t cur = __hip_atomic_load(&lt_lo[ls], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (cur == EMPTY64) {
+                        if (__hip_atomic_load(&lt_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= LT_LIMIT) break;
+                        cur = atomicCAS((unsigned long long*)&lt_lo[ls], (unsigned long long)EMPTY64, (unsigned long long)lo);
+                        if (cur == EMPTY64) {
+                            __hip_atomic_store(&lt_hi[ls], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            atomicAdd(&lt_count, 1u);
+                            atomicMin((unsigned long long*)&lt_first[ls], (unsigned long long)fs);
+                            break;
+                        }
+                    }
+                    if (cur == lo) {
+                        const uint64_t h2 = __hip_atomic_load(&lt_hi[ls], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (h2 == EMPTY64) continue;          // claimed, not yet published: look again
+                        if (h2 == hi) { atomicMin((unsigned long long*)&lt_first[ls], (unsigned long long)fs); break; }
+                    }
+                    ls = (ls + 1) & (LT_SLOTS - 1);
+                    probes++;
+                }
+            }
+        }
+        sout[i] = res;
+    }
+    __syncthreads();
+    // pass 2: one insert into the run-global table per distinct pattern of this item
+    for (uint32_t t = tid; t < LT_SLOTS; t += EMIT_THREADS) {
+        const uint64_t lo = lt_lo[t];
+        if (lo == EMPTY64) continue;
+        const uint64_t hi = lt_hi[t];
+        lt_pid[t] = pattern_insert(p.pt, lo, (uint32_t)(hi >> 32), lt_first[t]);
+    }
+    __syncthreads();
+    // pass 3: pattern id per kept k-mer, outputs
+    for (uint32_t i = tid; i < ns; i += EMIT_THREADS) {
+        const uint32_t kb = sout[i];
+        if (kb == 0xFFFFFFFFu) continue;
+        const uint64_t o_idx = obase + kb;
+        if (o_idx >= p.out_cap) { p.pt.counters[1] = 2; continue; }
+        const uint4 h = p.slot_hash[(size_t)slice * NS + i];
+        uint64_t lo = ((uint64_t)h.x << 32) | h.y, hi = ((uint64_t)h.z << 32) | h.w;
+        if (lo == EMPTY64) lo--;
+        if (hi == EMPTY64) hi--;
+        uint32_t ls = (uint32_t)(lo ^ (hi >> 7)) & (LT_SLOTS - 1);
+        uint32_t pid = 0xFFFFFFFFu;
+        bool found = false;
+        for (uint32_t probes = 0; probes < LT_SLOTS; probes++) {
+            const uint64_t cur = lt_lo[ls];
+            if (cur == EMPTY64) break;
+            if (cur == lo && lt_hi[ls] == hi) { pid = lt_pid[ls]; found = true; break; }
+            ls = (ls + 1) & (LT_SLOTS - 1);
+        }
+        // not in the local table (it was full): straight to the run-global table
+        if (!found) pid = pattern_insert(p.pt, lo, (uint32_t)(hi >> 32), p.out_first[o_idx]);
+        p.out_key[o_idx * KW] = p.tab_key[((size_t)slice * KW) * NS + i];
+        if (KW == 2) p.out_key[o_idx * KW + 1] = p.tab_key[((size_t)slice * KW + 1) * NS + i];
+        p.out_pid[o_idx] = pid;
     }
 }
 
@@ -801,11 +1288,14 @@ __global__ __launch_bounds__(256) void emit_kernel(EmitParams p) {
 // ---------------------------------------------------------------------------------------------
 struct PatRowsParams {
     const uint32_t* item_cluster; const uint32_t* item_scratch; const uint32_t* item_unique;
+    const uint32_t* item_nslots; const uint32_t* item_is_extra;
     const uint32_t* item_sib0; const uint32_t* item_nsib;
     const uint32_t* cluster_overflow;
+    const uint32_t* v_mode; const uint32_t* v_nstr;
     const uint32_t* cluster_nstrains; const uint32_t* cluster_npresab; const uint32_t* cluster_presab;
     const uint64_t* cluster_kmer_off;
     const uint64_t* sorted_pair; const uint32_t* kept_prefix; const uint32_t* chunkbits; const uint32_t* chunkmask;
+    const uint32_t* slot_out; const uint32_t* mrows;
     const uint32_t* out_pid; const uint64_t* out_first;
     const uint32_t* cluster_pattern; const uint64_t* cluster_first;
     const uint64_t* pat_first_seen;
@@ -815,8 +1305,16 @@ struct PatRowsParams {
     uint32_t item0, W, NS;
     uint32_t consider_missing;
 };
+constexpr uint32_t PR_LIST = 2048;   // winners collected per round
+
 __global__ __launch_bounds__(256) void pattern_rows_kernel(PatRowsParams p) {
-    const uint32_t tid = threadIdx.x;
+    // phase 1: every thread looks for k-mers whose first_seen won their pattern and appends (slot, pid) to an
+    // LDS list; phase 2: one wave per list entry builds the row with its lanes spread over the words.
+    __shared__ uint32_t l_slot[PR_LIST];
+    __shared__ uint32_t l_pid[PR_LIST];
+    __shared__ uint32_t l_count;
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const uint32_t item = p.item0 + blockIdx.x;
     const uint32_t c = p.item_cluster[item];
     if (p.cluster_overflow[c]) return;
@@ -828,10 +1326,16 @@ __global__ __launch_bounds__(256) void pattern_rows_kernel(PatRowsParams p) {
     const uint32_t nchunks = (nstr + 31) >> 5;
     const uint32_t* presab = p.cluster_presab + (size_t)c * W;
     const uint64_t obase = p.cluster_kmer_off[c] - p.out_base;
-    const uint64_t* sp = p.sorted_pair + (size_t)slice * NS;
-    const uint32_t* kp = p.kept_prefix + (size_t)slice * (NS + 1);
     const uint32_t* cb = p.chunkbits + (size_t)slice * W * NS;
     const uint32_t* cm = p.chunkmask + slice * 8;
+    const uint32_t mode = p.v_mode[c];
+    const uint32_t ns = p.item_nslots[item];
+    const bool expand = mode == 1 && !p.item_is_extra[item];
+    const uint32_t Wp = (W + 3) & ~3u;
+    const uint32_t* M = p.mrows + (size_t)slice * DEDUP_MROWS;
+    const uint32_t* sout = p.slot_out + (size_t)slice * NS;
+    const uint64_t* sp = p.sorted_pair + (size_t)slice * NS;
+    const uint32_t* kp = p.kept_prefix + (size_t)slice * (NS + 1);
 
     if (item == sib0 && tid == 0) {
         const uint32_t pid = p.cluster_pattern[c];
@@ -844,38 +1348,87 @@ __global__ __launch_bounds__(256) void pattern_rows_kernel(PatRowsParams p) {
             p.pat_n[pid] = npres | 0x80000000u;
         }
     }
-    for (uint32_t r = tid; r < U; r += blockDim.x) {
-        const uint32_t kb = kp[r];
-        if (kp[r + 1] == kb) continue;
-        const uint64_t pr = sp[r];
-        const uint32_t ord = (uint32_t)(pr >> 32), slot = (uint32_t)pr;
-        uint32_t kept_before = kb;
-        for (uint32_t q = 0; q < nsib; q++) {
-            const uint32_t it = sib0 + q;
-            if (it == item) continue;
-            const uint32_t sl = p.item_scratch[it];
-            const uint32_t lb = pair_lower_bound(p.sorted_pair + (size_t)sl * NS, p.item_unique[it], ord);
-            kept_before += p.kept_prefix[(size_t)sl * (NS + 1) + lb];
+    auto nan_word = [&](uint32_t w) -> uint32_t {
+        uint32_t nn = 0;
+        if (p.consider_missing && w < nchunks) {
+            nn = ~presab[w];
+            const uint32_t rem = nstr - (w << 5);
+            if (rem < 32) nn &= (1u << rem) - 1;
         }
-        const uint64_t o = obase + kept_before;
-        if (o >= p.out_cap) continue;
-        const uint32_t pid = p.out_pid[o];
-        if (pid >= p.pool || p.pat_first_seen[pid] != p.out_first[o]) continue;
-        for (uint32_t w = 0; w < W; w++) {
-            uint32_t v = 0;
-            if (w < nchunks && ((cm[w >> 5] >> (w & 31)) & 1)) v = cb[(size_t)w * NS + slot];
-            p.pat_bits[(size_t)pid * W + w] = v;
-            if (p.pat_nan) {
-                uint32_t nn = 0;
-                if (p.consider_missing && w < nchunks) {
-                    nn = ~presab[w];
-                    const uint32_t rem = nstr - (w << 5);
-                    if (rem < 32) nn &= (1u << rem) - 1;
+        return nn;
+    };
+    const uint32_t total = mode == 0 ? U : ns;
+    const uint32_t stride = blockDim.x;
+    const uint32_t rounds_total = (total + stride - 1) / stride;
+    uint32_t round = 0;
+    while (round < rounds_total) {          // uniform: every thread walks the same number of rounds
+        if (tid == 0) l_count = 0;
+        __syncthreads();
+        // PR_LIST / stride rounds fit the list even if every thread appends in every round
+        for (uint32_t r8 = 0; r8 < PR_LIST / 256 && round < rounds_total; r8++, round++) {
+            const uint32_t i = round * stride + tid;
+            uint32_t slot = 0xFFFFFFFFu, kept_before = 0;
+            if (i < total) {
+                if (mode == 0) {
+                    const uint32_t kb = kp[i];
+                    if (kp[i + 1] != kb) {
+                        const uint64_t pr = sp[i];
+                        const uint32_t ord = (uint32_t)(pr >> 32);
+                        slot = (uint32_t)pr;
+                        kept_before = kb;
+                        for (uint32_t q = 0; q < nsib; q++) {
+                            const uint32_t it = sib0 + q;
+                            if (it == item) continue;
+                            const uint32_t sl = p.item_scratch[it];
+                            const uint32_t lb = pair_lower_bound(p.sorted_pair + (size_t)sl * NS, p.item_unique[it], ord);
+                            kept_before += p.kept_prefix[(size_t)sl * (NS + 1) + lb];
+                        }
+                    }
+                } else {
+                    const uint32_t kb = sout[i];
+                    if (kb != 0xFFFFFFFFu) { slot = i; kept_before = kb; }
                 }
-                p.pat_nan[(size_t)pid * W + w] = nn;
+            }
+            if (slot != 0xFFFFFFFFu) {
+                const uint64_t o = obase + kept_before;
+                if (o < p.out_cap) {
+                    const uint32_t pid = p.out_pid[o];
+                    if (pid < p.pool && p.pat_first_seen[pid] == p.out_first[o]) {
+                        const uint32_t at = atomicAdd(&l_count, 1u);
+                        if (at < PR_LIST) { l_slot[at] = slot; l_pid[at] = pid; }
+                    }
+                }
             }
         }
-        p.pat_n[pid] = nstr;
+        __syncthreads();
+        const uint32_t cnt = min(l_count, PR_LIST);
+        for (uint32_t e = wave; e < cnt; e += nwaves) {
+            const uint32_t slot = l_slot[e], pid = l_pid[e];
+            uint64_t amask = 0;
+            if (expand) {
+                const bool f0 = (cm[0] & 1) != 0, f1 = (cm[0] & 2) != 0;
+                amask = (f0 ? (uint64_t)cb[slot] : 0) | (f1 ? (uint64_t)cb[(size_t)NS + slot] << 32 : 0);
+            }
+            for (uint32_t w = lane; w < W; w += 64) {
+                uint32_t v = 0;
+                if (w < nchunks) {
+                    if (expand) {
+                        uint64_t t = amask;
+                        while (t) {
+                            const uint32_t d = __ffsll((unsigned long long)t) - 1;
+                            t &= t - 1;
+                            v |= M[d * Wp + w];
+                        }
+                    } else if ((cm[w >> 5] >> (w & 31)) & 1) {
+                        v = cb[(size_t)w * NS + slot];
+                    }
+                }
+                p.pat_bits[(size_t)pid * W + w] = v;
+                if (p.pat_nan) p.pat_nan[(size_t)pid * W + w] = nan_word(w);
+            }
+            if (lane == 0) p.pat_n[pid] = nstr;
+        }
+        __syncthreads();
     }
 }
 
@@ -990,19 +1543,30 @@ __global__ __launch_bounds__(256) void md5_kernel(Md5Params p) {
 // ---------------------------------------------------------------------------------------------
 // misc kernels
 // ---------------------------------------------------------------------------------------------
-// per-cluster instance counts (trip count of panfeed.py:64)
-__global__ void cluster_ninst_kernel(const uint32_t* cluster_seg_off, const uint32_t* seg_len, uint32_t k,
-                                     uint32_t n_clusters, uint64_t* cluster_ninst, uint64_t* cluster_words) {
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+// per-cluster instance counts: the trip count of panfeed.py:64 over the caller's segments, and the
+// instances / packed words the scan will actually visit (the view); one wave per cluster
+__global__ __launch_bounds__(256) void cluster_ninst_kernel(const uint32_t* cluster_seg_off, const uint32_t* seg_len,
+                                                            const uint32_t* v_len, const uint32_t* v_nseg, uint32_t k,
+                                                            uint32_t n_clusters, uint64_t* cluster_ninst,
+                                                            uint64_t* cluster_vinst, uint64_t* cluster_vwords) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (c >= n_clusters) return;
-    uint64_t n = 0, w = 0;
-    for (uint32_t s = cluster_seg_off[c]; s < cluster_seg_off[c + 1]; s++) {
+    const uint32_t s0 = cluster_seg_off[c], s1 = cluster_seg_off[c + 1], sv = s0 + v_nseg[c];
+    uint64_t n = 0, nv = 0, wv = 0;
+    for (uint32_t s = s0 + lane; s < s1; s += 64) {
         const uint32_t len = seg_len[s];
         if (len >= k) n += len - k + 1;
-        w += 2 * (uint64_t)((len + 63) >> 6);
     }
-    cluster_ninst[c] = n;
-    cluster_words[c] = w;
+    for (uint32_t s = s0 + lane; s < sv; s += 64) {
+        const uint32_t len = v_len[s];
+        if (len >= k) nv += len - k + 1;
+        wv += 2 * (uint64_t)((len + 63) >> 6);
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        n += __shfl_down(n, d); nv += __shfl_down(nv, d); wv += __shfl_down(wv, d);
+    }
+    if (lane == 0) { cluster_ninst[c] = n; cluster_vinst[c] = nv; cluster_vwords[c] = wv; }
 }
 
 __global__ void fill_u64_kernel(uint64_t* p, uint64_t v, uint64_t n) {

@@ -47,9 +47,11 @@ class DeviceBatch:
         _lib.check(self.L.pf_dev_download(self.engine.ctx, out.ctypes.data_as(C.c_void_p), self.ptrs[name], out.nbytes))
         return out
 
-    def submit(self):
+    def submit(self, engine=None):
+        """run the batch on `engine` (default: the engine that owns the buffers; any context on the same
+        device can read them)"""
         res = _lib.Result()
-        _lib.check(self.L.pf_submit(self.engine.ctx, C.byref(self.batch), C.byref(res)))
+        _lib.check(self.L.pf_submit((engine or self.engine).ctx, C.byref(self.batch), C.byref(res)))
         return res
 
 

@@ -26,9 +26,11 @@ def _headers(case):
     return KMERS_TSV_HEADER, KMERS_TO_HASHES_HEADER, hashes_to_patterns_header(case["all_strains"])
 
 
+@pytest.mark.parametrize("dedup", [True, False], ids=["dedup", "nodedup"])
 @pytest.mark.parametrize("case", CASES, ids=case_ids(CASES))
-def test_golden_engine(case):
-    """Engine.run over the whole case as ONE batch vs the reference's files."""
+def test_golden_engine(case, dedup):
+    """Engine.run over the whole case as ONE batch vs the reference's files (with and without the
+    identical-segment shortcut: both must give the reference's bytes)."""
     from panfeed_amd._lib import PanfeedHipError
     o = case["opts"]
     ms = max(32, (len(case["all_strains"]) + 31) // 32 * 32)
@@ -36,7 +38,7 @@ def test_golden_engine(case):
         with pytest.raises(PanfeedHipError):
             _engine(o, ms)
         return
-    eng = _engine(o, ms)
+    eng = _engine(o, ms, dedup=dedup)
     out = eng.run(case_records(case))
     hk, hkh, hhp = _headers(case)
     exp = case["expect"]
@@ -85,8 +87,9 @@ def _oracle_texts(records, stroi=(), **kw):
     return run.texts(), run.stats()
 
 
+@pytest.mark.parametrize("dedup", [True, False], ids=["dedup", "nodedup"])
 @pytest.mark.parametrize("k,canon,S,flank", [(31, True, 200, 0), (31, False, 96, 10), (51, True, 130, 0), (21, True, 333, 25)])
-def test_seeded_vs_oracle(k, canon, S, flank):
+def test_seeded_vs_oracle(k, canon, S, flank, dedup):
     """mid-size seeded clusters (multi-word rows, several sample chunks, paralogs, Ns)"""
     from panfeed_amd import synth
     from panfeed_amd.engine import Engine
@@ -94,8 +97,10 @@ def test_seeded_vs_oracle(k, canon, S, flank):
                         paralog_rate=0.03, shuffle_columns=5)
     recs = [c.record() for c in cl]
     stroi = {cl[0].names[3], cl[0].names[S // 2]}
-    eng = Engine(klength=k, canon=canon, max_strains=(S + 31) // 32 * 32, stroi=stroi)
+    eng = Engine(klength=k, canon=canon, max_strains=(S + 31) // 32 * 32, stroi=stroi, dedup=dedup)
     out = eng.run(recs)
+    if dedup:
+        assert out.timing["n_dedup_clusters"] > 0
     (ek, ekh, ehp), st = _oracle_texts(recs, stroi=stroi, klength=k, canon=canon)
     assert out.kmers_to_hashes == ekh
     assert out.hashes_to_patterns == ehp
@@ -179,3 +184,43 @@ def test_device_resident_batch_matches_host_batch():
     db.free()
     eng.close()
     eng2.close()
+
+
+@pytest.mark.parametrize("flags", [dict(), dict(consider_missing=True), dict(patfilt=False, maf=0.0), dict(canon=False)])
+def test_dedup_big_alleles_repartition(flags):
+    """few distinct but long alleles x many samples: mode 1 with a table overflow (key partitions) and,
+    in a second cluster, more distinct sequences than the dedup path takes (falls back to mode 0)"""
+    from panfeed_amd.classes import Seqinfo
+    from panfeed_amd.engine import Engine
+    rng = np.random.default_rng(5)
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    names = [f"q{i:03d}" for i in range(90)]
+
+    def mk(seq, i, j):
+        return Seqinfo(seq.decode(), seq.translate(comp).decode(), f"g{i}_{j}", "ctg", 5, 5 + len(seq) - 1, -1 if i % 3 else 1, 2)
+
+    def alleles(n, L):
+        return [np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, L)].tobytes() for _ in range(n)]
+    recs = []
+    a1 = alleles(5, 4000)                      # 5 x 4000 distinct windows > one table
+    a1[2] = a1[2][:1500] + b"N" + a1[2][1501:]  # a slow-path row inside a deduplicated cluster
+    gs = {nm: [mk(a1[(i * 7) % 5], i, 0)] + ([mk(a1[0], i, 1)] if i % 11 == 0 else []) for i, nm in enumerate(names)}
+    recs.append((gs, "big5", np.ones(90, dtype=np.int64)))
+    a2 = alleles(70, 120)                      # 70 distinct sequences > DEDUP_MAX_D
+    pres = np.ones(90, dtype=np.int64)
+    pres[::9] = 0
+    gs = {nm: ([mk(a2[i % 70], i, 0)] if pres[sorted(names).index(nm)] else []) for i, nm in enumerate(names)}
+    recs.append((gs, "many", pres))
+    a3 = alleles(3, 200)
+    gs = {nm: [mk(a3[i % 3], i, 0)] for i, nm in enumerate(names)}
+    recs.append((gs, "small3", np.ones(90, dtype=np.int64)))
+    kw = dict(klength=31, canon=True, consider_missing=False, patfilt=True, maf=0.01)
+    kw.update(flags)
+    eng = Engine(max_strains=96, stroi={names[4]}, **kw)
+    out = eng.run(recs)
+    assert out.timing["n_dedup_clusters"] == 2 and out.timing["n_retried"] >= 1
+    (ek, ekh, ehp), st = _oracle_texts(recs, stroi={names[4]}, **kw)
+    assert out.kmers_to_hashes == ekh
+    assert out.hashes_to_patterns == ehp
+    assert out.kmers_tsv == ek
+    eng.close()
