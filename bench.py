@@ -115,7 +115,7 @@ def main():
         from panfeed_amd import _lib
         _lib.check(eng.L.pf_reset_patterns(eng.ctx))
         tot = {"kept": 0, "new": 0, "scan_ms": 0.0, "rows_ms": 0.0, "emit_ms": 0.0, "total_ms": 0.0, "dedup_ms": 0.0,
-               "patrows_ms": 0.0, "md5_ms": 0.0,
+               "patrows_ms": 0.0, "md5_ms": 0.0, "finish_ms": 0.0,
                "launches": 0, "items": 0, "retried": 0, "unique": 0, "dedup_clusters": 0, "scan_bytes": 0}
         for d in dbs:
             res = d.submit(eng)
@@ -123,6 +123,7 @@ def main():
             tot["dedup_ms"] += tm["dedup_ms"]
             tot["patrows_ms"] += tm["patrows_ms"]
             tot["md5_ms"] += tm["md5_ms"]
+            tot["finish_ms"] += tm["finish_ms"]
             tot["dedup_clusters"] += tm["n_dedup_clusters"]
             tot["scan_bytes"] += tm["scan_packed_bytes"]
             tot["kept"] += int(res.n_kept)
@@ -182,7 +183,8 @@ def main():
         alg = algorithmic_bytes(packed_bytes, last["kept"], last["new"], S, k)   # this rank, one step
         kern_ms = {"cluster_dedup_kernel": last["dedup_ms"], "kmer_scan_kernel": last["scan_ms"],
                    "rows_kernel": last["rows_ms"], "emit_kernel": last["emit_ms"],
-                   "pattern_rows_kernel": last["patrows_ms"], "md5_kernel": last["md5_ms"]}
+                   "pattern_rows_kernel": last["patrows_ms"], "md5_kernel": last["md5_ms"],
+                   "finish_kernel": last["finish_ms"]}
         dom = max(kern_ms, key=kern_ms.get)
         dom_launches = {"cluster_dedup_kernel": len(dbs), "md5_kernel": len(dbs)}.get(dom, last["launches"])
         dom_s = kern_ms[dom] / 1e3

@@ -148,7 +148,7 @@ typedef struct {
     float dedup_ms;    /* cluster_dedup_kernel */
     float patrows_ms;  /* pattern_rows_kernel (emit_ms excludes it) */
     float md5_ms;      /* md5_kernel (emit_ms excludes it) */
-    float reserved;
+    float finish_ms;   /* finish_kernel (fused rows+emit of single-item deduplicated clusters) */
 } pf_timing;
 
 const char* pf_last_error(void);

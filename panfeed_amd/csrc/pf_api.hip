@@ -103,7 +103,7 @@ struct pf_ctx {
     DevBuf bm_occ, bm_keep, pre_occ, pre_keep, mrows, slot_out, it_is_extra;
     DevBuf strand_bits;
     DevBuf it_cluster, it_part, it_nparts, it_nslots, it_slice, it_sib0, it_nsib, it_extra_first, it_count,
-        it_unique, it_kept, work_scan, work_extra, sub_cluster, sub_item0, sub_nitems;
+        it_unique, it_kept, work_scan, work_extra, work_fin, work_rows, sub_cluster, sub_item0, sub_nitems;
     std::vector<Arena*> arenas;
     // last batch bookkeeping
     bool have_batch = false;
@@ -219,7 +219,7 @@ void pf_destroy(pf_ctx* c) {
                       &c->bm_occ, &c->bm_keep, &c->pre_occ, &c->pre_keep, &c->mrows, &c->slot_out, &c->it_is_extra, &c->cl_overflow, &c->cl_kmer_off, &c->cl_kmer_cnt, &c->cl_unique, &c->cl_pattern,
                       &c->cl_first, &c->cursor, &c->strand_bits, &c->it_cluster, &c->it_part, &c->it_nparts,
                       &c->it_nslots, &c->it_slice, &c->it_sib0, &c->it_nsib, &c->it_extra_first, &c->it_count,
-                      &c->it_unique, &c->it_kept, &c->work_scan, &c->work_extra, &c->sub_cluster, &c->sub_item0,
+                      &c->it_unique, &c->it_kept, &c->work_scan, &c->work_extra, &c->work_fin, &c->work_rows, &c->sub_cluster, &c->sub_item0,
                       &c->sub_nitems};
     for (DevBuf* b : bufs) b->release();
     for (Arena* a : c->arenas) { a->key.release(); a->pid.release(); a->first.release(); delete a; }
@@ -478,7 +478,7 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
 
     // ---- identical segments -> scan view (mode 1) or the caller's list as it is (mode 0)
     std::vector<uint64_t> ninst(C), vinst(C), words(C);
-    std::vector<uint32_t> h_mode(C);
+    std::vector<uint32_t> h_mode(C), h_dense(C);
     if (C) {
         pf::DedupParams dp{};
         dp.packed = d.packed; dp.seg_word_off = d.seg_word_off; dp.seg_len = d.seg_len;
@@ -505,6 +505,7 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
         HIPCHK(hipMemcpyAsync(vinst.data(), c->cl_vinst.p, (size_t)C * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(words.data(), c->cl_vwords.p, (size_t)C * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(h_mode.data(), c->v_mode.p, (size_t)C * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(h_dense.data(), c->v_dense.p, (size_t)C * 4, hipMemcpyDeviceToHost, c->stream));
     }
     // ---- strand bits of target-strain segments (canonical mode)
     c->n_strand_words = (b->seg_strand_off && c->o.canon) ? b->n_strand_words : 0;
@@ -541,6 +542,7 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
     while (!todo.empty()) {
         // ---- items of this pass
         std::vector<Item> items;
+        std::vector<uint8_t> item_fused;
         struct Sub { uint32_t item0, nitems, cl0, ncl; };
         std::vector<Sub> subs;
         std::vector<uint32_t> sub_cluster, sub_item0, sub_nitems;
@@ -562,20 +564,27 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
             uint32_t ns = NS;
             const uint64_t inst = vinst[ci] * mult;
             if (np == 1 && NS > 4096 + pf::INSERT_SLACK && inst <= pf::insert_limit(4096)) ns = 4096;
-            for (uint32_t q = 0; q < np; q++)
+            // a deduplicated cluster that is one work item is finished by one fused kernel (rows + emit in LDS)
+            const bool fused = h_mode[ci] == 1 && nit == 1 && (h_dense[ci] + 31) / 32 <= pf::FUSED_DENSE_WORDS;
+            for (uint32_t q = 0; q < np; q++) {
                 items.push_back(Item{ci, q, np, ns, cur.nitems + q, sib0, nit, 0, 0});
+                item_fused.push_back(fused ? 1 : 0);
+            }
             for (uint32_t q = 0; q < nex_items; q++) {
                 const uint32_t first = ex_first[ci] + q * lim_full;
                 const uint32_t cnt = std::min(lim_full, ex_first[ci + 1] - first);
                 items.push_back(Item{ci, 0, 1, cnt, cur.nitems + np + q, sib0, nit, first, 1});
+                item_fused.push_back(0);
             }
             for (uint32_t q = 0; q < np; q++) arena_cap += std::min<uint64_t>(pf::insert_limit(ns), inst);
             arena_cap += nex;
-            sub_cluster.push_back(ci);
-            sub_item0.push_back(sib0);
-            sub_nitems.push_back(nit);
+            if (!fused) {
+                sub_cluster.push_back(ci);
+                sub_item0.push_back(sib0);
+                sub_nitems.push_back(nit);
+                cur.ncl++;
+            }
             cur.nitems += nit;
-            cur.ncl++;
             c->cluster_arena[ci] = pass;
         }
         if (cur.nitems) subs.push_back(cur);
@@ -592,7 +601,7 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
         // ---- item arrays
         const size_t NI = items.size();
         std::vector<uint32_t> v_cluster(NI), v_part(NI), v_nparts(NI), v_nslots(NI), v_slice(NI), v_sib0(NI), v_nsib(NI),
-            v_exfirst(NI), v_isex(NI), w_scan, w_extra;
+            v_exfirst(NI), v_isex(NI), w_scan, w_extra, w_fin, w_rows;
         for (size_t i = 0; i < NI; i++) {
             v_cluster[i] = items[i].cluster; v_part[i] = items[i].part; v_nparts[i] = items[i].nparts;
             v_nslots[i] = items[i].nslots; v_slice[i] = items[i].slice; v_sib0[i] = items[i].sib0;
@@ -614,18 +623,26 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
         PFCHK(c->it_unique.ensure(std::max<size_t>(NI, 1) * 4));
         PFCHK(c->it_kept.ensure(std::max<size_t>(NI, 1) * 4));
         // work lists per sub-batch, concatenated; scan items heaviest first (the grid drains evenly)
-        std::vector<uint32_t> scan_off(subs.size() + 1, 0), extra_off(subs.size() + 1, 0);
+        std::vector<uint32_t> scan_off(subs.size() + 1, 0), extra_off(subs.size() + 1, 0), fin_off(subs.size() + 1, 0),
+            rows_off(subs.size() + 1, 0);
         for (size_t s = 0; s < subs.size(); s++) {
-            const size_t w0 = w_scan.size();
-            for (uint32_t i = subs[s].item0; i < subs[s].item0 + subs[s].nitems; i++)
+            const size_t w0 = w_scan.size(), f0 = w_fin.size();
+            for (uint32_t i = subs[s].item0; i < subs[s].item0 + subs[s].nitems; i++) {
                 (items[i].is_extra ? w_extra : w_scan).push_back(i);
-            std::stable_sort(w_scan.begin() + w0, w_scan.end(),
-                             [&](uint32_t x, uint32_t y) { return vinst[items[x].cluster] > vinst[items[y].cluster]; });
+                (item_fused[i] ? w_fin : w_rows).push_back(i);
+            }
+            auto heavier = [&](uint32_t x, uint32_t y) { return vinst[items[x].cluster] > vinst[items[y].cluster]; };
+            std::stable_sort(w_scan.begin() + w0, w_scan.end(), heavier);
+            std::stable_sort(w_fin.begin() + f0, w_fin.end(), heavier);
             scan_off[s + 1] = (uint32_t)w_scan.size();
             extra_off[s + 1] = (uint32_t)w_extra.size();
+            fin_off[s + 1] = (uint32_t)w_fin.size();
+            rows_off[s + 1] = (uint32_t)w_rows.size();
         }
         PFCHK(upload_vec(c, c->work_scan, w_scan));
         PFCHK(upload_vec(c, c->work_extra, w_extra));
+        PFCHK(upload_vec(c, c->work_fin, w_fin));
+        PFCHK(upload_vec(c, c->work_rows, w_rows));
         // the cursor's next free index restarts at this arena's base
         {
             uint64_t cur0 = arena_base;
@@ -669,6 +686,35 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
                 PFCHK(mark_end(c));
                 c->timing.scan_launches++;
             }
+            const uint32_t n_fin = fin_off[s + 1] - fin_off[s], n_rows = rows_off[s + 1] - rows_off[s];
+            if (n_fin) {
+                pf::FinishParams fp{};
+                fp.work = c->work_fin.as<uint32_t>() + fin_off[s];
+                fp.item_cluster = c->it_cluster.as<uint32_t>(); fp.item_nslots = c->it_nslots.as<uint32_t>();
+                fp.item_scratch = c->it_slice.as<uint32_t>(); fp.cluster_overflow = c->cl_overflow.as<uint32_t>();
+                fp.cluster_seg_off = d.cluster_seg_off; fp.seg_sample = d.seg_sample;
+                fp.seg_distinct = c->seg_distinct.as<uint32_t>();
+                fp.v_nstr = c->v_nstr.as<uint32_t>(); fp.v_dense = c->v_dense.as<uint32_t>();
+                fp.cluster_nstrains = d.cluster_nstrains; fp.cluster_npresab = d.cluster_npresab;
+                fp.cluster_presab = d.cluster_presab; fp.cluster_ordinal = d.cluster_ordinal;
+                fp.maf_lo = c->d_maf_lo.as<uint32_t>(); fp.maf_hi = c->d_maf_hi.as<uint32_t>();
+                fp.tab_key = c->tab_key.as<uint64_t>(); fp.tab_ord = c->tab_ord.as<uint32_t>();
+                fp.chunkbits = c->chunkbits.as<uint32_t>(); fp.chunkmask = c->chunkmask.as<uint32_t>();
+                fp.out_key = ar->key.as<uint64_t>(); fp.out_pid = ar->pid.as<uint32_t>();
+                fp.cluster_kmer_off = c->cl_kmer_off.as<uint64_t>(); fp.cluster_kmer_cnt = c->cl_kmer_cnt.as<uint32_t>();
+                fp.cluster_unique = c->cl_unique.as<uint32_t>(); fp.cluster_pattern = c->cl_pattern.as<uint32_t>();
+                fp.cursor = c->cursor.as<uint64_t>(); fp.pt = c->pt;
+                fp.pat_bits = c->pat_bits.as<uint32_t>();
+                fp.pat_nan = c->o.consider_missing ? c->pat_nan.as<uint32_t>() : nullptr;
+                fp.pat_n = c->pat_n.as<uint32_t>();
+                fp.out_base = ar->base; fp.out_cap = ar->cap; fp.W = W; fp.NS = NS; fp.KW = KW;
+                fp.consider_missing = c->o.consider_missing; fp.patfilt = c->o.patfilt; fp.multiple_files = c->o.multiple_files;
+                PFCHK(mark_begin(c, 6));
+                hipLaunchKernelGGL(pf::finish_kernel, dim3(n_fin), dim3(pf::FIN_THREADS), 0, c->stream, fp);
+                HIPCHK(hipGetLastError());
+                PFCHK(mark_end(c));
+            }
+            if (!n_rows) continue;
             pf::RowsParams rp{};
             rp.item_cluster = c->it_cluster.as<uint32_t>(); rp.item_nslots = c->it_nslots.as<uint32_t>();
             rp.item_scratch = c->it_slice.as<uint32_t>(); rp.item_count = c->it_count.as<uint32_t>();
@@ -688,10 +734,10 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
             rp.pre_occ = c->pre_occ.as<uint32_t>(); rp.pre_keep = c->pre_keep.as<uint32_t>();
             rp.mrows = c->mrows.as<uint32_t>();
             rp.item_unique = c->it_unique.as<uint32_t>(); rp.item_kept = c->it_kept.as<uint32_t>();
-            rp.item0 = sb.item0; rp.W = W; rp.NS = NS;
+            rp.work = c->work_rows.as<uint32_t>() + rows_off[s]; rp.W = W; rp.NS = NS;
             rp.consider_missing = c->o.consider_missing; rp.patfilt = c->o.patfilt; rp.multiple_files = c->o.multiple_files;
             PFCHK(mark_begin(c, 1));
-            hipLaunchKernelGGL(pf::rows_kernel, dim3(sb.nitems), dim3(pf::ROWS_THREADS), 0, c->stream, rp);
+            hipLaunchKernelGGL(pf::rows_kernel, dim3(n_rows), dim3(pf::ROWS_THREADS), 0, c->stream, rp);
             HIPCHK(hipGetLastError());
             PFCHK(mark_end(c));
 
@@ -726,9 +772,9 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
             em.out_key = ar->key.as<uint64_t>(); em.out_pid = ar->pid.as<uint32_t>(); em.out_first = ar->first.as<uint64_t>();
             em.cluster_pattern = c->cl_pattern.as<uint32_t>(); em.cluster_first = c->cl_first.as<uint64_t>();
             em.pt = c->pt; em.out_base = ar->base; em.out_cap = ar->cap;
-            em.item0 = sb.item0; em.W = W; em.NS = NS; em.KW = KW;
+            em.work = c->work_rows.as<uint32_t>() + rows_off[s]; em.W = W; em.NS = NS; em.KW = KW;
             em.consider_missing = c->o.consider_missing; em.multiple_files = c->o.multiple_files;
-            hipLaunchKernelGGL(pf::emit_kernel, dim3(sb.nitems), dim3(pf::EMIT_THREADS), 0, c->stream, em);
+            hipLaunchKernelGGL(pf::emit_kernel, dim3(n_rows), dim3(pf::EMIT_THREADS), 0, c->stream, em);
             HIPCHK(hipGetLastError());
             PFCHK(mark_end(c));
             PFCHK(mark_begin(c, 4));
@@ -750,8 +796,8 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
             pr.pat_nan = c->o.consider_missing ? c->pat_nan.as<uint32_t>() : nullptr;
             pr.pat_n = c->pat_n.as<uint32_t>();
             pr.out_base = ar->base; pr.out_cap = ar->cap; pr.pool = c->pt.pool;
-            pr.item0 = sb.item0; pr.W = W; pr.NS = NS; pr.consider_missing = c->o.consider_missing;
-            hipLaunchKernelGGL(pf::pattern_rows_kernel, dim3(sb.nitems), dim3(256), 0, c->stream, pr);
+            pr.work = em.work; pr.W = W; pr.NS = NS; pr.consider_missing = c->o.consider_missing;
+            hipLaunchKernelGGL(pf::pattern_rows_kernel, dim3(n_rows), dim3(256), 0, c->stream, pr);
             HIPCHK(hipGetLastError());
             PFCHK(mark_end(c));
         }
@@ -818,6 +864,7 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
         else if (e.cat == 3) c->timing.dedup_ms += ms;
         else if (e.cat == 4) c->timing.patrows_ms += ms;
         else if (e.cat == 5) c->timing.md5_ms += ms;
+        else if (e.cat == 6) c->timing.finish_ms += ms;
         else c->timing.emit_ms += ms;
     }
 

@@ -695,7 +695,8 @@ struct RowsParams {
     uint32_t* mrows;         // [slice][DEDUP_MROWS]  M[d][Wp]: samples that carry distinct sequence d
     uint32_t* item_unique;   // [item]
     uint32_t* item_kept;     // [item]
-    uint32_t item0, W, NS;
+    const uint32_t* work;    // [gridDim.x] item ids of this launch
+    uint32_t W, NS;
     uint32_t consider_missing, patfilt, multiple_files;
 };
 
@@ -736,7 +737,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
     __shared__ uint32_t at_keep[AT_SLOTS];
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t item = p.item0 + blockIdx.x;
+    const uint32_t item = p.work[blockIdx.x];
     const uint32_t c = p.item_cluster[item];
     const uint32_t slice = p.item_scratch[item];
     const uint32_t NS = p.NS, W = p.W;
@@ -1103,7 +1104,8 @@ struct EmitParams {
     PatternTable pt;
     uint64_t out_base;      // global index of out_key[0] (arena base)
     uint64_t out_cap;       // entries in the arena
-    uint32_t item0, W, NS, KW;
+    const uint32_t* work;   // [gridDim.x] item ids of this launch
+    uint32_t W, NS, KW;
     uint32_t consider_missing, multiple_files;
 };
 
@@ -1130,7 +1132,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
     __shared__ uint32_t lt_count;
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t item = p.item0 + blockIdx.x;
+    const uint32_t item = p.work[blockIdx.x];
     const uint32_t c = p.item_cluster[item];
     if (p.cluster_overflow[c]) return;
     const uint32_t slice = p.item_scratch[item];
@@ -1284,6 +1286,320 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// finish_kernel: rows + emit in one workgroup for a deduplicated cluster that is a single work item
+// ---------------------------------------------------------------------------------------------
+// (mode 1, one key partition, no slow-path rows, dense ordinal space <= FUSED_DENSE_WORDS*32.)  Everything
+// between the scan's table dump and the outputs happens in LDS: sample sets M, the table of distinct allele
+// masks with their row hash / keep flag, ordinal bitmaps for ranks, one insert into the run-global pattern
+// table per distinct mask, and the pattern row is written by whoever lowers the pattern's first_seen (all
+// writers of one pattern write identical bytes).
+constexpr uint32_t FUSED_DENSE_WORDS = 2048;     // 65536 dense ordinals
+constexpr uint32_t FIN_THREADS = 1024;
+
+struct FinishParams {
+    const uint32_t* work;            // [gridDim.x] item ids
+    const uint32_t* item_cluster; const uint32_t* item_nslots; const uint32_t* item_scratch;
+    const uint32_t* cluster_overflow;
+    const uint32_t* cluster_seg_off; const uint32_t* seg_sample; const uint32_t* seg_distinct;
+    const uint32_t* v_nstr; const uint32_t* v_dense;
+    const uint32_t* cluster_nstrains; const uint32_t* cluster_npresab; const uint32_t* cluster_presab;
+    const uint64_t* cluster_ordinal;
+    const uint32_t* maf_lo; const uint32_t* maf_hi;
+    const uint64_t* tab_key; const uint32_t* tab_ord; const uint32_t* chunkbits; const uint32_t* chunkmask;
+    uint64_t* out_key; uint32_t* out_pid;
+    uint64_t* cluster_kmer_off; uint32_t* cluster_kmer_cnt; uint32_t* cluster_unique; uint32_t* cluster_pattern;
+    uint64_t* cursor;                // [0] next free output index [1] unique total [2] kept total
+    PatternTable pt;
+    uint32_t* pat_bits; uint32_t* pat_nan; uint32_t* pat_n;
+    uint64_t out_base, out_cap;
+    uint32_t W, NS, KW;
+    uint32_t consider_missing, patfilt, multiple_files;
+};
+
+// atomicMin on first_seen; true when this call lowered it (the caller then writes the pattern's row)
+__device__ __forceinline__ uint32_t pattern_insert_lower(const PatternTable& t, uint64_t lo, uint32_t hi32,
+                                                         uint64_t first_seen, bool* lowered) {
+    if (lo == EMPTY64) lo = EMPTY64 - 1;
+    uint64_t slot = (lo ^ ((uint64_t)hi32 * 0x9E3779B97F4A7C15ull)) & (t.cap - 1);
+    uint32_t pid = 0xFFFFFFFFu;
+    for (uint64_t probes = 0; probes < t.cap; ) {
+        uint64_t cur = __hip_atomic_load(&t.lo[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == EMPTY64) {
+            cur = atomicCAS((unsigned long long*)&t.lo[slot], (unsigned long long)EMPTY64, (unsigned long long)lo);
+            if (cur == EMPTY64) {
+                const uint32_t id = atomicAdd(&t.counters[0], 1u);
+                if (id >= t.pool) { t.counters[1] = 1; pid = 0xFFFFFFFFu; }
+                else pid = id;
+                __hip_atomic_store(&t.val[slot], ((uint64_t)hi32 << 32) | pid, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        if (cur == lo) {
+            const uint64_t v = __hip_atomic_load(&t.val[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v == EMPTY64) continue;
+            if ((uint32_t)(v >> 32) == hi32) { pid = (uint32_t)v; break; }
+        }
+        slot = (slot + 1) & (t.cap - 1);
+        probes++;
+    }
+    *lowered = false;
+    if (pid == 0xFFFFFFFFu) { t.counters[1] = 1; return pid; }
+    const uint64_t old = atomicMin((unsigned long long*)&t.first_seen[pid], (unsigned long long)first_seen);
+    *lowered = old > first_seen;
+    return pid;
+}
+
+__global__ __launch_bounds__(FIN_THREADS) void finish_kernel(FinishParams p) {
+    __shared__ __align__(16) uint32_t M[DEDUP_MROWS];           // 16 KiB
+    __shared__ uint32_t occ[FUSED_DENSE_WORDS], keepbm[FUSED_DENSE_WORDS];
+    __shared__ uint32_t pocc[FUSED_DENSE_WORDS], pkeep[FUSED_DENSE_WORDS];   // exclusive prefix popcounts
+    __shared__ uint64_t at_key[AT_SLOTS];
+    __shared__ uint4 at_hash[AT_SLOTS];
+    __shared__ uint32_t at_keep[AT_SLOTS], at_minord[AT_SLOTS], at_slot[AT_SLOTS], at_pid[AT_SLOTS];
+    __shared__ uint16_t slot_at[12288];                          // per slot: entry index, 0xFFFF free, 0xFFFE untabled
+    __shared__ uint32_t wave_tot[FIN_THREADS / 64 + 1];
+    __shared__ uint32_t sh_npres, at_count;
+    __shared__ uint64_t sh_base;
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t item = p.work[blockIdx.x];
+    const uint32_t c = p.item_cluster[item];
+    if (p.cluster_overflow[c]) return;
+    const uint32_t slice = p.item_scratch[item];
+    const uint32_t NS = p.NS, W = p.W, KW = p.KW;
+    const uint32_t ns = p.item_nslots[item];
+    const uint32_t nstr = p.cluster_nstrains[c], npres = p.cluster_npresab[c];
+    const uint32_t nchunks = (nstr + 31) >> 5;
+    const uint32_t Wp = (W + 3) & ~3u;
+    const uint32_t* presab = p.cluster_presab + (size_t)c * W;
+    const uint32_t dense_words = (p.v_dense[c] + 31) >> 5;      // <= FUSED_DENSE_WORDS (host-checked)
+    const uint64_t ordinal = p.cluster_ordinal[c];
+    const uint32_t* ordp = p.tab_ord + (size_t)slice * NS;
+    const uint32_t* cb = p.chunkbits + (size_t)slice * W * NS;
+    const uint32_t cm0 = p.chunkmask[slice * 8];
+    const bool f0 = (cm0 & 1) != 0, f1 = (cm0 & 2) != 0;
+
+    for (uint32_t i = tid; i < DEDUP_MROWS; i += FIN_THREADS) M[i] = 0;
+    for (uint32_t i = tid; i < FUSED_DENSE_WORDS; i += FIN_THREADS) { occ[i] = 0; keepbm[i] = 0; }
+    for (uint32_t i = tid; i < AT_SLOTS; i += FIN_THREADS) { at_key[i] = 0; at_minord[i] = NO_ORD; }
+    if (tid == 0) {
+        at_count = 0;
+        uint32_t np = 0;
+        for (uint32_t w = 0; w < W; w++) np += __popc(presab[w]);
+        sh_npres = np;
+    }
+    __syncthreads();
+    {   // M[d] = samples that carry distinct sequence d
+        const uint32_t s0 = p.cluster_seg_off[c], s1 = p.cluster_seg_off[c + 1];
+        for (uint32_t s = s0 + tid; s < s1; s += FIN_THREADS) {
+            const uint32_t d = p.seg_distinct[s], smp = p.seg_sample[s];
+            atomicOr(&M[d * Wp + (smp >> 5)], 1u << (smp & 31));
+        }
+    }
+    // phase A: distinct allele masks
+    for (uint32_t i = tid; i < ns; i += FIN_THREADS) {
+        uint16_t tag = 0xFFFF;
+        if (ordp[i] != NO_ORD) {
+            const uint64_t amask = (f0 ? (uint64_t)cb[i] : 0) | (f1 ? (uint64_t)cb[(size_t)NS + i] << 32 : 0);
+            tag = 0xFFFE;
+            uint32_t a = (uint32_t)mix64(amask) & (AT_SLOTS - 1);
+            for (uint32_t probes = 0; amask && probes < AT_SLOTS; probes++) {
+                uint64_t cur = __hip_atomic_load(&at_key[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (cur == 0) {
+                    if (__hip_atomic_load(&at_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= AT_LIMIT) break;
+                    cur = atomicCAS((unsigned long long*)&at_key[a], 0ull, (unsigned long long)amask);
+                    if (cur == 0) { atomicAdd(&at_count, 1u); at_slot[a] = i; cur = amask; }
+                }
+                if (cur == amask) { tag = (uint16_t)a; break; }
+                a = (a + 1) & (AT_SLOTS - 1);
+            }
+        }
+        slot_at[i] = tag;
+    }
+    __syncthreads();
+    const uint32_t npresent = sh_npres;
+    const uint32_t n_eff = p.consider_missing ? npresent : nstr;               // panfeed.py:191 / :196
+    const uint32_t lo = p.maf_lo[n_eff], hi = p.maf_hi[n_eff];
+    const bool same_possible = !p.patfilt && nstr == npres && (!p.consider_missing || npresent == nstr);
+
+    auto row_word4 = [&](uint64_t amask, uint32_t ch, uint32_t wv[4]) {
+        wv[0] = wv[1] = wv[2] = wv[3] = 0;
+        uint64_t t = amask;
+        while (t) {
+            const uint32_t d = __ffsll((unsigned long long)t) - 1;
+            t &= t - 1;
+            const uint4 m = *reinterpret_cast<const uint4*>(&M[d * Wp + ch]);
+            wv[0] |= m.x; wv[1] |= m.y; wv[2] |= m.z; wv[3] |= m.w;
+        }
+    };
+    auto row_eval = [&](uint64_t amask, uint4& hout) -> bool {
+        H128 s;
+        s.h1 = 0x9747b28cu ^ nstr; s.h2 = 0x1b873593u; s.h3 = 0xe6546b64u; s.h4 = 0x85ebca6bu;
+        if (p.multiple_files) { s.h2 ^= (uint32_t)ordinal; s.h3 ^= (uint32_t)(ordinal >> 32); }
+        uint32_t cnt = 0;
+        bool eq = true;
+        for (uint32_t ch = 0; ch < nchunks; ch += 4) {
+            uint32_t wv[4];
+            row_word4(amask, ch, wv);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (ch + j < nchunks) { cnt += __popc(wv[j]); eq = eq && (wv[j] == presab[ch + j]); }
+            mm3_block(s, wv[0], wv[1], wv[2], wv[3]);
+        }
+        if (p.consider_missing) {
+            for (uint32_t ch = 0; ch < nchunks; ch += 4) {
+                uint32_t wv[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) wv[j] = (ch + j < nchunks) ? ~presab[ch + j] : 0;
+                mm3_block(s, wv[0], wv[1], wv[2], wv[3]);
+            }
+        }
+        mm3_final(s, nchunks * 4);
+        bool keep = cnt >= lo && cnt <= hi;                 // panfeed.py:197-200
+        if (same_possible && eq) keep = false;              // panfeed.py:202-204
+        hout = make_uint4(s.h1, s.h2, s.h3, s.h4);
+        return keep;
+    };
+    auto write_row = [&](uint32_t pid, uint64_t amask) {
+        for (uint32_t w = 0; w < W; w += 4) {
+            uint32_t wv[4] = {0, 0, 0, 0};
+            if (w < nchunks) row_word4(amask, w, wv);
+            for (uint32_t j = 0; j < 4 && w + j < W; j++) {
+                p.pat_bits[(size_t)pid * W + w + j] = (w + j < nchunks) ? wv[j] : 0;
+                if (p.pat_nan) {
+                    uint32_t nn = 0;
+                    if (p.consider_missing && w + j < nchunks) {
+                        nn = ~presab[w + j];
+                        const uint32_t rem = nstr - ((w + j) << 5);
+                        if (rem < 32) nn &= (1u << rem) - 1;
+                    }
+                    p.pat_nan[(size_t)pid * W + w + j] = nn;
+                }
+            }
+        }
+        p.pat_n[pid] = nstr;
+    };
+
+    // phase B: one row evaluation per distinct mask
+    for (uint32_t t = tid; t < AT_SLOTS; t += FIN_THREADS) {
+        const uint64_t key = at_key[t];
+        if (!key) continue;
+        uint4 h;
+        at_keep[t] = row_eval(key, h) ? 1u : 0u;
+        at_hash[t] = h;
+    }
+    __syncthreads();
+    // phase C: ordinal bitmaps, lowest ordinal per mask
+    for (uint32_t i = tid; i < ns; i += FIN_THREADS) {
+        const uint16_t tag = slot_at[i];
+        if (tag == 0xFFFF) continue;
+        const uint32_t o = ordp[i];
+        if ((o >> 5) >= dense_words) continue;
+        bool keep;
+        if (tag == 0xFFFE) {
+            const uint64_t amask = (f0 ? (uint64_t)cb[i] : 0) | (f1 ? (uint64_t)cb[(size_t)NS + i] << 32 : 0);
+            uint4 h;
+            keep = row_eval(amask, h);
+        } else {
+            keep = at_keep[tag] != 0;
+            if (keep) atomicMin(&at_minord[tag], o);
+        }
+        atomicOr(&occ[o >> 5], 1u << (o & 31));
+        if (keep) atomicOr(&keepbm[o >> 5], 1u << (o & 31));
+    }
+    __syncthreads();
+    // prefix popcounts over the bitmap words
+    uint32_t tot_o, tot_k;
+    {
+        constexpr uint32_t PW = FUSED_DENSE_WORDS / FIN_THREADS;   // 2
+        uint32_t so = 0, sk = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < PW; j++) { so += __popc(occ[tid * PW + j]); sk += __popc(keepbm[tid * PW + j]); }
+        uint32_t bo = block_exscan(so, wave_tot, &tot_o);
+        uint32_t bk = block_exscan(sk, wave_tot, &tot_k);
+#pragma unroll
+        for (uint32_t j = 0; j < PW; j++) {
+            const uint32_t w = tid * PW + j;
+            pocc[w] = bo; pkeep[w] = bk;
+            bo += __popc(occ[w]); bk += __popc(keepbm[w]);
+        }
+    }
+    if (tid == 0) {
+        sh_base = atomicAdd((unsigned long long*)&p.cursor[0], (unsigned long long)tot_k);
+        atomicAdd((unsigned long long*)&p.cursor[1], (unsigned long long)tot_o);
+        atomicAdd((unsigned long long*)&p.cursor[2], (unsigned long long)tot_k);
+        p.cluster_kmer_off[c] = sh_base;
+        p.cluster_kmer_cnt[c] = tot_k;
+        p.cluster_unique[c] = tot_o;
+        // the cluster's own row: md5 of the int64 image of clusterpresab (panfeed.py:175-187)
+        const uint32_t nw = (npres + 31) >> 5;
+        H128 s;
+        s.h1 = 0x9747b28cu ^ npres; s.h2 = 0x1b873593u ^ 0x5bd1e995u; s.h3 = 0xe6546b64u; s.h4 = 0x85ebca6bu;
+        if (p.multiple_files) { s.h2 ^= (uint32_t)ordinal; s.h3 ^= (uint32_t)(ordinal >> 32); }
+        for (uint32_t w = 0; w < nw; w += 4) {
+            uint32_t wv[4];
+            for (int j = 0; j < 4; j++) wv[j] = (w + j < nw) ? presab[w + j] : 0;
+            mm3_block(s, wv[0], wv[1], wv[2], wv[3]);
+        }
+        mm3_final(s, nw * 4 + 1);
+        bool lowered;
+        const uint32_t pid = pattern_insert_lower(p.pt, ((uint64_t)s.h1 << 32) | s.h2, s.h3, ordinal << 32, &lowered);
+        p.cluster_pattern[c] = pid;
+        if (lowered && pid < p.pt.pool) {
+            for (uint32_t w = 0; w < W; w++) {
+                p.pat_bits[(size_t)pid * W + w] = presab[w];
+                if (p.pat_nan) p.pat_nan[(size_t)pid * W + w] = 0;
+            }
+            p.pat_n[pid] = npres | 0x80000000u;
+        }
+    }
+    __syncthreads();
+    const uint64_t obase = sh_base - p.out_base;
+    auto rank_of = [&](uint32_t o) -> uint32_t { return pocc[o >> 5] + __popc(occ[o >> 5] & ((1u << (o & 31)) - 1)); };
+    auto kept_before = [&](uint32_t o) -> uint32_t { return pkeep[o >> 5] + __popc(keepbm[o >> 5] & ((1u << (o & 31)) - 1)); };
+    // one insert into the run-global table per distinct kept mask
+    for (uint32_t t = tid; t < AT_SLOTS; t += FIN_THREADS) {
+        const uint64_t key = at_key[t];
+        if (!key || !at_keep[t]) continue;
+        const uint32_t mo = at_minord[t];
+        if (mo == NO_ORD) { at_pid[t] = 0xFFFFFFFFu; continue; }
+        const uint64_t fs = (ordinal << 32) | (uint64_t)(rank_of(mo) + 1);
+        const uint4 h = at_hash[t];
+        bool lowered;
+        const uint32_t pid = pattern_insert_lower(p.pt, ((uint64_t)h.x << 32) | h.y, h.z, fs, &lowered);
+        at_pid[t] = pid;
+        if (lowered && pid < p.pt.pool) write_row(pid, key);
+    }
+    __syncthreads();
+    // outputs: key + pattern id per kept k-mer, in first-occurrence order
+    for (uint32_t i = tid; i < ns; i += FIN_THREADS) {
+        const uint16_t tag = slot_at[i];
+        if (tag == 0xFFFF) continue;
+        const uint32_t o = ordp[i];
+        if ((o >> 5) >= dense_words || !((keepbm[o >> 5] >> (o & 31)) & 1)) continue;
+        uint32_t pid;
+        if (tag == 0xFFFE) {
+            // mask table was full: this slot goes to the run-global table on its own
+            const uint64_t amask = (f0 ? (uint64_t)cb[i] : 0) | (f1 ? (uint64_t)cb[(size_t)NS + i] << 32 : 0);
+            uint4 h;
+            row_eval(amask, h);
+            bool lowered;
+            pid = pattern_insert_lower(p.pt, ((uint64_t)h.x << 32) | h.y, h.z,
+                                       (ordinal << 32) | (uint64_t)(rank_of(o) + 1), &lowered);
+            if (lowered && pid < p.pt.pool) write_row(pid, amask);
+        } else {
+            pid = at_pid[tag];
+        }
+        const uint64_t oi = obase + kept_before(o);
+        if (oi >= p.out_cap) { p.pt.counters[1] = 2; continue; }
+        p.out_key[oi * KW] = p.tab_key[((size_t)slice * KW) * NS + i];
+        if (KW == 2) p.out_key[oi * KW + 1] = p.tab_key[((size_t)slice * KW + 1) * NS + i];
+        p.out_pid[oi] = pid;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // pattern_rows_kernel: the k-mer (or cluster row) that holds a pattern's first_seen writes its row
 // ---------------------------------------------------------------------------------------------
 struct PatRowsParams {
@@ -1302,7 +1618,8 @@ struct PatRowsParams {
     uint32_t* pat_bits; uint32_t* pat_nan; uint32_t* pat_n;
     uint64_t out_base, out_cap;
     uint32_t pool;
-    uint32_t item0, W, NS;
+    const uint32_t* work;   // [gridDim.x] item ids of this launch
+    uint32_t W, NS;
     uint32_t consider_missing;
 };
 constexpr uint32_t PR_LIST = 2048;   // winners collected per round
@@ -1315,7 +1632,7 @@ __global__ __launch_bounds__(256) void pattern_rows_kernel(PatRowsParams p) {
     __shared__ uint32_t l_count;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-    const uint32_t item = p.item0 + blockIdx.x;
+    const uint32_t item = p.work[blockIdx.x];
     const uint32_t c = p.item_cluster[item];
     if (p.cluster_overflow[c]) return;
     const uint32_t slice = p.item_scratch[item];
