@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--samples", type=int, default=1000)
     ap.add_argument("--flank", type=int, default=100)
     ap.add_argument("--k", type=int, default=31)
-    ap.add_argument("--max-items", type=int, default=2048)
+    ap.add_argument("--max-items", type=int, default=4096)
     ap.add_argument("--cpu-clusters", type=int, default=0, help="clusters in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dedup", action="store_true", help="scan every copy of identical sequences (PF_FLAG_NO_DEDUP)")
@@ -83,13 +83,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
+    # rehearsal mode for a 1-GPU box: every rank on cuda:0, gloo collectives on host tensors (control flow only)
+    shared = os.environ.get("PANFEED_BENCH_SHARED_GPU") == "1"
+    if shared:
+        local = 0
+    torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    else:
-        torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cpu") if shared else torch.device("cuda", local)
 
     from panfeed_amd import devbatch, synth
     from panfeed_amd.distributed import merge_patterns

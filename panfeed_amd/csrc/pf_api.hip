@@ -10,6 +10,7 @@
 #include "../../include/panfeed_hip.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -47,7 +48,9 @@ int fail(int code, const char* fmt, ...) {
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    bool view = false;     // points into another DevBuf (staged uploads): never freed, never grown
     int ensure(size_t bytes) {
+        if (view) { p = nullptr; cap = 0; view = false; }
         if (bytes <= cap) return PF_OK;
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
         size_t want = bytes + bytes / 8 + 256;
@@ -59,7 +62,7 @@ struct DevBuf {
         cap = want;
         return PF_OK;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p && !view) (void)hipFree(p); p = nullptr; cap = 0; view = false; }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
@@ -105,6 +108,9 @@ struct pf_ctx {
     DevBuf it_cluster, it_part, it_nparts, it_nslots, it_slice, it_sib0, it_nsib, it_extra_first, it_count,
         it_unique, it_kept, work_scan, work_extra, work_fin, work_rows, sub_cluster, sub_item0, sub_nitems;
     std::vector<Arena*> arenas;
+    DevBuf stage_dev;              // one device block for the small per-pass arrays
+    void* stage_pin = nullptr;     // pinned host mirror of it
+    size_t stage_pin_cap = 0;
     // last batch bookkeeping
     bool have_batch = false;
     uint32_t n_clusters = 0;
@@ -173,6 +179,35 @@ int reset_patterns(pf_ctx* c) {
     return PF_OK;
 }
 
+// Upload many small uint32 arrays with ONE pinned-host -> device copy; each DevBuf becomes a view into stage_dev.
+int staged_upload(pf_ctx* c, std::vector<std::pair<DevBuf*, const std::vector<uint32_t>*>>& arrs) {
+    size_t total = 0;
+    std::vector<size_t> off(arrs.size());
+    for (size_t i = 0; i < arrs.size(); i++) {
+        off[i] = total;
+        total += (std::max<size_t>(arrs[i].second->size(), 1) * 4 + 255) & ~(size_t)255;
+    }
+    for (auto& a : arrs) if (!a.first->view) a.first->release();
+    PFCHK(c->stage_dev.ensure(total));
+    if (total > c->stage_pin_cap) {
+        if (c->stage_pin) (void)hipHostFree(c->stage_pin);
+        c->stage_pin = nullptr; c->stage_pin_cap = 0;
+        const size_t want = total + total / 4;
+        hipError_t e = hipHostMalloc(&c->stage_pin, want, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(PF_ERR_OOM, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        c->stage_pin_cap = want;
+    }
+    for (size_t i = 0; i < arrs.size(); i++) {
+        const auto& v = *arrs[i].second;
+        if (!v.empty()) memcpy((char*)c->stage_pin + off[i], v.data(), v.size() * 4);
+        arrs[i].first->p = (char*)c->stage_dev.p + off[i];
+        arrs[i].first->cap = 0;
+        arrs[i].first->view = true;
+    }
+    HIPCHK(hipMemcpyAsync(c->stage_dev.p, c->stage_pin, total, hipMemcpyHostToDevice, c->stream));
+    return PF_OK;
+}
+
 template <int KW, bool CANON>
 int launch_scan_t(pf_ctx* c, const pf::ScanParams& sp, uint32_t n) {
     static bool attr_done = false;
@@ -225,6 +260,8 @@ void pf_destroy(pf_ctx* c) {
     for (Arena* a : c->arenas) { a->key.release(); a->pid.release(); a->first.release(); delete a; }
     for (auto& e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->stage_pin) (void)hipHostFree(c->stage_pin);
+    c->stage_dev.release();
     if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
     if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -394,6 +431,14 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
     for (auto& e : c->events) { c->ev_pool.push_back(e.a); c->ev_pool.push_back(e.b); }
     c->events.clear();
     c->timing = pf_timing{};
+    const bool dbg = getenv("PF_DEBUG_TIMING") != nullptr;
+    auto t_host0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!dbg) return;
+        auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[pf_submit] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_host0).count());
+        t_host0 = t;
+    };
     HIPCHK(hipEventRecord(c->ev_t0, c->stream));
 
     // ---- batch arrays on the device
@@ -478,7 +523,7 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
 
     // ---- identical segments -> scan view (mode 1) or the caller's list as it is (mode 0)
     std::vector<uint64_t> ninst(C), vinst(C), words(C);
-    std::vector<uint32_t> h_mode(C), h_dense(C);
+    std::vector<uint32_t> h_mode(C), h_dense(C), h_vnstr(C);
     if (C) {
         pf::DedupParams dp{};
         dp.packed = d.packed; dp.seg_word_off = d.seg_word_off; dp.seg_len = d.seg_len;
@@ -506,6 +551,7 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
         HIPCHK(hipMemcpyAsync(words.data(), c->cl_vwords.p, (size_t)C * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(h_mode.data(), c->v_mode.p, (size_t)C * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(h_dense.data(), c->v_dense.p, (size_t)C * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(h_vnstr.data(), c->v_nstr.p, (size_t)C * 4, hipMemcpyDeviceToHost, c->stream));
     }
     // ---- strand bits of target-strain segments (canonical mode)
     c->n_strand_words = (b->seg_strand_off && c->o.canon) ? b->n_strand_words : 0;
@@ -521,7 +567,9 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
                                d.seg_len, d.seg_strand_off, NSEG, c->o.klength, c->strand_bits.as<uint64_t>());
         HIPCHK(hipGetLastError());
     }
+    lap("upload+dedup launch");
     HIPCHK(hipStreamSynchronize(c->stream));
+    lap("sync after dedup");
     const uint64_t mult = c->o.canon ? 1 : 2;
     uint64_t total_inst = 0;
     for (uint32_t i = 0; i < C; i++) {
@@ -535,6 +583,11 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
 
     std::vector<uint32_t> todo(C), nparts(C, 1);
     std::iota(todo.begin(), todo.end(), 0u);
+    // a deduplicated cluster whose distinct sequences alone carry far more windows than one table holds will
+    // overflow it: start it with two key partitions instead of paying for a failed first scan (a wrong guess
+    // only costs time: an overflow still triggers the doubling retry)
+    for (uint32_t i = 0; i < C; i++)
+        if (h_mode[i] == 1 && vinst[i] * mult * 2 > (uint64_t)pf::insert_limit(NS) * 5) nparts[i] = 2;
     uint32_t pass = 0;
     const uint32_t lim_full = pf::insert_limit(NS);
     uint64_t arena_base = 0;
@@ -565,7 +618,8 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
             const uint64_t inst = vinst[ci] * mult;
             if (np == 1 && NS > 4096 + pf::INSERT_SLACK && inst <= pf::insert_limit(4096)) ns = 4096;
             // a deduplicated cluster that is one work item is finished by one fused kernel (rows + emit in LDS)
-            const bool fused = h_mode[ci] == 1 && nit == 1 && (h_dense[ci] + 31) / 32 <= pf::FUSED_DENSE_WORDS;
+            const bool fused = h_mode[ci] == 1 && nit == 1 && h_dense[ci] < pf::FUSED_DENSE_WORDS * 32 - 1 &&
+                               h_vnstr[ci] * ((W + 3) & ~3u) <= pf::FUSED_MROWS && NS <= 9600;
             for (uint32_t q = 0; q < np; q++) {
                 items.push_back(Item{ci, q, np, ns, cur.nitems + q, sib0, nit, 0, 0});
                 item_fused.push_back(fused ? 1 : 0);
@@ -589,6 +643,7 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
         }
         if (cur.nitems) subs.push_back(cur);
 
+        lap("build items");
         // ---- arena of this pass
         while (c->arenas.size() <= pass) c->arenas.push_back(new Arena());
         Arena* ar = c->arenas[pass];
@@ -607,48 +662,60 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
             v_nslots[i] = items[i].nslots; v_slice[i] = items[i].slice; v_sib0[i] = items[i].sib0;
             v_nsib[i] = items[i].nsib; v_exfirst[i] = items[i].extra_first; v_isex[i] = items[i].is_extra;
         }
-        PFCHK(upload_vec(c, c->it_cluster, v_cluster));
-        PFCHK(upload_vec(c, c->it_part, v_part));
-        PFCHK(upload_vec(c, c->it_nparts, v_nparts));
-        PFCHK(upload_vec(c, c->it_nslots, v_nslots));
-        PFCHK(upload_vec(c, c->it_slice, v_slice));
-        PFCHK(upload_vec(c, c->it_sib0, v_sib0));
-        PFCHK(upload_vec(c, c->it_nsib, v_nsib));
-        PFCHK(upload_vec(c, c->it_extra_first, v_exfirst));
-        PFCHK(upload_vec(c, c->it_is_extra, v_isex));
-        PFCHK(upload_vec(c, c->sub_cluster, sub_cluster));
-        PFCHK(upload_vec(c, c->sub_item0, sub_item0));
-        PFCHK(upload_vec(c, c->sub_nitems, sub_nitems));
         PFCHK(c->it_count.ensure(std::max<size_t>(NI, 1) * 4));
         PFCHK(c->it_unique.ensure(std::max<size_t>(NI, 1) * 4));
         PFCHK(c->it_kept.ensure(std::max<size_t>(NI, 1) * 4));
         // work lists per sub-batch, concatenated; scan items heaviest first (the grid drains evenly)
         std::vector<uint32_t> scan_off(subs.size() + 1, 0), extra_off(subs.size() + 1, 0), fin_off(subs.size() + 1, 0),
             rows_off(subs.size() + 1, 0);
-        for (size_t s = 0; s < subs.size(); s++) {
-            const size_t w0 = w_scan.size(), f0 = w_fin.size();
-            for (uint32_t i = subs[s].item0; i < subs[s].item0 + subs[s].nitems; i++) {
-                (items[i].is_extra ? w_extra : w_scan).push_back(i);
-                (item_fused[i] ? w_fin : w_rows).push_back(i);
+        // heaviest items first inside each launch (the grid then drains evenly): a coarse O(n) order by
+        // log2(scan instances) is enough
+        auto wclass = [&](uint32_t it) -> int {
+            const uint64_t w = vinst[items[it].cluster];
+            return w ? 63 - __builtin_clzll(w) : 0;
+        };
+        std::vector<uint32_t> tmp_scan, tmp_fin;
+        auto append_by_weight = [&](std::vector<uint32_t>& src, std::vector<uint32_t>& dst) {
+            if (src.size() > 64) {
+                size_t cnt[65] = {0};
+                for (uint32_t it : src) cnt[64 - wclass(it)]++;
+                size_t run = dst.size();
+                for (int b = 0; b < 65; b++) { const size_t n = cnt[b]; cnt[b] = run; run += n; }
+                dst.resize(run);
+                for (uint32_t it : src) dst[cnt[64 - wclass(it)]++] = it;
+            } else {
+                dst.insert(dst.end(), src.begin(), src.end());
             }
-            auto heavier = [&](uint32_t x, uint32_t y) { return vinst[items[x].cluster] > vinst[items[y].cluster]; };
-            std::stable_sort(w_scan.begin() + w0, w_scan.end(), heavier);
-            std::stable_sort(w_fin.begin() + f0, w_fin.end(), heavier);
+            src.clear();
+        };
+        for (size_t s = 0; s < subs.size(); s++) {
+            for (uint32_t i = subs[s].item0; i < subs[s].item0 + subs[s].nitems; i++) {
+                if (items[i].is_extra) w_extra.push_back(i); else tmp_scan.push_back(i);
+                if (item_fused[i]) tmp_fin.push_back(i); else w_rows.push_back(i);
+            }
+            append_by_weight(tmp_scan, w_scan);
+            append_by_weight(tmp_fin, w_fin);
             scan_off[s + 1] = (uint32_t)w_scan.size();
             extra_off[s + 1] = (uint32_t)w_extra.size();
             fin_off[s + 1] = (uint32_t)w_fin.size();
             rows_off[s + 1] = (uint32_t)w_rows.size();
         }
-        PFCHK(upload_vec(c, c->work_scan, w_scan));
-        PFCHK(upload_vec(c, c->work_extra, w_extra));
-        PFCHK(upload_vec(c, c->work_fin, w_fin));
-        PFCHK(upload_vec(c, c->work_rows, w_rows));
+        {
+            std::vector<std::pair<DevBuf*, const std::vector<uint32_t>*>> arrs = {
+                {&c->it_cluster, &v_cluster}, {&c->it_part, &v_part}, {&c->it_nparts, &v_nparts},
+                {&c->it_nslots, &v_nslots}, {&c->it_slice, &v_slice}, {&c->it_sib0, &v_sib0}, {&c->it_nsib, &v_nsib},
+                {&c->it_extra_first, &v_exfirst}, {&c->it_is_extra, &v_isex}, {&c->sub_cluster, &sub_cluster},
+                {&c->sub_item0, &sub_item0}, {&c->sub_nitems, &sub_nitems}, {&c->work_scan, &w_scan},
+                {&c->work_extra, &w_extra}, {&c->work_fin, &w_fin}, {&c->work_rows, &w_rows}};
+            PFCHK(staged_upload(c, arrs));
+        }
         // the cursor's next free index restarts at this arena's base
         {
             uint64_t cur0 = arena_base;
             HIPCHK(hipMemcpyAsync(c->cursor.p, &cur0, 8, hipMemcpyHostToDevice, c->stream));
         }
 
+        lap("upload items");
         for (size_t s = 0; s < subs.size(); s++) {
             const Sub& sb = subs[s];
             const uint32_t n_scan = scan_off[s + 1] - scan_off[s], n_extra_items = extra_off[s + 1] - extra_off[s];
@@ -804,12 +871,14 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
         c->timing.n_items += (uint32_t)NI;
         for (uint32_t ci : todo) c->timing.scan_packed_bytes += words[ci] * 8 * nparts[ci];
 
+        lap("launch pass");
         // ---- who overflowed?
         std::vector<uint32_t> ovf(C);
         uint64_t cur3[3];
         HIPCHK(hipMemcpyAsync(ovf.data(), c->cl_overflow.p, (size_t)C * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(cur3, c->cursor.p, 24, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
+        lap("sync pass");
         ar->used = cur3[0] - ar->base;
         if (ar->used > ar->cap) return fail(PF_ERR_CAPACITY, "output arena overflow (%llu > %llu)",
                                             (unsigned long long)ar->used, (unsigned long long)ar->cap);
@@ -854,6 +923,7 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
     HIPCHK(hipEventRecord(c->ev_t1, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
 
+    lap("md5 + final sync");
     // ---- timing
     HIPCHK(hipEventElapsedTime(&c->timing.total_ms, c->ev_t0, c->ev_t1));
     for (auto& e : c->events) {

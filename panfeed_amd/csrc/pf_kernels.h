@@ -480,9 +480,10 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
 constexpr uint32_t DEDUP_THREADS = 1024;
 
 __global__ __launch_bounds__(DEDUP_THREADS) void cluster_dedup_kernel(DedupParams p) {
+    // 64 KiB in all: two workgroups per CU
     __shared__ uint64_t s_hash[DEDUP_MAX_SEGS];
-    __shared__ uint64_t t_key[DEDUP_TAB];
-    __shared__ uint64_t t_val[DEDUP_TAB];      // min over the group of (ord_base << 32 | local index)
+    __shared__ uint64_t t_val[DEDUP_TAB];      // per hash group: min of (ord_base << 32 | local index); the group's
+                                               // hash is s_hash[] of whichever member currently holds the minimum
     __shared__ uint32_t s_rep[DEDUP_MAX_SEGS]; // local index of the representative
     __shared__ uint32_t s_rank[DEDUP_MAX_SEGS];// distinct index of a representative
     __shared__ uint32_t r_list[DEDUP_MAX_D];   // representatives (local indices), unordered
@@ -501,7 +502,7 @@ __global__ __launch_bounds__(DEDUP_THREADS) void cluster_dedup_kernel(DedupParam
     bool mode1 = p.enable && n >= 4 && n <= DEDUP_MAX_SEGS;
     if (tid == 0) { sh_bad = 0; sh_nrep = 0; sh_total = 0; }
     if (mode1) {
-        for (uint32_t i = tid; i < DEDUP_TAB; i += DEDUP_THREADS) { t_key[i] = EMPTY64; t_val[i] = EMPTY64; }
+        for (uint32_t i = tid; i < DEDUP_TAB; i += DEDUP_THREADS) t_val[i] = EMPTY64;
     }
     __syncthreads();
     if (mode1) {
@@ -533,18 +534,20 @@ __global__ __launch_bounds__(DEDUP_THREADS) void cluster_dedup_kernel(DedupParam
         // ---- 2. group by hash; the group's representative is the copy with the lowest ordinal
         for (uint32_t s = tid; s < n; s += DEDUP_THREADS) {
             const uint64_t h = s_hash[s];
+            const uint64_t mine = ((uint64_t)p.seg_ord_base[seg0 + s] << 32) | s;
             uint32_t slot = (uint32_t)h & (DEDUP_TAB - 1);
             for (;;) {
-                uint64_t cur = __hip_atomic_load(&t_key[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                uint64_t cur = __hip_atomic_load(&t_val[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (cur == EMPTY64) {
-                    cur = atomicCAS((unsigned long long*)&t_key[slot], (unsigned long long)EMPTY64, (unsigned long long)h);
-                    if (cur == EMPTY64) cur = h;
+                    cur = atomicCAS((unsigned long long*)&t_val[slot], (unsigned long long)EMPTY64, (unsigned long long)mine);
+                    if (cur == EMPTY64) break;                       // first member of a new group
                 }
-                if (cur == h) break;
+                if (s_hash[(uint32_t)cur] == h) {                    // any holder of the slot is a member of its group
+                    atomicMin((unsigned long long*)&t_val[slot], (unsigned long long)mine);
+                    break;
+                }
                 slot = (slot + 1) & (DEDUP_TAB - 1);
             }
-            atomicMin((unsigned long long*)&t_val[slot],
-                      (unsigned long long)(((uint64_t)p.seg_ord_base[seg0 + s] << 32) | s));
             s_rep[s] = slot;     // table slot for now
         }
         __syncthreads();
@@ -1293,8 +1296,11 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
 // masks with their row hash / keep flag, ordinal bitmaps for ranks, one insert into the run-global pattern
 // table per distinct mask, and the pattern row is written by whoever lowers the pattern's first_seen (all
 // writers of one pattern write identical bytes).
-constexpr uint32_t FUSED_DENSE_WORDS = 2048;     // 65536 dense ordinals
+constexpr uint32_t FUSED_DENSE_WORDS = 2048;     // < 65536 dense ordinals (prefix counts are 16-bit)
+constexpr uint32_t FUSED_MROWS = 2048;           // D * ceil4(W) words of M
+constexpr uint32_t FAT_SLOTS = 512, FAT_LIMIT = 384;   // distinct allele masks held in LDS
 constexpr uint32_t FIN_THREADS = 1024;
+static_assert(nslots_max(1) <= 9600, "slot_at too small");
 
 struct FinishParams {
     const uint32_t* work;            // [gridDim.x] item ids
@@ -1351,13 +1357,14 @@ __device__ __forceinline__ uint32_t pattern_insert_lower(const PatternTable& t, 
 }
 
 __global__ __launch_bounds__(FIN_THREADS) void finish_kernel(FinishParams p) {
-    __shared__ __align__(16) uint32_t M[DEDUP_MROWS];           // 16 KiB
+    // 76 KiB in all: two workgroups per CU
+    __shared__ __align__(16) uint32_t M[FUSED_MROWS];            // 8 KiB
     __shared__ uint32_t occ[FUSED_DENSE_WORDS], keepbm[FUSED_DENSE_WORDS];
-    __shared__ uint32_t pocc[FUSED_DENSE_WORDS], pkeep[FUSED_DENSE_WORDS];   // exclusive prefix popcounts
-    __shared__ uint64_t at_key[AT_SLOTS];
-    __shared__ uint4 at_hash[AT_SLOTS];
-    __shared__ uint32_t at_keep[AT_SLOTS], at_minord[AT_SLOTS], at_slot[AT_SLOTS], at_pid[AT_SLOTS];
-    __shared__ uint16_t slot_at[12288];                          // per slot: entry index, 0xFFFF free, 0xFFFE untabled
+    __shared__ uint16_t pocc[FUSED_DENSE_WORDS], pkeep[FUSED_DENSE_WORDS];   // exclusive prefix popcounts (< 65536)
+    __shared__ uint64_t at_key[FAT_SLOTS];
+    __shared__ uint4 at_hash[FAT_SLOTS];
+    __shared__ uint32_t at_keep[FAT_SLOTS], at_minord[FAT_SLOTS], at_pid[FAT_SLOTS];
+    __shared__ uint16_t slot_at[9600];                           // per slot: entry index, 0xFFFF free, 0xFFFE untabled
     __shared__ uint32_t wave_tot[FIN_THREADS / 64 + 1];
     __shared__ uint32_t sh_npres, at_count;
     __shared__ uint64_t sh_base;
@@ -1380,9 +1387,9 @@ __global__ __launch_bounds__(FIN_THREADS) void finish_kernel(FinishParams p) {
     const uint32_t cm0 = p.chunkmask[slice * 8];
     const bool f0 = (cm0 & 1) != 0, f1 = (cm0 & 2) != 0;
 
-    for (uint32_t i = tid; i < DEDUP_MROWS; i += FIN_THREADS) M[i] = 0;
+    for (uint32_t i = tid; i < FUSED_MROWS; i += FIN_THREADS) M[i] = 0;
     for (uint32_t i = tid; i < FUSED_DENSE_WORDS; i += FIN_THREADS) { occ[i] = 0; keepbm[i] = 0; }
-    for (uint32_t i = tid; i < AT_SLOTS; i += FIN_THREADS) { at_key[i] = 0; at_minord[i] = NO_ORD; }
+    for (uint32_t i = tid; i < FAT_SLOTS; i += FIN_THREADS) { at_key[i] = 0; at_minord[i] = NO_ORD; }
     if (tid == 0) {
         at_count = 0;
         uint32_t np = 0;
@@ -1403,16 +1410,16 @@ __global__ __launch_bounds__(FIN_THREADS) void finish_kernel(FinishParams p) {
         if (ordp[i] != NO_ORD) {
             const uint64_t amask = (f0 ? (uint64_t)cb[i] : 0) | (f1 ? (uint64_t)cb[(size_t)NS + i] << 32 : 0);
             tag = 0xFFFE;
-            uint32_t a = (uint32_t)mix64(amask) & (AT_SLOTS - 1);
-            for (uint32_t probes = 0; amask && probes < AT_SLOTS; probes++) {
+            uint32_t a = (uint32_t)mix64(amask) & (FAT_SLOTS - 1);
+            for (uint32_t probes = 0; amask && probes < FAT_SLOTS; probes++) {
                 uint64_t cur = __hip_atomic_load(&at_key[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (cur == 0) {
-                    if (__hip_atomic_load(&at_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= AT_LIMIT) break;
+                    if (__hip_atomic_load(&at_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= FAT_LIMIT) break;
                     cur = atomicCAS((unsigned long long*)&at_key[a], 0ull, (unsigned long long)amask);
-                    if (cur == 0) { atomicAdd(&at_count, 1u); at_slot[a] = i; cur = amask; }
+                    if (cur == 0) { atomicAdd(&at_count, 1u); cur = amask; }
                 }
                 if (cur == amask) { tag = (uint16_t)a; break; }
-                a = (a + 1) & (AT_SLOTS - 1);
+                a = (a + 1) & (FAT_SLOTS - 1);
             }
         }
         slot_at[i] = tag;
@@ -1482,7 +1489,7 @@ __global__ __launch_bounds__(FIN_THREADS) void finish_kernel(FinishParams p) {
     };
 
     // phase B: one row evaluation per distinct mask
-    for (uint32_t t = tid; t < AT_SLOTS; t += FIN_THREADS) {
+    for (uint32_t t = tid; t < FAT_SLOTS; t += FIN_THREADS) {
         const uint64_t key = at_key[t];
         if (!key) continue;
         uint4 h;
@@ -1521,7 +1528,7 @@ __global__ __launch_bounds__(FIN_THREADS) void finish_kernel(FinishParams p) {
 #pragma unroll
         for (uint32_t j = 0; j < PW; j++) {
             const uint32_t w = tid * PW + j;
-            pocc[w] = bo; pkeep[w] = bk;
+            pocc[w] = (uint16_t)bo; pkeep[w] = (uint16_t)bk;
             bo += __popc(occ[w]); bk += __popc(keepbm[w]);
         }
     }
@@ -1559,7 +1566,7 @@ __global__ __launch_bounds__(FIN_THREADS) void finish_kernel(FinishParams p) {
     auto rank_of = [&](uint32_t o) -> uint32_t { return pocc[o >> 5] + __popc(occ[o >> 5] & ((1u << (o & 31)) - 1)); };
     auto kept_before = [&](uint32_t o) -> uint32_t { return pkeep[o >> 5] + __popc(keepbm[o >> 5] & ((1u << (o & 31)) - 1)); };
     // one insert into the run-global table per distinct kept mask
-    for (uint32_t t = tid; t < AT_SLOTS; t += FIN_THREADS) {
+    for (uint32_t t = tid; t < FAT_SLOTS; t += FIN_THREADS) {
         const uint64_t key = at_key[t];
         if (!key || !at_keep[t]) continue;
         const uint32_t mo = at_minord[t];
