@@ -106,7 +106,7 @@ struct pf_ctx {
     DevBuf bm_occ, bm_keep, pre_occ, pre_keep, mrows, slot_out, it_is_extra;
     DevBuf strand_bits;
     DevBuf it_cluster, it_part, it_nparts, it_nslots, it_slice, it_sib0, it_nsib, it_extra_first, it_count,
-        it_unique, it_kept, work_scan, work_extra, work_fin, work_rows, sub_cluster, sub_item0, sub_nitems;
+        it_unique, it_kept, work_scan, work_extra, work_fin, work_fin2, work_rows, sub_cluster, sub_item0, sub_nitems;
     std::vector<Arena*> arenas;
     DevBuf stage_dev;              // one device block for the small per-pass arrays
     void* stage_pin = nullptr;     // pinned host mirror of it
@@ -254,7 +254,7 @@ void pf_destroy(pf_ctx* c) {
                       &c->bm_occ, &c->bm_keep, &c->pre_occ, &c->pre_keep, &c->mrows, &c->slot_out, &c->it_is_extra, &c->cl_overflow, &c->cl_kmer_off, &c->cl_kmer_cnt, &c->cl_unique, &c->cl_pattern,
                       &c->cl_first, &c->cursor, &c->strand_bits, &c->it_cluster, &c->it_part, &c->it_nparts,
                       &c->it_nslots, &c->it_slice, &c->it_sib0, &c->it_nsib, &c->it_extra_first, &c->it_count,
-                      &c->it_unique, &c->it_kept, &c->work_scan, &c->work_extra, &c->work_fin, &c->work_rows, &c->sub_cluster, &c->sub_item0,
+                      &c->it_unique, &c->it_kept, &c->work_scan, &c->work_extra, &c->work_fin, &c->work_fin2, &c->work_rows, &c->sub_cluster, &c->sub_item0,
                       &c->sub_nitems};
     for (DevBuf* b : bufs) b->release();
     for (Arena* a : c->arenas) { a->key.release(); a->pid.release(); a->first.release(); delete a; }
@@ -595,7 +595,7 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
     while (!todo.empty()) {
         // ---- items of this pass
         std::vector<Item> items;
-        std::vector<uint8_t> item_fused;
+        std::vector<uint8_t> item_fused;      // 0 unfused, 1 fused small class, 2 fused large class
         struct Sub { uint32_t item0, nitems, cl0, ncl; };
         std::vector<Sub> subs;
         std::vector<uint32_t> sub_cluster, sub_item0, sub_nitems;
@@ -618,11 +618,15 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
             const uint64_t inst = vinst[ci] * mult;
             if (np == 1 && NS > 4096 + pf::INSERT_SLACK && inst <= pf::insert_limit(4096)) ns = 4096;
             // a deduplicated cluster that is one work item is finished by one fused kernel (rows + emit in LDS)
-            const bool fused = h_mode[ci] == 1 && nit == 1 && h_dense[ci] < pf::FUSED_DENSE_WORDS * 32 - 1 &&
-                               h_vnstr[ci] * ((W + 3) & ~3u) <= pf::FUSED_MROWS && NS <= 9600;
+            const uint32_t mwords = h_vnstr[ci] * ((W + 3) & ~3u);
+            uint8_t fused = 0;
+            if (h_mode[ci] == 1 && nit == 1 && NS <= 9600) {
+                if (h_dense[ci] < pf::FinSmall::DW * 32 - 1 && mwords <= pf::FinSmall::MR) fused = 1;
+                else if (h_dense[ci] < pf::FinLarge::DW * 32 - 1 && mwords <= pf::FinLarge::MR) fused = 2;
+            }
             for (uint32_t q = 0; q < np; q++) {
                 items.push_back(Item{ci, q, np, ns, cur.nitems + q, sib0, nit, 0, 0});
-                item_fused.push_back(fused ? 1 : 0);
+                item_fused.push_back(fused);
             }
             for (uint32_t q = 0; q < nex_items; q++) {
                 const uint32_t first = ex_first[ci] + q * lim_full;
@@ -656,7 +660,7 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
         // ---- item arrays
         const size_t NI = items.size();
         std::vector<uint32_t> v_cluster(NI), v_part(NI), v_nparts(NI), v_nslots(NI), v_slice(NI), v_sib0(NI), v_nsib(NI),
-            v_exfirst(NI), v_isex(NI), w_scan, w_extra, w_fin, w_rows;
+            v_exfirst(NI), v_isex(NI), w_scan, w_extra, w_fin, w_fin2, w_rows;
         for (size_t i = 0; i < NI; i++) {
             v_cluster[i] = items[i].cluster; v_part[i] = items[i].part; v_nparts[i] = items[i].nparts;
             v_nslots[i] = items[i].nslots; v_slice[i] = items[i].slice; v_sib0[i] = items[i].sib0;
@@ -667,14 +671,14 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
         PFCHK(c->it_kept.ensure(std::max<size_t>(NI, 1) * 4));
         // work lists per sub-batch, concatenated; scan items heaviest first (the grid drains evenly)
         std::vector<uint32_t> scan_off(subs.size() + 1, 0), extra_off(subs.size() + 1, 0), fin_off(subs.size() + 1, 0),
-            rows_off(subs.size() + 1, 0);
+            fin2_off(subs.size() + 1, 0), rows_off(subs.size() + 1, 0);
         // heaviest items first inside each launch (the grid then drains evenly): a coarse O(n) order by
         // log2(scan instances) is enough
         auto wclass = [&](uint32_t it) -> int {
             const uint64_t w = vinst[items[it].cluster];
             return w ? 63 - __builtin_clzll(w) : 0;
         };
-        std::vector<uint32_t> tmp_scan, tmp_fin;
+        std::vector<uint32_t> tmp_scan, tmp_fin, tmp_fin2;
         auto append_by_weight = [&](std::vector<uint32_t>& src, std::vector<uint32_t>& dst) {
             if (src.size() > 64) {
                 size_t cnt[65] = {0};
@@ -691,13 +695,17 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
         for (size_t s = 0; s < subs.size(); s++) {
             for (uint32_t i = subs[s].item0; i < subs[s].item0 + subs[s].nitems; i++) {
                 if (items[i].is_extra) w_extra.push_back(i); else tmp_scan.push_back(i);
-                if (item_fused[i]) tmp_fin.push_back(i); else w_rows.push_back(i);
+                if (item_fused[i] == 1) tmp_fin.push_back(i);
+                else if (item_fused[i] == 2) tmp_fin2.push_back(i);
+                else w_rows.push_back(i);
             }
             append_by_weight(tmp_scan, w_scan);
             append_by_weight(tmp_fin, w_fin);
+            append_by_weight(tmp_fin2, w_fin2);
             scan_off[s + 1] = (uint32_t)w_scan.size();
             extra_off[s + 1] = (uint32_t)w_extra.size();
             fin_off[s + 1] = (uint32_t)w_fin.size();
+            fin2_off[s + 1] = (uint32_t)w_fin2.size();
             rows_off[s + 1] = (uint32_t)w_rows.size();
         }
         {
@@ -706,7 +714,7 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
                 {&c->it_nslots, &v_nslots}, {&c->it_slice, &v_slice}, {&c->it_sib0, &v_sib0}, {&c->it_nsib, &v_nsib},
                 {&c->it_extra_first, &v_exfirst}, {&c->it_is_extra, &v_isex}, {&c->sub_cluster, &sub_cluster},
                 {&c->sub_item0, &sub_item0}, {&c->sub_nitems, &sub_nitems}, {&c->work_scan, &w_scan},
-                {&c->work_extra, &w_extra}, {&c->work_fin, &w_fin}, {&c->work_rows, &w_rows}};
+                {&c->work_extra, &w_extra}, {&c->work_fin, &w_fin}, {&c->work_fin2, &w_fin2}, {&c->work_rows, &w_rows}};
             PFCHK(staged_upload(c, arrs));
         }
         // the cursor's next free index restarts at this arena's base
@@ -753,8 +761,9 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
                 PFCHK(mark_end(c));
                 c->timing.scan_launches++;
             }
-            const uint32_t n_fin = fin_off[s + 1] - fin_off[s], n_rows = rows_off[s + 1] - rows_off[s];
-            if (n_fin) {
+            const uint32_t n_fin = fin_off[s + 1] - fin_off[s], n_fin2 = fin2_off[s + 1] - fin2_off[s],
+                           n_rows = rows_off[s + 1] - rows_off[s];
+            if (n_fin || n_fin2) {
                 pf::FinishParams fp{};
                 fp.work = c->work_fin.as<uint32_t>() + fin_off[s];
                 fp.item_cluster = c->it_cluster.as<uint32_t>(); fp.item_nslots = c->it_nslots.as<uint32_t>();
@@ -777,8 +786,15 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
                 fp.out_base = ar->base; fp.out_cap = ar->cap; fp.W = W; fp.NS = NS; fp.KW = KW;
                 fp.consider_missing = c->o.consider_missing; fp.patfilt = c->o.patfilt; fp.multiple_files = c->o.multiple_files;
                 PFCHK(mark_begin(c, 6));
-                hipLaunchKernelGGL(pf::finish_kernel, dim3(n_fin), dim3(pf::FIN_THREADS), 0, c->stream, fp);
-                HIPCHK(hipGetLastError());
+                if (n_fin) {
+                    hipLaunchKernelGGL(pf::finish_kernel<pf::FinSmall>, dim3(n_fin), dim3(pf::FinSmall::THREADS), 0, c->stream, fp);
+                    HIPCHK(hipGetLastError());
+                }
+                if (n_fin2) {
+                    fp.work = c->work_fin2.as<uint32_t>() + fin2_off[s];
+                    hipLaunchKernelGGL(pf::finish_kernel<pf::FinLarge>, dim3(n_fin2), dim3(pf::FinLarge::THREADS), 0, c->stream, fp);
+                    HIPCHK(hipGetLastError());
+                }
                 PFCHK(mark_end(c));
             }
             if (!n_rows) continue;

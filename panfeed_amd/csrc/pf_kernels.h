@@ -1296,10 +1296,12 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
 // masks with their row hash / keep flag, ordinal bitmaps for ranks, one insert into the run-global pattern
 // table per distinct mask, and the pattern row is written by whoever lowers the pattern's first_seen (all
 // writers of one pattern write identical bytes).
-constexpr uint32_t FUSED_DENSE_WORDS = 2048;     // < 65536 dense ordinals (prefix counts are 16-bit)
-constexpr uint32_t FUSED_MROWS = 2048;           // D * ceil4(W) words of M
-constexpr uint32_t FAT_SLOTS = 512, FAT_LIMIT = 384;   // distinct allele masks held in LDS
-constexpr uint32_t FIN_THREADS = 1024;
+// Two size classes: the small one (most clusters) keeps four 512-thread workgroups resident per CU, which is
+// what hides the latency of the global atomics and dependent loads this kernel is made of.
+struct FinSmall { static constexpr uint32_t THREADS = 512, DW = 1024, MR = 1024, AT = 256, ATL = 192; typedef uint8_t tag_t; };
+struct FinLarge { static constexpr uint32_t THREADS = 1024, DW = 2048, MR = 2048, AT = 512, ATL = 384; typedef uint16_t tag_t; };
+constexpr uint32_t FUSED_DENSE_WORDS = FinLarge::DW;   // < 65536 dense ordinals (prefix counts are 16-bit)
+constexpr uint32_t FUSED_MROWS = FinLarge::MR;         // D * ceil4(W) words of M
 static_assert(nslots_max(1) <= 9600, "slot_at too small");
 
 struct FinishParams {
@@ -1356,16 +1358,20 @@ __device__ __forceinline__ uint32_t pattern_insert_lower(const PatternTable& t, 
     return pid;
 }
 
-__global__ __launch_bounds__(FIN_THREADS) void finish_kernel(FinishParams p) {
-    // 76 KiB in all: two workgroups per CU
-    __shared__ __align__(16) uint32_t M[FUSED_MROWS];            // 8 KiB
-    __shared__ uint32_t occ[FUSED_DENSE_WORDS], keepbm[FUSED_DENSE_WORDS];
-    __shared__ uint16_t pocc[FUSED_DENSE_WORDS], pkeep[FUSED_DENSE_WORDS];   // exclusive prefix popcounts (< 65536)
-    __shared__ uint64_t at_key[FAT_SLOTS];
-    __shared__ uint4 at_hash[FAT_SLOTS];
-    __shared__ uint32_t at_keep[FAT_SLOTS], at_minord[FAT_SLOTS], at_pid[FAT_SLOTS];
-    __shared__ uint16_t slot_at[9600];                           // per slot: entry index, 0xFFFF free, 0xFFFE untabled
-    __shared__ uint32_t wave_tot[FIN_THREADS / 64 + 1];
+template <class CFG>
+__global__ __launch_bounds__(CFG::THREADS) void finish_kernel(FinishParams p) {
+    constexpr uint32_t T = CFG::THREADS, DW = CFG::DW, AT = CFG::AT;
+    __shared__ __align__(16) uint32_t M[CFG::MR];
+    __shared__ uint32_t occ[DW], keepbm[DW];
+    __shared__ uint16_t pocc[DW], pkeep[DW];                     // exclusive prefix popcounts (< 65536)
+    __shared__ uint64_t at_key[AT];
+    __shared__ uint4 at_hash[AT];
+    __shared__ uint32_t at_keep[AT], at_minord[AT], at_pid[AT];
+    typedef typename CFG::tag_t tag_t;
+    constexpr uint32_t PROBE = AT - 1;                           // table positions 0..AT-2; AT-1 = "not in the table"
+    constexpr tag_t UNTABLED = (tag_t)(AT - 1);
+    __shared__ tag_t slot_at[9600];                              // per occupied slot: its mask's table position
+    __shared__ uint32_t wave_tot[T / 64 + 1];
     __shared__ uint32_t sh_npres, at_count;
     __shared__ uint64_t sh_base;
 
@@ -1380,16 +1386,16 @@ __global__ __launch_bounds__(FIN_THREADS) void finish_kernel(FinishParams p) {
     const uint32_t nchunks = (nstr + 31) >> 5;
     const uint32_t Wp = (W + 3) & ~3u;
     const uint32_t* presab = p.cluster_presab + (size_t)c * W;
-    const uint32_t dense_words = (p.v_dense[c] + 31) >> 5;      // <= FUSED_DENSE_WORDS (host-checked)
+    const uint32_t dense_words = (p.v_dense[c] + 31) >> 5;      // <= DW (host-checked)
     const uint64_t ordinal = p.cluster_ordinal[c];
     const uint32_t* ordp = p.tab_ord + (size_t)slice * NS;
     const uint32_t* cb = p.chunkbits + (size_t)slice * W * NS;
     const uint32_t cm0 = p.chunkmask[slice * 8];
     const bool f0 = (cm0 & 1) != 0, f1 = (cm0 & 2) != 0;
 
-    for (uint32_t i = tid; i < FUSED_MROWS; i += FIN_THREADS) M[i] = 0;
-    for (uint32_t i = tid; i < FUSED_DENSE_WORDS; i += FIN_THREADS) { occ[i] = 0; keepbm[i] = 0; }
-    for (uint32_t i = tid; i < FAT_SLOTS; i += FIN_THREADS) { at_key[i] = 0; at_minord[i] = NO_ORD; }
+    for (uint32_t i = tid; i < CFG::MR; i += T) M[i] = 0;
+    for (uint32_t i = tid; i < DW; i += T) { occ[i] = 0; keepbm[i] = 0; }
+    for (uint32_t i = tid; i < AT; i += T) { at_key[i] = 0; at_minord[i] = NO_ORD; }
     if (tid == 0) {
         at_count = 0;
         uint32_t np = 0;
@@ -1399,27 +1405,27 @@ __global__ __launch_bounds__(FIN_THREADS) void finish_kernel(FinishParams p) {
     __syncthreads();
     {   // M[d] = samples that carry distinct sequence d
         const uint32_t s0 = p.cluster_seg_off[c], s1 = p.cluster_seg_off[c + 1];
-        for (uint32_t s = s0 + tid; s < s1; s += FIN_THREADS) {
+        for (uint32_t s = s0 + tid; s < s1; s += T) {
             const uint32_t d = p.seg_distinct[s], smp = p.seg_sample[s];
             atomicOr(&M[d * Wp + (smp >> 5)], 1u << (smp & 31));
         }
     }
     // phase A: distinct allele masks
-    for (uint32_t i = tid; i < ns; i += FIN_THREADS) {
-        uint16_t tag = 0xFFFF;
-        if (ordp[i] != NO_ORD) {
-            const uint64_t amask = (f0 ? (uint64_t)cb[i] : 0) | (f1 ? (uint64_t)cb[(size_t)NS + i] << 32 : 0);
-            tag = 0xFFFE;
-            uint32_t a = (uint32_t)mix64(amask) & (FAT_SLOTS - 1);
-            for (uint32_t probes = 0; amask && probes < FAT_SLOTS; probes++) {
+    for (uint32_t i = tid; i < ns; i += T) {
+        const uint32_t o = ordp[i];
+        const uint64_t amask = (f0 ? (uint64_t)cb[i] : 0) | (f1 ? (uint64_t)cb[(size_t)NS + i] << 32 : 0);
+        tag_t tag = UNTABLED;
+        if (o != NO_ORD) {
+            uint32_t a = (uint32_t)mix64(amask) % PROBE;
+            for (uint32_t probes = 0; amask && probes < PROBE; probes++) {
                 uint64_t cur = __hip_atomic_load(&at_key[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (cur == 0) {
-                    if (__hip_atomic_load(&at_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= FAT_LIMIT) break;
+                    if (__hip_atomic_load(&at_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= CFG::ATL) break;
                     cur = atomicCAS((unsigned long long*)&at_key[a], 0ull, (unsigned long long)amask);
                     if (cur == 0) { atomicAdd(&at_count, 1u); cur = amask; }
                 }
-                if (cur == amask) { tag = (uint16_t)a; break; }
-                a = (a + 1) & (FAT_SLOTS - 1);
+                if (cur == amask) { tag = (tag_t)a; break; }
+                a = a + 1 == PROBE ? 0 : a + 1;
             }
         }
         slot_at[i] = tag;
@@ -1489,7 +1495,7 @@ __global__ __launch_bounds__(FIN_THREADS) void finish_kernel(FinishParams p) {
     };
 
     // phase B: one row evaluation per distinct mask
-    for (uint32_t t = tid; t < FAT_SLOTS; t += FIN_THREADS) {
+    for (uint32_t t = tid; t < AT; t += T) {
         const uint64_t key = at_key[t];
         if (!key) continue;
         uint4 h;
@@ -1498,13 +1504,12 @@ __global__ __launch_bounds__(FIN_THREADS) void finish_kernel(FinishParams p) {
     }
     __syncthreads();
     // phase C: ordinal bitmaps, lowest ordinal per mask
-    for (uint32_t i = tid; i < ns; i += FIN_THREADS) {
-        const uint16_t tag = slot_at[i];
-        if (tag == 0xFFFF) continue;
+    for (uint32_t i = tid; i < ns; i += T) {
         const uint32_t o = ordp[i];
-        if ((o >> 5) >= dense_words) continue;
+        if (o == NO_ORD || (o >> 5) >= dense_words) continue;
+        const tag_t tag = slot_at[i];
         bool keep;
-        if (tag == 0xFFFE) {
+        if (tag == UNTABLED) {
             const uint64_t amask = (f0 ? (uint64_t)cb[i] : 0) | (f1 ? (uint64_t)cb[(size_t)NS + i] << 32 : 0);
             uint4 h;
             keep = row_eval(amask, h);
@@ -1519,7 +1524,7 @@ __global__ __launch_bounds__(FIN_THREADS) void finish_kernel(FinishParams p) {
     // prefix popcounts over the bitmap words
     uint32_t tot_o, tot_k;
     {
-        constexpr uint32_t PW = FUSED_DENSE_WORDS / FIN_THREADS;   // 2
+        constexpr uint32_t PW = DW / T;   // 2
         uint32_t so = 0, sk = 0;
 #pragma unroll
         for (uint32_t j = 0; j < PW; j++) { so += __popc(occ[tid * PW + j]); sk += __popc(keepbm[tid * PW + j]); }
@@ -1532,13 +1537,20 @@ __global__ __launch_bounds__(FIN_THREADS) void finish_kernel(FinishParams p) {
             bo += __popc(occ[w]); bk += __popc(keepbm[w]);
         }
     }
-    if (tid == 0) {
+    __syncthreads();
+    auto rank_of = [&](uint32_t o) -> uint32_t { return pocc[o >> 5] + __popc(occ[o >> 5] & ((1u << (o & 31)) - 1)); };
+    auto kept_before = [&](uint32_t o) -> uint32_t { return pkeep[o >> 5] + __popc(keepbm[o >> 5] & ((1u << (o & 31)) - 1)); };
+    // every global atomic of the item in one phase, on different threads, so that their latencies overlap:
+    // the output range (last thread), the cluster's own row (second to last), one insert per distinct kept mask
+    if (tid == T - 1) {
         sh_base = atomicAdd((unsigned long long*)&p.cursor[0], (unsigned long long)tot_k);
         atomicAdd((unsigned long long*)&p.cursor[1], (unsigned long long)tot_o);
         atomicAdd((unsigned long long*)&p.cursor[2], (unsigned long long)tot_k);
         p.cluster_kmer_off[c] = sh_base;
         p.cluster_kmer_cnt[c] = tot_k;
         p.cluster_unique[c] = tot_o;
+    }
+    if (tid == T - 2) {
         // the cluster's own row: md5 of the int64 image of clusterpresab (panfeed.py:175-187)
         const uint32_t nw = (npres + 31) >> 5;
         H128 s;
@@ -1561,12 +1573,7 @@ __global__ __launch_bounds__(FIN_THREADS) void finish_kernel(FinishParams p) {
             p.pat_n[pid] = npres | 0x80000000u;
         }
     }
-    __syncthreads();
-    const uint64_t obase = sh_base - p.out_base;
-    auto rank_of = [&](uint32_t o) -> uint32_t { return pocc[o >> 5] + __popc(occ[o >> 5] & ((1u << (o & 31)) - 1)); };
-    auto kept_before = [&](uint32_t o) -> uint32_t { return pkeep[o >> 5] + __popc(keepbm[o >> 5] & ((1u << (o & 31)) - 1)); };
-    // one insert into the run-global table per distinct kept mask
-    for (uint32_t t = tid; t < FAT_SLOTS; t += FIN_THREADS) {
+    for (uint32_t t = tid; t < AT; t += T) {
         const uint64_t key = at_key[t];
         if (!key || !at_keep[t]) continue;
         const uint32_t mo = at_minord[t];
@@ -1579,14 +1586,14 @@ __global__ __launch_bounds__(FIN_THREADS) void finish_kernel(FinishParams p) {
         if (lowered && pid < p.pt.pool) write_row(pid, key);
     }
     __syncthreads();
+    const uint64_t obase = sh_base - p.out_base;
     // outputs: key + pattern id per kept k-mer, in first-occurrence order
-    for (uint32_t i = tid; i < ns; i += FIN_THREADS) {
-        const uint16_t tag = slot_at[i];
-        if (tag == 0xFFFF) continue;
+    for (uint32_t i = tid; i < ns; i += T) {
         const uint32_t o = ordp[i];
-        if ((o >> 5) >= dense_words || !((keepbm[o >> 5] >> (o & 31)) & 1)) continue;
+        if (o == NO_ORD || (o >> 5) >= dense_words || !((keepbm[o >> 5] >> (o & 31)) & 1)) continue;
+        const tag_t tag = slot_at[i];
         uint32_t pid;
-        if (tag == 0xFFFE) {
+        if (tag == UNTABLED) {
             // mask table was full: this slot goes to the run-global table on its own
             const uint64_t amask = (f0 ? (uint64_t)cb[i] : 0) | (f1 ? (uint64_t)cb[(size_t)NS + i] << 32 : 0);
             uint4 h;
