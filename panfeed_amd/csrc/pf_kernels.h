@@ -484,8 +484,10 @@ __global__ __launch_bounds__(DEDUP_THREADS) void cluster_dedup_kernel(DedupParam
     __shared__ uint64_t s_hash[DEDUP_MAX_SEGS];
     __shared__ uint64_t t_val[DEDUP_TAB];      // per hash group: min of (ord_base << 32 | local index); the group's
                                                // hash is s_hash[] of whichever member currently holds the minimum
-    __shared__ uint32_t s_rep[DEDUP_MAX_SEGS]; // local index of the representative
-    __shared__ uint32_t s_rank[DEDUP_MAX_SEGS];// distinct index of a representative
+    __shared__ uint32_t s_rep[DEDUP_MAX_SEGS]; // low 16 bits: local index of the representative; a representative
+                                               // also carries its distinct index in the high 16 bits
+    __shared__ uint32_t s_woff[DEDUP_MAX_SEGS];// word offset relative to the cluster's first segment
+    __shared__ uint32_t s_len[DEDUP_MAX_SEGS];
     __shared__ uint32_t r_list[DEDUP_MAX_D];   // representatives (local indices), unordered
     __shared__ uint32_t r_ord0[DEDUP_MAX_D], r_ninst[DEDUP_MAX_D], r_dense[DEDUP_MAX_D];   // by distinct index
     __shared__ uint32_t sh_bad, sh_nrep, sh_total;
@@ -506,29 +508,52 @@ __global__ __launch_bounds__(DEDUP_THREADS) void cluster_dedup_kernel(DedupParam
     }
     __syncthreads();
     if (mode1) {
-        // ---- 1. 64-bit content hash per segment: 16 lanes per segment, 16 bytes per lane and step
+        // ---- 0. segment metadata into LDS (coalesced) so that the data loads below are not behind it
+        const uint64_t wbase = p.seg_word_off[seg0];
+        const uint64_t wspan = p.seg_word_off[seg1 - 1] - wbase;
+        for (uint32_t s = tid; s < n; s += DEDUP_THREADS) {
+            s_woff[s] = (uint32_t)(p.seg_word_off[seg0 + s] - wbase);
+            s_len[s] = p.seg_len[seg0 + s];
+        }
+        __syncthreads();
+        if (wspan >= 0xFFFFFFFFull) mode1 = false;      // uniform; a cluster this large is not worth it anyway
+    }
+    if (mode1) {
+        // ---- 1. 64-bit content hash per segment: 16 lanes per segment, four segments in flight per group
+        const ulonglong2* cbase = reinterpret_cast<const ulonglong2*>(p.packed + p.seg_word_off[seg0]);
         const uint32_t grp = tid >> 4, gl = tid & 15, ngrp = DEDUP_THREADS >> 4;
-        for (uint32_t s = grp; s < n; s += 2 * ngrp) {
-            // two segments per group and step: their loads are issued together (more bytes in flight)
-            const uint32_t s2 = s + ngrp;
-            const bool has2 = s2 < n;
-            const uint32_t lenA = p.seg_len[seg0 + s], lenB = has2 ? p.seg_len[seg0 + s2] : 0;
-            const ulonglong2* wa = reinterpret_cast<const ulonglong2*>(p.packed + p.seg_word_off[seg0 + s]);
-            const ulonglong2* wb = reinterpret_cast<const ulonglong2*>(p.packed + p.seg_word_off[seg0 + (has2 ? s2 : s)]);
-            const uint32_t pa = (lenA + 63) >> 6, pb = (lenB + 63) >> 6;
-            uint64_t accA = 0, accB = 0;
-            for (uint32_t j = gl; j < max(pa, pb); j += 16) {
-                ulonglong2 va = make_ulonglong2(0, 0), vb = make_ulonglong2(0, 0);
-                if (j < pa) va = wa[j];
-                if (j < pb) vb = wb[j];
-                if (j < pa) accA += mix64(va.x + 0x9E3779B97F4A7C15ull * (2 * j + 1)) ^ mix64(va.y + 0xC2B2AE3D27D4EB4Full * (2 * j + 2));
-                if (j < pb) accB += mix64(vb.x + 0x9E3779B97F4A7C15ull * (2 * j + 1)) ^ mix64(vb.y + 0xC2B2AE3D27D4EB4Full * (2 * j + 2));
+        for (uint32_t s = grp; s < n; s += 4 * ngrp) {
+            uint32_t len[4], pc[4], pmax = 0;
+            const ulonglong2* w[4];
+            uint64_t acc[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t si = s + u * ngrp;
+                const bool has = si < n;
+                len[u] = has ? s_len[si] : 0;
+                pc[u] = (len[u] + 63) >> 6;
+                w[u] = cbase + ((has ? s_woff[si] : 0) >> 1);
+                pmax = max(pmax, pc[u]);
             }
-            for (int d = 1; d < 16; d <<= 1) { accA += __shfl_xor(accA, d); accB += __shfl_xor(accB, d); }
-            uint64_t hA = mix64(accA ^ ((uint64_t)lenA << 40)), hB = mix64(accB ^ ((uint64_t)lenB << 40));
-            if (hA == EMPTY64) hA = EMPTY64 - 1;
-            if (hB == EMPTY64) hB = EMPTY64 - 1;
-            if (gl == 0) { s_hash[s] = hA; if (has2) s_hash[s2] = hB; }
+            for (uint32_t j = gl; j < pmax; j += 16) {
+                ulonglong2 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) v[u] = j < pc[u] ? w[u][j] : make_ulonglong2(0, 0);
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (j < pc[u])
+                        acc[u] += mix64(v[u].x + 0x9E3779B97F4A7C15ull * (2 * j + 1)) ^
+                                  mix64(v[u].y + 0xC2B2AE3D27D4EB4Full * (2 * j + 2));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                uint64_t a = acc[u];
+                for (int d = 1; d < 16; d <<= 1) a += __shfl_xor(a, d);
+                uint64_t h = mix64(a ^ ((uint64_t)len[u] << 40));
+                if (h == EMPTY64) h = EMPTY64 - 1;
+                const uint32_t si = s + u * ngrp;
+                if (gl == 0 && si < n) s_hash[si] = h;
+            }
         }
         __syncthreads();
         // ---- 2. group by hash; the group's representative is the copy with the lowest ordinal
@@ -553,19 +578,36 @@ __global__ __launch_bounds__(DEDUP_THREADS) void cluster_dedup_kernel(DedupParam
         __syncthreads();
         for (uint32_t s = tid; s < n; s += DEDUP_THREADS) s_rep[s] = (uint32_t)t_val[s_rep[s]];
         __syncthreads();
-        // ---- 3. verify every copy against its representative, word for word
-        for (uint32_t s = grp; s < n; s += ngrp) {
-            const uint32_t r = s_rep[s];
-            if (r == s) continue;
-            const uint32_t len = p.seg_len[seg0 + s];
-            bool diff = len != p.seg_len[seg0 + r];
+        // ---- 3. verify every copy against its representative, word for word (two copies in flight per group)
+        for (uint32_t s = grp; s < n; s += 2 * ngrp) {
+            bool diff = false;
+            uint32_t pc[2];
+            const ulonglong2 *a[2], *b[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const uint32_t si = s + u * ngrp;
+                pc[u] = 0; a[u] = cbase; b[u] = cbase;
+                if (si < n) {
+                    const uint32_t r = s_rep[si];
+                    if (r != si) {
+                        const uint32_t len = s_len[si];
+                        diff = diff || len != s_len[r];
+                        pc[u] = (len + 63) >> 6;
+                        a[u] = cbase + (s_woff[si] >> 1);
+                        b[u] = cbase + (s_woff[r] >> 1);
+                    }
+                }
+            }
             if (!diff) {
-                const ulonglong2* a = reinterpret_cast<const ulonglong2*>(p.packed + p.seg_word_off[seg0 + s]);
-                const ulonglong2* b = reinterpret_cast<const ulonglong2*>(p.packed + p.seg_word_off[seg0 + r]);
-                const uint32_t pieces = (len + 63) >> 6;
-                for (uint32_t j = gl; j < pieces; j += 16) {
-                    const ulonglong2 x = a[j], y = b[j];
-                    diff = diff || x.x != y.x || x.y != y.y;
+                for (uint32_t j = gl; j < max(pc[0], pc[1]); j += 16) {
+                    ulonglong2 x[2], y[2];
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        x[u] = j < pc[u] ? a[u][j] : make_ulonglong2(0, 0);
+                        y[u] = j < pc[u] ? b[u][j] : make_ulonglong2(0, 0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; u++) diff = diff || x[u].x != y[u].x || x[u].y != y[u].y;
                 }
             }
             if (diff) sh_bad = 1;     // a 64-bit hash collision: give up on this cluster (mode 0), stay exact
@@ -573,7 +615,7 @@ __global__ __launch_bounds__(DEDUP_THREADS) void cluster_dedup_kernel(DedupParam
         __syncthreads();
         // ---- 4. representatives -> distinct indices in ordinal order
         for (uint32_t s = tid; s < n; s += DEDUP_THREADS)
-            if (s_rep[s] == s) {
+            if ((s_rep[s] & 0xFFFFu) == s) {
                 const uint32_t at = atomicAdd(&sh_nrep, 1u);
                 if (at < DEDUP_MAX_D) r_list[at] = s;
             }
@@ -586,8 +628,8 @@ __global__ __launch_bounds__(DEDUP_THREADS) void cluster_dedup_kernel(DedupParam
                 const uint32_t o = p.seg_ord_base[seg0 + s];
                 uint32_t rank = 0;
                 for (uint32_t j = 0; j < D; j++) rank += p.seg_ord_base[seg0 + r_list[j]] < o ? 1u : 0u;
-                s_rank[s] = rank;
-                const uint32_t len = p.seg_len[seg0 + s];
+                s_rep[s] = s | (rank << 16);
+                const uint32_t len = s_len[s];
                 r_ord0[rank] = o;
                 r_ninst[rank] = len >= k ? len - k + 1 : 0;
             }
@@ -607,9 +649,9 @@ __global__ __launch_bounds__(DEDUP_THREADS) void cluster_dedup_kernel(DedupParam
             const uint64_t dense_bits = ((uint64_t)sh_total + (ex1 - ex0)) * mult;
             mode1 = dense_bits <= (uint64_t)DENSE_WORDS * 32;
             if (mode1) {
-                for (uint32_t s = tid; s < n; s += DEDUP_THREADS) p.seg_distinct[seg0 + s] = s_rank[s_rep[s]];
+                for (uint32_t s = tid; s < n; s += DEDUP_THREADS) p.seg_distinct[seg0 + s] = s_rep[s_rep[s] & 0xFFFFu] >> 16;
                 if (tid < D) {
-                    const uint32_t s = r_list[tid], d = s_rank[s];
+                    const uint32_t s = r_list[tid], d = s_rep[s] >> 16;
                     p.v_word_off[seg0 + d] = p.seg_word_off[seg0 + s];
                     p.v_len[seg0 + d] = p.seg_len[seg0 + s];
                     p.v_sample[seg0 + d] = d;
