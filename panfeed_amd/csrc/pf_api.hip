@@ -106,7 +106,7 @@ struct pf_ctx {
     DevBuf bm_occ, bm_keep, pre_occ, pre_keep, mrows, slot_out, it_is_extra;
     DevBuf strand_bits;
     DevBuf it_cluster, it_part, it_nparts, it_nslots, it_slice, it_sib0, it_nsib, it_extra_first, it_count,
-        it_unique, it_kept, work_scan, work_extra, work_fin, work_fin2, work_rows, sub_cluster, sub_item0, sub_nitems;
+        it_unique, it_kept, work_scan, work_extra, work_fin, work_fin2, work_fin3, work_rows, sub_cluster, sub_item0, sub_nitems;
     std::vector<Arena*> arenas;
     DevBuf stage_dev;              // one device block for the small per-pass arrays
     void* stage_pin = nullptr;     // pinned host mirror of it
@@ -254,7 +254,7 @@ void pf_destroy(pf_ctx* c) {
                       &c->bm_occ, &c->bm_keep, &c->pre_occ, &c->pre_keep, &c->mrows, &c->slot_out, &c->it_is_extra, &c->cl_overflow, &c->cl_kmer_off, &c->cl_kmer_cnt, &c->cl_unique, &c->cl_pattern,
                       &c->cl_first, &c->cursor, &c->strand_bits, &c->it_cluster, &c->it_part, &c->it_nparts,
                       &c->it_nslots, &c->it_slice, &c->it_sib0, &c->it_nsib, &c->it_extra_first, &c->it_count,
-                      &c->it_unique, &c->it_kept, &c->work_scan, &c->work_extra, &c->work_fin, &c->work_fin2, &c->work_rows, &c->sub_cluster, &c->sub_item0,
+                      &c->it_unique, &c->it_kept, &c->work_scan, &c->work_extra, &c->work_fin, &c->work_fin2, &c->work_fin3, &c->work_rows, &c->sub_cluster, &c->sub_item0,
                       &c->sub_nitems};
     for (DevBuf* b : bufs) b->release();
     for (Arena* a : c->arenas) { a->key.release(); a->pid.release(); a->first.release(); delete a; }
@@ -619,14 +619,17 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
             if (np == 1 && NS > 4096 + pf::INSERT_SLACK && inst <= pf::insert_limit(4096)) ns = 4096;
             // a deduplicated cluster that is one work item is finished by one fused kernel (rows + emit in LDS)
             const uint32_t mwords = h_vnstr[ci] * ((W + 3) & ~3u);
-            uint8_t fused = 0;
-            if (h_mode[ci] == 1 && nit == 1 && NS <= 9600) {
-                if (h_dense[ci] < pf::FinSmall::DW * 32 - 1 && mwords <= pf::FinSmall::MR) fused = 1;
-                else if (h_dense[ci] < pf::FinLarge::DW * 32 - 1 && mwords <= pf::FinLarge::MR) fused = 2;
+            uint8_t fused = 0;   // 1/2: single item, small/large class; 3: first of several partitions; 4: the others
+            if (h_mode[ci] == 1 && nex == 0 && NS <= 9600) {
+                const bool fits_large = h_dense[ci] < pf::FinLarge::DW * 32 - 1 && mwords <= pf::FinLarge::MR;
+                if (np == 1) {
+                    if (h_dense[ci] < pf::FinSmall::DW * 32 - 1 && mwords <= pf::FinSmall::MR) fused = 1;
+                    else if (fits_large) fused = 2;
+                } else if (fits_large) fused = 3;
             }
             for (uint32_t q = 0; q < np; q++) {
                 items.push_back(Item{ci, q, np, ns, cur.nitems + q, sib0, nit, 0, 0});
-                item_fused.push_back(fused);
+                item_fused.push_back(fused == 3 && q > 0 ? 4 : fused);
             }
             for (uint32_t q = 0; q < nex_items; q++) {
                 const uint32_t first = ex_first[ci] + q * lim_full;
@@ -660,7 +663,7 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
         // ---- item arrays
         const size_t NI = items.size();
         std::vector<uint32_t> v_cluster(NI), v_part(NI), v_nparts(NI), v_nslots(NI), v_slice(NI), v_sib0(NI), v_nsib(NI),
-            v_exfirst(NI), v_isex(NI), w_scan, w_extra, w_fin, w_fin2, w_rows;
+            v_exfirst(NI), v_isex(NI), w_scan, w_extra, w_fin, w_fin2, w_fin3, w_rows;
         for (size_t i = 0; i < NI; i++) {
             v_cluster[i] = items[i].cluster; v_part[i] = items[i].part; v_nparts[i] = items[i].nparts;
             v_nslots[i] = items[i].nslots; v_slice[i] = items[i].slice; v_sib0[i] = items[i].sib0;
@@ -671,7 +674,7 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
         PFCHK(c->it_kept.ensure(std::max<size_t>(NI, 1) * 4));
         // work lists per sub-batch, concatenated; scan items heaviest first (the grid drains evenly)
         std::vector<uint32_t> scan_off(subs.size() + 1, 0), extra_off(subs.size() + 1, 0), fin_off(subs.size() + 1, 0),
-            fin2_off(subs.size() + 1, 0), rows_off(subs.size() + 1, 0);
+            fin2_off(subs.size() + 1, 0), fin3_off(subs.size() + 1, 0), rows_off(subs.size() + 1, 0);
         // heaviest items first inside each launch (the grid then drains evenly): a coarse O(n) order by
         // log2(scan instances) is enough
         auto wclass = [&](uint32_t it) -> int {
@@ -697,7 +700,8 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
                 if (items[i].is_extra) w_extra.push_back(i); else tmp_scan.push_back(i);
                 if (item_fused[i] == 1) tmp_fin.push_back(i);
                 else if (item_fused[i] == 2) tmp_fin2.push_back(i);
-                else w_rows.push_back(i);
+                else if (item_fused[i] == 3) w_fin3.push_back(i);
+                else if (item_fused[i] == 0) w_rows.push_back(i);
             }
             append_by_weight(tmp_scan, w_scan);
             append_by_weight(tmp_fin, w_fin);
@@ -706,6 +710,7 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
             extra_off[s + 1] = (uint32_t)w_extra.size();
             fin_off[s + 1] = (uint32_t)w_fin.size();
             fin2_off[s + 1] = (uint32_t)w_fin2.size();
+            fin3_off[s + 1] = (uint32_t)w_fin3.size();
             rows_off[s + 1] = (uint32_t)w_rows.size();
         }
         {
@@ -714,7 +719,7 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
                 {&c->it_nslots, &v_nslots}, {&c->it_slice, &v_slice}, {&c->it_sib0, &v_sib0}, {&c->it_nsib, &v_nsib},
                 {&c->it_extra_first, &v_exfirst}, {&c->it_is_extra, &v_isex}, {&c->sub_cluster, &sub_cluster},
                 {&c->sub_item0, &sub_item0}, {&c->sub_nitems, &sub_nitems}, {&c->work_scan, &w_scan},
-                {&c->work_extra, &w_extra}, {&c->work_fin, &w_fin}, {&c->work_fin2, &w_fin2}, {&c->work_rows, &w_rows}};
+                {&c->work_extra, &w_extra}, {&c->work_fin, &w_fin}, {&c->work_fin2, &w_fin2}, {&c->work_fin3, &w_fin3}, {&c->work_rows, &w_rows}};
             PFCHK(staged_upload(c, arrs));
         }
         // the cursor's next free index restarts at this arena's base
@@ -762,12 +767,13 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
                 c->timing.scan_launches++;
             }
             const uint32_t n_fin = fin_off[s + 1] - fin_off[s], n_fin2 = fin2_off[s + 1] - fin2_off[s],
-                           n_rows = rows_off[s + 1] - rows_off[s];
-            if (n_fin || n_fin2) {
+                           n_fin3 = fin3_off[s + 1] - fin3_off[s], n_rows = rows_off[s + 1] - rows_off[s];
+            if (n_fin || n_fin2 || n_fin3) {
                 pf::FinishParams fp{};
                 fp.work = c->work_fin.as<uint32_t>() + fin_off[s];
                 fp.item_cluster = c->it_cluster.as<uint32_t>(); fp.item_nslots = c->it_nslots.as<uint32_t>();
                 fp.item_scratch = c->it_slice.as<uint32_t>(); fp.cluster_overflow = c->cl_overflow.as<uint32_t>();
+                fp.item_nparts = c->it_nparts.as<uint32_t>();
                 fp.cluster_seg_off = d.cluster_seg_off; fp.seg_sample = d.seg_sample;
                 fp.seg_distinct = c->seg_distinct.as<uint32_t>();
                 fp.v_nstr = c->v_nstr.as<uint32_t>(); fp.v_dense = c->v_dense.as<uint32_t>();
@@ -786,13 +792,19 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
                 fp.out_base = ar->base; fp.out_cap = ar->cap; fp.W = W; fp.NS = NS; fp.KW = KW;
                 fp.consider_missing = c->o.consider_missing; fp.patfilt = c->o.patfilt; fp.multiple_files = c->o.multiple_files;
                 PFCHK(mark_begin(c, 6));
-                if (n_fin) {
-                    hipLaunchKernelGGL(pf::finish_kernel<pf::FinSmall>, dim3(n_fin), dim3(pf::FinSmall::THREADS), 0, c->stream, fp);
+                if (n_fin3) {   // the heaviest clusters first
+                    fp.work = c->work_fin3.as<uint32_t>() + fin3_off[s];
+                    hipLaunchKernelGGL((pf::finish_kernel<pf::FinLarge, true>), dim3(n_fin3), dim3(pf::FinLarge::THREADS), 0, c->stream, fp);
                     HIPCHK(hipGetLastError());
                 }
                 if (n_fin2) {
                     fp.work = c->work_fin2.as<uint32_t>() + fin2_off[s];
-                    hipLaunchKernelGGL(pf::finish_kernel<pf::FinLarge>, dim3(n_fin2), dim3(pf::FinLarge::THREADS), 0, c->stream, fp);
+                    hipLaunchKernelGGL((pf::finish_kernel<pf::FinLarge, false>), dim3(n_fin2), dim3(pf::FinLarge::THREADS), 0, c->stream, fp);
+                    HIPCHK(hipGetLastError());
+                }
+                if (n_fin) {
+                    fp.work = c->work_fin.as<uint32_t>() + fin_off[s];
+                    hipLaunchKernelGGL((pf::finish_kernel<pf::FinSmall, false>), dim3(n_fin), dim3(pf::FinSmall::THREADS), 0, c->stream, fp);
                     HIPCHK(hipGetLastError());
                 }
                 PFCHK(mark_end(c));

@@ -1349,6 +1349,7 @@ static_assert(nslots_max(1) <= 9600, "slot_at too small");
 struct FinishParams {
     const uint32_t* work;            // [gridDim.x] item ids
     const uint32_t* item_cluster; const uint32_t* item_nslots; const uint32_t* item_scratch;
+    const uint32_t* item_nparts;     // key partitions of the item's cluster (MULTI: items item .. item+nparts-1)
     const uint32_t* cluster_overflow;
     const uint32_t* cluster_seg_off; const uint32_t* seg_sample; const uint32_t* seg_distinct;
     const uint32_t* v_nstr; const uint32_t* v_dense;
@@ -1400,7 +1401,10 @@ __device__ __forceinline__ uint32_t pattern_insert_lower(const PatternTable& t, 
     return pid;
 }
 
-template <class CFG>
+// MULTI: the work item is the first of several key partitions of the cluster; the slot loops run over all of
+// them (the mask table, ordinal bitmaps and M are per cluster anyway) and slot tags are looked up again instead
+// of being kept per slot.
+template <class CFG, bool MULTI>
 __global__ __launch_bounds__(CFG::THREADS) void finish_kernel(FinishParams p) {
     constexpr uint32_t T = CFG::THREADS, DW = CFG::DW, AT = CFG::AT;
     __shared__ __align__(16) uint32_t M[CFG::MR];
@@ -1412,7 +1416,7 @@ __global__ __launch_bounds__(CFG::THREADS) void finish_kernel(FinishParams p) {
     typedef typename CFG::tag_t tag_t;
     constexpr uint32_t PROBE = AT - 1;                           // table positions 0..AT-2; AT-1 = "not in the table"
     constexpr tag_t UNTABLED = (tag_t)(AT - 1);
-    __shared__ tag_t slot_at[9600];                              // per occupied slot: its mask's table position
+    __shared__ tag_t slot_at[MULTI ? 1 : 9600];                  // per occupied slot: its mask's table position
     __shared__ uint32_t wave_tot[T / 64 + 1];
     __shared__ uint32_t sh_npres, at_count;
     __shared__ uint64_t sh_base;
@@ -1421,19 +1425,37 @@ __global__ __launch_bounds__(CFG::THREADS) void finish_kernel(FinishParams p) {
     const uint32_t item = p.work[blockIdx.x];
     const uint32_t c = p.item_cluster[item];
     if (p.cluster_overflow[c]) return;
-    const uint32_t slice = p.item_scratch[item];
     const uint32_t NS = p.NS, W = p.W, KW = p.KW;
-    const uint32_t ns = p.item_nslots[item];
+    const uint32_t nparts = MULTI ? p.item_nparts[item] : 1;
     const uint32_t nstr = p.cluster_nstrains[c], npres = p.cluster_npresab[c];
     const uint32_t nchunks = (nstr + 31) >> 5;
     const uint32_t Wp = (W + 3) & ~3u;
     const uint32_t* presab = p.cluster_presab + (size_t)c * W;
     const uint32_t dense_words = (p.v_dense[c] + 31) >> 5;      // <= DW (host-checked)
     const uint64_t ordinal = p.cluster_ordinal[c];
-    const uint32_t* ordp = p.tab_ord + (size_t)slice * NS;
-    const uint32_t* cb = p.chunkbits + (size_t)slice * W * NS;
-    const uint32_t cm0 = p.chunkmask[slice * 8];
-    const bool f0 = (cm0 & 1) != 0, f1 = (cm0 & 2) != 0;
+    // per key partition q: scratch slice, slots, ordinals, allele-mask words
+    uint32_t slice = 0, ns = 0;
+    const uint32_t* ordp = nullptr;
+    const uint32_t* cb = nullptr;
+    bool f0 = false, f1 = false;
+    auto set_part = [&](uint32_t q) {
+        slice = p.item_scratch[item + q];
+        ns = p.item_nslots[item + q];
+        ordp = p.tab_ord + (size_t)slice * NS;
+        cb = p.chunkbits + (size_t)slice * W * NS;
+        const uint32_t cm0 = p.chunkmask[slice * 8];
+        f0 = (cm0 & 1) != 0; f1 = (cm0 & 2) != 0;
+    };
+    auto find_tag = [&](uint64_t amask) -> tag_t {
+        uint32_t a = (uint32_t)mix64(amask) % PROBE;
+        for (uint32_t probes = 0; amask && probes < PROBE; probes++) {
+            const uint64_t cur = at_key[a];
+            if (cur == 0) break;
+            if (cur == amask) return (tag_t)a;
+            a = a + 1 == PROBE ? 0 : a + 1;
+        }
+        return UNTABLED;
+    };
 
     for (uint32_t i = tid; i < CFG::MR; i += T) M[i] = 0;
     for (uint32_t i = tid; i < DW; i += T) { occ[i] = 0; keepbm[i] = 0; }
@@ -1453,6 +1475,8 @@ __global__ __launch_bounds__(CFG::THREADS) void finish_kernel(FinishParams p) {
         }
     }
     // phase A: distinct allele masks
+    for (uint32_t q = 0; q < nparts; q++) {
+    set_part(q);
     for (uint32_t i = tid; i < ns; i += T) {
         const uint32_t o = ordp[i];
         const uint64_t amask = (f0 ? (uint64_t)cb[i] : 0) | (f1 ? (uint64_t)cb[(size_t)NS + i] << 32 : 0);
@@ -1470,7 +1494,8 @@ __global__ __launch_bounds__(CFG::THREADS) void finish_kernel(FinishParams p) {
                 a = a + 1 == PROBE ? 0 : a + 1;
             }
         }
-        slot_at[i] = tag;
+        if (!MULTI) slot_at[i] = tag;
+    }
     }
     __syncthreads();
     const uint32_t npresent = sh_npres;
@@ -1546,13 +1571,17 @@ __global__ __launch_bounds__(CFG::THREADS) void finish_kernel(FinishParams p) {
     }
     __syncthreads();
     // phase C: ordinal bitmaps, lowest ordinal per mask
+    for (uint32_t q = 0; q < nparts; q++) {
+    set_part(q);
     for (uint32_t i = tid; i < ns; i += T) {
         const uint32_t o = ordp[i];
         if (o == NO_ORD || (o >> 5) >= dense_words) continue;
-        const tag_t tag = slot_at[i];
+        uint64_t amask = 0;
+        if (MULTI) amask = (f0 ? (uint64_t)cb[i] : 0) | (f1 ? (uint64_t)cb[(size_t)NS + i] << 32 : 0);
+        const tag_t tag = MULTI ? find_tag(amask) : slot_at[i];
         bool keep;
         if (tag == UNTABLED) {
-            const uint64_t amask = (f0 ? (uint64_t)cb[i] : 0) | (f1 ? (uint64_t)cb[(size_t)NS + i] << 32 : 0);
+            if (!MULTI) amask = (f0 ? (uint64_t)cb[i] : 0) | (f1 ? (uint64_t)cb[(size_t)NS + i] << 32 : 0);
             uint4 h;
             keep = row_eval(amask, h);
         } else {
@@ -1561,6 +1590,7 @@ __global__ __launch_bounds__(CFG::THREADS) void finish_kernel(FinishParams p) {
         }
         atomicOr(&occ[o >> 5], 1u << (o & 31));
         if (keep) atomicOr(&keepbm[o >> 5], 1u << (o & 31));
+    }
     }
     __syncthreads();
     // prefix popcounts over the bitmap words
@@ -1630,14 +1660,18 @@ __global__ __launch_bounds__(CFG::THREADS) void finish_kernel(FinishParams p) {
     __syncthreads();
     const uint64_t obase = sh_base - p.out_base;
     // outputs: key + pattern id per kept k-mer, in first-occurrence order
+    for (uint32_t q = 0; q < nparts; q++) {
+    set_part(q);
     for (uint32_t i = tid; i < ns; i += T) {
         const uint32_t o = ordp[i];
         if (o == NO_ORD || (o >> 5) >= dense_words || !((keepbm[o >> 5] >> (o & 31)) & 1)) continue;
-        const tag_t tag = slot_at[i];
+        uint64_t amask = 0;
+        if (MULTI) amask = (f0 ? (uint64_t)cb[i] : 0) | (f1 ? (uint64_t)cb[(size_t)NS + i] << 32 : 0);
+        const tag_t tag = MULTI ? find_tag(amask) : slot_at[i];
         uint32_t pid;
         if (tag == UNTABLED) {
             // mask table was full: this slot goes to the run-global table on its own
-            const uint64_t amask = (f0 ? (uint64_t)cb[i] : 0) | (f1 ? (uint64_t)cb[(size_t)NS + i] << 32 : 0);
+            if (!MULTI) amask = (f0 ? (uint64_t)cb[i] : 0) | (f1 ? (uint64_t)cb[(size_t)NS + i] << 32 : 0);
             uint4 h;
             row_eval(amask, h);
             bool lowered;
@@ -1652,6 +1686,7 @@ __global__ __launch_bounds__(CFG::THREADS) void finish_kernel(FinishParams p) {
         p.out_key[oi * KW] = p.tab_key[((size_t)slice * KW) * NS + i];
         if (KW == 2) p.out_key[oi * KW + 1] = p.tab_key[((size_t)slice * KW + 1) * NS + i];
         p.out_pid[oi] = pid;
+    }
     }
 }
 

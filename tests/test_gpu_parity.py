@@ -214,11 +214,17 @@ def test_dedup_big_alleles_repartition(flags):
     a3 = alleles(3, 200)
     gs = {nm: [mk(a3[i % 3], i, 0)] for i, nm in enumerate(names)}
     recs.append((gs, "small3", np.ones(90, dtype=np.int64)))
+    a4 = alleles(6, 3500)                      # pure ACGT, several key partitions, finished by the fused kernel
+    gs = {nm: [mk(a4[(i * 5) % 6], i, 0)] for i, nm in enumerate(names)}
+    recs.append((gs, "big6", np.ones(90, dtype=np.int64)))
+    a5 = alleles(4, 1800)                      # single partition, large fused class (dense ordinals > 32k? no: 7k) 
+    gs = {nm: [mk(a5[i % 4], i, 0), mk(a5[(i + 1) % 4], i, 1)] for i, nm in enumerate(names)}
+    recs.append((gs, "para4", np.ones(90, dtype=np.int64)))
     kw = dict(klength=31, canon=True, consider_missing=False, patfilt=True, maf=0.01)
     kw.update(flags)
     eng = Engine(max_strains=96, stroi={names[4]}, **kw)
     out = eng.run(recs)
-    assert out.timing["n_dedup_clusters"] == 2 and out.timing["n_retried"] >= 1
+    assert out.timing["n_dedup_clusters"] == 4 and out.timing["n_retried"] >= 1
     (ek, ekh, ehp), st = _oracle_texts(recs, stroi={names[4]}, **kw)
     assert out.kmers_to_hashes == ekh
     assert out.hashes_to_patterns == ehp
