@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--samples", type=int, default=1000)
     ap.add_argument("--flank", type=int, default=100)
     ap.add_argument("--k", type=int, default=31)
-    ap.add_argument("--max-items", type=int, default=4096)
+    ap.add_argument("--max-items", type=int, default=8192)
     ap.add_argument("--cpu-clusters", type=int, default=0, help="clusters in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dedup", action="store_true", help="scan every copy of identical sequences (PF_FLAG_NO_DEDUP)")
@@ -106,7 +106,7 @@ def main():
     eng = Engine(klength=k, max_strains=(S + 31) // 32 * 32, device=local, max_items=args.max_items,
                  pattern_capacity=1 << 25, dedup=not args.no_dedup)
     # generate + upload in slabs so the host never holds more than a slab of cluster objects
-    slab = 25000
+    slab = 50000
     dbs = []
     for s0 in range(0, args.clusters, slab):
         cl = synth.generate(min(slab, args.clusters - s0), S, first=first + s0, flank=args.flank, n_rate=0.0)

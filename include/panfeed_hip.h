@@ -204,6 +204,18 @@ uint64_t pf_pack_acgt(const char* seq, uint32_t len, uint64_t* dst);
 /* Host helper: md5 + base64 of a digest -- panfeed.py:175-176 -- for writers. */
 void pf_b64_digest(const uint8_t md5[16], char out[24]);
 
+/* Writers (host threads, after pf_fetch): the bytes pattern_hasher appends to kmers_to_hashes.tsv for the last
+ * batch -- "idx\t\thash\n" per cluster then "idx\tkmer\thash\n" per kept k-mer (panfeed.py:177, 208) -- and to
+ * hashes_to_patterns.tsv -- "hash\tv0\tv1...\n" per pattern first seen in this batch, in first-seen order
+ * (panfeed.py:181-187, 217-223).  cluster_names: n_clusters NUL-terminated names (batch order); extra_keys: the
+ * k-mer strings of the batch's slow-path rows (klength bytes each), may be NULL without such rows.
+ * cluster_end (may be NULL): [n_clusters] byte offset where each cluster's rows end.
+ * The buffers are malloc'ed; release them with pf_free_text. */
+int pf_render_kmers_to_hashes(pf_ctx* ctx, const char* const* cluster_names, const char* const* extra_keys,
+                              char** out, uint64_t* nbytes, uint64_t* cluster_end);
+int pf_render_hashes_to_patterns(pf_ctx* ctx, char** out, uint64_t* nbytes);
+void pf_free_text(char* p);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,7 +61,8 @@ FLAG_NO_DEDUP = 1
 EXPORTS = ["pf_last_error", "pf_version", "pf_device_count", "pf_create", "pf_destroy", "pf_reset_patterns",
            "pf_submit", "pf_fetch", "pf_get_timing", "pf_export_patterns", "pf_export_patterns_dev",
            "pf_pattern_count", "pf_dev_alloc", "pf_dev_free",
-           "pf_dev_upload", "pf_dev_download", "pf_synth_expand", "pf_pack_acgt", "pf_b64_digest"]
+           "pf_dev_upload", "pf_dev_download", "pf_synth_expand", "pf_pack_acgt", "pf_b64_digest",
+           "pf_render_kmers_to_hashes", "pf_render_hashes_to_patterns", "pf_free_text"]
 
 _lib = None
 
@@ -100,6 +101,11 @@ def load():
     L.pf_pack_acgt.restype = C.c_uint64
     L.pf_b64_digest.argtypes = [C.c_void_p, C.c_char_p]
     L.pf_b64_digest.restype = None
+    L.pf_render_kmers_to_hashes.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
+                                            C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.pf_render_hashes_to_patterns.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.pf_free_text.argtypes = [C.c_void_p]
+    L.pf_free_text.restype = None
     _lib = L
     return L
 

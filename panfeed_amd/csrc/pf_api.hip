@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstring>
 #include <numeric>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -125,6 +126,7 @@ struct pf_ctx {
     std::vector<uint64_t> h_kmer_off, h_kmer_key, h_first_seen, h_strand;
     std::vector<uint32_t> h_kmer_cnt, h_cl_pattern, h_cl_unique, h_kmer_pid, h_new_pid, h_pat_bits, h_pat_nan, h_pat_n;
     std::vector<uint8_t> h_pat_md5;
+    std::vector<char> h_b64;       // 24 chars per pattern
 };
 
 namespace {
@@ -176,6 +178,7 @@ int reset_patterns(pf_ctx* c) {
     c->n_patterns = 0;
     c->pid0 = 0;
     c->h_pat_bits.clear(); c->h_pat_nan.clear(); c->h_pat_n.clear(); c->h_pat_md5.clear(); c->h_first_seen.clear();
+    c->h_b64.clear();
     return PF_OK;
 }
 
@@ -228,6 +231,29 @@ int launch_scan(pf_ctx* c, const pf::ScanParams& sp, uint32_t n) {
 }
 
 }  // namespace
+
+namespace {
+template <class F>
+void parallel_for(uint64_t n, F f) {
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = std::max(1u, std::min(nt, 32u));
+    if (n < 4096 || nt == 1) { f(0, n); return; }
+    std::vector<std::thread> th;
+    const uint64_t chunk = (n + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; t++) {
+        const uint64_t a = t * chunk, b = std::min<uint64_t>(n, a + chunk);
+        if (a < b) th.emplace_back([=] { f(a, b); });
+    }
+    for (auto& x : th) x.join();
+}
+void ensure_b64(pf_ctx* c) {
+    // 24-char base64 of every pattern's digest (panfeed.py:176, 207), extended incrementally
+    const size_t have = c->h_b64.size() / 24, want = c->h_pat_md5.size() / 16;
+    c->h_b64.resize(want * 24);
+    for (size_t p = have; p < want; p++) pf_b64_digest(c->h_pat_md5.data() + p * 16, c->h_b64.data() + p * 24);
+}
+}  // namespace
+
 
 extern "C" {
 
@@ -1085,6 +1111,107 @@ int pf_export_patterns_dev(pf_ctx* c, uint64_t cap, void* d_md5, void* d_first_s
     *n = m;
     return PF_OK;
 }
+
+int pf_render_kmers_to_hashes(pf_ctx* c, const char* const* names, const char* const* extra_keys, char** out,
+                              uint64_t* nbytes, uint64_t* cluster_end) {
+    if (!c || !names || !out || !nbytes) return fail(PF_ERR_ARG, "null argument");
+    if (!c->have_batch || c->h_kmer_off.size() != c->n_clusters) return fail(PF_ERR_STATE, "pf_render_* needs pf_fetch first");
+    ensure_b64(c);
+    const uint32_t C = c->n_clusters, k = c->o.klength, KW = (uint32_t)c->KW;
+    std::vector<uint64_t> off(C + 1, 0);
+    std::vector<uint32_t> nlen(C);
+    for (uint32_t i = 0; i < C; i++) {
+        nlen[i] = (uint32_t)strlen(names[i]);
+        off[i + 1] = off[i] + (nlen[i] + 2 + 24 + 1) + (uint64_t)c->h_kmer_cnt[i] * (nlen[i] + 1 + k + 1 + 24 + 1);
+    }
+    char* buf = (char*)malloc(off[C] + 1);
+    if (!buf) return fail(PF_ERR_OOM, "malloc(%llu) failed", (unsigned long long)off[C]);
+    const char* b64 = c->h_b64.data();
+    const uint64_t npat = c->h_b64.size() / 24;
+    bool bad = false;
+    parallel_for(C, [&](uint64_t a, uint64_t b) {
+        for (uint64_t i = a; i < b; i++) {
+            char* w = buf + off[i];
+            const uint32_t L = nlen[i];
+            const uint32_t cp = c->h_cl_pattern[i];
+            if (cp >= npat) { bad = true; continue; }
+            memcpy(w, names[i], L); w += L; *w++ = '\t'; *w++ = '\t';
+            memcpy(w, b64 + (size_t)cp * 24, 24); w += 24; *w++ = '\n';
+            const uint64_t o = c->h_kmer_off[i];
+            for (uint32_t j = 0; j < c->h_kmer_cnt[i]; j++) {
+                memcpy(w, names[i], L); w += L; *w++ = '\t';
+                const uint64_t* key = c->h_kmer_key.data() + (o + j) * KW;
+                if (key[0] >> 63) {
+                    if (!extra_keys) { bad = true; memset(w, '?', k); }
+                    else memcpy(w, extra_keys[(uint32_t)key[0]], k);
+                } else {
+                    // 2k-bit value, first base most significant; two words = two 63-bit halves
+                    uint64_t hi = 0, lo = key[0];
+                    if (KW == 2) { hi = key[0] >> 1; lo = ((key[0] & 1) << 63) | key[1]; }
+                    for (uint32_t q = 0; q < k; q++) {
+                        const uint32_t bit = 2 * (k - 1 - q);
+                        const uint32_t code = bit >= 64 ? (uint32_t)(hi >> (bit - 64)) & 3 : (uint32_t)(lo >> bit) & 3;
+                        w[q] = "ACGT"[code];
+                    }
+                }
+                w += k; *w++ = '\t';
+                const uint32_t pid = c->h_kmer_pid[o + j];
+                if (pid >= npat) { bad = true; memset(w, '?', 24); }
+                else memcpy(w, b64 + (size_t)pid * 24, 24);
+                w += 24; *w++ = '\n';
+            }
+        }
+    });
+    if (bad) { free(buf); return fail(PF_ERR_STATE, "pf_render_kmers_to_hashes: inconsistent result (pattern id / extra key)"); }
+    buf[off[C]] = 0;
+    if (cluster_end) for (uint32_t i = 0; i < C; i++) cluster_end[i] = off[i + 1];
+    *out = buf;
+    *nbytes = off[C];
+    return PF_OK;
+}
+
+int pf_render_hashes_to_patterns(pf_ctx* c, char** out, uint64_t* nbytes) {
+    if (!c || !out || !nbytes) return fail(PF_ERR_ARG, "null argument");
+    if (!c->have_batch || c->h_new_pid.size() != c->n_patterns - c->pid0) return fail(PF_ERR_STATE, "pf_render_* needs pf_fetch first");
+    ensure_b64(c);
+    const uint32_t W = c->W;
+    const size_t P = c->h_new_pid.size();
+    const bool miss = c->o.consider_missing != 0;
+    std::vector<uint64_t> off(P + 1, 0);
+    for (size_t i = 0; i < P; i++) {
+        const uint32_t pid = c->h_new_pid[i];
+        const uint32_t nk = c->h_pat_n[pid], n = nk & 0x7FFFFFFFu;
+        uint32_t nn = 0;
+        if (miss && !(nk >> 31))
+            for (uint32_t w = 0; w < W; w++) nn += __builtin_popcount(c->h_pat_nan[(size_t)pid * W + w]);
+        off[i + 1] = off[i] + 24 + n + (n - nn) + 1;
+    }
+    char* buf = (char*)malloc(off[P] + 1);
+    if (!buf) return fail(PF_ERR_OOM, "malloc(%llu) failed", (unsigned long long)off[P]);
+    parallel_for(P, [&](uint64_t a, uint64_t b) {
+        for (uint64_t i = a; i < b; i++) {
+            char* w = buf + off[i];
+            const uint32_t pid = c->h_new_pid[i];
+            const uint32_t nk = c->h_pat_n[pid], n = nk & 0x7FFFFFFFu;
+            const bool use_nan = miss && !(nk >> 31);
+            const uint32_t* bits = c->h_pat_bits.data() + (size_t)pid * W;
+            const uint32_t* nan = use_nan ? c->h_pat_nan.data() + (size_t)pid * W : nullptr;
+            memcpy(w, c->h_b64.data() + (size_t)pid * 24, 24); w += 24;
+            for (uint32_t e = 0; e < n; e++) {
+                *w++ = '\t';
+                if (nan && ((nan[e >> 5] >> (e & 31)) & 1)) continue;          // '' for NaN (panfeed.py:220)
+                *w++ = ((bits[e >> 5] >> (e & 31)) & 1) ? '1' : '0';
+            }
+            *w++ = '\n';
+        }
+    });
+    buf[off[P]] = 0;
+    *out = buf;
+    *nbytes = off[P];
+    return PF_OK;
+}
+
+void pf_free_text(char* p) { free(p); }
 
 int pf_pattern_count(pf_ctx* c, uint64_t* n) {
     if (!c || !n) return fail(PF_ERR_ARG, "null argument");

@@ -157,38 +157,39 @@ class Engine:
     def _render(self, hb, res):
         out = BatchOutput()
         C_ = hb.n_clusters
-        kw = int(res.key_words)
-        hashes = self._hash_strings(res)
-        off = _view(res.cluster_kmer_off, C_, np.uint64)
-        cnt = _view(res.cluster_kmer_cnt, C_, np.uint32)
-        cpat = _view(res.cluster_pattern, C_, np.uint32)
-        total = int((off + cnt).max()) if C_ and cnt.any() else 0
-        keys = _view(res.kmer_key, total * kw, np.uint64).reshape(-1, kw) if total else np.zeros((0, kw), np.uint64)
-        pids = _view(res.kmer_pattern, total, np.uint32)
         first_seen = _view(res.pattern_first_seen, int(res.n_patterns), np.uint64)
         new_ids = _view(res.new_pattern_id, int(res.n_new_patterns), np.uint32)
 
-        # kmers_to_hashes.tsv body, cluster by cluster (panfeed.py:177, 208)
+        # kmers_to_hashes.tsv body (panfeed.py:177, 208): rendered by the library's host threads
+        names = (C.c_char_p * max(C_, 1))(*[s.encode() for s in hb.idx])
+        extra = (C.c_char_p * len(hb.extra_keys))(*[k.encode() for k in hb.extra_keys]) if hb.extra_keys else None
+        buf, nb = C.c_void_p(), C.c_uint64()
+        ends = (C.c_uint64 * max(C_, 1))()
+        _lib.check(self.L.pf_render_kmers_to_hashes(self.ctx, names, extra, C.byref(buf), C.byref(nb), ends))
+        kh_bytes = C.string_at(buf, nb.value)
+        self.L.pf_free_text(buf)
+        kh_all = kh_bytes.decode()
         kh_parts = []
-        for ci in range(C_):
-            idx = hb.idx[ci]
-            lines = [f"{idx}\t\t{hashes[int(cpat[ci])]}\n"]
-            o, n = int(off[ci]), int(cnt[ci])
-            if n:
-                kk = keys[o:o + n]
-                is_extra = (kk[:, 0] >> np.uint64(63)).astype(bool)
-                strs = decode_keys(np.where(is_extra[:, None], np.uint64(0), kk), self.k, kw)
-                for j in range(n):
-                    kmer = hb.extra_keys[int(kk[j, 0] & np.uint64(0xFFFFFFFF))] if is_extra[j] else strs[j]
-                    lines.append(f"{idx}\t{kmer}\t{hashes[int(pids[o + j])]}\n")
-            kh_parts.append("".join(lines))
+        if self.multiple_files:
+            prev = 0
+            for ci in range(C_):
+                kh_parts.append(kh_bytes[prev:ends[ci]].decode())
+                prev = ends[ci]
         # hashes_to_patterns.tsv body: new patterns in first-seen order (panfeed.py:179-187, 210-223)
         hp_by_cluster = [[] for _ in range(C_)]
-        ord0 = int(hb.cluster_ordinal[0]) if C_ else 0
-        for pid in new_ids:
-            pid = int(pid)
-            ci = int(first_seen[pid] >> np.uint64(32)) - ord0
-            hp_by_cluster[ci].append(self._pattern_row(res, pid))
+        if self.multiple_files:
+            hashes = self._hash_strings(res)
+            ord0 = int(hb.cluster_ordinal[0]) if C_ else 0
+            for pid in new_ids:
+                pid = int(pid)
+                ci = int(first_seen[pid] >> np.uint64(32)) - ord0
+                hp_by_cluster[ci].append(self._pattern_row(res, pid))
+            hp_all = "".join("".join(x) for x in hp_by_cluster)
+        else:
+            buf, nb = C.c_void_p(), C.c_uint64()
+            _lib.check(self.L.pf_render_hashes_to_patterns(self.ctx, C.byref(buf), C.byref(nb)))
+            hp_all = C.string_at(buf, nb.value).decode()
+            self.L.pf_free_text(buf)
         # kmers.tsv body (panfeed.py:90-107)
         kt_by_cluster = [[] for _ in range(C_)]
         strand = _view(res.strand_bits, hb.n_strand_words, np.uint64) if hb.n_strand_words else None
@@ -199,8 +200,8 @@ class Engine:
             for ci in range(C_):
                 out.per_cluster.append((hb.idx[ci], "".join(kt_by_cluster[ci]), kh_parts[ci],
                                         "".join(hp_by_cluster[ci])))
-        out.kmers_to_hashes = "".join(kh_parts)
-        out.hashes_to_patterns = "".join("".join(x) for x in hp_by_cluster)
+        out.kmers_to_hashes = kh_all
+        out.hashes_to_patterns = hp_all
         out.kmers_tsv = "".join("".join(x) for x in kt_by_cluster)
         out.stats = {"instances": int(hb.n_instances),
                      "device_instances": int(res.n_instances),
