@@ -643,6 +643,7 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
             uint32_t ns = NS;
             const uint64_t inst = vinst[ci] * mult;
             if (np == 1 && NS > 4096 + pf::INSERT_SLACK && inst <= pf::insert_limit(4096)) ns = 4096;
+            else if (np == 1 && NS > 6144 + pf::INSERT_SLACK && inst <= pf::insert_limit(6144)) ns = 6144;
             // a deduplicated cluster that is one work item is finished by one fused kernel (rows + emit in LDS)
             const uint32_t mwords = h_vnstr[ci] * ((W + 3) & ~3u);
             uint8_t fused = 0;   // 1/2: single item, small/large class; 3: first of several partitions; 4: the others
@@ -967,7 +968,9 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
         mp.pat_n = c->pat_n.as<uint32_t>(); mp.pat_md5 = c->pat_md5.as<uint8_t>();
         mp.pid0 = c->pid0; mp.pid1 = pid1; mp.W = W;
         PFCHK(mark_begin(c, 5));
-        hipLaunchKernelGGL(pf::md5_kernel, dim3((pid1 - c->pid0 + 255) / 256), dim3(256), 0, c->stream, mp);
+        const uint32_t md5_lds = pf::MD5_THREADS * (pf::MD5_TILE + 1) * 4 * (c->o.consider_missing ? 2 : 1);
+        hipLaunchKernelGGL(pf::md5_kernel, dim3((pid1 - c->pid0 + pf::MD5_THREADS - 1) / pf::MD5_THREADS), dim3(pf::MD5_THREADS),
+                           md5_lds, c->stream, mp);
         HIPCHK(hipGetLastError());
         PFCHK(mark_end(c));
     }

@@ -1404,6 +1404,31 @@ __device__ __forceinline__ uint32_t pattern_insert_lower(const PatternTable& t, 
 // MULTI: the work item is the first of several key partitions of the cluster; the slot loops run over all of
 // them (the mask table, ordinal bitmaps and M are per cluster anyway) and slot tags are looked up again instead
 // of being kept per slot.
+// First half of a bulk insert: find the pattern or claim a free slot WITHOUT allocating an id and without ever
+// waiting.  Returns 0 = found (*pid), 1 = claimed (*slot is ours, val still unpublished), 2 = some other
+// workgroup has claimed a slot with our `lo` and not published it yet (resolve later, after publishing ours).
+__device__ __forceinline__ int pattern_find_or_claim(const PatternTable& t, uint64_t lo, uint32_t hi32,
+                                                     uint64_t* slot_out, uint32_t* pid) {
+    if (lo == EMPTY64) lo = EMPTY64 - 1;
+    uint64_t slot = (lo ^ ((uint64_t)hi32 * 0x9E3779B97F4A7C15ull)) & (t.cap - 1);
+    for (uint64_t probes = 0; probes < t.cap; probes++) {
+        uint64_t cur = __hip_atomic_load(&t.lo[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == EMPTY64) {
+            cur = atomicCAS((unsigned long long*)&t.lo[slot], (unsigned long long)EMPTY64, (unsigned long long)lo);
+            if (cur == EMPTY64) { *slot_out = slot; return 1; }
+        }
+        if (cur == lo) {
+            const uint64_t v = __hip_atomic_load(&t.val[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v == EMPTY64) return 2;
+            if ((uint32_t)(v >> 32) == hi32) { *pid = (uint32_t)v; return 0; }
+        }
+        slot = (slot + 1) & (t.cap - 1);
+    }
+    t.counters[1] = 1;
+    *pid = 0xFFFFFFFFu;
+    return 0;
+}
+
 template <class CFG, bool MULTI>
 __global__ __launch_bounds__(CFG::THREADS) void finish_kernel(FinishParams p) {
     constexpr uint32_t T = CFG::THREADS, DW = CFG::DW, AT = CFG::AT;
@@ -1609,12 +1634,22 @@ __global__ __launch_bounds__(CFG::THREADS) void finish_kernel(FinishParams p) {
             bo += __popc(occ[w]); bk += __popc(keepbm[w]);
         }
     }
+    if (tid == 0) at_count = 0;      // from here on: number of pattern-table slots this workgroup claims
     __syncthreads();
     auto rank_of = [&](uint32_t o) -> uint32_t { return pocc[o >> 5] + __popc(occ[o >> 5] & ((1u << (o & 31)) - 1)); };
     auto kept_before = [&](uint32_t o) -> uint32_t { return pkeep[o >> 5] + __popc(keepbm[o >> 5] & ((1u << (o & 31)) - 1)); };
-    // every global atomic of the item in one phase, on different threads, so that their latencies overlap:
-    // the output range (last thread), the cluster's own row (second to last), one insert per distinct kept mask
-    if (tid == T - 1) {
+    // ---- run-global pattern table, bulk protocol.  Entry AT-1 of the mask table (never a hash position) stands
+    // for the cluster's own row.  Step 1: every entry finds its pattern or claims a free slot (no waiting, no id);
+    // the output range is reserved meanwhile.  Step 2: ONE atomicAdd on the global id counter for all claims of
+    // this workgroup, ids published.  Step 3: entries that ran into another workgroup's unpublished claim go
+    // through the ordinary blocking insert (safe now: nobody waits on us).  Step 4: first_seen minima; whoever
+    // lowers one writes the pattern's row.
+    const bool is_row_entry = tid == AT - 1;      // T >= AT
+    uint64_t e_lo = 0, e_fs = 0, e_gslot = 0;
+    uint32_t e_hi = 0, e_pid = 0xFFFFFFFFu, e_newidx = 0;
+    int e_state = -1;                             // -1 no entry, 0 found, 1 claimed, 2 deferred
+    uint64_t e_key = 0;
+    if (tid == T - 1 && !is_row_entry) {
         sh_base = atomicAdd((unsigned long long*)&p.cursor[0], (unsigned long long)tot_k);
         atomicAdd((unsigned long long*)&p.cursor[1], (unsigned long long)tot_o);
         atomicAdd((unsigned long long*)&p.cursor[2], (unsigned long long)tot_k);
@@ -1622,40 +1657,74 @@ __global__ __launch_bounds__(CFG::THREADS) void finish_kernel(FinishParams p) {
         p.cluster_kmer_cnt[c] = tot_k;
         p.cluster_unique[c] = tot_o;
     }
-    if (tid == T - 2) {
+    if (is_row_entry) {
         // the cluster's own row: md5 of the int64 image of clusterpresab (panfeed.py:175-187)
         const uint32_t nw = (npres + 31) >> 5;
-        H128 s;
-        s.h1 = 0x9747b28cu ^ npres; s.h2 = 0x1b873593u ^ 0x5bd1e995u; s.h3 = 0xe6546b64u; s.h4 = 0x85ebca6bu;
-        if (p.multiple_files) { s.h2 ^= (uint32_t)ordinal; s.h3 ^= (uint32_t)(ordinal >> 32); }
+        H128 hs;
+        hs.h1 = 0x9747b28cu ^ npres; hs.h2 = 0x1b873593u ^ 0x5bd1e995u; hs.h3 = 0xe6546b64u; hs.h4 = 0x85ebca6bu;
+        if (p.multiple_files) { hs.h2 ^= (uint32_t)ordinal; hs.h3 ^= (uint32_t)(ordinal >> 32); }
         for (uint32_t w = 0; w < nw; w += 4) {
             uint32_t wv[4];
             for (int j = 0; j < 4; j++) wv[j] = (w + j < nw) ? presab[w + j] : 0;
-            mm3_block(s, wv[0], wv[1], wv[2], wv[3]);
+            mm3_block(hs, wv[0], wv[1], wv[2], wv[3]);
         }
-        mm3_final(s, nw * 4 + 1);
-        bool lowered;
-        const uint32_t pid = pattern_insert_lower(p.pt, ((uint64_t)s.h1 << 32) | s.h2, s.h3, ordinal << 32, &lowered);
-        p.cluster_pattern[c] = pid;
-        if (lowered && pid < p.pt.pool) {
-            for (uint32_t w = 0; w < W; w++) {
-                p.pat_bits[(size_t)pid * W + w] = presab[w];
-                if (p.pat_nan) p.pat_nan[(size_t)pid * W + w] = 0;
+        mm3_final(hs, nw * 4 + 1);
+        e_lo = ((uint64_t)hs.h1 << 32) | hs.h2; e_hi = hs.h3; e_fs = ordinal << 32;
+        e_state = 0;
+    } else if (tid < AT - 1) {
+        e_key = at_key[tid];
+        if (e_key && at_keep[tid]) {
+            const uint32_t mo = at_minord[tid];
+            if (mo != NO_ORD) {
+                const uint4 h = at_hash[tid];
+                e_lo = ((uint64_t)h.x << 32) | h.y; e_hi = h.z;
+                e_fs = (ordinal << 32) | (uint64_t)(rank_of(mo) + 1);
+                e_state = 0;
             }
-            p.pat_n[pid] = npres | 0x80000000u;
         }
+        if (e_state < 0) at_pid[tid] = 0xFFFFFFFFu;
     }
-    for (uint32_t t = tid; t < AT; t += T) {
-        const uint64_t key = at_key[t];
-        if (!key || !at_keep[t]) continue;
-        const uint32_t mo = at_minord[t];
-        if (mo == NO_ORD) { at_pid[t] = 0xFFFFFFFFu; continue; }
-        const uint64_t fs = (ordinal << 32) | (uint64_t)(rank_of(mo) + 1);
-        const uint4 h = at_hash[t];
-        bool lowered;
-        const uint32_t pid = pattern_insert_lower(p.pt, ((uint64_t)h.x << 32) | h.y, h.z, fs, &lowered);
-        at_pid[t] = pid;
-        if (lowered && pid < p.pt.pool) write_row(pid, key);
+    if (e_state == 0) {
+        e_state = pattern_find_or_claim(p.pt, e_lo, e_hi, &e_gslot, &e_pid);
+        if (e_state == 1) e_newidx = atomicAdd(&at_count, 1u);     // at_count: claims of this workgroup (reused)
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t nnew = at_count;
+        uint32_t base = 0;
+        if (nnew) {
+            base = atomicAdd(&p.pt.counters[0], nnew);
+            if ((uint64_t)base + nnew > p.pt.pool) p.pt.counters[1] = 1;
+        }
+        sh_npres = base;                                           // reused: first id of this workgroup's claims
+    }
+    __syncthreads();
+    if (e_state == 1) {
+        const uint32_t id = sh_npres + e_newidx;
+        e_pid = id < p.pt.pool ? id : 0xFFFFFFFFu;
+        __hip_atomic_store(&p.pt.val[e_gslot], ((uint64_t)e_hi << 32) | e_pid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    bool lowered = false;
+    if (e_state == 2) {
+        e_pid = pattern_insert_lower(p.pt, e_lo, e_hi, e_fs, &lowered);
+    } else if (e_state >= 0 && e_pid < p.pt.pool) {
+        const uint64_t old = atomicMin((unsigned long long*)&p.pt.first_seen[e_pid], (unsigned long long)e_fs);
+        lowered = old > e_fs;
+    }
+    if (e_state >= 0) {
+        if (is_row_entry) {
+            p.cluster_pattern[c] = e_pid;
+            if (lowered && e_pid < p.pt.pool) {
+                for (uint32_t w = 0; w < W; w++) {
+                    p.pat_bits[(size_t)e_pid * W + w] = presab[w];
+                    if (p.pat_nan) p.pat_nan[(size_t)e_pid * W + w] = 0;
+                }
+                p.pat_n[e_pid] = npres | 0x80000000u;
+            }
+        } else {
+            at_pid[tid] = e_pid;
+            if (lowered && e_pid < p.pt.pool) write_row(e_pid, e_key);
+        }
     }
     __syncthreads();
     const uint64_t obase = sh_base - p.out_base;
@@ -1891,48 +1960,77 @@ struct Md5Params {
     uint8_t* pat_md5;
     uint32_t pid0, pid1, W;
 };
-__global__ __launch_bounds__(256) void md5_kernel(Md5Params p) {
-    const uint32_t pid = p.pid0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (pid >= p.pid1) return;
-    const uint32_t nk = p.pat_n[pid];
+constexpr uint32_t MD5_THREADS = 256;
+constexpr uint32_t MD5_TILE = 16;     // row words staged per round (512 vector elements = 64 MD5 blocks)
+
+__global__ __launch_bounds__(MD5_THREADS) void md5_kernel(Md5Params p) {
+    // The rows of a block's 256 patterns are contiguous in the pool: they are loaded coalesced into LDS, 32 words
+    // per row and round (odd row stride: conflict-free), and every lane then walks its own row.  (row stride 17 words)
+    extern __shared__ uint32_t md5_lds[];            // 17 KiB (+17 KiB with a NaN mask): 8 waves per SIMD stay resident
+    uint32_t* t_bits = md5_lds;
+    uint32_t* t_nan = md5_lds + MD5_THREADS * (MD5_TILE + 1);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t pbase = p.pid0 + blockIdx.x * MD5_THREADS;
+    const uint32_t pid = pbase + tid;
+    const bool live = pid < p.pid1;
+    const uint32_t rows = min(MD5_THREADS, p.pid1 - pbase);
+    const uint32_t nk = live ? p.pat_n[pid] : 0;
     const bool is_int = (nk >> 31) != 0;
     const uint32_t n = nk & 0x7FFFFFFFu;
-    const uint32_t* bits = p.pat_bits + (size_t)pid * p.W;
-    const uint32_t* nan = p.pat_nan ? p.pat_nan + (size_t)pid * p.W : nullptr;
+    const bool has_nan = p.pat_nan != nullptr;
     uint32_t st[4] = {0x67452301u, 0xefcdab89u, 0x98badcfeu, 0x10325476u};
     const uint64_t nbytes = (uint64_t)n * 8;
     const uint32_t full = n >> 3;             // whole 64-byte blocks = 8 elements each
-    uint32_t m[16];
-    for (uint32_t blk = 0; blk < full; blk++) {
-        const uint32_t e0 = blk << 3;
-        const uint32_t bw = (bits[e0 >> 5] >> (e0 & 31)) & 0xFF;
-        const uint32_t nw = nan ? (nan[e0 >> 5] >> (e0 & 31)) & 0xFF : 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const uint32_t bit = (bw >> j) & 1, isn = (nw >> j) & 1;
-            // int64 LE: 01 00.. ; float64 LE: 1.0 = 0x3FF00000:00000000, NaN = 0x7FF80000:00000000 (np.nan)
-            m[2 * j] = is_int ? bit : 0;
-            m[2 * j + 1] = is_int ? 0 : (bit ? 0x3FF00000u : (isn ? 0x7FF80000u : 0));
-        }
-        md5_block(st, m);
-    }
-    // tail: remaining elements, 0x80, zero pad, 64-bit length
     const uint32_t rem = n & 7;
+    uint32_t m[16];
+    uint32_t tail_bw = 0, tail_nw = 0;
+    const uint32_t W = p.W;
+    for (uint32_t w0 = 0; w0 < W; w0 += MD5_TILE) {
+        const uint32_t tw = min(MD5_TILE, W - w0);
+        __syncthreads();
+        for (uint32_t i = tid; i < rows * tw; i += MD5_THREADS) {
+            const uint32_t r = i / tw, w = i - r * tw;
+            t_bits[r * (MD5_TILE + 1) + w] = p.pat_bits[(size_t)(pbase + r) * W + w0 + w];
+            if (has_nan) t_nan[r * (MD5_TILE + 1) + w] = p.pat_nan[(size_t)(pbase + r) * W + w0 + w];
+        }
+        __syncthreads();
+        if (!live) continue;
+        const uint32_t* rb = t_bits + tid * (MD5_TILE + 1);
+        const uint32_t* rn = t_nan + tid * (MD5_TILE + 1);
+        // blocks whose 8 elements lie in this tile: block b covers elements 8b..8b+7 -> word b/4
+        const uint32_t b0 = w0 * 4, b1 = min(full, (w0 + tw) * 4);
+        for (uint32_t blk = b0; blk < b1; blk++) {
+            const uint32_t e0 = (blk << 3) - (w0 << 5);
+            const uint32_t bw = (rb[e0 >> 5] >> (e0 & 31)) & 0xFF;
+            const uint32_t nw = has_nan ? (rn[e0 >> 5] >> (e0 & 31)) & 0xFF : 0;
 #pragma unroll
-    for (int j = 0; j < 16; j++) m[j] = 0;
-    {
-        const uint32_t e0 = full << 3;
-        const uint32_t bw = rem ? (bits[e0 >> 5] >> (e0 & 31)) & 0xFF : 0;
-        const uint32_t nw = (rem && nan) ? (nan[e0 >> 5] >> (e0 & 31)) & 0xFF : 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const uint32_t bit = (bw >> j) & 1, isn = (nw >> j) & 1;
-            if ((uint32_t)j < rem) {
+            for (int j = 0; j < 8; j++) {
+                const uint32_t bit = (bw >> j) & 1, isn = (nw >> j) & 1;
+                // int64 LE: 01 00.. ; float64 LE: 1.0 = 0x3FF00000:00000000, NaN = 0x7FF80000:00000000 (np.nan)
                 m[2 * j] = is_int ? bit : 0;
                 m[2 * j + 1] = is_int ? 0 : (bit ? 0x3FF00000u : (isn ? 0x7FF80000u : 0));
-            } else if ((uint32_t)j == rem) {
-                m[2 * j] = 0x80;              // first pad byte right after the data
             }
+            md5_block(st, m);
+        }
+        // the (at most 7) elements after the last whole block, if they live in this tile
+        if (rem && (full >> 2) >= w0 && (full >> 2) < w0 + tw) {
+            const uint32_t e0 = (full << 3) - (w0 << 5);
+            tail_bw = (rb[e0 >> 5] >> (e0 & 31)) & 0xFF;
+            tail_nw = has_nan ? (rn[e0 >> 5] >> (e0 & 31)) & 0xFF : 0;
+        }
+    }
+    if (!live) return;
+    // tail: remaining elements, 0x80, zero pad, 64-bit length
+#pragma unroll
+    for (int j = 0; j < 16; j++) m[j] = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t bit = (tail_bw >> j) & 1, isn = (tail_nw >> j) & 1;
+        if ((uint32_t)j < rem) {
+            m[2 * j] = is_int ? bit : 0;
+            m[2 * j + 1] = is_int ? 0 : (bit ? 0x3FF00000u : (isn ? 0x7FF80000u : 0));
+        } else if ((uint32_t)j == rem) {
+            m[2 * j] = 0x80;              // first pad byte right after the data
         }
     }
     if (rem == 7) {                           // 56 data bytes + 0x80 leaves no room for the length
@@ -1944,8 +2042,9 @@ __global__ __launch_bounds__(256) void md5_kernel(Md5Params p) {
     m[15] = (uint32_t)((nbytes << 3) >> 32);
     md5_block(st, m);
     uint8_t* out = p.pat_md5 + (size_t)pid * 16;
-    for (int i = 0; i < 4; i++)
-        for (int j = 0; j < 4; j++) out[4 * i + j] = (uint8_t)(st[i] >> (8 * j));
+    uint32_t o4[4];
+    for (int i = 0; i < 4; i++) o4[i] = st[i];
+    *reinterpret_cast<uint4*>(out) = make_uint4(o4[0], o4[1], o4[2], o4[3]);   // little-endian words = MD5 byte order
 }
 
 // ---------------------------------------------------------------------------------------------
