@@ -194,6 +194,18 @@ def main():
         dom_launches = {"cluster_dedup_kernel": len(dbs), "md5_kernel": len(dbs)}.get(dom, last["launches"])
         dom_s = kern_ms[dom] / 1e3
         achieved = alg / dom_s / 1e9 if dom_s > 0 else 0.0
+        # HBM traffic of that kernel from the committed PMC summary of this same command (rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 correction on the read side); per launch
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(REPO, "profiles", "r01", "final_pmc_traffic.json")
+        default_cmd = (args.clusters, S, k, args.flank, world, args.no_dedup) == (50000, 1000, 31, 100, 1, False)
+        if default_cmd and os.path.exists(pmc_path):
+            with open(pmc_path) as fh:
+                pmc = json.load(fh)
+            tot = sum(v["hbm_bytes_per_step"] for kn, v in pmc["kernels"].items() if kn.startswith("pf::" + dom))
+            if tot:
+                traffic = tot / max(1, dom_launches)
+                traffic_src = "profiles/r01/final_pmc_traffic.json"
         out = {
             "metric": "k-mer instances/s (+ unique patterns/s), k=31, 50k clusters x 1k samples",
             "value": tot_inst * args.steps / dt,
@@ -209,7 +221,7 @@ def main():
                        "unique_kmers": last["unique"], "kept_kmers": last["kept"], "patterns": last["global_patterns"],
                        "sharding": f"{world} x contiguous cluster ranges" + (", RCCL all-gather of pattern digests" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_step": alg, "kernel_ms_per_step": kern_ms[dom],
                          "launches_per_step": dom_launches,
                          "avg_launch_ms": kern_ms[dom] / max(1, dom_launches),
