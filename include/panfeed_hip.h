@@ -214,6 +214,27 @@ void pf_b64_digest(const uint8_t md5[16], char out[24]);
 int pf_render_kmers_to_hashes(pf_ctx* ctx, const char* const* cluster_names, const char* const* extra_keys,
                               char** out, uint64_t* nbytes, uint64_t* cluster_end);
 int pf_render_hashes_to_patterns(pf_ctx* ctx, char** out, uint64_t* nbytes);
+
+/* One Seqinfo of a target strain (panfeed/classes.py:11-18) for the positional rows of kmers.tsv
+ * (panfeed.py:90-107).  Its pure-ACGT windows take used_strand from the strand bits of the last fetched batch
+ * (segment `seg_index[j]` covers windows seg_start[j] .. seg_start[j]+seg_nwin[j]-1 of the sequence); windows
+ * that contain another base come with their canonical k-mer and used_strand from the caller's slow path. */
+typedef struct {
+    const char* cluster; const char* strain; const char* id; const char* chromosome;   /* NUL-terminated */
+    const char* sequence; const char* compsequence;                                    /* `len` bytes each */
+    uint32_t len;
+    int32_t strand;
+    int64_t start, end, offset;
+    uint32_t n_segs; uint32_t n_ambig;
+    const uint32_t* seg_index; const uint32_t* seg_start; const uint32_t* seg_nwin;
+    const uint32_t* ambig_pos; const int8_t* ambig_used; const char* const* ambig_key;   /* sorted by ambig_pos */
+} pf_target_seq;
+
+/* Rows of kmers.tsv for `n` target sequences, in the given order: one row per window ("cluster, strain,
+ * feature_id, contig, feature_strand, contig_start, contig_end, gene_start, gene_end, strand, k-mer"), two per
+ * window in non-canonical mode (panfeed.py:104-107).  seg_strand_off: the batch's array. */
+int pf_render_kmers_tsv(pf_ctx* ctx, const pf_target_seq* seqs, uint32_t n, const uint32_t* seg_strand_off,
+                        char** out, uint64_t* nbytes);
 void pf_free_text(char* p);
 
 #ifdef __cplusplus

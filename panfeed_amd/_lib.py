@@ -48,6 +48,16 @@ class Result(C.Structure):
                 ("pattern_first_seen", C.POINTER(C.c_uint64)), ("strand_bits", C.POINTER(C.c_uint64))]
 
 
+class TargetSeq(C.Structure):
+    _fields_ = [("cluster", C.c_char_p), ("strain", C.c_char_p), ("id", C.c_char_p), ("chromosome", C.c_char_p),
+                ("sequence", C.c_char_p), ("compsequence", C.c_char_p), ("len", C.c_uint32), ("strand", C.c_int32),
+                ("start", C.c_int64), ("end", C.c_int64), ("offset", C.c_int64),
+                ("n_segs", C.c_uint32), ("n_ambig", C.c_uint32),
+                ("seg_index", C.POINTER(C.c_uint32)), ("seg_start", C.POINTER(C.c_uint32)),
+                ("seg_nwin", C.POINTER(C.c_uint32)), ("ambig_pos", C.POINTER(C.c_uint32)),
+                ("ambig_used", C.POINTER(C.c_int8)), ("ambig_key", C.POINTER(C.c_char_p))]
+
+
 class Timing(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("scan_ms", C.c_float), ("rows_ms", C.c_float), ("emit_ms", C.c_float),
                 ("scan_launches", C.c_uint32), ("n_items", C.c_uint32), ("n_retried", C.c_uint32),
@@ -62,7 +72,7 @@ EXPORTS = ["pf_last_error", "pf_version", "pf_device_count", "pf_create", "pf_de
            "pf_submit", "pf_fetch", "pf_get_timing", "pf_export_patterns", "pf_export_patterns_dev",
            "pf_pattern_count", "pf_dev_alloc", "pf_dev_free",
            "pf_dev_upload", "pf_dev_download", "pf_synth_expand", "pf_pack_acgt", "pf_b64_digest",
-           "pf_render_kmers_to_hashes", "pf_render_hashes_to_patterns", "pf_free_text"]
+           "pf_render_kmers_to_hashes", "pf_render_hashes_to_patterns", "pf_render_kmers_tsv", "pf_free_text"]
 
 _lib = None
 
@@ -104,6 +114,8 @@ def load():
     L.pf_render_kmers_to_hashes.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
                                             C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.pf_render_hashes_to_patterns.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.pf_render_kmers_tsv.argtypes = [C.c_void_p, C.POINTER(TargetSeq), C.c_uint32, C.c_void_p,
+                                      C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.pf_free_text.argtypes = [C.c_void_p]
     L.pf_free_text.restype = None
     _lib = L

@@ -190,12 +190,17 @@ class Engine:
             _lib.check(self.L.pf_render_hashes_to_patterns(self.ctx, C.byref(buf), C.byref(nb)))
             hp_all = C.string_at(buf, nb.value).decode()
             self.L.pf_free_text(buf)
-        # kmers.tsv body (panfeed.py:90-107)
+        # kmers.tsv body (panfeed.py:90-107): one row per window of the target strains' sequences
         kt_by_cluster = [[] for _ in range(C_)]
-        strand = _view(res.strand_bits, hb.n_strand_words, np.uint64) if hb.n_strand_words else None
-        for meta in hb.targets:
-            kt_by_cluster[meta.cluster].append(self._positional_rows(hb, meta, strand))
-
+        if hb.targets:
+            if self.multiple_files:
+                by_cl = {}
+                for meta in hb.targets:
+                    by_cl.setdefault(meta.cluster, []).append(meta)
+                for ci, metas in by_cl.items():
+                    kt_by_cluster[ci].append(self._render_targets(hb, metas))
+            else:
+                kt_by_cluster[0].append(self._render_targets(hb, hb.targets))
         if self.multiple_files:
             for ci in range(C_):
                 out.per_cluster.append((hb.idx[ci], "".join(kt_by_cluster[ci]), kh_parts[ci],
@@ -209,6 +214,37 @@ class Engine:
                      "new_patterns": int(res.n_new_patterns), "patterns": int(res.n_patterns)}
         out.timing = self.timing()
         return out
+
+    def _render_targets(self, hb, metas):
+        """kmers.tsv rows of `metas` (packing.SeqMeta, in order) through pf_render_kmers_tsv"""
+        n = len(metas)
+        arr = (_lib.TargetSeq * n)()
+        keep = []
+        for i, m in enumerate(metas):
+            s = m.seq
+            seq, comp = s.sequence.encode(), s.compsequence.encode()
+            segs = np.asarray(m.segs, dtype=np.uint32).reshape(-1, 3)
+            si = np.ascontiguousarray(segs[:, 0])
+            ss = np.ascontiguousarray(segs[:, 1])
+            sn = np.ascontiguousarray(segs[:, 2])
+            apos = sorted(m.ambig)
+            ap = np.asarray(apos, dtype=np.uint32)
+            au = np.asarray([m.ambig[q][1] for q in apos], dtype=np.int8)
+            ak = (C.c_char_p * max(1, len(apos)))(*[m.ambig[q][0].encode() for q in apos])
+            keep += [seq, comp, si, ss, sn, ap, au, ak]
+            arr[i] = _lib.TargetSeq(
+                hb.idx[m.cluster].encode(), str(m.strain).encode(), str(s.id).encode(), str(s.chromosome).encode(),
+                seq, comp, len(seq), int(s.strand), int(s.start), int(s.end), int(s.offset), len(si), len(apos),
+                si.ctypes.data_as(C.POINTER(C.c_uint32)), ss.ctypes.data_as(C.POINTER(C.c_uint32)),
+                sn.ctypes.data_as(C.POINTER(C.c_uint32)), ap.ctypes.data_as(C.POINTER(C.c_uint32)),
+                au.ctypes.data_as(C.POINTER(C.c_int8)), ak)
+        buf, nb = C.c_void_p(), C.c_uint64()
+        sso = hb.seg_strand_off.ctypes.data_as(C.c_void_p) if hb.n_strand_words else None
+        _lib.check(self.L.pf_render_kmers_tsv(self.ctx, arr, n, sso, C.byref(buf), C.byref(nb)))
+        text = C.string_at(buf, nb.value).decode()
+        self.L.pf_free_text(buf)
+        del keep
+        return text
 
     def _positional_rows(self, hb, meta, strand):
         """one row per instance for a target strain's sequence (panfeed.py:90-107)"""

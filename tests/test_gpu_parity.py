@@ -230,3 +230,31 @@ def test_dedup_big_alleles_repartition(flags):
     assert out.hashes_to_patterns == ehp
     assert out.kmers_tsv == ek
     eng.close()
+
+
+def test_pattern_export_device_path_and_merge():
+    """the tensors the RCCL all-gather starts from: device-to-device export == host export, and the
+    single-process merge keeps every pattern exactly once"""
+    import torch
+    from panfeed_amd import synth
+    from panfeed_amd.distributed import export_patterns, merge_pattern_tensors
+    from panfeed_amd.engine import Engine
+    cl = synth.generate(6, 48, first=77, mean_len=200, min_len=60, max_len=500, n_rate=0.0)
+    eng = Engine(klength=21, max_strains=64)
+    out = eng.run([c.record() for c in cl])
+    md5_d, fs_d = export_patterns(eng, torch.device("cuda", 0))
+    md5_h, fs_h = export_patterns(eng, torch.device("cpu"))
+    assert md5_d.shape[0] == out.stats["patterns"] == md5_h.shape[0]
+    assert torch.equal(md5_d.cpu(), md5_h) and torch.equal(fs_d.cpu(), fs_h)
+    keep, n_global = merge_pattern_tensors(md5_d, fs_d)
+    assert n_global == out.stats["patterns"] and bool(keep.all())
+    # first_seen order == order of hashes_to_patterns.tsv
+    order = torch.argsort(fs_h).tolist()
+    import ctypes as C
+    buf = C.create_string_buffer(24)
+    hashes = []
+    for i in order:
+        eng.L.pf_b64_digest(md5_h[i].numpy().tobytes(), buf)
+        hashes.append(buf.raw[:24].decode())
+    assert hashes == [ln.split("\t")[0] for ln in out.hashes_to_patterns.splitlines()]
+    eng.close()
