@@ -201,6 +201,45 @@ int pf_synth_expand(pf_ctx* ctx, const uint64_t* allele_words, const uint64_t* a
  * 2*ceil(len/64) words; returns the number of words written. */
 uint64_t pf_pack_acgt(const char* seq, uint32_t len, uint64_t* dst);
 
+/*
+ * Host-side batch packer (no GPU involved): the Seqinfo records of a batch of clusters
+ * (/root/reference/panfeed/classes.py:11-18, iteration order of panfeed.py:54-55, cluster-major) -> the segment
+ * arrays of pf_batch, the slow-path rows for windows with a non-ACGT base (grouped as panfeed.py:64-88 does),
+ * strand-bit offsets for target strains, and what the kmers.tsv writer needs per target sequence.
+ */
+typedef struct {
+    uint32_t n_clusters, n_seqs;
+    const char* const* seq;           /* [n_seqs] Seqinfo.sequence (upper case), seq_len bytes */
+    const char* const* comp;          /* [n_seqs] Seqinfo.compsequence; checked to be the complement on A/C/G/T */
+    const uint32_t* seq_len;          /* [n_seqs] */
+    const uint32_t* seq_col;          /* [n_seqs] column of the strain in sorted(cluster.keys()) (panfeed.py:47-49) */
+    const uint8_t* seq_target;        /* [n_seqs] `strain in stroi` (panfeed.py:90), may be NULL */
+    const uint32_t* cluster_seq_off;  /* [n_clusters+1] */
+    uint32_t klength, canon, W, want_strand;
+} pf_pack_in;
+
+typedef struct pf_packed pf_packed;
+
+typedef struct {
+    uint32_t n_segs, n_extra, n_targets, reserved;
+    uint64_t n_words, n_strand_words, n_instances;
+    const uint64_t* packed; const uint64_t* seg_word_off;
+    const uint32_t* seg_len; const uint32_t* seg_sample; const uint32_t* seg_ord_base; const uint32_t* seg_strand_off;
+    const uint32_t* cluster_seg_off;  /* [n_clusters+1] */
+    const uint64_t* cluster_ninst;    /* [n_clusters] trip count of panfeed.py:64 (x2 non-canonical) */
+    const uint32_t* extra_cluster; const uint32_t* extra_ord; const uint32_t* extra_bits;
+    const char* extra_keys;           /* n_extra * klength bytes */
+    /* target sequences (input index), their pure segments and slow-path windows (CSR) */
+    const uint32_t* target_seq; const uint32_t* target_seg_off; const uint32_t* target_seg_index;
+    const uint32_t* target_seg_start; const uint32_t* target_seg_nwin;
+    const uint32_t* target_ambig_off; const uint32_t* target_ambig_pos; const int8_t* target_ambig_used;
+    const char* target_ambig_keys;    /* klength bytes per slow-path window */
+} pf_packed_view_t;
+
+int pf_pack_records(const pf_pack_in* in, pf_packed** out);
+int pf_packed_view(const pf_packed* p, pf_packed_view_t* view);
+void pf_packed_free(pf_packed* p);
+
 /* Host helper: md5 + base64 of a digest -- panfeed.py:175-176 -- for writers. */
 void pf_b64_digest(const uint8_t md5[16], char out[24]);
 

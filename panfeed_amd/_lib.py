@@ -58,6 +58,29 @@ class TargetSeq(C.Structure):
                 ("ambig_used", C.POINTER(C.c_int8)), ("ambig_key", C.POINTER(C.c_char_p))]
 
 
+class PackIn(C.Structure):
+    _fields_ = [("n_clusters", C.c_uint32), ("n_seqs", C.c_uint32),
+                ("seq", C.POINTER(C.c_char_p)), ("comp", C.POINTER(C.c_char_p)), ("seq_len", C.c_void_p),
+                ("seq_col", C.c_void_p), ("seq_target", C.c_void_p), ("cluster_seq_off", C.c_void_p),
+                ("klength", C.c_uint32), ("canon", C.c_uint32), ("W", C.c_uint32), ("want_strand", C.c_uint32)]
+
+
+class PackedView(C.Structure):
+    _fields_ = [("n_segs", C.c_uint32), ("n_extra", C.c_uint32), ("n_targets", C.c_uint32), ("reserved", C.c_uint32),
+                ("n_words", C.c_uint64), ("n_strand_words", C.c_uint64), ("n_instances", C.c_uint64),
+                ("packed", C.POINTER(C.c_uint64)), ("seg_word_off", C.POINTER(C.c_uint64)),
+                ("seg_len", C.POINTER(C.c_uint32)), ("seg_sample", C.POINTER(C.c_uint32)),
+                ("seg_ord_base", C.POINTER(C.c_uint32)), ("seg_strand_off", C.POINTER(C.c_uint32)),
+                ("cluster_seg_off", C.POINTER(C.c_uint32)), ("cluster_ninst", C.POINTER(C.c_uint64)),
+                ("extra_cluster", C.POINTER(C.c_uint32)), ("extra_ord", C.POINTER(C.c_uint32)),
+                ("extra_bits", C.POINTER(C.c_uint32)), ("extra_keys", C.POINTER(C.c_char)),
+                ("target_seq", C.POINTER(C.c_uint32)), ("target_seg_off", C.POINTER(C.c_uint32)),
+                ("target_seg_index", C.POINTER(C.c_uint32)), ("target_seg_start", C.POINTER(C.c_uint32)),
+                ("target_seg_nwin", C.POINTER(C.c_uint32)), ("target_ambig_off", C.POINTER(C.c_uint32)),
+                ("target_ambig_pos", C.POINTER(C.c_uint32)), ("target_ambig_used", C.POINTER(C.c_int8)),
+                ("target_ambig_keys", C.POINTER(C.c_char))]
+
+
 class Timing(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("scan_ms", C.c_float), ("rows_ms", C.c_float), ("emit_ms", C.c_float),
                 ("scan_launches", C.c_uint32), ("n_items", C.c_uint32), ("n_retried", C.c_uint32),
@@ -72,7 +95,8 @@ EXPORTS = ["pf_last_error", "pf_version", "pf_device_count", "pf_create", "pf_de
            "pf_submit", "pf_fetch", "pf_get_timing", "pf_export_patterns", "pf_export_patterns_dev",
            "pf_pattern_count", "pf_dev_alloc", "pf_dev_free",
            "pf_dev_upload", "pf_dev_download", "pf_synth_expand", "pf_pack_acgt", "pf_b64_digest",
-           "pf_render_kmers_to_hashes", "pf_render_hashes_to_patterns", "pf_render_kmers_tsv", "pf_free_text"]
+           "pf_render_kmers_to_hashes", "pf_render_hashes_to_patterns", "pf_render_kmers_tsv", "pf_free_text",
+           "pf_pack_records", "pf_packed_view", "pf_packed_free"]
 
 _lib = None
 
@@ -116,6 +140,10 @@ def load():
     L.pf_render_hashes_to_patterns.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.pf_render_kmers_tsv.argtypes = [C.c_void_p, C.POINTER(TargetSeq), C.c_uint32, C.c_void_p,
                                       C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.pf_pack_records.argtypes = [C.POINTER(PackIn), C.POINTER(C.c_void_p)]
+    L.pf_packed_view.argtypes = [C.c_void_p, C.POINTER(PackedView)]
+    L.pf_packed_free.argtypes = [C.c_void_p]
+    L.pf_packed_free.restype = None
     L.pf_free_text.argtypes = [C.c_void_p]
     L.pf_free_text.restype = None
     _lib = L

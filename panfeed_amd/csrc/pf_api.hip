@@ -258,6 +258,7 @@ void ensure_b64(pf_ctx* c) {
 extern "C" {
 
 const char* pf_last_error(void) { return g_err.c_str(); }
+void pf_set_error_(const char* msg) { g_err = msg; }   /* for the other translation units of the library */
 const char* pf_version(void) { return "panfeed_hip 0.1 (gfx950)"; }
 
 int pf_device_count(void) {

@@ -1,0 +1,285 @@
+// pf_pack.cpp -- host side of the device boundary in native code: reference-shaped sequences -> the packed
+// segment arrays of include/panfeed_hip.h, plus the slow path for windows that contain a non-ACGT base
+// (grouped with the reference's own string semantics, /root/reference/panfeed/panfeed.py:64-88).
+// No GPU involved; panfeed_amd/packing.py holds the same logic in numpy and tests compare the two array for array.
+#include "../../include/panfeed_hip.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+extern "C" const char* pf_last_error(void);
+extern "C" void pf_set_error_(const char* msg);   // pf_api.hip
+
+namespace {
+
+int pk_fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    pf_set_error_(buf);
+    return code;
+}
+
+struct Extra { uint32_t ord; std::vector<uint32_t> bits; std::string key; };
+
+struct ClusterOut {
+    std::vector<uint64_t> words;                 // packed segments of the cluster, in final (sorted) order
+    std::vector<uint32_t> seg_woff, seg_len, seg_sample, seg_ord, seg_strand_nw;   // woff: words into `words`
+    std::vector<uint8_t> seg_wants_strand;
+    std::vector<Extra> extras;
+    // per target sequence (iteration order)
+    std::vector<uint32_t> t_seq, t_seg_off, t_seg_local, t_seg_start, t_seg_nwin, t_amb_off, t_amb_pos;
+    std::vector<int8_t> t_amb_used;
+    std::string t_amb_keys;
+    uint64_t n_inst = 0;
+    std::string error;
+};
+
+inline int code_of(unsigned char ch) {
+    switch (ch) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return -1; }
+}
+
+void pack_cluster(const pf_pack_in* in, uint32_t ci, ClusterOut& o) {
+    const uint32_t k = in->klength, W = in->W;
+    const uint32_t s0 = in->cluster_seq_off[ci], s1 = in->cluster_seq_off[ci + 1];
+    struct Seg { uint32_t col, order, a, len, ord, seq; bool strand; };
+    std::vector<Seg> segs;
+    std::unordered_map<std::string, uint32_t> amb_index;      // key -> index in o.extras (insertion order kept)
+    uint64_t ord_base = 0;
+    uint32_t order = 0;
+    std::vector<int8_t> codes;
+    std::string rev(k, 'A');
+    for (uint32_t q = s0; q < s1; q++) {
+        const char* seq = in->seq[q];
+        const char* comp = in->comp[q];
+        const uint32_t L = in->seq_len[q];
+        const uint32_t col = in->seq_col[q];
+        const bool target = in->seq_target && in->seq_target[q];
+        const uint64_t num_kmer = L >= k ? (uint64_t)L - k + 1 : 0;              // panfeed.py:59,64
+        codes.resize(L);
+        std::vector<uint32_t> bad;
+        for (uint32_t i = 0; i < L; i++) {
+            codes[i] = (int8_t)code_of((unsigned char)seq[i]);
+            if (codes[i] < 0) bad.push_back(i);
+            else if (code_of((unsigned char)comp[i]) != 3 - codes[i]) {
+                o.error = "compsequence is not the complement of sequence";
+                return;
+            }
+        }
+        if (target) {
+            o.t_seq.push_back(q);
+            o.t_seg_off.push_back((uint32_t)o.t_seg_local.size());
+            o.t_amb_off.push_back((uint32_t)o.t_amb_pos.size());
+        }
+        // maximal A/C/G/T runs -> device segments
+        uint32_t a = 0;
+        for (size_t bi = 0; bi <= bad.size(); bi++) {
+            const uint32_t b = bi < bad.size() ? bad[bi] : L;
+            if (b >= a && b - a >= k) {
+                const bool strand = target && in->canon && in->want_strand;
+                segs.push_back(Seg{col, order, a, b - a, (uint32_t)(ord_base + a), q, strand});
+                if (target) {
+                    o.t_seg_local.push_back(order);
+                    o.t_seg_start.push_back(a);
+                    o.t_seg_nwin.push_back(b - a - k + 1);
+                }
+                order++;
+            }
+            a = b + 1;
+        }
+        // windows touching a non-ACGT base: the reference's own string semantics
+        if (!bad.empty() && num_kmer > 0) {
+            std::vector<uint8_t> touched(num_kmer, 0);
+            for (uint32_t p : bad) {
+                const uint64_t lo = p + 1 >= k ? (uint64_t)p - k + 1 : 0, hi = std::min<uint64_t>(num_kmer, (uint64_t)p + 1);
+                for (uint64_t x = lo; x < hi; x++) touched[x] = 1;
+            }
+            for (uint64_t pos = 0; pos < num_kmer; pos++) {
+                if (!touched[pos]) continue;
+                const char* spec = seq + pos;                                   // panfeed.py:65
+                for (uint32_t j = 0; j < k; j++) rev[j] = comp[pos + k - 1 - j]; // panfeed.py:67
+                auto add = [&](const char* key, uint32_t ord) {
+                    std::string ks(key, k);
+                    auto it = amb_index.find(ks);
+                    uint32_t e;
+                    if (it == amb_index.end()) {
+                        e = (uint32_t)o.extras.size();
+                        amb_index.emplace(ks, e);
+                        o.extras.push_back(Extra{ord, std::vector<uint32_t>(W, 0), ks});
+                    } else e = it->second;
+                    o.extras[e].bits[col >> 5] |= 1u << (col & 31);
+                };
+                if (in->canon) {
+                    const bool fwd = memcmp(spec, rev.data(), k) <= 0;          // panfeed.py:70-75
+                    add(fwd ? spec : rev.data(), (uint32_t)(ord_base + pos));
+                    if (target) {
+                        o.t_amb_pos.push_back((uint32_t)pos);
+                        o.t_amb_used.push_back(fwd ? 1 : -1);
+                        o.t_amb_keys.append(fwd ? spec : rev.data(), k);
+                    }
+                } else {                                                        // panfeed.py:82-88
+                    add(spec, (uint32_t)(2 * (ord_base + pos)));
+                    add(rev.data(), (uint32_t)(2 * (ord_base + pos) + 1));
+                }
+            }
+        }
+        ord_base += num_kmer;
+    }
+    o.n_inst = ord_base * (in->canon ? 1 : 2);
+    if (ord_base * 2 >= 0xFFFFFFF0ull) { o.error = "too many k-mer instances for 32-bit ordinals"; return; }
+    // segments sorted by sample column (stable); local order -> final position for the strand bits
+    std::stable_sort(segs.begin(), segs.end(), [](const Seg& x, const Seg& y) { return x.col < y.col; });
+    std::vector<uint32_t> where(segs.size());
+    for (size_t j = 0; j < segs.size(); j++) {
+        const Seg& g = segs[j];
+        where[g.order] = (uint32_t)j;
+        const uint32_t nw = 2 * ((g.len + 63) / 64);
+        const uint32_t w0 = (uint32_t)o.words.size();
+        o.words.resize(w0 + nw, 0);
+        const char* seq = in->seq[g.seq] + g.a;
+        for (uint32_t i = 0; i < g.len; i++)
+            o.words[w0 + (i >> 5)] |= (uint64_t)code_of((unsigned char)seq[i]) << (62 - 2 * (i & 31));
+        o.seg_woff.push_back(w0);
+        o.seg_len.push_back(g.len);
+        o.seg_sample.push_back(g.col);
+        o.seg_ord.push_back(g.ord);
+        o.seg_wants_strand.push_back(g.strand ? 1 : 0);
+        o.seg_strand_nw.push_back(g.strand ? (g.len - k + 1 + 63) / 64 : 0);
+    }
+    for (auto& x : o.t_seg_local) x = where[x];
+}
+
+}  // namespace
+
+struct pf_packed {
+    std::vector<uint64_t> packed;
+    std::vector<uint64_t> seg_word_off;
+    std::vector<uint32_t> seg_len, seg_sample, seg_ord_base, seg_strand_off, cluster_seg_off;
+    std::vector<uint32_t> extra_cluster, extra_ord, extra_bits;
+    std::string extra_keys;                       // klength bytes each
+    std::vector<uint32_t> t_seq, t_seg_off, t_seg_index, t_seg_start, t_seg_nwin, t_amb_off, t_amb_pos;
+    std::vector<int8_t> t_amb_used;
+    std::string t_amb_keys;
+    std::vector<uint64_t> cluster_ninst;
+    uint64_t n_strand_words = 0, n_instances = 0;
+};
+
+extern "C" {
+
+int pf_pack_records(const pf_pack_in* in, pf_packed** out) {
+    if (!in || !out) return pk_fail(PF_ERR_ARG, "pf_pack_records: null argument");
+    *out = nullptr;
+    if (in->klength < 1) return pk_fail(PF_ERR_ARG, "pf_pack_records: klength must be >= 1");
+    const uint32_t C = in->n_clusters;
+    std::vector<ClusterOut> outs(C);
+    unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+    if (C < 8) nt = 1;
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++)
+            th.emplace_back([&, t] { for (uint32_t ci = t; ci < C; ci += nt) pack_cluster(in, ci, outs[ci]); });
+        for (auto& x : th) x.join();
+    }
+    for (uint32_t ci = 0; ci < C; ci++)
+        if (!outs[ci].error.empty()) return pk_fail(PF_ERR_ARG, "cluster %u: %s", ci, outs[ci].error.c_str());
+    pf_packed* p = new pf_packed();
+    p->cluster_seg_off.assign(1, 0);
+    uint64_t woff = 0, strand_words = 0;
+    for (uint32_t ci = 0; ci < C; ci++) {
+        ClusterOut& o = outs[ci];
+        const uint32_t seg_base = (uint32_t)p->seg_len.size();
+        for (size_t j = 0; j < o.seg_len.size(); j++) {
+            p->seg_word_off.push_back(woff + o.seg_woff[j]);
+            p->seg_len.push_back(o.seg_len[j]);
+            p->seg_sample.push_back(o.seg_sample[j]);
+            p->seg_ord_base.push_back(o.seg_ord[j]);
+        }
+        // strand-bit offsets follow the order in which the sequences were visited (as packing.py assigns them):
+        // walk the target sequences' segments in iteration order
+        std::vector<uint32_t> soff(o.seg_len.size(), 0xFFFFFFFFu);
+        for (size_t t = 0; t < o.t_seq.size(); t++) {
+            const uint32_t a = o.t_seg_off[t], b = t + 1 < o.t_seq.size() ? o.t_seg_off[t + 1] : (uint32_t)o.t_seg_local.size();
+            for (uint32_t j = a; j < b; j++) {
+                const uint32_t sj = o.t_seg_local[j];
+                if (o.seg_wants_strand[sj]) { soff[sj] = (uint32_t)strand_words; strand_words += o.seg_strand_nw[sj]; }
+            }
+        }
+        p->seg_strand_off.insert(p->seg_strand_off.end(), soff.begin(), soff.end());
+        p->packed.insert(p->packed.end(), o.words.begin(), o.words.end());
+        woff += o.words.size();
+        p->cluster_seg_off.push_back((uint32_t)p->seg_len.size());
+        for (auto& e : o.extras) {
+            p->extra_cluster.push_back(ci);
+            p->extra_ord.push_back(e.ord);
+            p->extra_bits.insert(p->extra_bits.end(), e.bits.begin(), e.bits.end());
+            p->extra_keys += e.key;
+        }
+        const uint32_t tsb = (uint32_t)p->t_seg_index.size(), tab = (uint32_t)p->t_amb_pos.size();
+        for (size_t t = 0; t < o.t_seq.size(); t++) {
+            p->t_seq.push_back(o.t_seq[t]);
+            p->t_seg_off.push_back(tsb + o.t_seg_off[t]);
+            p->t_amb_off.push_back(tab + o.t_amb_off[t]);
+        }
+        for (size_t j = 0; j < o.t_seg_local.size(); j++) {
+            p->t_seg_index.push_back(seg_base + o.t_seg_local[j]);
+            p->t_seg_start.push_back(o.t_seg_start[j]);
+            p->t_seg_nwin.push_back(o.t_seg_nwin[j]);
+        }
+        p->t_amb_pos.insert(p->t_amb_pos.end(), o.t_amb_pos.begin(), o.t_amb_pos.end());
+        p->t_amb_used.insert(p->t_amb_used.end(), o.t_amb_used.begin(), o.t_amb_used.end());
+        p->t_amb_keys += o.t_amb_keys;
+        p->cluster_ninst.push_back(o.n_inst);
+        p->n_instances += o.n_inst;
+    }
+    p->t_seg_off.push_back((uint32_t)p->t_seg_index.size());
+    p->t_amb_off.push_back((uint32_t)p->t_amb_pos.size());
+    p->packed.push_back(0);
+    p->packed.push_back(0);                       // 16 bytes of tail padding
+    p->n_strand_words = strand_words;
+    *out = p;
+    return PF_OK;
+}
+
+void pf_packed_free(pf_packed* p) { delete p; }
+
+int pf_packed_view(const pf_packed* p, pf_packed_view_t* v) {
+    if (!p || !v) return pk_fail(PF_ERR_ARG, "pf_packed_view: null argument");
+    v->n_segs = (uint32_t)p->seg_len.size();
+    v->n_words = p->packed.size();
+    v->packed = p->packed.data();
+    v->seg_word_off = p->seg_word_off.data();
+    v->seg_len = p->seg_len.data();
+    v->seg_sample = p->seg_sample.data();
+    v->seg_ord_base = p->seg_ord_base.data();
+    v->seg_strand_off = p->seg_strand_off.data();
+    v->cluster_seg_off = p->cluster_seg_off.data();
+    v->n_extra = (uint32_t)p->extra_ord.size();
+    v->extra_cluster = p->extra_cluster.data();
+    v->extra_ord = p->extra_ord.data();
+    v->extra_bits = p->extra_bits.data();
+    v->extra_keys = p->extra_keys.data();
+    v->n_targets = (uint32_t)p->t_seq.size();
+    v->target_seq = p->t_seq.data();
+    v->target_seg_off = p->t_seg_off.data();
+    v->target_seg_index = p->t_seg_index.data();
+    v->target_seg_start = p->t_seg_start.data();
+    v->target_seg_nwin = p->t_seg_nwin.data();
+    v->target_ambig_off = p->t_amb_off.data();
+    v->target_ambig_pos = p->t_amb_pos.data();
+    v->target_ambig_used = p->t_amb_used.data();
+    v->target_ambig_keys = p->t_amb_keys.data();
+    v->cluster_ninst = p->cluster_ninst.data();
+    v->n_strand_words = p->n_strand_words;
+    v->n_instances = p->n_instances;
+    return PF_OK;
+}
+
+}  // extern "C"

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .packing import build_batch, decode_keys, maf_tables
+from .packing import build_batch_native, decode_keys, maf_tables
 
 KMERS_TSV_HEADER = ("cluster\tstrain\tfeature_id\tcontig\tfeature_strand\tcontig_start\tcontig_end\t"
                     "gene_start\tgene_end\tstrand\tk-mer\n")           # input.py:243
@@ -121,8 +121,8 @@ class Engine:
     def run(self, records):
         """cluster_cutter + pattern_hasher over `records` (in processing order)."""
         records = list(records)
-        hb = build_batch(records, self.k, self.canon, self.W, stroi=self.stroi,
-                         first_ordinal=self.next_ordinal)
+        hb = build_batch_native(records, self.k, self.canon, self.W, stroi=self.stroi,
+                                first_ordinal=self.next_ordinal)
         self.next_ordinal += len(records)
         self.submit_host_batch(hb)
         res = self.fetch()

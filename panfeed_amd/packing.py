@@ -262,3 +262,110 @@ def decode_keys(keys, k, key_words):
             code = (lo >> np.uint64(bit)) & np.uint64(3)
         out[:, i] = _ASCII[code.astype(np.intp)]
     return [row.tobytes().decode() for row in out]
+
+
+def build_batch_native(records, klength, canon, W, stroi=(), first_ordinal=0, want_strand=True):
+    """Same result as build_batch, with the per-base work (packing, non-ACGT splitting, slow-path grouping)
+    done by the library's host threads (pf_pack_records, csrc/pf_pack.cpp)."""
+    import ctypes as C
+
+    from . import _lib
+    L = _lib.load()
+    k = int(klength)
+    hb = HostBatch(k=k, canon=bool(canon), W=W)
+    seqs, comps, lens, cols, tgts, seq_ref = [], [], [], [], [], []
+    cl_off = [0]
+    cl_nstr, cl_npres, cl_presab, cl_ord = [], [], [], []
+    any_target = False
+    for ci, (gs, idx, presab) in enumerate(records):
+        names = list(gs.keys())
+        n = len(names)
+        if n > W * 32:
+            raise ValueError(f"cluster {idx}: {n} strains exceed the context's max_strains")
+        sorted_names = sorted(names)
+        col = {x: i for i, x in enumerate(sorted_names)}          # panfeed.py:47-49
+        presab = np.asarray(presab)
+        if len(presab) > W * 32:
+            raise ValueError(f"cluster {idx}: clusterpresab longer than max_strains")
+        if presab.size and not np.isin(presab, (0, 1)).all():
+            raise ValueError(f"cluster {idx}: clusterpresab must hold 0/1")
+        pb = np.zeros(W, dtype=np.uint32)
+        nz = np.flatnonzero(presab)
+        np.bitwise_or.at(pb, nz >> 5, (np.uint32(1) << (nz & 31).astype(np.uint32)))
+        hb.idx.append(str(idx))
+        hb.sorted_strains.append(sorted_names)
+        hb.presab.append(presab)
+        cl_nstr.append(n)
+        cl_npres.append(len(presab))
+        cl_presab.append(pb)
+        cl_ord.append(first_ordinal + ci)
+        for strain in names:                                      # panfeed.py:54
+            c = col[strain]
+            t = 1 if (bool(stroi) and strain in stroi) else 0     # panfeed.py:90
+            any_target = any_target or bool(t)
+            for s in gs[strain]:                                  # panfeed.py:55
+                sq, cp = s.sequence.encode("latin-1"), s.compsequence.encode("latin-1")
+                if len(sq) != len(cp):
+                    raise ValueError(f"{idx}/{strain}: sequence and compsequence differ in length")
+                seqs.append(sq); comps.append(cp); lens.append(len(sq)); cols.append(c); tgts.append(t)
+                seq_ref.append((ci, strain, s))
+        cl_off.append(len(seqs))
+    nseq = len(seqs)
+    a_seq = (C.c_char_p * max(nseq, 1))(*seqs)
+    a_comp = (C.c_char_p * max(nseq, 1))(*comps)
+    a_len = np.asarray(lens, dtype=np.uint32)
+    a_col = np.asarray(cols, dtype=np.uint32)
+    a_tgt = np.asarray(tgts, dtype=np.uint8)
+    a_off = np.asarray(cl_off, dtype=np.uint32)
+    pin = _lib.PackIn(len(cl_nstr), nseq, a_seq, a_comp, a_len.ctypes.data, a_col.ctypes.data,
+                      a_tgt.ctypes.data if any_target else None, a_off.ctypes.data, k, int(bool(canon)), W,
+                      int(bool(want_strand)))
+    handle = C.c_void_p()
+    _lib.check(L.pf_pack_records(C.byref(pin), C.byref(handle)))
+    try:
+        v = _lib.PackedView()
+        _lib.check(L.pf_packed_view(handle, C.byref(v)))
+
+        def arr(ptr, n, dtype):
+            return np.ctypeslib.as_array(ptr, shape=(n,)).view(dtype).copy() if n else np.zeros(0, dtype=dtype)
+        hb.packed = arr(v.packed, v.n_words, np.uint64)
+        hb.seg_word_off = arr(v.seg_word_off, v.n_segs, np.uint64)
+        hb.seg_len = arr(v.seg_len, v.n_segs, np.uint32)
+        hb.seg_sample = arr(v.seg_sample, v.n_segs, np.uint32)
+        hb.seg_ord_base = arr(v.seg_ord_base, v.n_segs, np.uint32)
+        hb.seg_strand_off = arr(v.seg_strand_off, v.n_segs, np.uint32)
+        hb.n_strand_words = int(v.n_strand_words)
+        hb.cluster_seg_off = arr(v.cluster_seg_off, len(cl_nstr) + 1, np.uint32)
+        hb.extra_cluster = arr(v.extra_cluster, v.n_extra, np.uint32)
+        hb.extra_ord = arr(v.extra_ord, v.n_extra, np.uint32)
+        hb.extra_bits = arr(v.extra_bits, v.n_extra * W, np.uint32).reshape(-1, W)
+        keys = C.string_at(v.extra_keys, v.n_extra * k) if v.n_extra else b""
+        hb.extra_keys = [keys[i * k:(i + 1) * k].decode("latin-1") for i in range(v.n_extra)]
+        hb.n_instances = int(v.n_instances)
+        nt = v.n_targets
+        t_seq = arr(v.target_seq, nt, np.uint32)
+        t_so = arr(v.target_seg_off, nt + 1, np.uint32)
+        t_ao = arr(v.target_ambig_off, nt + 1, np.uint32)
+        nts, nta = (int(t_so[-1]), int(t_ao[-1])) if nt else (0, 0)
+        t_si = arr(v.target_seg_index, nts, np.uint32)
+        t_ss = arr(v.target_seg_start, nts, np.uint32)
+        t_sn = arr(v.target_seg_nwin, nts, np.uint32)
+        t_ap = arr(v.target_ambig_pos, nta, np.uint32)
+        t_au = arr(v.target_ambig_used, nta, np.int8)
+        akeys = C.string_at(v.target_ambig_keys, nta * k) if nta else b""
+        ord_running = {}
+        for ti in range(nt):
+            q = int(t_seq[ti])
+            ci, strain, s = seq_ref[q]
+            segs = [(int(t_si[j]), int(t_ss[j]), int(t_sn[j])) for j in range(t_so[ti], t_so[ti + 1])]
+            ambig = {int(t_ap[j]): (akeys[j * k:(j + 1) * k].decode("latin-1"), int(t_au[j]))
+                     for j in range(t_ao[ti], t_ao[ti + 1])}
+            hb.targets.append(SeqMeta(ci, strain, s, 0, max(len(s.sequence) - k + 1, 0), segs, ambig))
+        del ord_running
+    finally:
+        L.pf_packed_free(handle)
+    hb.cluster_nstrains = np.asarray(cl_nstr, dtype=np.uint32)
+    hb.cluster_npresab = np.asarray(cl_npres, dtype=np.uint32)
+    hb.cluster_presab = (np.stack(cl_presab) if cl_presab else np.zeros((0, W), dtype=np.uint32)).astype(np.uint32)
+    hb.cluster_ordinal = np.asarray(cl_ord, dtype=np.uint64)
+    return hb

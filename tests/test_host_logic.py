@@ -108,3 +108,46 @@ def test_build_batch_invariants():
         assert hb.n_instances == total
         assert len(hb.extra_keys) == len(hb.extra_ord) == len(hb.extra_cluster)
         assert (np.diff(hb.extra_cluster.astype(np.int64)) >= 0).all()
+
+
+def _same_batch(a, b):
+    for f in ("packed", "seg_word_off", "seg_len", "seg_sample", "seg_ord_base", "seg_strand_off", "cluster_seg_off",
+              "cluster_nstrains", "cluster_npresab", "cluster_presab", "cluster_ordinal", "extra_cluster",
+              "extra_ord", "extra_bits"):
+        x, y = getattr(a, f), getattr(b, f)
+        assert x.dtype == y.dtype and x.shape == y.shape and np.array_equal(x, y), f
+    assert a.extra_keys == b.extra_keys and a.n_strand_words == b.n_strand_words
+    assert a.n_instances == b.n_instances and a.idx == b.idx and a.sorted_strains == b.sorted_strains
+    assert len(a.targets) == len(b.targets)
+    for s, t in zip(a.targets, b.targets):
+        assert (s.cluster, s.strain, s.seq, s.num_kmer, s.segs, s.ambig) == (t.cluster, t.strain, t.seq, t.num_kmer, t.segs, t.ambig)
+
+
+def test_native_packer_equals_numpy_packer():
+    """csrc/pf_pack.cpp (host threads) vs packing.build_batch on every golden case and on seeded clusters"""
+    from panfeed_amd import synth
+    for case in all_cases():
+        o = case["opts"]
+        if o["klength"] > 63:
+            continue
+        recs = case_records(case)
+        W = max(1, (len(case["all_strains"]) + 31) // 32)
+        kw = dict(stroi=set(o["stroi"] or ()), first_ordinal=17)
+        _same_batch(packing.build_batch(recs, o["klength"], o["canon"], W, **kw),
+                    packing.build_batch_native(recs, o["klength"], o["canon"], W, **kw))
+    for canon in (True, False):
+        cl = synth.generate(12, 90, first=31, flank=20, mean_len=250, min_len=40, max_len=700, n_rate=0.05,
+                            paralog_rate=0.05, shuffle_columns=3)
+        recs = [c.record() for c in cl]
+        st = {cl[0].names[0], cl[0].names[50]}
+        _same_batch(packing.build_batch(recs, 31, canon, 3, stroi=st), packing.build_batch_native(recs, 31, canon, 3, stroi=st))
+
+
+def test_native_packer_rejects_bad_complement():
+    from panfeed_amd._lib import PanfeedHipError
+    from panfeed_amd.classes import Seqinfo
+    rec = ({"a": [Seqinfo("ACGTACGT", "TGCATGCT", "g", "c", 1, 8, 1, 0)]}, "x", np.array([1]))
+    with pytest.raises(PanfeedHipError):
+        packing.build_batch_native([rec], 5, True, 1)
+    with pytest.raises(ValueError):
+        packing.build_batch([rec], 5, True, 1)
