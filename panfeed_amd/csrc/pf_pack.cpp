@@ -43,9 +43,12 @@ struct ClusterOut {
     std::string error;
 };
 
-inline int code_of(unsigned char ch) {
-    switch (ch) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return -1; }
-}
+struct CodeLut {
+    int8_t t[256];
+    CodeLut() { for (int i = 0; i < 256; i++) t[i] = -1; t['A'] = 0; t['C'] = 1; t['G'] = 2; t['T'] = 3; }
+};
+const CodeLut g_lut;
+inline int code_of(unsigned char ch) { return g_lut.t[ch]; }   // table lookup: no data-dependent branches
 
 void pack_cluster(const pf_pack_in* in, uint32_t ci, ClusterOut& o) {
     const uint32_t k = in->klength, W = in->W;
@@ -145,8 +148,12 @@ void pack_cluster(const pf_pack_in* in, uint32_t ci, ClusterOut& o) {
         const uint32_t w0 = (uint32_t)o.words.size();
         o.words.resize(w0 + nw, 0);
         const char* seq = in->seq[g.seq] + g.a;
-        for (uint32_t i = 0; i < g.len; i++)
-            o.words[w0 + (i >> 5)] |= (uint64_t)code_of((unsigned char)seq[i]) << (62 - 2 * (i & 31));
+        for (uint32_t i0 = 0; i0 < g.len; i0 += 32) {
+            uint64_t w = 0;
+            const uint32_t m = std::min<uint32_t>(32, g.len - i0);
+            for (uint32_t i = 0; i < m; i++) w = (w << 2) | (uint64_t)code_of((unsigned char)seq[i0 + i]);
+            o.words[w0 + (i0 >> 5)] = w << (2 * (32 - m));
+        }
         o.seg_woff.push_back(w0);
         o.seg_len.push_back(g.len);
         o.seg_sample.push_back(g.col);

@@ -128,6 +128,36 @@ class Engine:
         res = self.fetch()
         return self._render(hb, res)
 
+    def run_stream(self, records, batch_clusters=256, prefetch=2):
+        """Generator over BatchOutput: packs batch i+1 (host threads, pf_pack_records) while the GPU works on
+        batch i and the caller writes batch i-1 -- the reference's reader / workers / writer pipeline
+        (__main__.py:39-81,299-344) with the GPU in the workers' place and a deterministic order
+        (always the --cores 1 order, whatever finishes first)."""
+        import itertools
+        from concurrent.futures import ThreadPoolExecutor
+        it = iter(records)
+        state = {"ordinal": self.next_ordinal}
+
+        def pack_next():
+            chunk = list(itertools.islice(it, batch_clusters))
+            if not chunk:
+                return None
+            first = state["ordinal"]
+            state["ordinal"] += len(chunk)
+            return build_batch_native(chunk, self.k, self.canon, self.W, stroi=self.stroi, first_ordinal=first)
+
+        with ThreadPoolExecutor(max_workers=1) as pool:      # one packer thread keeps the record order
+            pending = [pool.submit(pack_next) for _ in range(max(1, prefetch))]
+            while pending:
+                hb = pending.pop(0).result()
+                if hb is None:
+                    break
+                pending.append(pool.submit(pack_next))
+                self.next_ordinal = int(hb.cluster_ordinal[-1]) + 1 if hb.n_clusters else self.next_ordinal
+                self.submit_host_batch(hb)
+                res = self.fetch()
+                yield self._render(hb, res)
+
     def _hash_strings(self, res):
         p0, p1 = self.n_patterns, int(res.n_patterns)
         if p1 > p0:

@@ -258,3 +258,21 @@ def test_pattern_export_device_path_and_merge():
         hashes.append(buf.raw[:24].decode())
     assert hashes == [ln.split("\t")[0] for ln in out.hashes_to_patterns.splitlines()]
     eng.close()
+
+
+def test_run_stream_equals_one_batch():
+    """the pipelined driver (pack ahead on a host thread, GPU, render) == one big batch, any batch size"""
+    from panfeed_amd import synth
+    from panfeed_amd.engine import Engine
+    cl = synth.generate(23, 40, first=900, flank=10, mean_len=150, min_len=40, max_len=400, n_rate=0.03, paralog_rate=0.05)
+    recs = [c.record() for c in cl]
+    st = {cl[0].names[7]}
+    ref = Engine(klength=25, max_strains=64, stroi=st).run(recs)
+    for bc in (1, 5, 64):
+        eng = Engine(klength=25, max_strains=64, stroi=st)
+        outs = list(eng.run_stream(iter(recs), batch_clusters=bc))
+        assert "".join(o.kmers_to_hashes for o in outs) == ref.kmers_to_hashes
+        assert "".join(o.hashes_to_patterns for o in outs) == ref.hashes_to_patterns
+        assert "".join(o.kmers_tsv for o in outs) == ref.kmers_tsv
+        assert outs[-1].stats["patterns"] == ref.stats["patterns"]
+        eng.close()
