@@ -276,3 +276,72 @@ def test_run_stream_equals_one_batch():
         assert "".join(o.kmers_tsv for o in outs) == ref.kmers_tsv
         assert outs[-1].stats["patterns"] == ref.stats["patterns"]
         eng.close()
+
+
+def test_config1_scale_properties():
+    """BASELINE configs[1] shape (200 samples, no flanks) at a size the oracle cannot cover in seconds:
+    the whole pipeline with and without the identical-sequence shortcut must agree k-mer for k-mer and digest
+    for digest; totals must add up; first_seen must be a strict order; the head of the run equals the oracle."""
+    import ctypes as C
+    from panfeed_amd import devbatch, synth
+    from panfeed_amd.engine import Engine
+    S, k, n = 200, 31, 1500
+    cl = synth.generate(n, S, first=0, flank=0, n_rate=0.0)
+    res = {}
+    for dedup in (True, False):
+        eng = Engine(klength=k, max_strains=224, dedup=dedup, max_items=512)
+        db = devbatch.from_synth(eng, cl, k)
+        r = db.submit()
+        f = eng.fetch()
+        C_ = n
+        off = np.ctypeslib.as_array(f.cluster_kmer_off, shape=(C_,)).copy()
+        cnt = np.ctypeslib.as_array(f.cluster_kmer_cnt, shape=(C_,)).copy()
+        uniq = np.ctypeslib.as_array(f.cluster_unique, shape=(C_,)).copy()
+        cpat = np.ctypeslib.as_array(f.cluster_pattern, shape=(C_,)).copy()
+        tot = int(cnt.sum())
+        keys = np.ctypeslib.as_array(f.kmer_key, shape=(tot,)).copy()
+        pids = np.ctypeslib.as_array(f.kmer_pattern, shape=(tot,)).copy()
+        P = int(f.n_patterns)
+        md5 = np.ctypeslib.as_array(f.pattern_md5, shape=(P * 16,)).reshape(P, 16).copy()
+        fs = np.ctypeslib.as_array(f.pattern_first_seen, shape=(P,)).copy()
+        assert int(r.n_kept) == tot and int(r.n_unique) == int(uniq.sum()) and int(r.n_instances) == db.n_instances
+        assert len(np.unique(fs)) == P                       # first_seen is a strict order over patterns
+        assert len(np.unique(md5.view([("a", "u8"), ("b", "u8")]))) == P      # one pool entry per digest
+        # per cluster: keys in order + digest per k-mer, independent of arena placement
+        order = np.concatenate([np.arange(o, o + c) for o, c in zip(off, cnt)]) if tot else np.zeros(0, np.int64)
+        res[dedup] = (cnt, uniq, keys[order], md5[pids[order]], md5[cpat], np.sort(fs))
+        if dedup:
+            assert eng.timing()["n_dedup_clusters"] > n * 0.9
+            hb_head = [c.record() for c in cl[:25]]
+        db.free()
+        eng.close()
+    for a, b in zip(res[True], res[False]):
+        assert np.array_equal(a, b)
+    # the first 25 clusters against the oracle, text for text
+    eng = Engine(klength=k, max_strains=224)
+    out = eng.run(hb_head)
+    (ek, ekh, ehp), st = _oracle_texts(hb_head, klength=k)
+    assert out.kmers_to_hashes == ekh and out.hashes_to_patterns == ehp
+    eng.close()
+
+
+def test_error_paths():
+    """capacity errors are reported, not silently truncated"""
+    from panfeed_amd import synth
+    from panfeed_amd._lib import PanfeedHipError
+    from panfeed_amd.engine import Engine
+    cl = synth.generate(30, 40, first=5, mean_len=200, min_len=60, max_len=500, n_rate=0.0)
+    recs = [c.record() for c in cl]
+    eng = Engine(klength=21, max_strains=64, pattern_capacity=1024)      # pool of 512 patterns
+    with pytest.raises(PanfeedHipError) as e:
+        eng.run(recs)
+    assert e.value.status == -4 and "pattern" in str(e.value)
+    eng.close()
+    with pytest.raises(PanfeedHipError):
+        Engine(klength=0, max_strains=64)
+    with pytest.raises(PanfeedHipError):
+        Engine(klength=31, max_strains=9000)
+    eng = Engine(klength=21, max_strains=32)
+    with pytest.raises(ValueError):
+        eng.run(recs)                                                    # 40 strains > max_strains 32
+    eng.close()
