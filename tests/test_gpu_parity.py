@@ -308,7 +308,7 @@ def test_config1_scale_properties():
         assert len(np.unique(fs)) == P                       # first_seen is a strict order over patterns
         assert len(np.unique(md5.view([("a", "u8"), ("b", "u8")]))) == P      # one pool entry per digest
         # per cluster: keys in order + digest per k-mer, independent of arena placement
-        order = np.concatenate([np.arange(o, o + c) for o, c in zip(off, cnt)]) if tot else np.zeros(0, np.int64)
+        order = np.concatenate([np.arange(int(o), int(o) + int(c), dtype=np.int64) for o, c in zip(off, cnt)]) if tot else np.zeros(0, np.int64)
         res[dedup] = (cnt, uniq, keys[order], md5[pids[order]], md5[cpat], np.sort(fs))
         if dedup:
             assert eng.timing()["n_dedup_clusters"] > n * 0.9
@@ -330,7 +330,7 @@ def test_error_paths():
     from panfeed_amd import synth
     from panfeed_amd._lib import PanfeedHipError
     from panfeed_amd.engine import Engine
-    cl = synth.generate(30, 40, first=5, mean_len=200, min_len=60, max_len=500, n_rate=0.0)
+    cl = synth.generate(150, 40, first=5, mean_len=200, min_len=60, max_len=500, n_rate=0.0)
     recs = [c.record() for c in cl]
     eng = Engine(klength=21, max_strains=64, pattern_capacity=1024)      # pool of 512 patterns
     with pytest.raises(PanfeedHipError) as e:
