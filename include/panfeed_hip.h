@@ -179,6 +179,12 @@ int pf_export_patterns(pf_ctx* ctx, uint64_t* n, const uint8_t** md5, const uint
 /* Same, device to device: copies min(count, cap) entries into caller-owned DEVICE buffers
  * (d_md5: 16 B each, d_first_seen: 8 B each) so the all-gather can start from HBM. */
 int pf_export_patterns_dev(pf_ctx* ctx, uint64_t cap, void* d_md5, void* d_first_seen, uint64_t* n);
+/* After the all-gather: d_gathered (DEVICE) holds n_total rows {md5[0:8], md5[8:16], first_seen} (3 x uint64) of all
+ * ranks; this rank's rows are [my_first, my_first+my_count).  Writes d_keep[j] = 1 (DEVICE, uint8) when this rank's
+ * row j holds the lowest first_seen of its digest, and *n_global = number of distinct digests.  O(n_total) atomics
+ * in a scratch hash table, no sort. */
+int pf_merge_patterns(pf_ctx* ctx, const void* d_gathered, uint64_t n_total, uint64_t my_first, uint64_t my_count,
+                      void* d_keep, uint64_t* n_global);
 /* Number of patterns in the run-global set after the last pf_submit. */
 int pf_pattern_count(pf_ctx* ctx, uint64_t* n);
 

@@ -109,6 +109,7 @@ struct pf_ctx {
     DevBuf it_cluster, it_part, it_nparts, it_nslots, it_slice, it_sib0, it_nsib, it_extra_first, it_count,
         it_unique, it_kept, work_scan, work_extra, work_fin, work_fin2, work_fin3, work_rows, sub_cluster, sub_item0, sub_nitems;
     std::vector<Arena*> arenas;
+    DevBuf mg_lo, mg_hi, mg_min, mg_cnt;   // pf_merge_patterns scratch table
     DevBuf stage_dev;              // one device block for the small per-pass arrays
     void* stage_pin = nullptr;     // pinned host mirror of it
     size_t stage_pin_cap = 0;
@@ -289,6 +290,7 @@ void pf_destroy(pf_ctx* c) {
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->stage_pin) (void)hipHostFree(c->stage_pin);
     c->stage_dev.release();
+    c->mg_lo.release(); c->mg_hi.release(); c->mg_min.release(); c->mg_cnt.release();
     if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
     if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1336,6 +1338,41 @@ int pf_render_kmers_tsv(pf_ctx* c, const pf_target_seq* seqs, uint32_t n, const 
 }
 
 void pf_free_text(char* p) { free(p); }
+
+int pf_merge_patterns(pf_ctx* c, const void* d_gathered, uint64_t n_total, uint64_t my_first, uint64_t my_count,
+                      void* d_keep, uint64_t* n_global) {
+    if (!c || !n_global) return fail(PF_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    *n_global = 0;
+    if (!n_total) return PF_OK;
+    if (!d_gathered || (my_count && !d_keep) || my_first + my_count > n_total) return fail(PF_ERR_ARG, "pf_merge_patterns: bad range");
+    uint64_t cap = 1024;
+    while (cap < 2 * n_total) cap <<= 1;
+    PFCHK(c->mg_lo.ensure(cap * 8));
+    PFCHK(c->mg_hi.ensure(cap * 8));
+    PFCHK(c->mg_min.ensure(cap * 8));
+    PFCHK(c->mg_cnt.ensure(8));
+    PFCHK(fill_u64(c, c->mg_lo.p, pf::EMPTY64, cap));
+    PFCHK(fill_u64(c, c->mg_hi.p, pf::EMPTY64, cap));
+    PFCHK(fill_u64(c, c->mg_min.p, pf::EMPTY64, cap));
+    HIPCHK(hipMemsetAsync(c->mg_cnt.p, 0, 8, c->stream));
+    pf::MergeParams mp{};
+    mp.gathered = (const uint64_t*)d_gathered; mp.n = n_total;
+    mp.t_lo = c->mg_lo.as<uint64_t>(); mp.t_hi = c->mg_hi.as<uint64_t>(); mp.t_min = c->mg_min.as<uint64_t>();
+    mp.cap = cap; mp.my_first = my_first; mp.my_count = my_count; mp.keep = (uint8_t*)d_keep;
+    mp.n_global = c->mg_cnt.as<unsigned long long>();
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_total + 255) / 256, 8192);
+    hipLaunchKernelGGL(pf::merge_insert_kernel, dim3(blocks), dim3(256), 0, c->stream, mp);
+    HIPCHK(hipGetLastError());
+    if (my_count) {
+        const uint32_t b2 = (uint32_t)std::min<uint64_t>((my_count + 255) / 256, 8192);
+        hipLaunchKernelGGL(pf::merge_lookup_kernel, dim3(b2), dim3(256), 0, c->stream, mp);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipMemcpyAsync(n_global, c->mg_cnt.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PF_OK;
+}
 
 int pf_pattern_count(pf_ctx* c, uint64_t* n) {
     if (!c || !n) return fail(PF_ERR_ARG, "null argument");

@@ -2048,6 +2048,63 @@ __global__ __launch_bounds__(MD5_THREADS) void md5_kernel(Md5Params p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// merge_digests_kernel: multi-GPU pattern dedup after the all-gather
+// ---------------------------------------------------------------------------------------------
+// gathered[i] = {md5 lo, md5 hi, first_seen} from every rank.  Pass 1 inserts every row into an open-addressing
+// table keyed by the full 128-bit digest and keeps the minimum first_seen per digest; pass 2 looks this rank's
+// own rows up again: a row is kept iff it holds that minimum (first_seen values are unique across the run).
+struct MergeParams {
+    const uint64_t* gathered;   // [n][3]
+    uint64_t n;
+    uint64_t* t_lo; uint64_t* t_hi; uint64_t* t_min;   // [cap], t_lo/t_hi EMPTY64-filled, t_min EMPTY64-filled
+    uint64_t cap;               // power of two
+    uint64_t my_first, my_count;
+    uint8_t* keep;              // [my_count]
+    unsigned long long* n_global;
+};
+__device__ __forceinline__ uint64_t merge_slot(const MergeParams& p, uint64_t lo, uint64_t hi, bool insert) {
+    // md5 words are already uniform; keep EMPTY64 out of the key space
+    if (lo == EMPTY64) lo = EMPTY64 - 1;
+    if (hi == EMPTY64) hi = EMPTY64 - 1;
+    uint64_t slot = (lo ^ (hi >> 17)) & (p.cap - 1);
+    for (uint64_t probes = 0; probes < p.cap; ) {
+        uint64_t cur = __hip_atomic_load(&p.t_lo[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == EMPTY64) {
+            if (!insert) return EMPTY64;
+            cur = atomicCAS((unsigned long long*)&p.t_lo[slot], (unsigned long long)EMPTY64, (unsigned long long)lo);
+            if (cur == EMPTY64) {
+                __hip_atomic_store(&p.t_hi[slot], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicAdd(p.n_global, 1ull);
+                return slot;
+            }
+        }
+        if (cur == lo) {
+            const uint64_t h = __hip_atomic_load(&p.t_hi[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (h == EMPTY64) continue;                 // claimed, not yet published: look again
+            if (h == hi) return slot;
+        }
+        slot = (slot + 1) & (p.cap - 1);
+        probes++;
+    }
+    return EMPTY64;
+}
+__global__ __launch_bounds__(256) void merge_insert_kernel(MergeParams p) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < p.n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t lo = p.gathered[3 * i], hi = p.gathered[3 * i + 1], fs = p.gathered[3 * i + 2];
+        const uint64_t slot = merge_slot(p, lo, hi, true);
+        if (slot != EMPTY64) atomicMin((unsigned long long*)&p.t_min[slot], (unsigned long long)fs);
+    }
+}
+__global__ __launch_bounds__(256) void merge_lookup_kernel(MergeParams p) {
+    for (uint64_t j = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; j < p.my_count; j += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = p.my_first + j;
+        const uint64_t lo = p.gathered[3 * i], hi = p.gathered[3 * i + 1], fs = p.gathered[3 * i + 2];
+        const uint64_t slot = merge_slot(p, lo, hi, false);
+        p.keep[j] = (slot != EMPTY64 && p.t_min[slot] == fs) ? 1 : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // misc kernels
 // ---------------------------------------------------------------------------------------------
 // per-cluster instance counts: the trip count of panfeed.py:64 over the caller's segments, and the

@@ -34,12 +34,15 @@ def shard_range(n_clusters, rank, world, weights=None):
     return cuts[rank], cuts[rank + 1]
 
 
-def merge_pattern_tensors(md5, first_seen, dist=None):
+def merge_pattern_tensors(md5, first_seen, dist=None, engine=None):
     """md5: uint8 [n,16], first_seen: int64 [n] (this rank's patterns, any device).
     Returns (keep_mask [n] bool: this rank's row is the global first for its digest,
-             n_global: number of distinct digests over all ranks)."""
+             n_global: number of distinct digests over all ranks).
+    With CUDA tensors and an `engine`, the dedup after the all-gather runs in the library's hash-table kernels
+    (pf_merge_patterns, O(rows) atomics); otherwise (CPU / gloo tests) by a lexicographic sort in torch."""
     dev = md5.device
     n = md5.shape[0]
+    use_kernel = engine is not None and md5.is_cuda
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
         world, rank = dist.get_world_size(), dist.get_rank()
         counts = torch.zeros(world, dtype=torch.int64, device=dev)
@@ -54,14 +57,18 @@ def merge_pattern_tensors(md5, first_seen, dist=None):
         allpay = torch.empty((world * nmax, 3), dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(allpay, pay)
         valid = (torch.arange(nmax, device=dev)[None, :] < counts[:, None]).reshape(-1)
-        owner = torch.arange(world, device=dev).repeat_interleave(nmax)[valid]
         allpay = allpay[valid]
+        if use_kernel:
+            return _merge_on_device(engine, allpay, sum(cl[:rank]), n)
+        owner = torch.arange(world, device=dev).repeat_interleave(nmax)[valid]
     else:
         rank = 0
         allpay = torch.empty((n, 3), dtype=torch.int64, device=dev)
         if n:
             allpay[:, :2] = md5.contiguous().view(torch.int64).view(n, 2)
             allpay[:, 2] = first_seen
+        if use_kernel:
+            return _merge_on_device(engine, allpay, 0, n)
         owner = torch.zeros(n, dtype=torch.int64, device=dev)
     m = allpay.shape[0]
     if m == 0:
@@ -85,6 +92,18 @@ def merge_pattern_tensors(md5, first_seen, dist=None):
         my_pos = torch.cumsum((owner == rank).to(torch.int64), 0) - 1
         keep[my_pos[order][mine_sorted]] = is_first[mine_sorted]
     return keep, n_global
+
+
+def _merge_on_device(engine, allpay, my_first, my_count):
+    """allpay: int64 [rows,3] on the GPU = {md5 lo, md5 hi, first_seen} of every rank, this rank's rows at
+    [my_first, my_first+my_count)."""
+    allpay = allpay.contiguous()
+    keep = torch.zeros(max(my_count, 1), dtype=torch.uint8, device=allpay.device)
+    torch.cuda.synchronize(allpay.device)        # the library runs on its own stream
+    n_global = C.c_uint64()
+    _lib.check(engine.L.pf_merge_patterns(engine.ctx, C.c_void_p(allpay.data_ptr()), allpay.shape[0], int(my_first),
+                                          int(my_count), C.c_void_p(keep.data_ptr()), C.byref(n_global)))
+    return keep[:my_count].bool(), int(n_global.value)
 
 
 def export_patterns(engine, device):
@@ -119,5 +138,5 @@ def engine_n_patterns(engine):
 def merge_patterns(engine, dist, device):
     """All-gather the engine's pattern digests and return the number of run-global unique patterns."""
     md5, fs = export_patterns(engine, device)
-    _keep, n_global = merge_pattern_tensors(md5, fs, dist)
+    _keep, n_global = merge_pattern_tensors(md5, fs, dist, engine=engine)
     return n_global

@@ -345,3 +345,36 @@ def test_error_paths():
     with pytest.raises(ValueError):
         eng.run(recs)                                                    # 40 strains > max_strains 32
     eng.close()
+
+
+def test_merge_kernel_matches_sort_merge():
+    """pf_merge_patterns (device hash table) == the torch sort-based merge on a simulated 3-rank gather"""
+    import torch
+    from panfeed_amd import synth
+    from panfeed_amd.distributed import _merge_on_device, export_patterns, merge_pattern_tensors
+    from panfeed_amd.engine import Engine
+    cl = synth.generate(40, 48, first=3, mean_len=200, min_len=60, max_len=500, n_rate=0.0)
+    eng = Engine(klength=21, max_strains=64)
+    eng.run([c.record() for c in cl])
+    dev = torch.device("cuda", 0)
+    md5, fs = export_patterns(eng, dev)
+    P = md5.shape[0]
+    rows = torch.empty((P, 3), dtype=torch.int64, device=dev)
+    rows[:, :2] = md5.contiguous().view(torch.int64).view(P, 2)
+    rows[:, 2] = fs
+    g = torch.Generator(device="cpu").manual_seed(1)
+    dup = torch.randperm(P, generator=g)[: P // 2].to(dev)
+    rank1 = rows[dup].clone()
+    rank1[:, 2] += (1 << 40)                                   # a later rank saw half of them again
+    early = rows[dup[: P // 8]].clone()
+    early[:, 2] -= 1                                           # ... and a few of them earlier than rank 0
+    rank2 = torch.cat([early, torch.randint(-2**62, 2**62, (P // 3, 3), generator=g).to(dev)])
+    allpay = torch.cat([rows, rank1, rank2])
+    # single-process torch merge over the concatenation: which rows are the global firsts
+    allmd5 = allpay[:, :2].contiguous().view(torch.uint8).view(-1, 16)
+    keep_all, n_ref = merge_pattern_tensors(allmd5.cpu(), allpay[:, 2].cpu())
+    for first, cnt in ((0, P), (P, rank1.shape[0]), (P + rank1.shape[0], rank2.shape[0])):
+        keep, n_glob = _merge_on_device(eng, allpay, first, cnt)
+        assert n_glob == n_ref
+        assert torch.equal(keep.cpu(), keep_all[first:first + cnt])
+    eng.close()
