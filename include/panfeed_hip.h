@@ -185,6 +185,11 @@ int pf_export_patterns_dev(pf_ctx* ctx, uint64_t cap, void* d_md5, void* d_first
  * in a scratch hash table, no sort. */
 int pf_merge_patterns(pf_ctx* ctx, const void* d_gathered, uint64_t n_total, uint64_t my_first, uint64_t my_count,
                       void* d_keep, uint64_t* n_global);
+/* Same on the padded buffer all_gather_into_tensor leaves: `world` slots of slot_rows rows, of which the first
+ * d_slot_counts[r] (DEVICE int64) are real; this rank's rows are the first my_count of slot `rank`. */
+int pf_merge_patterns_padded(pf_ctx* ctx, const void* d_gathered, uint64_t world, uint64_t slot_rows,
+                             const void* d_slot_counts, uint64_t rank, uint64_t my_count, void* d_keep,
+                             uint64_t* n_global);
 /* Number of patterns in the run-global set after the last pf_submit. */
 int pf_pattern_count(pf_ctx* ctx, uint64_t* n);
 

@@ -1339,9 +1339,9 @@ int pf_render_kmers_tsv(pf_ctx* c, const pf_target_seq* seqs, uint32_t n, const 
 
 void pf_free_text(char* p) { free(p); }
 
-int pf_merge_patterns(pf_ctx* c, const void* d_gathered, uint64_t n_total, uint64_t my_first, uint64_t my_count,
-                      void* d_keep, uint64_t* n_global) {
-    if (!c || !n_global) return fail(PF_ERR_ARG, "null argument");
+namespace {
+int merge_impl(pf_ctx* c, const void* d_gathered, uint64_t n_total, uint64_t my_first, uint64_t my_count,
+               const void* d_slot_counts, uint64_t slot_rows, void* d_keep, uint64_t* n_global) {
     HIPCHK(hipSetDevice(c->device));
     *n_global = 0;
     if (!n_total) return PF_OK;
@@ -1360,6 +1360,7 @@ int pf_merge_patterns(pf_ctx* c, const void* d_gathered, uint64_t n_total, uint6
     mp.gathered = (const uint64_t*)d_gathered; mp.n = n_total;
     mp.t_lo = c->mg_lo.as<uint64_t>(); mp.t_hi = c->mg_hi.as<uint64_t>(); mp.t_min = c->mg_min.as<uint64_t>();
     mp.cap = cap; mp.my_first = my_first; mp.my_count = my_count; mp.keep = (uint8_t*)d_keep;
+    mp.slot_counts = (const int64_t*)d_slot_counts; mp.slot_rows = d_slot_counts ? slot_rows : 0;
     mp.n_global = c->mg_cnt.as<unsigned long long>();
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_total + 255) / 256, 8192);
     hipLaunchKernelGGL(pf::merge_insert_kernel, dim3(blocks), dim3(256), 0, c->stream, mp);
@@ -1372,6 +1373,20 @@ int pf_merge_patterns(pf_ctx* c, const void* d_gathered, uint64_t n_total, uint6
     HIPCHK(hipMemcpyAsync(n_global, c->mg_cnt.p, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return PF_OK;
+}
+}  // namespace
+
+int pf_merge_patterns(pf_ctx* c, const void* d_gathered, uint64_t n_total, uint64_t my_first, uint64_t my_count,
+                      void* d_keep, uint64_t* n_global) {
+    if (!c || !n_global) return fail(PF_ERR_ARG, "null argument");
+    return merge_impl(c, d_gathered, n_total, my_first, my_count, nullptr, 0, d_keep, n_global);
+}
+
+int pf_merge_patterns_padded(pf_ctx* c, const void* d_gathered, uint64_t world, uint64_t slot_rows,
+                             const void* d_slot_counts, uint64_t rank, uint64_t my_count, void* d_keep,
+                             uint64_t* n_global) {
+    if (!c || !n_global || !d_slot_counts || rank >= world || my_count > slot_rows) return fail(PF_ERR_ARG, "pf_merge_patterns_padded: bad argument");
+    return merge_impl(c, d_gathered, world * slot_rows, rank * slot_rows, my_count, d_slot_counts, slot_rows, d_keep, n_global);
 }
 
 int pf_pattern_count(pf_ctx* c, uint64_t* n) {

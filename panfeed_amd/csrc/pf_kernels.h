@@ -2059,10 +2059,12 @@ struct MergeParams {
     uint64_t* t_lo; uint64_t* t_hi; uint64_t* t_min;   // [cap], t_lo/t_hi EMPTY64-filled, t_min EMPTY64-filled
     uint64_t cap;               // power of two
     uint64_t my_first, my_count;
+    const int64_t* slot_counts; // padded layout: rows come in equal slots of `slot_rows` per rank, only the first
+    uint64_t slot_rows;         // slot_counts[rank] rows of a slot are real (0 / null: every row is real)
     uint8_t* keep;              // [my_count]
     unsigned long long* n_global;
 };
-__device__ __forceinline__ uint64_t merge_slot(const MergeParams& p, uint64_t lo, uint64_t hi, bool insert) {
+__device__ __forceinline__ uint64_t merge_slot(const MergeParams& p, uint64_t lo, uint64_t hi, bool insert, uint32_t* claimed) {
     // md5 words are already uniform; keep EMPTY64 out of the key space
     if (lo == EMPTY64) lo = EMPTY64 - 1;
     if (hi == EMPTY64) hi = EMPTY64 - 1;
@@ -2074,7 +2076,7 @@ __device__ __forceinline__ uint64_t merge_slot(const MergeParams& p, uint64_t lo
             cur = atomicCAS((unsigned long long*)&p.t_lo[slot], (unsigned long long)EMPTY64, (unsigned long long)lo);
             if (cur == EMPTY64) {
                 __hip_atomic_store(&p.t_hi[slot], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                atomicAdd(p.n_global, 1ull);
+                ++*claimed;
                 return slot;
             }
         }
@@ -2089,17 +2091,22 @@ __device__ __forceinline__ uint64_t merge_slot(const MergeParams& p, uint64_t lo
     return EMPTY64;
 }
 __global__ __launch_bounds__(256) void merge_insert_kernel(MergeParams p) {
+    uint32_t claimed = 0;      // distinct digests this thread was first to insert
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < p.n; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (p.slot_rows && (int64_t)(i % p.slot_rows) >= p.slot_counts[i / p.slot_rows]) continue;   // padding
         const uint64_t lo = p.gathered[3 * i], hi = p.gathered[3 * i + 1], fs = p.gathered[3 * i + 2];
-        const uint64_t slot = merge_slot(p, lo, hi, true);
+        const uint64_t slot = merge_slot(p, lo, hi, true, &claimed);
         if (slot != EMPTY64) atomicMin((unsigned long long*)&p.t_min[slot], (unsigned long long)fs);
     }
+    for (int d = 32; d > 0; d >>= 1) claimed += __shfl_down(claimed, d);
+    if ((threadIdx.x & 63) == 0 && claimed) atomicAdd(p.n_global, (unsigned long long)claimed);   // one per wave
 }
 __global__ __launch_bounds__(256) void merge_lookup_kernel(MergeParams p) {
     for (uint64_t j = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; j < p.my_count; j += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t i = p.my_first + j;
         const uint64_t lo = p.gathered[3 * i], hi = p.gathered[3 * i + 1], fs = p.gathered[3 * i + 2];
-        const uint64_t slot = merge_slot(p, lo, hi, false);
+        uint32_t unused = 0;
+        const uint64_t slot = merge_slot(p, lo, hi, false, &unused);
         p.keep[j] = (slot != EMPTY64 && p.t_min[slot] == fs) ? 1 : 0;
     }
 }

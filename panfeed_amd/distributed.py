@@ -56,10 +56,17 @@ def merge_pattern_tensors(md5, first_seen, dist=None, engine=None):
             pay[:n, 2] = first_seen
         allpay = torch.empty((world * nmax, 3), dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(allpay, pay)
+        if use_kernel:
+            # straight from the padded gather buffer: no compaction, no sort
+            keep = torch.zeros(max(n, 1), dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize(dev)
+            n_global = C.c_uint64()
+            _lib.check(engine.L.pf_merge_patterns_padded(engine.ctx, C.c_void_p(allpay.data_ptr()), world, nmax,
+                                                         C.c_void_p(counts.data_ptr()), rank, n,
+                                                         C.c_void_p(keep.data_ptr()), C.byref(n_global)))
+            return keep[:n].bool(), int(n_global.value)
         valid = (torch.arange(nmax, device=dev)[None, :] < counts[:, None]).reshape(-1)
         allpay = allpay[valid]
-        if use_kernel:
-            return _merge_on_device(engine, allpay, sum(cl[:rank]), n)
         owner = torch.arange(world, device=dev).repeat_interleave(nmax)[valid]
     else:
         rank = 0

@@ -377,4 +377,24 @@ def test_merge_kernel_matches_sort_merge():
         keep, n_glob = _merge_on_device(eng, allpay, first, cnt)
         assert n_glob == n_ref
         assert torch.equal(keep.cpu(), keep_all[first:first + cnt])
+    # the padded layout all_gather_into_tensor leaves (equal slots per rank, garbage behind the real rows)
+    import ctypes as C
+    from panfeed_amd import _lib
+    parts = [rows, rank1, rank2]
+    counts = torch.tensor([x.shape[0] for x in parts], dtype=torch.int64, device=dev)
+    nmax = int(counts.max())
+    padded = torch.randint(-2**62, 2**62, (3 * nmax, 3), generator=g).to(dev)
+    for r, x in enumerate(parts):
+        padded[r * nmax:r * nmax + x.shape[0]] = x
+    first = 0
+    for r, x in enumerate(parts):
+        keep = torch.zeros(x.shape[0], dtype=torch.uint8, device=dev)
+        ng = C.c_uint64()
+        torch.cuda.synchronize()
+        _lib.check(eng.L.pf_merge_patterns_padded(eng.ctx, C.c_void_p(padded.data_ptr()), 3, nmax,
+                                                  C.c_void_p(counts.data_ptr()), r, x.shape[0],
+                                                  C.c_void_p(keep.data_ptr()), C.byref(ng)))
+        assert ng.value == n_ref
+        assert torch.equal(keep.bool().cpu(), keep_all[first:first + x.shape[0]])
+        first += x.shape[0]
     eng.close()
