@@ -56,12 +56,15 @@ __device__ __forceinline__ uint32_t mix32(uint32_t h) {
 }
 template <int KW>
 __device__ __forceinline__ uint32_t key_hash(const Key<KW>& k) {
-    uint32_t h = (uint32_t)k.w[0] * 0x9E3779B1u ^ (uint32_t)(k.w[0] >> 32) * 0x85EBCA77u;
-    if (KW == 2) {
-        h = rotl32(h, 13) ^ ((uint32_t)k.w[1] * 0xC2B2AE3Du);
-        h = rotl32(h, 13) ^ ((uint32_t)(k.w[1] >> 32) * 0x27D4EB2Fu);
-    }
-    return mix32(h);
+    // two 32-bit multiplies (quarter-rate on CDNA): fold the halves with a rotate, then xor-shift / multiply.
+    // The slot takes the high bits (umulhi), the key partition the low 16.
+    uint32_t x = (uint32_t)k.w[0] ^ rotl32((uint32_t)(k.w[0] >> 32), 15);
+    if (KW == 2) x ^= rotl32((uint32_t)k.w[1], 7) ^ rotl32((uint32_t)(k.w[1] >> 32), 23);
+    x *= 0x9E3779B1u;
+    x ^= x >> 15;
+    x *= 0x85EBCA77u;
+    x ^= x >> 13;
+    return x;
 }
 // swap the two bits of every 2-bit group
 __device__ __forceinline__ uint64_t pairswap(uint64_t x) {
