@@ -104,7 +104,7 @@ struct pf_ctx {
     DevBuf cl_ninst, cl_vinst, cl_vwords, cl_overflow, cl_kmer_off, cl_kmer_cnt, cl_unique, cl_pattern, cl_first, cursor;
     // scan view built by cluster_dedup_kernel
     DevBuf v_word_off, v_len, v_sample, v_ord, seg_distinct, v_nseg, v_nstr, v_mode, v_dense, extra_off, extra_dense;
-    DevBuf bm_occ, bm_keep, pre_occ, pre_keep, mrows, slot_out, it_is_extra;
+    DevBuf bm_occ, bm_keep, pre_occ, pre_keep, mrows, slot_out, it_is_extra, cmask_lo, cmask_hi, it_compact;
     DevBuf strand_bits;
     DevBuf it_cluster, it_part, it_nparts, it_nslots, it_slice, it_sib0, it_nsib, it_extra_first, it_count,
         it_unique, it_kept, work_scan, work_extra, work_fin, work_fin2, work_fin3, work_rows, sub_cluster, sub_item0, sub_nitems;
@@ -279,7 +279,8 @@ void pf_destroy(pf_ctx* c) {
                       &c->b_seg_sample, &c->b_seg_ord, &c->b_cl_seg_off, &c->b_cl_nstr, &c->b_cl_npres, &c->b_cl_presab,
                       &c->b_cl_ordinal, &c->b_extra_ord, &c->b_extra_bits, &c->b_seg_strand_off, &c->cl_ninst, &c->cl_vinst, &c->cl_vwords, &c->v_word_off, &c->v_len, &c->v_sample, &c->v_ord,
                       &c->seg_distinct, &c->v_nseg, &c->v_nstr, &c->v_mode, &c->v_dense, &c->extra_off, &c->extra_dense,
-                      &c->bm_occ, &c->bm_keep, &c->pre_occ, &c->pre_keep, &c->mrows, &c->slot_out, &c->it_is_extra, &c->cl_overflow, &c->cl_kmer_off, &c->cl_kmer_cnt, &c->cl_unique, &c->cl_pattern,
+                      &c->bm_occ, &c->bm_keep, &c->pre_occ, &c->pre_keep, &c->mrows, &c->slot_out, &c->it_is_extra,
+                      &c->cmask_lo, &c->cmask_hi, &c->it_compact, &c->cl_overflow, &c->cl_kmer_off, &c->cl_kmer_cnt, &c->cl_unique, &c->cl_pattern,
                       &c->cl_first, &c->cursor, &c->strand_bits, &c->it_cluster, &c->it_part, &c->it_nparts,
                       &c->it_nslots, &c->it_slice, &c->it_sib0, &c->it_nsib, &c->it_extra_first, &c->it_count,
                       &c->it_unique, &c->it_kept, &c->work_scan, &c->work_extra, &c->work_fin, &c->work_fin2, &c->work_fin3, &c->work_rows, &c->sub_cluster, &c->sub_item0,
@@ -360,7 +361,8 @@ int pf_create(pf_ctx** out, int device, const pf_opts* o) {
             !guard(c->kept_prefix.ensure(S * (NS + 1) * 4)) || !guard(c->cursor.ensure(64)) ||
             !guard(c->bm_occ.ensure(S * pf::DENSE_WORDS * 4)) || !guard(c->bm_keep.ensure(S * pf::DENSE_WORDS * 4)) ||
             !guard(c->pre_occ.ensure(S * pf::DENSE_WORDS * 4)) || !guard(c->pre_keep.ensure(S * pf::DENSE_WORDS * 4)) ||
-            !guard(c->mrows.ensure(S * pf::DEDUP_MROWS * 4)) || !guard(c->slot_out.ensure(S * NS * 4)))
+            !guard(c->mrows.ensure(S * pf::DEDUP_MROWS * 4)) || !guard(c->slot_out.ensure(S * NS * 4)) ||
+            !guard(c->cmask_lo.ensure(S * NS * 4)) || !guard(c->cmask_hi.ensure(S * NS * 4)))
             break;
         e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { rc = fail(PF_ERR_HIP, "pf_create sync: %s", hipGetErrorString(e)); break; }
@@ -693,11 +695,12 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
         // ---- item arrays
         const size_t NI = items.size();
         std::vector<uint32_t> v_cluster(NI), v_part(NI), v_nparts(NI), v_nslots(NI), v_slice(NI), v_sib0(NI), v_nsib(NI),
-            v_exfirst(NI), v_isex(NI), w_scan, w_extra, w_fin, w_fin2, w_fin3, w_rows;
+            v_exfirst(NI), v_isex(NI), v_compact(NI), w_scan, w_extra, w_fin, w_fin2, w_fin3, w_rows;
         for (size_t i = 0; i < NI; i++) {
             v_cluster[i] = items[i].cluster; v_part[i] = items[i].part; v_nparts[i] = items[i].nparts;
             v_nslots[i] = items[i].nslots; v_slice[i] = items[i].slice; v_sib0[i] = items[i].sib0;
             v_nsib[i] = items[i].nsib; v_exfirst[i] = items[i].extra_first; v_isex[i] = items[i].is_extra;
+            v_compact[i] = item_fused[i] ? 1 : 0;
         }
         PFCHK(c->it_count.ensure(std::max<size_t>(NI, 1) * 4));
         PFCHK(c->it_unique.ensure(std::max<size_t>(NI, 1) * 4));
@@ -747,7 +750,8 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
             std::vector<std::pair<DevBuf*, const std::vector<uint32_t>*>> arrs = {
                 {&c->it_cluster, &v_cluster}, {&c->it_part, &v_part}, {&c->it_nparts, &v_nparts},
                 {&c->it_nslots, &v_nslots}, {&c->it_slice, &v_slice}, {&c->it_sib0, &v_sib0}, {&c->it_nsib, &v_nsib},
-                {&c->it_extra_first, &v_exfirst}, {&c->it_is_extra, &v_isex}, {&c->sub_cluster, &sub_cluster},
+                {&c->it_extra_first, &v_exfirst}, {&c->it_is_extra, &v_isex}, {&c->it_compact, &v_compact},
+                {&c->sub_cluster, &sub_cluster},
                 {&c->sub_item0, &sub_item0}, {&c->sub_nitems, &sub_nitems}, {&c->work_scan, &w_scan},
                 {&c->work_extra, &w_extra}, {&c->work_fin, &w_fin}, {&c->work_fin2, &w_fin2}, {&c->work_fin3, &w_fin3}, {&c->work_rows, &w_rows}};
             PFCHK(staged_upload(c, arrs));
@@ -785,7 +789,8 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
                 sp.cluster_vnstr = c->v_nstr.as<uint32_t>();
                 sp.item_cluster = c->it_cluster.as<uint32_t>(); sp.item_part = c->it_part.as<uint32_t>();
                 sp.item_nparts = c->it_nparts.as<uint32_t>(); sp.item_nslots = c->it_nslots.as<uint32_t>();
-                sp.item_scratch = c->it_slice.as<uint32_t>();
+                sp.item_scratch = c->it_slice.as<uint32_t>(); sp.item_compact = c->it_compact.as<uint32_t>();
+                sp.cmask_lo = c->cmask_lo.as<uint32_t>(); sp.cmask_hi = c->cmask_hi.as<uint32_t>();
                 sp.tab_key = c->tab_key.as<uint64_t>(); sp.tab_ord = c->tab_ord.as<uint32_t>();
                 sp.chunkbits = c->chunkbits.as<uint32_t>(); sp.chunkmask = c->chunkmask.as<uint32_t>();
                 sp.item_count = c->it_count.as<uint32_t>(); sp.cluster_overflow = c->cl_overflow.as<uint32_t>();
@@ -811,7 +816,8 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
                 fp.cluster_presab = d.cluster_presab; fp.cluster_ordinal = d.cluster_ordinal;
                 fp.maf_lo = c->d_maf_lo.as<uint32_t>(); fp.maf_hi = c->d_maf_hi.as<uint32_t>();
                 fp.tab_key = c->tab_key.as<uint64_t>(); fp.tab_ord = c->tab_ord.as<uint32_t>();
-                fp.chunkbits = c->chunkbits.as<uint32_t>(); fp.chunkmask = c->chunkmask.as<uint32_t>();
+                fp.cmask_lo = c->cmask_lo.as<uint32_t>(); fp.cmask_hi = c->cmask_hi.as<uint32_t>();
+                fp.item_count = c->it_count.as<uint32_t>();
                 fp.out_key = ar->key.as<uint64_t>(); fp.out_pid = ar->pid.as<uint32_t>();
                 fp.cluster_kmer_off = c->cl_kmer_off.as<uint64_t>(); fp.cluster_kmer_cnt = c->cl_kmer_cnt.as<uint32_t>();
                 fp.cluster_unique = c->cl_unique.as<uint32_t>(); fp.cluster_pattern = c->cl_pattern.as<uint32_t>();

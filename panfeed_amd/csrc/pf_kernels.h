@@ -120,6 +120,9 @@ struct ScanParams {
     const uint32_t* item_nparts;
     const uint32_t* item_nslots;
     const uint32_t* item_scratch;     // scratch slice of the item
+    const uint32_t* item_compact;     // 1: deduplicated cluster finished by finish_kernel -> compact table dump:
+                                      //    only occupied slots, {key, ordinal, 64-bit allele mask}, any order
+    uint32_t* cmask_lo; uint32_t* cmask_hi;   // [slice][NS] allele mask words of the compact dump
     // scratch, indexed by slice
     uint64_t* tab_key;                // [slice][KW][NS]
     uint32_t* tab_ord;                // [slice][NS]
@@ -248,6 +251,9 @@ __device__ __forceinline__ void scan_unit(uint64_t* keys, uint32_t* ord, uint32_
     }
 }
 
+// chunkmask word 0 is accumulated by thread 0
+__device__ __forceinline__ uint32_t mask_word_any(uint32_t mask_word, uint32_t tid) { return tid == 0 ? mask_word : 0u; }
+
 // misc[] layout (uint32 words)
 constexpr uint32_t M_COUNT = 0, M_OVERFLOW = 1, M_CHUNK = 2;            // chunk offsets: MAX_CHUNKS + 2 words
 constexpr uint32_t SEG_TILE = 256;                                       // segments staged per tile
@@ -256,7 +262,8 @@ constexpr uint32_t M_NINST = M_WOFF + 2 * SEG_TILE;
 constexpr uint32_t M_ORDB = M_NINST + SEG_TILE;
 constexpr uint32_t M_SAMPLE = M_ORDB + SEG_TILE;
 constexpr uint32_t M_UPREF = M_SAMPLE + SEG_TILE;                        // [SEG_TILE + 1] unit prefix
-static_assert(M_UPREF + SEG_TILE + 1 <= MISC_WORDS, "misc area too small");
+constexpr uint32_t M_TMP = M_UPREF + SEG_TILE + 2;                       // one scratch word
+static_assert(M_TMP + 1 <= MISC_WORDS, "misc area too small");
 
 template <int KW, bool CANON>
 __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
@@ -406,10 +413,37 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
         }
         // the next tile overwrites the staged metadata: everyone is past the barrier above
     }
-    if (!overflow && chunk_dirty) { flush_chunk(); __syncthreads(); }
+    const bool compact = p.item_compact[item] != 0;      // view has <= 64 columns: at most chunks 0 and 1
+    if (!overflow && chunk_dirty && !compact) { flush_chunk(); __syncthreads(); }
 
     if (overflow) {
         if (tid == 0) { atomicOr(&p.cluster_overflow[c], 1u); p.item_count[item] = 0; }
+        return;
+    }
+    if (compact) {
+        // chunk 0 words were flushed to global memory iff a chunk 1 followed; the last chunk is still in bits[]
+        const bool last_live = chunk_dirty;
+        const bool c0_flushed = (mask_word_any(mask_word, tid) & 1u) != 0;
+        if (tid == 0) { misc[M_TMP] = c0_flushed ? 1u : 0u; misc[M_COUNT] = 0; }
+        __syncthreads();
+        const bool have_c0 = misc[M_TMP] != 0;
+        const uint32_t* g0 = p.chunkbits + ((size_t)slice * p.W) * NS;
+        for (uint32_t i = tid; i < ns; i += SCAN_THREADS) {
+            const uint32_t o = ord[i];
+            if (o == NO_ORD) continue;
+            uint32_t lo = 0, hi = 0;
+            if (last_live && ch == 0) lo = bits[i];
+            else if (have_c0) lo = g0[i];
+            if (last_live && ch == 1) hi = bits[i];
+            const uint32_t e = atomicAdd(&misc[M_COUNT], 1u);
+            p.tab_key[((size_t)slice * KW) * NS + e] = keys[i];
+            if (KW == 2) p.tab_key[((size_t)slice * KW + 1) * NS + e] = keys[NS + i];
+            p.tab_ord[(size_t)slice * NS + e] = o;
+            p.cmask_lo[(size_t)slice * NS + e] = lo;
+            p.cmask_hi[(size_t)slice * NS + e] = hi;
+        }
+        __syncthreads();
+        if (tid == 0) p.item_count[item] = misc[M_COUNT];
         return;
     }
     for (uint32_t i = tid; i < ns; i += SCAN_THREADS) {
@@ -1359,7 +1393,8 @@ struct FinishParams {
     const uint32_t* cluster_nstrains; const uint32_t* cluster_npresab; const uint32_t* cluster_presab;
     const uint64_t* cluster_ordinal;
     const uint32_t* maf_lo; const uint32_t* maf_hi;
-    const uint64_t* tab_key; const uint32_t* tab_ord; const uint32_t* chunkbits; const uint32_t* chunkmask;
+    const uint32_t* item_count;      // entries of the item's compact table
+    const uint64_t* tab_key; const uint32_t* tab_ord; const uint32_t* cmask_lo; const uint32_t* cmask_hi;
     uint64_t* out_key; uint32_t* out_pid;
     uint64_t* cluster_kmer_off; uint32_t* cluster_kmer_cnt; uint32_t* cluster_unique; uint32_t* cluster_pattern;
     uint64_t* cursor;                // [0] next free output index [1] unique total [2] kept total
@@ -1461,18 +1496,18 @@ __global__ __launch_bounds__(CFG::THREADS) void finish_kernel(FinishParams p) {
     const uint32_t* presab = p.cluster_presab + (size_t)c * W;
     const uint32_t dense_words = (p.v_dense[c] + 31) >> 5;      // <= DW (host-checked)
     const uint64_t ordinal = p.cluster_ordinal[c];
-    // per key partition q: scratch slice, slots, ordinals, allele-mask words
+    // per key partition q: scratch slice and its compact table (occupied entries only, any order):
+    // ordinals, 64-bit allele masks (which distinct sequences contain the k-mer), keys
     uint32_t slice = 0, ns = 0;
     const uint32_t* ordp = nullptr;
-    const uint32_t* cb = nullptr;
-    bool f0 = false, f1 = false;
+    const uint32_t* mlo = nullptr;
+    const uint32_t* mhi = nullptr;
     auto set_part = [&](uint32_t q) {
         slice = p.item_scratch[item + q];
-        ns = p.item_nslots[item + q];
+        ns = p.item_count[item + q];
         ordp = p.tab_ord + (size_t)slice * NS;
-        cb = p.chunkbits + (size_t)slice * W * NS;
-        const uint32_t cm0 = p.chunkmask[slice * 8];
-        f0 = (cm0 & 1) != 0; f1 = (cm0 & 2) != 0;
+        mlo = p.cmask_lo + (size_t)slice * NS;
+        mhi = p.cmask_hi + (size_t)slice * NS;
     };
     auto find_tag = [&](uint64_t amask) -> tag_t {
         uint32_t a = (uint32_t)mix64(amask) % PROBE;
@@ -1506,10 +1541,9 @@ __global__ __launch_bounds__(CFG::THREADS) void finish_kernel(FinishParams p) {
     for (uint32_t q = 0; q < nparts; q++) {
     set_part(q);
     for (uint32_t i = tid; i < ns; i += T) {
-        const uint32_t o = ordp[i];
-        const uint64_t amask = (f0 ? (uint64_t)cb[i] : 0) | (f1 ? (uint64_t)cb[(size_t)NS + i] << 32 : 0);
+        const uint64_t amask = (uint64_t)mlo[i] | ((uint64_t)mhi[i] << 32);
         tag_t tag = UNTABLED;
-        if (o != NO_ORD) {
+        {
             uint32_t a = (uint32_t)mix64(amask) % PROBE;
             for (uint32_t probes = 0; amask && probes < PROBE; probes++) {
                 uint64_t cur = __hip_atomic_load(&at_key[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1603,13 +1637,13 @@ __global__ __launch_bounds__(CFG::THREADS) void finish_kernel(FinishParams p) {
     set_part(q);
     for (uint32_t i = tid; i < ns; i += T) {
         const uint32_t o = ordp[i];
-        if (o == NO_ORD || (o >> 5) >= dense_words) continue;
+        if ((o >> 5) >= dense_words) continue;
         uint64_t amask = 0;
-        if (MULTI) amask = (f0 ? (uint64_t)cb[i] : 0) | (f1 ? (uint64_t)cb[(size_t)NS + i] << 32 : 0);
+        if (MULTI) amask = (uint64_t)mlo[i] | ((uint64_t)mhi[i] << 32);
         const tag_t tag = MULTI ? find_tag(amask) : slot_at[i];
         bool keep;
         if (tag == UNTABLED) {
-            if (!MULTI) amask = (f0 ? (uint64_t)cb[i] : 0) | (f1 ? (uint64_t)cb[(size_t)NS + i] << 32 : 0);
+            if (!MULTI) amask = (uint64_t)mlo[i] | ((uint64_t)mhi[i] << 32);
             uint4 h;
             keep = row_eval(amask, h);
         } else {
@@ -1736,14 +1770,14 @@ __global__ __launch_bounds__(CFG::THREADS) void finish_kernel(FinishParams p) {
     set_part(q);
     for (uint32_t i = tid; i < ns; i += T) {
         const uint32_t o = ordp[i];
-        if (o == NO_ORD || (o >> 5) >= dense_words || !((keepbm[o >> 5] >> (o & 31)) & 1)) continue;
+        if ((o >> 5) >= dense_words || !((keepbm[o >> 5] >> (o & 31)) & 1)) continue;
         uint64_t amask = 0;
-        if (MULTI) amask = (f0 ? (uint64_t)cb[i] : 0) | (f1 ? (uint64_t)cb[(size_t)NS + i] << 32 : 0);
+        if (MULTI) amask = (uint64_t)mlo[i] | ((uint64_t)mhi[i] << 32);
         const tag_t tag = MULTI ? find_tag(amask) : slot_at[i];
         uint32_t pid;
         if (tag == UNTABLED) {
             // mask table was full: this slot goes to the run-global table on its own
-            if (!MULTI) amask = (f0 ? (uint64_t)cb[i] : 0) | (f1 ? (uint64_t)cb[(size_t)NS + i] << 32 : 0);
+            if (!MULTI) amask = (uint64_t)mlo[i] | ((uint64_t)mhi[i] << 32);
             uint4 h;
             row_eval(amask, h);
             bool lowered;
