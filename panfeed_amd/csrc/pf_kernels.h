@@ -1949,46 +1949,74 @@ __global__ __launch_bounds__(256) void pattern_rows_kernel(PatRowsParams p) {
 // ---------------------------------------------------------------------------------------------
 // md5_kernel: one lane per pattern, MD5 (RFC 1321) of the 8*n-byte image generated from the bits
 // ---------------------------------------------------------------------------------------------
-__device__ __constant__ uint32_t MD5_K[64] = {
-    0xd76aa478, 0xe8c7b756, 0x242070db, 0xc1bdceee, 0xf57c0faf, 0x4787c62a, 0xa8304613, 0xfd469501,
-    0x698098d8, 0x8b44f7af, 0xffff5bb1, 0x895cd7be, 0x6b901122, 0xfd987193, 0xa679438e, 0x49b40821,
-    0xf61e2562, 0xc040b340, 0x265e5a51, 0xe9b6c7aa, 0xd62f105d, 0x02441453, 0xd8a1e681, 0xe7d3fbc8,
-    0x21e1cde6, 0xc33707d6, 0xf4d50d87, 0x455a14ed, 0xa9e3e905, 0xfcefa3f8, 0x676f02d9, 0x8d2a4c8a,
-    0xfffa3942, 0x8771f681, 0x6d9d6122, 0xfde5380c, 0xa4beea44, 0x4bdecfa9, 0xf6bb4b60, 0xbebfbc70,
-    0x289b7ec6, 0xeaa127fa, 0xd4ef3085, 0x04881d05, 0xd9d4d039, 0xe6db99e5, 0x1fa27cf8, 0xc4ac5665,
-    0xf4292244, 0x432aff97, 0xab9423a7, 0xfc93a039, 0x655b59c3, 0x8f0ccc92, 0xffeff47d, 0x85845dd1,
-    0x6fa87e4f, 0xfe2ce6e0, 0xa3014314, 0x4e0811a1, 0xf7537e82, 0xbd3af235, 0x2ad7d2bb, 0xeb86d391};
-
-#define PF_MD5_STEP(f, a, b, c, d, m, kc, s)            \
-    {                                                   \
-        uint32_t t_ = (a) + (f) + (kc) + (m);           \
-        (a) = (b) + ((t_ << (s)) | (t_ >> (32 - (s)))); \
-    }
-
+// MD5 (RFC 1321), fully unrolled with literal constants: F1/F2 in their 3-operation forms, K and the rotation
+// amounts as immediates
 __device__ __forceinline__ void md5_block(uint32_t st[4], const uint32_t m[16]) {
     uint32_t a = st[0], b = st[1], c = st[2], d = st[3];
-#define F1(x, y, z) (((x) & (y)) | (~(x) & (z)))
-#define F2(x, y, z) (((x) & (z)) | ((y) & ~(z)))
-#define F3(x, y, z) ((x) ^ (y) ^ (z))
-#define F4(x, y, z) ((y) ^ ((x) | ~(z)))
-#define R4(F, i, g0, g1, g2, g3, s0, s1, s2, s3)                      \
-    PF_MD5_STEP(F(b, c, d), a, b, c, d, m[g0], MD5_K[i], s0)          \
-    PF_MD5_STEP(F(a, b, c), d, a, b, c, m[g1], MD5_K[i + 1], s1)      \
-    PF_MD5_STEP(F(d, a, b), c, d, a, b, m[g2], MD5_K[i + 2], s2)      \
-    PF_MD5_STEP(F(c, d, a), b, c, d, a, m[g3], MD5_K[i + 3], s3)
-    R4(F1, 0, 0, 1, 2, 3, 7, 12, 17, 22) R4(F1, 4, 4, 5, 6, 7, 7, 12, 17, 22)
-    R4(F1, 8, 8, 9, 10, 11, 7, 12, 17, 22) R4(F1, 12, 12, 13, 14, 15, 7, 12, 17, 22)
-    R4(F2, 16, 1, 6, 11, 0, 5, 9, 14, 20) R4(F2, 20, 5, 10, 15, 4, 5, 9, 14, 20)
-    R4(F2, 24, 9, 14, 3, 8, 5, 9, 14, 20) R4(F2, 28, 13, 2, 7, 12, 5, 9, 14, 20)
-    R4(F3, 32, 5, 8, 11, 14, 4, 11, 16, 23) R4(F3, 36, 1, 4, 7, 10, 4, 11, 16, 23)
-    R4(F3, 40, 13, 0, 3, 6, 4, 11, 16, 23) R4(F3, 44, 9, 12, 15, 2, 4, 11, 16, 23)
-    R4(F4, 48, 0, 7, 14, 5, 6, 10, 15, 21) R4(F4, 52, 12, 3, 10, 1, 6, 10, 15, 21)
-    R4(F4, 56, 8, 15, 6, 13, 6, 10, 15, 21) R4(F4, 60, 4, 11, 2, 9, 6, 10, 15, 21)
-#undef R4
-#undef F1
-#undef F2
-#undef F3
-#undef F4
+    a += (d ^ (b & (c ^ d))) + 0xd76aa478u + m[0]; a = b + ((a << 7) | (a >> 25));
+    d += (c ^ (a & (b ^ c))) + 0xe8c7b756u + m[1]; d = a + ((d << 12) | (d >> 20));
+    c += (b ^ (d & (a ^ b))) + 0x242070dbu + m[2]; c = d + ((c << 17) | (c >> 15));
+    b += (a ^ (c & (d ^ a))) + 0xc1bdceeeu + m[3]; b = c + ((b << 22) | (b >> 10));
+    a += (d ^ (b & (c ^ d))) + 0xf57c0fafu + m[4]; a = b + ((a << 7) | (a >> 25));
+    d += (c ^ (a & (b ^ c))) + 0x4787c62au + m[5]; d = a + ((d << 12) | (d >> 20));
+    c += (b ^ (d & (a ^ b))) + 0xa8304613u + m[6]; c = d + ((c << 17) | (c >> 15));
+    b += (a ^ (c & (d ^ a))) + 0xfd469501u + m[7]; b = c + ((b << 22) | (b >> 10));
+    a += (d ^ (b & (c ^ d))) + 0x698098d8u + m[8]; a = b + ((a << 7) | (a >> 25));
+    d += (c ^ (a & (b ^ c))) + 0x8b44f7afu + m[9]; d = a + ((d << 12) | (d >> 20));
+    c += (b ^ (d & (a ^ b))) + 0xffff5bb1u + m[10]; c = d + ((c << 17) | (c >> 15));
+    b += (a ^ (c & (d ^ a))) + 0x895cd7beu + m[11]; b = c + ((b << 22) | (b >> 10));
+    a += (d ^ (b & (c ^ d))) + 0x6b901122u + m[12]; a = b + ((a << 7) | (a >> 25));
+    d += (c ^ (a & (b ^ c))) + 0xfd987193u + m[13]; d = a + ((d << 12) | (d >> 20));
+    c += (b ^ (d & (a ^ b))) + 0xa679438eu + m[14]; c = d + ((c << 17) | (c >> 15));
+    b += (a ^ (c & (d ^ a))) + 0x49b40821u + m[15]; b = c + ((b << 22) | (b >> 10));
+    a += (c ^ (d & (b ^ c))) + 0xf61e2562u + m[1]; a = b + ((a << 5) | (a >> 27));
+    d += (b ^ (c & (a ^ b))) + 0xc040b340u + m[6]; d = a + ((d << 9) | (d >> 23));
+    c += (a ^ (b & (d ^ a))) + 0x265e5a51u + m[11]; c = d + ((c << 14) | (c >> 18));
+    b += (d ^ (a & (c ^ d))) + 0xe9b6c7aau + m[0]; b = c + ((b << 20) | (b >> 12));
+    a += (c ^ (d & (b ^ c))) + 0xd62f105du + m[5]; a = b + ((a << 5) | (a >> 27));
+    d += (b ^ (c & (a ^ b))) + 0x02441453u + m[10]; d = a + ((d << 9) | (d >> 23));
+    c += (a ^ (b & (d ^ a))) + 0xd8a1e681u + m[15]; c = d + ((c << 14) | (c >> 18));
+    b += (d ^ (a & (c ^ d))) + 0xe7d3fbc8u + m[4]; b = c + ((b << 20) | (b >> 12));
+    a += (c ^ (d & (b ^ c))) + 0x21e1cde6u + m[9]; a = b + ((a << 5) | (a >> 27));
+    d += (b ^ (c & (a ^ b))) + 0xc33707d6u + m[14]; d = a + ((d << 9) | (d >> 23));
+    c += (a ^ (b & (d ^ a))) + 0xf4d50d87u + m[3]; c = d + ((c << 14) | (c >> 18));
+    b += (d ^ (a & (c ^ d))) + 0x455a14edu + m[8]; b = c + ((b << 20) | (b >> 12));
+    a += (c ^ (d & (b ^ c))) + 0xa9e3e905u + m[13]; a = b + ((a << 5) | (a >> 27));
+    d += (b ^ (c & (a ^ b))) + 0xfcefa3f8u + m[2]; d = a + ((d << 9) | (d >> 23));
+    c += (a ^ (b & (d ^ a))) + 0x676f02d9u + m[7]; c = d + ((c << 14) | (c >> 18));
+    b += (d ^ (a & (c ^ d))) + 0x8d2a4c8au + m[12]; b = c + ((b << 20) | (b >> 12));
+    a += (b ^ c ^ d) + 0xfffa3942u + m[5]; a = b + ((a << 4) | (a >> 28));
+    d += (a ^ b ^ c) + 0x8771f681u + m[8]; d = a + ((d << 11) | (d >> 21));
+    c += (d ^ a ^ b) + 0x6d9d6122u + m[11]; c = d + ((c << 16) | (c >> 16));
+    b += (c ^ d ^ a) + 0xfde5380cu + m[14]; b = c + ((b << 23) | (b >> 9));
+    a += (b ^ c ^ d) + 0xa4beea44u + m[1]; a = b + ((a << 4) | (a >> 28));
+    d += (a ^ b ^ c) + 0x4bdecfa9u + m[4]; d = a + ((d << 11) | (d >> 21));
+    c += (d ^ a ^ b) + 0xf6bb4b60u + m[7]; c = d + ((c << 16) | (c >> 16));
+    b += (c ^ d ^ a) + 0xbebfbc70u + m[10]; b = c + ((b << 23) | (b >> 9));
+    a += (b ^ c ^ d) + 0x289b7ec6u + m[13]; a = b + ((a << 4) | (a >> 28));
+    d += (a ^ b ^ c) + 0xeaa127fau + m[0]; d = a + ((d << 11) | (d >> 21));
+    c += (d ^ a ^ b) + 0xd4ef3085u + m[3]; c = d + ((c << 16) | (c >> 16));
+    b += (c ^ d ^ a) + 0x04881d05u + m[6]; b = c + ((b << 23) | (b >> 9));
+    a += (b ^ c ^ d) + 0xd9d4d039u + m[9]; a = b + ((a << 4) | (a >> 28));
+    d += (a ^ b ^ c) + 0xe6db99e5u + m[12]; d = a + ((d << 11) | (d >> 21));
+    c += (d ^ a ^ b) + 0x1fa27cf8u + m[15]; c = d + ((c << 16) | (c >> 16));
+    b += (c ^ d ^ a) + 0xc4ac5665u + m[2]; b = c + ((b << 23) | (b >> 9));
+    a += (c ^ (b | ~d)) + 0xf4292244u + m[0]; a = b + ((a << 6) | (a >> 26));
+    d += (b ^ (a | ~c)) + 0x432aff97u + m[7]; d = a + ((d << 10) | (d >> 22));
+    c += (a ^ (d | ~b)) + 0xab9423a7u + m[14]; c = d + ((c << 15) | (c >> 17));
+    b += (d ^ (c | ~a)) + 0xfc93a039u + m[5]; b = c + ((b << 21) | (b >> 11));
+    a += (c ^ (b | ~d)) + 0x655b59c3u + m[12]; a = b + ((a << 6) | (a >> 26));
+    d += (b ^ (a | ~c)) + 0x8f0ccc92u + m[3]; d = a + ((d << 10) | (d >> 22));
+    c += (a ^ (d | ~b)) + 0xffeff47du + m[10]; c = d + ((c << 15) | (c >> 17));
+    b += (d ^ (c | ~a)) + 0x85845dd1u + m[1]; b = c + ((b << 21) | (b >> 11));
+    a += (c ^ (b | ~d)) + 0x6fa87e4fu + m[8]; a = b + ((a << 6) | (a >> 26));
+    d += (b ^ (a | ~c)) + 0xfe2ce6e0u + m[15]; d = a + ((d << 10) | (d >> 22));
+    c += (a ^ (d | ~b)) + 0xa3014314u + m[6]; c = d + ((c << 15) | (c >> 17));
+    b += (d ^ (c | ~a)) + 0x4e0811a1u + m[13]; b = c + ((b << 21) | (b >> 11));
+    a += (c ^ (b | ~d)) + 0xf7537e82u + m[4]; a = b + ((a << 6) | (a >> 26));
+    d += (b ^ (a | ~c)) + 0xbd3af235u + m[11]; d = a + ((d << 10) | (d >> 22));
+    c += (a ^ (d | ~b)) + 0x2ad7d2bbu + m[2]; c = d + ((c << 15) | (c >> 17));
+    b += (d ^ (c | ~a)) + 0xeb86d391u + m[9]; b = c + ((b << 21) | (b >> 11));
     st[0] += a; st[1] += b; st[2] += c; st[3] += d;
 }
 
@@ -2019,6 +2047,9 @@ __global__ __launch_bounds__(MD5_THREADS) void md5_kernel(Md5Params p) {
     const uint64_t nbytes = (uint64_t)n * 8;
     const uint32_t full = n >> 3;             // whole 64-byte blocks = 8 elements each
     const uint32_t rem = n & 7;
+    const uint32_t c_even = is_int ? 1u : 0u;                 // low word of a set element
+    const uint32_t c_odd = is_int ? 0u : 0x3FF00000u;         // high word of a set element
+    const uint32_t c_nan = is_int ? 0u : 0x7FF80000u;         // high word of a NaN element (never also set)
     uint32_t m[16];
     uint32_t tail_bw = 0, tail_nw = 0;
     const uint32_t W = p.W;
@@ -2042,10 +2073,11 @@ __global__ __launch_bounds__(MD5_THREADS) void md5_kernel(Md5Params p) {
             const uint32_t nw = has_nan ? (rn[e0 >> 5] >> (e0 & 31)) & 0xFF : 0;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                const uint32_t bit = (bw >> j) & 1, isn = (nw >> j) & 1;
-                // int64 LE: 01 00.. ; float64 LE: 1.0 = 0x3FF00000:00000000, NaN = 0x7FF80000:00000000 (np.nan)
-                m[2 * j] = is_int ? bit : 0;
-                m[2 * j + 1] = is_int ? 0 : (bit ? 0x3FF00000u : (isn ? 0x7FF80000u : 0));
+                // int64 LE: 01 00.. ; float64 LE: 1.0 = 0x3FF00000:00000000, NaN = 0x7FF80000:00000000 (np.nan);
+                // branch-free: masks of the element's bit / NaN flag ANDed with per-lane constants
+                const uint32_t bm = 0u - ((bw >> j) & 1), nm = 0u - ((nw >> j) & 1);
+                m[2 * j] = bm & c_even;
+                m[2 * j + 1] = (bm & c_odd) | (nm & c_nan);
             }
             md5_block(st, m);
         }

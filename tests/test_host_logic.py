@@ -151,3 +151,30 @@ def test_native_packer_rejects_bad_complement():
         packing.build_batch_native([rec], 5, True, 1)
     with pytest.raises(ValueError):
         packing.build_batch([rec], 5, True, 1)
+
+
+def test_device_md5_block_source_on_host(tmp_path):
+    """the md5_block the GPU runs (csrc/pf_kernels.h) compiled for the host: RFC 1321 vectors"""
+    import hashlib
+    import subprocess
+    src = open(os.path.join(REPO, "panfeed_amd", "csrc", "pf_kernels.h")).read()
+    a = src.index("__device__ __forceinline__ void md5_block(uint32_t st[4], const uint32_t m[16]) {")
+    b = src.index("struct Md5Params {")
+    fn = src[a:b].replace("__device__ __forceinline__", "static")
+    msgs = [b"", b"abc", b"message digest", b"a" * 55, b"1234567890" * 8]
+    prog = ["#include <stdint.h>\n#include <stdio.h>\n#include <string.h>\n", fn, "int main(){\n"]
+    for msg in msgs:
+        pad = msg + b"\x80" + b"\x00" * ((55 - len(msg)) % 64) + (8 * len(msg)).to_bytes(8, "little")
+        words = np.frombuffer(pad, dtype="<u4")
+        prog.append("{uint32_t st[4]={0x67452301u,0xefcdab89u,0x98badcfeu,0x10325476u};\n")
+        for blk in range(len(words) // 16):
+            w = ",".join(f"0x{int(x):08x}u" for x in words[16 * blk:16 * blk + 16])
+            prog.append(f"{{uint32_t m[16]={{{w}}}; md5_block(st,m);}}\n")
+        prog.append('for(int i=0;i<4;i++)for(int j=0;j<4;j++)printf("%02x",(st[i]>>(8*j))&255);printf("\\n");}\n')
+    prog.append("return 0;}\n")
+    cpp = tmp_path / "md5t.cpp"
+    cpp.write_text("".join(prog))
+    exe = tmp_path / "md5t"
+    subprocess.check_call(["g++", "-O1", "-o", str(exe), str(cpp)])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    assert out == [hashlib.md5(m).hexdigest() for m in msgs]
