@@ -251,6 +251,54 @@ int pf_pack_records(const pf_pack_in* in, pf_packed** out);
 int pf_packed_view(const pf_packed* p, pf_packed_view_t* view);
 void pf_packed_free(pf_packed* p);
 
+/*
+ * Native reader in front of the path: the panaroo presence/absence table, GFF3 features and
+ * FASTA sequences -> the Seqinfo records iter_gene_clusters yields
+ * (/root/reference/panfeed/input.py:274-332 parse_gff, :335-468 iter_gene_clusters), as flat arrays whose
+ * sequence pointers feed pf_pack_records directly.  PARITY UNPINNED at the pyfaidx boundary.
+ */
+typedef struct {
+    const char* presence_absence_csv;       /* -p */
+    uint32_t n_genomes, reserved;
+    const char* const* genome_names;        /* file name minus ".gff" (input.py:31) */
+    const char* const* gff_paths;
+    const char* const* fasta_paths;         /* NULL, or per genome NULL = sequences embedded after ##FASTA */
+    uint32_t upstream, downstream, downstream_start_codon, raise_missing;
+    const char* const* target_strains; uint32_t n_targets, n_genes;
+    const char* const* gene_list;           /* --genes; NULL = every cluster */
+} pf_pangenome_opts;
+
+typedef struct pf_pangenome pf_pangenome;
+typedef struct pf_records pf_records;
+
+typedef struct { uint32_t n_clusters, n_strains, next_cluster, reserved; } pf_pangenome_info_t;
+
+typedef struct {
+    uint32_t n_clusters, n_seqs, W, reserved;
+    /* per Seqinfo, in the iteration order of panfeed.py:54-55, cluster-major */
+    const char* const* seq; const char* const* comp; const char* const* id; const char* const* chromosome;
+    const uint32_t* seq_len; const uint32_t* seq_col; const uint32_t* seq_strain;   /* strain: index in the cluster's dict */
+    const uint8_t* seq_target; const int32_t* seq_strand;
+    const int64_t* seq_start; const int64_t* seq_end; const int64_t* seq_offset;
+    /* per cluster */
+    const uint32_t* cluster_seq_off;        /* [n_clusters+1] */
+    const char* const* cluster_name;
+    const uint32_t* cluster_nstrains;       /* len(cluster.keys()) */
+    const uint32_t* cluster_npresab;        /* len(clusterpresab) = strains of the table */
+    const uint32_t* cluster_presab;         /* [n_clusters * W] bits over sorted(strains) */
+    const uint32_t* cluster_strain_off;     /* [n_clusters+1] into cluster_strain: the dict keys in insertion order */
+    const char* const* cluster_strain;
+} pf_records_view_t;
+
+int pf_pangenome_open(const pf_pangenome_opts* opts, pf_pangenome** out);
+void pf_pangenome_close(pf_pangenome* p);
+int pf_pangenome_info(pf_pangenome* p, pf_pangenome_info_t* info);
+const char* pf_pangenome_strain(pf_pangenome* p, uint32_t i, int sorted);
+const char* pf_pangenome_take_log(pf_pangenome* p);   /* warnings the reference sends to logger.warning */
+/* Records of the next (at most) max_clusters rows of the table; n_clusters == 0 at the end. */
+int pf_pangenome_next(pf_pangenome* p, uint32_t max_clusters, pf_records** out, pf_records_view_t* view);
+void pf_records_free(pf_records* r);
+
 /* Host helper: md5 + base64 of a digest -- panfeed.py:175-176 -- for writers. */
 void pf_b64_digest(const uint8_t md5[16], char out[24]);
 

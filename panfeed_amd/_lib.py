@@ -81,6 +81,33 @@ class PackedView(C.Structure):
                 ("target_ambig_keys", C.POINTER(C.c_char))]
 
 
+class PangenomeOpts(C.Structure):
+    _fields_ = [("presence_absence_csv", C.c_char_p), ("n_genomes", C.c_uint32), ("reserved", C.c_uint32),
+                ("genome_names", C.POINTER(C.c_char_p)), ("gff_paths", C.POINTER(C.c_char_p)),
+                ("fasta_paths", C.POINTER(C.c_char_p)),
+                ("upstream", C.c_uint32), ("downstream", C.c_uint32), ("downstream_start_codon", C.c_uint32),
+                ("raise_missing", C.c_uint32),
+                ("target_strains", C.POINTER(C.c_char_p)), ("n_targets", C.c_uint32), ("n_genes", C.c_uint32),
+                ("gene_list", C.POINTER(C.c_char_p))]
+
+
+class PangenomeInfo(C.Structure):
+    _fields_ = [("n_clusters", C.c_uint32), ("n_strains", C.c_uint32), ("next_cluster", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class RecordsView(C.Structure):
+    _fields_ = [("n_clusters", C.c_uint32), ("n_seqs", C.c_uint32), ("W", C.c_uint32), ("reserved", C.c_uint32),
+                ("seq", C.POINTER(C.c_char_p)), ("comp", C.POINTER(C.c_char_p)), ("id", C.POINTER(C.c_char_p)),
+                ("chromosome", C.POINTER(C.c_char_p)),
+                ("seq_len", C.POINTER(C.c_uint32)), ("seq_col", C.POINTER(C.c_uint32)), ("seq_strain", C.POINTER(C.c_uint32)),
+                ("seq_target", C.POINTER(C.c_uint8)), ("seq_strand", C.POINTER(C.c_int32)),
+                ("seq_start", C.POINTER(C.c_int64)), ("seq_end", C.POINTER(C.c_int64)), ("seq_offset", C.POINTER(C.c_int64)),
+                ("cluster_seq_off", C.POINTER(C.c_uint32)), ("cluster_name", C.POINTER(C.c_char_p)),
+                ("cluster_nstrains", C.POINTER(C.c_uint32)), ("cluster_npresab", C.POINTER(C.c_uint32)),
+                ("cluster_presab", C.POINTER(C.c_uint32)), ("cluster_strain_off", C.POINTER(C.c_uint32)),
+                ("cluster_strain", C.POINTER(C.c_char_p))]
+
+
 class Timing(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("scan_ms", C.c_float), ("rows_ms", C.c_float), ("emit_ms", C.c_float),
                 ("scan_launches", C.c_uint32), ("n_items", C.c_uint32), ("n_retried", C.c_uint32),
@@ -96,7 +123,9 @@ EXPORTS = ["pf_last_error", "pf_version", "pf_device_count", "pf_create", "pf_de
            "pf_merge_patterns", "pf_merge_patterns_padded", "pf_pattern_count", "pf_dev_alloc", "pf_dev_free",
            "pf_dev_upload", "pf_dev_download", "pf_synth_expand", "pf_pack_acgt", "pf_b64_digest",
            "pf_render_kmers_to_hashes", "pf_render_hashes_to_patterns", "pf_render_kmers_tsv", "pf_free_text",
-           "pf_pack_records", "pf_packed_view", "pf_packed_free"]
+           "pf_pack_records", "pf_packed_view", "pf_packed_free",
+           "pf_pangenome_open", "pf_pangenome_close", "pf_pangenome_info", "pf_pangenome_strain",
+           "pf_pangenome_take_log", "pf_pangenome_next", "pf_records_free"]
 
 _lib = None
 
@@ -148,6 +177,17 @@ def load():
     L.pf_packed_view.argtypes = [C.c_void_p, C.POINTER(PackedView)]
     L.pf_packed_free.argtypes = [C.c_void_p]
     L.pf_packed_free.restype = None
+    L.pf_pangenome_open.argtypes = [C.POINTER(PangenomeOpts), C.POINTER(C.c_void_p)]
+    L.pf_pangenome_close.argtypes = [C.c_void_p]
+    L.pf_pangenome_close.restype = None
+    L.pf_pangenome_info.argtypes = [C.c_void_p, C.POINTER(PangenomeInfo)]
+    L.pf_pangenome_strain.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
+    L.pf_pangenome_strain.restype = C.c_char_p
+    L.pf_pangenome_take_log.argtypes = [C.c_void_p]
+    L.pf_pangenome_take_log.restype = C.c_char_p
+    L.pf_pangenome_next.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(RecordsView)]
+    L.pf_records_free.argtypes = [C.c_void_p]
+    L.pf_records_free.restype = None
     L.pf_free_text.argtypes = [C.c_void_p]
     L.pf_free_text.restype = None
     _lib = L

@@ -1,0 +1,450 @@
+// pf_input.cpp -- native restatement of the serial producer in front of the hot path:
+//   parse_gff            /root/reference/panfeed/input.py:274-332
+//   iter_gene_clusters   /root/reference/panfeed/input.py:335-468
+// plus what they read: the panaroo gene_presence_absence.csv (input.py:188-191), GFF3 files and FASTA
+// (embedded after ##FASTA, input.py:103-108, or separate files).  Output: the Seqinfo records of a batch of
+// clusters as flat arrays whose sequence pointers go straight into pf_pack_records -- no per-base work in Python.
+//
+// PARITY UNPINNED at the pyfaidx boundary: pyfaidx is not in /root/reference and not installed; what it would return
+// is restated from its documented behaviour (record name = header up to the first whitespace, newline-free
+// sequence, sequence_always_upper, Python slice clipping, `-seq` = reverse complement with the IUPAC table below).
+#include "../../include/panfeed_hip.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+extern "C" void pf_set_error_(const char* msg);
+
+namespace {
+
+int in_fail(int code, const std::string& msg) { pf_set_error_(msg.c_str()); return code; }
+
+struct Feature { std::string id, chrom; long long start, end; int strand; };
+
+struct Genome {
+    std::unordered_map<std::string, std::string> contigs;       // name -> upper-case sequence
+    std::unordered_map<std::string, Feature> features;          // ID -> feature (later lines overwrite, as a dict)
+    std::string warnings;
+    std::string error;
+};
+
+bool read_file(const std::string& path, std::string& out) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    std::ostringstream ss;
+    ss << f.rdbuf();
+    out = ss.str();
+    return true;
+}
+
+inline bool is_space(char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; }
+
+// FASTA text -> contigs (pyfaidx: name up to first whitespace, lines joined, upper case)
+void parse_fasta(const char* p, const char* end, Genome& g) {
+    std::string* cur = nullptr;
+    while (p < end) {
+        const char* nl = (const char*)memchr(p, '\n', end - p);
+        const char* le = nl ? nl : end;
+        const char* e = le;
+        while (e > p && (e[-1] == '\r')) e--;
+        if (p < e && *p == '>') {
+            const char* q = p + 1;
+            while (q < e && !is_space(*q)) q++;
+            std::string name(p + 1, q);
+            auto ins = g.contigs.emplace(name, std::string());
+            cur = ins.second ? &ins.first->second : nullptr;      // a repeated name keeps its first record
+        } else if (cur) {
+            const size_t o = cur->size();
+            cur->resize(o + (e - p));
+            for (const char* q = p; q < e; q++) {
+                char c = *q;
+                if (c >= 'a' && c <= 'z') c = (char)(c - 32);
+                (*cur)[o + (q - p)] = c;
+            }
+        }
+        p = nl ? nl + 1 : end;
+    }
+}
+
+// Python int(): optional surrounding whitespace, sign, digits (underscores and other bases not handled -> error)
+bool py_int(const std::string& s, long long* out) {
+    size_t a = 0, b = s.size();
+    while (a < b && is_space(s[a])) a++;
+    while (b > a && is_space(s[b - 1])) b--;
+    if (a == b) return false;
+    bool neg = false;
+    if (s[a] == '+' || s[a] == '-') { neg = s[a] == '-'; a++; }
+    if (a == b) return false;
+    long long v = 0;
+    for (size_t i = a; i < b; i++) {
+        if (s[i] < '0' || s[i] > '9') return false;
+        v = v * 10 + (s[i] - '0');
+    }
+    *out = neg ? -v : v;
+    return true;
+}
+
+// input.py:274-332 (feature_types = {'CDS'})
+void parse_gff(const std::string& text, const std::string& file_name, Genome& g) {
+    const char* p = text.data();
+    const char* end = p + text.size();
+    while (p < end) {
+        const char* nl = (const char*)memchr(p, '\n', end - p);
+        const char* le = nl ? nl + 1 : end;                      // the line keeps its newline, as in `for line in gff`
+        std::string line(p, le);
+        p = le;
+        size_t a = 0;
+        while (a < line.size() && is_space(line[a])) a++;       // line.lstrip()
+        if (line.compare(a, 7, "##FASTA") == 0) break;            // input.py:286-288
+        if (a < line.size() && line[a] == '#') continue;          // input.py:290-292
+        std::vector<std::string> e;                               // line.split('\t')
+        size_t s0 = 0;
+        for (;;) {
+            size_t t = line.find('\t', s0);
+            if (t == std::string::npos) { e.push_back(line.substr(s0)); break; }
+            e.push_back(line.substr(s0, t - s0));
+            s0 = t + 1;
+        }
+        auto warn = [&](const char* what) {
+            std::string l = line;
+            while (!l.empty() && is_space(l.back())) l.pop_back();
+            g.warnings += std::string(what) + ", skipping line \"" + l + "\" from " + file_name + "\n";
+        };
+        if (e.size() < 3) { warn("list index out of range"); continue; }
+        if (e[2] != "CDS") continue;                              // input.py:300-301
+        if (e.size() < 9) { warn("list index out of range"); continue; }
+        long long st, en;
+        if (!py_int(e[3], &st) || !py_int(e[4], &en)) { warn("invalid literal for int() with base 10"); continue; }
+        const int strand = e[6] == "+" ? 1 : -1;                  // input.py:309-312
+        bool have = false;
+        std::string id;
+        size_t q0 = 0;
+        const std::string& attrs = e[8];
+        for (;;) {                                                // entries[8].split(';')
+            size_t t = attrs.find(';', q0);
+            std::string ent = attrs.substr(q0, t == std::string::npos ? std::string::npos : t - q0);
+            if (ent.compare(0, 2, "ID") == 0 && ent.find('=') != std::string::npos) {      // input.py:317
+                size_t eq = ent.find('=');
+                size_t eq2 = ent.find('=', eq + 1);
+                id = ent.substr(eq + 1, eq2 == std::string::npos ? std::string::npos : eq2 - eq - 1);   // split('=')[1]
+                have = true;
+            }
+            if (t == std::string::npos) break;
+            q0 = t + 1;
+        }
+        if (!have) continue;                                      // input.py:321-322
+        g.features[id] = Feature{id, e[0], st, en, strand};       // input.py:325
+    }
+}
+
+const char* COMP_FROM = "ACTGNactgnYRWSKMDVHBXyrwskmdvhbx";
+const char* COMP_TO = "TGACNtgacnRYWSMKHBDVXryswmkhbdvx";
+struct CompLut {
+    unsigned char t[256];
+    CompLut() { for (int i = 0; i < 256; i++) t[i] = (unsigned char)i; for (int i = 0; COMP_FROM[i]; i++) t[(unsigned char)COMP_FROM[i]] = (unsigned char)COMP_TO[i]; }
+};
+const CompLut g_comp;
+
+// pandas' default NA strings (read_csv): a cell equal to one of these is NaN
+const char* NA_STRINGS[] = {"", "#N/A", "#N/A N/A", "#NA", "-1.#IND", "-1.#QNAN", "-NaN", "-nan", "1.#IND", "1.#QNAN", "<NA>",
+                            "N/A", "NA", "NULL", "NaN", "None", "n/a", "nan", "null"};
+
+// RFC-4180-ish CSV record splitter (quotes, doubled quotes, embedded newlines)
+bool next_csv_record(const std::string& t, size_t& pos, std::vector<std::string>& out) {
+    out.clear();
+    if (pos >= t.size()) return false;
+    std::string cell;
+    bool inq = false, any = false;
+    for (;;) {
+        if (pos >= t.size()) { out.push_back(cell); return any || !out.empty(); }
+        char c = t[pos++];
+        any = true;
+        if (inq) {
+            if (c == '"') { if (pos < t.size() && t[pos] == '"') { cell += '"'; pos++; } else inq = false; }
+            else cell += c;
+        } else if (c == '"') inq = true;
+        else if (c == ',') { out.push_back(cell); cell.clear(); }
+        else if (c == '\n') { out.push_back(cell); return true; }
+        else if (c == '\r') { /* swallow */ }
+        else cell += c;
+    }
+}
+
+}  // namespace
+
+struct pf_pangenome {
+    std::vector<std::string> strains;          // CSV column order (genepres.columns)
+    std::vector<std::string> sorted_strains;
+    std::vector<uint32_t> sorted_pos;          // strains[i] -> index in sorted_strains
+    std::vector<std::string> cluster_names;
+    std::vector<std::vector<std::string>> cells;   // [row][strain] "" = NaN
+    std::unordered_map<std::string, Genome> genomes;
+    std::unordered_set<std::string> targets, genes;
+    bool have_genes = false;
+    long long up = 0, down = 0;
+    bool dsc = false, raise_missing = false;
+    size_t next_row = 0;
+    std::string log;
+    uint32_t W = 0;
+};
+
+struct pf_records {
+    // storage
+    std::vector<std::string> seq_store, comp_store, id_store, chrom_store;
+    std::vector<const char*> seq, comp, ids, chroms, cluster_name_ptr, strain_ptr;
+    std::vector<uint32_t> seq_len, seq_col, seq_strain, cluster_seq_off, cluster_nstrains, cluster_npresab, cluster_presab,
+        cluster_row, cluster_strain_off, strain_index;
+    std::vector<uint8_t> seq_target;
+    std::vector<int32_t> seq_strand;
+    std::vector<int64_t> seq_start, seq_end, seq_offset;
+    std::vector<std::string> strain_store;     // dict-order strain names of each cluster, concatenated (CSR)
+};
+
+extern "C" {
+
+int pf_pangenome_open(const pf_pangenome_opts* o, pf_pangenome** out) {
+    if (!o || !out || !o->presence_absence_csv) return in_fail(PF_ERR_ARG, "pf_pangenome_open: null argument");
+    *out = nullptr;
+    std::string csv;
+    if (!read_file(o->presence_absence_csv, csv)) return in_fail(PF_ERR_ARG, std::string("cannot read ") + o->presence_absence_csv);
+    pf_pangenome* P = new pf_pangenome();
+    P->up = o->upstream; P->down = o->downstream; P->dsc = o->downstream_start_codon != 0; P->raise_missing = o->raise_missing != 0;
+    for (uint32_t i = 0; i < o->n_targets; i++) P->targets.insert(o->target_strains[i]);
+    P->have_genes = o->gene_list != nullptr;
+    for (uint32_t i = 0; i < o->n_genes; i++) P->genes.insert(o->gene_list[i]);
+    // ---- panaroo table: index_col=0, drop 'Non-unique Gene name' and 'Annotation' (input.py:188-191)
+    size_t pos = 0;
+    std::vector<std::string> rec;
+    if (!next_csv_record(csv, pos, rec)) { delete P; return in_fail(PF_ERR_ARG, "empty presence/absence table"); }
+    std::vector<int> keep;     // header column -> strain index or -1
+    bool d1 = false, d2 = false;
+    for (size_t c = 1; c < rec.size(); c++) {
+        if (rec[c] == "Non-unique Gene name") { d1 = true; keep.push_back(-1); }
+        else if (rec[c] == "Annotation") { d2 = true; keep.push_back(-1); }
+        else { keep.push_back((int)P->strains.size()); P->strains.push_back(rec[c]); }
+    }
+    if (!d1 || !d2) { delete P; return in_fail(PF_ERR_ARG, "presence/absence table lacks 'Non-unique Gene name' / 'Annotation' columns"); }
+    std::unordered_set<std::string> na(std::begin(NA_STRINGS), std::end(NA_STRINGS));
+    while (next_csv_record(csv, pos, rec)) {
+        if (rec.size() == 1 && rec[0].empty()) continue;          // blank line
+        P->cluster_names.push_back(rec[0]);
+        std::vector<std::string> row(P->strains.size());
+        for (size_t c = 1; c < rec.size() && c - 1 < keep.size(); c++)
+            if (keep[c - 1] >= 0 && !na.count(rec[c])) row[keep[c - 1]] = rec[c];
+        P->cells.push_back(std::move(row));
+    }
+    P->sorted_strains = P->strains;
+    std::sort(P->sorted_strains.begin(), P->sorted_strains.end());
+    std::unordered_map<std::string, uint32_t> sp;
+    for (uint32_t i = 0; i < P->sorted_strains.size(); i++) sp[P->sorted_strains[i]] = i;
+    for (auto& s : P->strains) P->sorted_pos.push_back(sp[s]);
+    P->W = (uint32_t)(P->strains.size() + 31) / 32;
+    // ---- genomes: GFF features + FASTA (embedded or separate), loaded in parallel
+    std::vector<Genome> gs(o->n_genomes);
+    unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++)
+        th.emplace_back([&, t] {
+            for (uint32_t i = t; i < o->n_genomes; i += nt) {
+                Genome& g = gs[i];
+                std::string text;
+                if (!read_file(o->gff_paths[i], text)) { g.error = std::string("cannot read ") + o->gff_paths[i]; continue; }
+                parse_gff(text, o->gff_paths[i], g);
+                if (o->fasta_paths && o->fasta_paths[i]) {
+                    std::string fa;
+                    if (!read_file(o->fasta_paths[i], fa)) { g.error = std::string("cannot read ") + o->fasta_paths[i]; continue; }
+                    parse_fasta(fa.data(), fa.data() + fa.size(), g);
+                } else {
+                    // open(gff).read().split("##FASTA")[1]   (input.py:103-108)
+                    size_t a = text.find("##FASTA");
+                    if (a == std::string::npos) { g.error = std::string("no ##FASTA section in ") + o->gff_paths[i]; continue; }
+                    a += 7;
+                    size_t b = text.find("##FASTA", a);
+                    if (b == std::string::npos) b = text.size();
+                    parse_fasta(text.data() + a, text.data() + b, g);
+                }
+            }
+        });
+    for (auto& x : th) x.join();
+    for (uint32_t i = 0; i < o->n_genomes; i++) {
+        if (!gs[i].error.empty()) { std::string e = gs[i].error; delete P; return in_fail(PF_ERR_ARG, e); }
+        P->log += gs[i].warnings;
+        P->genomes.emplace(o->genome_names[i], std::move(gs[i]));
+    }
+    // input.py:338-348
+    size_t missing = 0;
+    for (auto& s : P->strains) if (!P->genomes.count(s)) missing++;
+    if (missing) {
+        P->log += "There are " + std::to_string(missing) + " strains present in the pangenome table but not in the GFF directory\n";
+        if (P->raise_missing) { delete P; return in_fail(PF_ERR_ARG, "Missing " + std::to_string(missing) + " from the GFF directory"); }
+    }
+    *out = P;
+    return PF_OK;
+}
+
+void pf_pangenome_close(pf_pangenome* P) { delete P; }
+
+int pf_pangenome_info(pf_pangenome* P, pf_pangenome_info_t* info) {
+    if (!P || !info) return in_fail(PF_ERR_ARG, "null argument");
+    info->n_clusters = (uint32_t)P->cluster_names.size();
+    info->n_strains = (uint32_t)P->strains.size();
+    info->next_cluster = (uint32_t)P->next_row;
+    return PF_OK;
+}
+
+const char* pf_pangenome_strain(pf_pangenome* P, uint32_t i, int sorted) {
+    if (!P || i >= P->strains.size()) return nullptr;
+    return sorted ? P->sorted_strains[i].c_str() : P->strains[i].c_str();
+}
+
+// the accumulated warnings (what the reference sends to logger.warning); cleared by the call
+const char* pf_pangenome_take_log(pf_pangenome* P) {
+    static thread_local std::string hold;
+    if (!P) return "";
+    hold.swap(P->log);
+    P->log.clear();
+    return hold.c_str();
+}
+
+void pf_records_free(pf_records* r) { delete r; }
+
+// iter_gene_clusters for the next `max_clusters` rows of the table (input.py:352-468)
+int pf_pangenome_next(pf_pangenome* P, uint32_t max_clusters, pf_records** out, pf_records_view_t* v) {
+    if (!P || !out || !v) return in_fail(PF_ERR_ARG, "null argument");
+    *out = nullptr;
+    pf_records* R = new pf_records();
+    R->cluster_seq_off.push_back(0);
+    R->cluster_strain_off.push_back(0);
+    const size_t S = P->strains.size();
+    uint32_t made = 0;
+    while (P->next_row < P->cluster_names.size() && made < max_clusters) {
+        const size_t row = P->next_row++;
+        const std::string& idx = P->cluster_names[row];
+        if (P->have_genes && !P->genes.count(idx)) continue;            // input.py:353-355
+        const auto& cells = P->cells[row];
+        std::vector<uint32_t> presab(P->W, 0);
+        // dict insertion order: present strains with genome data (CSV order), then absent strains (sorted)
+        std::vector<uint32_t> dict;                                      // strain indices
+        for (size_t s = 0; s < S; s++)
+            if (!cells[s].empty()) {
+                const uint32_t sp = P->sorted_pos[s];
+                presab[sp >> 5] |= 1u << (sp & 31);                      // input.py:375-377
+                if (P->genomes.count(P->strains[s])) dict.push_back((uint32_t)s);   // input.py:384-387
+            }
+        const size_t npresent_dict = dict.size();
+        {
+            std::vector<uint32_t> absent;
+            for (size_t s = 0; s < S; s++) if (cells[s].empty()) absent.push_back((uint32_t)s);
+            std::sort(absent.begin(), absent.end(), [&](uint32_t a, uint32_t b) { return P->strains[a] < P->strains[b]; });
+            dict.insert(dict.end(), absent.begin(), absent.end());      // input.py:465-466
+        }
+        // column of each dict strain in sorted(cluster.keys())  (panfeed.py:47-49)
+        std::vector<uint32_t> order(dict.size());
+        for (size_t i = 0; i < dict.size(); i++) order[i] = (uint32_t)i;
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return P->strains[dict[a]] < P->strains[dict[b]]; });
+        std::vector<uint32_t> col(dict.size());
+        for (size_t i = 0; i < order.size(); i++) col[order[i]] = (uint32_t)i;
+
+        for (size_t di = 0; di < npresent_dict; di++) {
+            const std::string& strain = P->strains[dict[di]];
+            const Genome& g = P->genomes.find(strain)->second;
+            const std::string& genes = cells[dict[di]];
+            size_t q0 = 0;
+            for (;;) {                                                   // genes.split(';')  input.py:393
+                size_t t = genes.find(';', q0);
+                std::string gene = genes.substr(q0, t == std::string::npos ? std::string::npos : t - q0);
+                auto fit = g.features.find(gene);
+                if (fit == g.features.end()) {                           // input.py:396-402
+                    P->log += "Could not find gene " + gene + " from " + idx + " in " + strain + "\n";
+                    if (P->raise_missing) { delete R; return in_fail(PF_ERR_ARG, "Could not find gene " + gene + " from " + idx + " in " + strain); }
+                } else {
+                    const Feature& f = fit->second;
+                    auto cit = g.contigs.find(f.chrom);
+                    if (cit == g.contigs.end()) {                        // input.py:404-411
+                        P->log += "Could not find chromosome " + f.chrom + " in " + strain + "\n";
+                        if (P->raise_missing) { delete R; return in_fail(PF_ERR_ARG, "Could not find chromosome " + f.chrom + " in " + strain); }
+                    } else {
+                        const std::string& ctg = cit->second;
+                        const long long up = P->up, down = P->down;
+                        const long long offset = (f.strand > 0 && f.start - 1 - up < 0) ? f.start - 1 : up;        // :415-418
+                        const long long offset_d = (f.strand < 0 && f.start - 1 - down < 0) ? f.start - 1 : down;  // :421-424
+                        long long a, b, seq_start, seq_end;
+                        if (!P->dsc) {                                   // :427-436
+                            if (f.strand > 0) { a = f.start - 1 - offset; b = f.end + offset_d; seq_start = f.start - offset; seq_end = f.end + offset_d; }
+                            else { a = f.start - 1 - offset_d; b = f.end + offset; seq_start = f.start - offset_d; seq_end = f.end + offset; }
+                        } else {                                         // :437-446
+                            if (f.strand > 0) { a = f.start - 1 - offset; b = f.start + offset_d; seq_start = f.start - offset; seq_end = f.start + offset_d; }
+                            else { a = f.end - 1 - offset_d; b = f.end + offset; seq_start = f.end - offset_d; seq_end = f.end + offset; }
+                        }
+                        // Python slice clipping of contig[a:b]
+                        const long long n = (long long)ctg.size();
+                        if (a < 0) a = std::max(0LL, a + n);
+                        if (b < 0) b = std::max(0LL, b + n);
+                        a = std::min(a, n); b = std::min(b, n);
+                        if (b < a) b = a;
+                        std::string seq = ctg.substr((size_t)a, (size_t)(b - a));
+                        if (f.strand < 0) {                              // -sequences[...]: reverse complement
+                            std::reverse(seq.begin(), seq.end());
+                            for (auto& ch : seq) ch = (char)g_comp.t[(unsigned char)ch];
+                        }
+                        std::string comp(seq.size(), 'N');               // revseq = (-seq)[::-1] : the complement (:449-452)
+                        for (size_t i = 0; i < seq.size(); i++) comp[i] = (char)g_comp.t[(unsigned char)seq[i]];
+                        R->seq_len.push_back((uint32_t)seq.size());
+                        R->seq_store.push_back(std::move(seq));
+                        R->comp_store.push_back(std::move(comp));
+                        R->id_store.push_back(f.id);
+                        R->chrom_store.push_back(f.chrom);
+                        R->seq_col.push_back(col[di]);
+                        R->seq_strain.push_back((uint32_t)di);
+                        R->seq_target.push_back(P->targets.count(strain) ? 1 : 0);
+                        R->seq_strand.push_back(f.strand);
+                        R->seq_start.push_back(seq_start);
+                        R->seq_end.push_back(seq_end);
+                        R->seq_offset.push_back(offset);
+                    }
+                }
+                if (t == std::string::npos) break;
+                q0 = t + 1;
+            }
+        }
+        R->cluster_seq_off.push_back((uint32_t)R->seq_len.size());
+        R->cluster_nstrains.push_back((uint32_t)dict.size());
+        R->cluster_npresab.push_back((uint32_t)S);
+        R->cluster_presab.insert(R->cluster_presab.end(), presab.begin(), presab.end());
+        R->cluster_row.push_back((uint32_t)row);
+        for (uint32_t s : dict) R->strain_index.push_back(s);
+        R->cluster_strain_off.push_back((uint32_t)R->strain_index.size());
+        made++;
+    }
+    const size_t n = R->seq_len.size();
+    R->seq.resize(n); R->comp.resize(n); R->ids.resize(n); R->chroms.resize(n);
+    for (size_t i = 0; i < n; i++) {
+        R->seq[i] = R->seq_store[i].c_str(); R->comp[i] = R->comp_store[i].c_str();
+        R->ids[i] = R->id_store[i].c_str(); R->chroms[i] = R->chrom_store[i].c_str();
+    }
+    R->cluster_name_ptr.resize(made);
+    for (uint32_t i = 0; i < made; i++) R->cluster_name_ptr[i] = P->cluster_names[R->cluster_row[i]].c_str();
+    R->strain_ptr.resize(R->strain_index.size());
+    for (size_t i = 0; i < R->strain_index.size(); i++) R->strain_ptr[i] = P->strains[R->strain_index[i]].c_str();
+    v->n_clusters = made; v->n_seqs = (uint32_t)n; v->W = P->W; v->reserved = 0;
+    v->seq = R->seq.data(); v->comp = R->comp.data(); v->id = R->ids.data(); v->chromosome = R->chroms.data();
+    v->seq_len = R->seq_len.data(); v->seq_col = R->seq_col.data(); v->seq_strain = R->seq_strain.data();
+    v->seq_target = R->seq_target.data(); v->seq_strand = R->seq_strand.data();
+    v->seq_start = R->seq_start.data(); v->seq_end = R->seq_end.data(); v->seq_offset = R->seq_offset.data();
+    v->cluster_seq_off = R->cluster_seq_off.data(); v->cluster_name = R->cluster_name_ptr.data();
+    v->cluster_nstrains = R->cluster_nstrains.data(); v->cluster_npresab = R->cluster_npresab.data();
+    v->cluster_presab = R->cluster_presab.data(); v->cluster_strain_off = R->cluster_strain_off.data();
+    v->cluster_strain = R->strain_ptr.data();
+    *out = R;
+    return PF_OK;
+}
+
+}  // extern "C"

@@ -134,17 +134,33 @@ class Engine:
         (__main__.py:39-81,299-344) with the GPU in the workers' place and a deterministic order
         (always the --cores 1 order, whatever finishes first)."""
         import itertools
-        from concurrent.futures import ThreadPoolExecutor
         it = iter(records)
-        state = {"ordinal": self.next_ordinal}
+
+        def host_batches():
+            ordinal = self.next_ordinal
+            while True:
+                chunk = list(itertools.islice(it, batch_clusters))
+                if not chunk:
+                    return
+                yield build_batch_native(chunk, self.k, self.canon, self.W, stroi=self.stroi, first_ordinal=ordinal)
+                ordinal += len(chunk)
+        return self.run_batches(host_batches(), prefetch)
+
+    def run_pangenome(self, pangenome, batch_clusters=256, prefetch=2):
+        """run_stream fed by the native reader (native_input.Pangenome): table rows -> records -> packed batches
+        without leaving the library, then the GPU; yields BatchOutput in table order."""
+        if tuple(sorted(pangenome.targets)) != tuple(sorted(self.stroi or ())):
+            raise ValueError("the pangenome reader and the engine were given different target strains")
+        return self.run_batches(pangenome.batches(self.k, self.canon, self.W, max_clusters=batch_clusters,
+                                                  first_ordinal=self.next_ordinal), prefetch)
+
+    def run_batches(self, host_batches, prefetch=2):
+        """GPU over an iterator of HostBatch, the next ones being prepared on one host thread meanwhile."""
+        from concurrent.futures import ThreadPoolExecutor
+        it = iter(host_batches)
 
         def pack_next():
-            chunk = list(itertools.islice(it, batch_clusters))
-            if not chunk:
-                return None
-            first = state["ordinal"]
-            state["ordinal"] += len(chunk)
-            return build_batch_native(chunk, self.k, self.canon, self.W, stroi=self.stroi, first_ordinal=first)
+            return next(it, None)
 
         with ThreadPoolExecutor(max_workers=1) as pool:      # one packer thread keeps the record order
             pending = [pool.submit(pack_next) for _ in range(max(1, prefetch))]

@@ -264,6 +264,51 @@ def decode_keys(keys, k, key_words):
     return [row.tobytes().decode() for row in out]
 
 
+
+def _fill_from_packed(L, hb, handle, n_clusters, seq_ref):
+    """Copy a pf_packed result into `hb`; seq_ref(q) -> (cluster index, strain, Seqinfo) of input sequence q."""
+    import ctypes as C
+
+    from . import _lib
+    k, W = hb.k, hb.W
+    v = _lib.PackedView()
+    _lib.check(L.pf_packed_view(handle, C.byref(v)))
+
+    def arr(ptr, n, dtype):
+        return np.ctypeslib.as_array(ptr, shape=(n,)).view(dtype).copy() if n else np.zeros(0, dtype=dtype)
+    hb.packed = arr(v.packed, v.n_words, np.uint64)
+    hb.seg_word_off = arr(v.seg_word_off, v.n_segs, np.uint64)
+    hb.seg_len = arr(v.seg_len, v.n_segs, np.uint32)
+    hb.seg_sample = arr(v.seg_sample, v.n_segs, np.uint32)
+    hb.seg_ord_base = arr(v.seg_ord_base, v.n_segs, np.uint32)
+    hb.seg_strand_off = arr(v.seg_strand_off, v.n_segs, np.uint32)
+    hb.n_strand_words = int(v.n_strand_words)
+    hb.cluster_seg_off = arr(v.cluster_seg_off, n_clusters + 1, np.uint32)
+    hb.extra_cluster = arr(v.extra_cluster, v.n_extra, np.uint32)
+    hb.extra_ord = arr(v.extra_ord, v.n_extra, np.uint32)
+    hb.extra_bits = arr(v.extra_bits, v.n_extra * W, np.uint32).reshape(-1, W)
+    keys = C.string_at(v.extra_keys, v.n_extra * k) if v.n_extra else b""
+    hb.extra_keys = [keys[i * k:(i + 1) * k].decode("latin-1") for i in range(v.n_extra)]
+    hb.n_instances = int(v.n_instances)
+    nt = v.n_targets
+    t_seq = arr(v.target_seq, nt, np.uint32)
+    t_so = arr(v.target_seg_off, nt + 1, np.uint32)
+    t_ao = arr(v.target_ambig_off, nt + 1, np.uint32)
+    nts, nta = (int(t_so[-1]), int(t_ao[-1])) if nt else (0, 0)
+    t_si = arr(v.target_seg_index, nts, np.uint32)
+    t_ss = arr(v.target_seg_start, nts, np.uint32)
+    t_sn = arr(v.target_seg_nwin, nts, np.uint32)
+    t_ap = arr(v.target_ambig_pos, nta, np.uint32)
+    t_au = arr(v.target_ambig_used, nta, np.int8)
+    akeys = C.string_at(v.target_ambig_keys, nta * k) if nta else b""
+    for ti in range(nt):
+        ci, strain, s = seq_ref(int(t_seq[ti]))
+        segs = [(int(t_si[j]), int(t_ss[j]), int(t_sn[j])) for j in range(t_so[ti], t_so[ti + 1])]
+        ambig = {int(t_ap[j]): (akeys[j * k:(j + 1) * k].decode("latin-1"), int(t_au[j]))
+                 for j in range(t_ao[ti], t_ao[ti + 1])}
+        hb.targets.append(SeqMeta(ci, strain, s, 0, max(len(s.sequence) - k + 1, 0), segs, ambig))
+
+
 def build_batch_native(records, klength, canon, W, stroi=(), first_ordinal=0, want_strand=True):
     """Same result as build_batch, with the per-base work (packing, non-ACGT splitting, slow-path grouping)
     done by the library's host threads (pf_pack_records, csrc/pf_pack.cpp)."""
@@ -323,45 +368,7 @@ def build_batch_native(records, klength, canon, W, stroi=(), first_ordinal=0, wa
     handle = C.c_void_p()
     _lib.check(L.pf_pack_records(C.byref(pin), C.byref(handle)))
     try:
-        v = _lib.PackedView()
-        _lib.check(L.pf_packed_view(handle, C.byref(v)))
-
-        def arr(ptr, n, dtype):
-            return np.ctypeslib.as_array(ptr, shape=(n,)).view(dtype).copy() if n else np.zeros(0, dtype=dtype)
-        hb.packed = arr(v.packed, v.n_words, np.uint64)
-        hb.seg_word_off = arr(v.seg_word_off, v.n_segs, np.uint64)
-        hb.seg_len = arr(v.seg_len, v.n_segs, np.uint32)
-        hb.seg_sample = arr(v.seg_sample, v.n_segs, np.uint32)
-        hb.seg_ord_base = arr(v.seg_ord_base, v.n_segs, np.uint32)
-        hb.seg_strand_off = arr(v.seg_strand_off, v.n_segs, np.uint32)
-        hb.n_strand_words = int(v.n_strand_words)
-        hb.cluster_seg_off = arr(v.cluster_seg_off, len(cl_nstr) + 1, np.uint32)
-        hb.extra_cluster = arr(v.extra_cluster, v.n_extra, np.uint32)
-        hb.extra_ord = arr(v.extra_ord, v.n_extra, np.uint32)
-        hb.extra_bits = arr(v.extra_bits, v.n_extra * W, np.uint32).reshape(-1, W)
-        keys = C.string_at(v.extra_keys, v.n_extra * k) if v.n_extra else b""
-        hb.extra_keys = [keys[i * k:(i + 1) * k].decode("latin-1") for i in range(v.n_extra)]
-        hb.n_instances = int(v.n_instances)
-        nt = v.n_targets
-        t_seq = arr(v.target_seq, nt, np.uint32)
-        t_so = arr(v.target_seg_off, nt + 1, np.uint32)
-        t_ao = arr(v.target_ambig_off, nt + 1, np.uint32)
-        nts, nta = (int(t_so[-1]), int(t_ao[-1])) if nt else (0, 0)
-        t_si = arr(v.target_seg_index, nts, np.uint32)
-        t_ss = arr(v.target_seg_start, nts, np.uint32)
-        t_sn = arr(v.target_seg_nwin, nts, np.uint32)
-        t_ap = arr(v.target_ambig_pos, nta, np.uint32)
-        t_au = arr(v.target_ambig_used, nta, np.int8)
-        akeys = C.string_at(v.target_ambig_keys, nta * k) if nta else b""
-        ord_running = {}
-        for ti in range(nt):
-            q = int(t_seq[ti])
-            ci, strain, s = seq_ref[q]
-            segs = [(int(t_si[j]), int(t_ss[j]), int(t_sn[j])) for j in range(t_so[ti], t_so[ti + 1])]
-            ambig = {int(t_ap[j]): (akeys[j * k:(j + 1) * k].decode("latin-1"), int(t_au[j]))
-                     for j in range(t_ao[ti], t_ao[ti + 1])}
-            hb.targets.append(SeqMeta(ci, strain, s, 0, max(len(s.sequence) - k + 1, 0), segs, ambig))
-        del ord_running
+        _fill_from_packed(L, hb, handle, len(cl_nstr), seq_ref.__getitem__)
     finally:
         L.pf_packed_free(handle)
     hb.cluster_nstrains = np.asarray(cl_nstr, dtype=np.uint32)

@@ -134,3 +134,83 @@ def generate_cluster(c, names, flank=0, mean_len=900, min_len=150, max_len=6000,
 def generate(n_clusters, n_samples, first=0, shuffle_columns=None, **kw):
     names = sample_names(n_samples, shuffle_columns)
     return [generate_cluster(first + i, names, **kw) for i in range(n_clusters)]
+
+
+def write_pangenome(outdir, clusters, seed=1, wrap=60, drop_gff_for=(), missing_gene_rate=0.01, lower_rate=0.02,
+                    separate_fasta_for=()):
+    """Write `clusters` (flank=0) as an on-disk pangenome the way panfeed reads it: one Prokka-style GFF3 per sample
+    (CDS features, ##FASTA section) and a panaroo gene_presence_absence.csv.  Genes sit on 1-3 contigs per sample with
+    random spacers, some flush against a contig edge (offset clipping), - strand genes stored reverse-complemented.
+    Returns (csv_path, {sample: gff_path}, {sample: fasta_path or None})."""
+    import os
+    rng = np.random.Generator(np.random.PCG64(seed))
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    names = clusters[0].names
+    per_sample = {nm: [] for nm in names}          # (cluster index, copy, seq bytes, strand)
+    cells = [dict() for _ in clusters]
+    for ci, cl in enumerate(clusters):
+        copies = {}
+        for q in range(cl.n_seqs):
+            nm = names[int(cl.seq_sample[q])]
+            k = copies.get(nm, 0)
+            copies[nm] = k + 1
+            gid = f"{nm}_{cl.index:05d}_{k}"
+            per_sample[nm].append((gid, cl.seq_string(q).encode(), int(cl.seq_strand[q])))
+            cells[ci].setdefault(nm, []).append(gid)
+    os.makedirs(os.path.join(outdir, "gffs"), exist_ok=True)
+    gffs, fastas = {}, {}
+    for nm in names:
+        genes = per_sample[nm]
+        ncontig = int(rng.integers(1, 4))
+        contigs = [[] for _ in range(ncontig)]
+        for g in genes:
+            contigs[int(rng.integers(0, ncontig))].append(g)
+        gff_lines = ["##gff-version 3"]
+        fasta_lines = []
+        for c, glist in enumerate(contigs):
+            cname = f"{nm}_contig{c + 1}"
+            seq = bytearray()
+            first = True
+            for gid, s, strand in glist:
+                spacer = 0 if (first and rng.random() < 0.3) else int(rng.integers(3, 180))
+                first = False
+                seq += np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, spacer)].tobytes()
+                start = len(seq) + 1
+                seq += s if strand > 0 else s[::-1].translate(comp)
+                end = len(seq)
+                if rng.random() >= missing_gene_rate:
+                    gff_lines.append(f"{cname}\tProdigal\tCDS\t{start}\t{end}\t.\t{'+' if strand > 0 else '-'}\t0\t"
+                                     f"ID={gid};Parent={gid}_gene;product=hypothetical protein")
+                    gff_lines.append(f"{cname}\tProdigal\tgene\t{start}\t{end}\t.\t{'+' if strand > 0 else '-'}\t.\tID={gid}_gene")
+            if rng.random() < 0.7:
+                seq += np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(rng.integers(1, 150)))].tobytes()
+            seq = bytes(seq)
+            if lower_rate:
+                arr = np.frombuffer(seq, np.uint8).copy()
+                low = rng.random(len(arr)) < lower_rate
+                arr[low] |= 0x20
+                seq = arr.tobytes()
+            fasta_lines.append(f">{cname} len={len(seq)}")
+            fasta_lines += [seq[i:i + wrap].decode() for i in range(0, len(seq), wrap)]
+            gff_lines.insert(1 + c, f"##sequence-region {cname} 1 {len(seq)}")
+        if nm in drop_gff_for:
+            continue
+        path = os.path.join(outdir, "gffs", f"{nm}.gff")
+        with open(path, "w") as fh:
+            fh.write("\n".join(gff_lines) + "\n")
+            if nm in separate_fasta_for:
+                fa = os.path.join(outdir, "gffs", f"{nm}.fasta")
+                with open(fa, "w") as f2:
+                    f2.write("\n".join(fasta_lines) + "\n")
+                fastas[nm] = fa
+            else:
+                fh.write("##FASTA\n" + "\n".join(fasta_lines) + "\n")
+                fastas[nm] = None
+        gffs[nm] = path
+    csv_path = os.path.join(outdir, "gene_presence_absence.csv")
+    with open(csv_path, "w") as fh:
+        fh.write(",".join(["Gene", "Non-unique Gene name", "Annotation"] + names) + "\n")
+        for ci, cl in enumerate(clusters):
+            row = [cl.idx, "", '"hypothetical protein, putative"'] + [";".join(cells[ci].get(nm, [])) for nm in names]
+            fh.write(",".join(row) + "\n")
+    return csv_path, gffs, fastas

@@ -1,0 +1,38 @@
+"""Row N1 end to end on the GPU: files on disk -> native reader -> packer -> HIP path -> the three TSV texts,
+against the oracle run over the Python restatement's records (oracle/input_restatement.py; parity unpinned at
+the pyfaidx boundary)."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("k,canon,up,down,dsc,cm", [(31, True, 0, 0, False, False), (21, False, 60, 40, False, True),
+                                                  (25, True, 30, 50, True, False)])
+def test_files_to_tsv(tmp_path, k, canon, up, down, dsc, cm):
+    from oracle import input_restatement as ir
+    from oracle import oracle as po
+    from panfeed_amd import native_input as ni
+    from panfeed_amd import synth
+    from panfeed_amd.engine import Engine
+    cl = synth.generate(40, 70, first=77, flank=0, mean_len=350, min_len=50, max_len=1200, n_rate=0.03,
+                        paralog_rate=0.05, shuffle_columns=9)
+    names = cl[0].names
+    csvp, gffs, fas = synth.write_pangenome(str(tmp_path), cl, drop_gff_for=(names[11],),
+                                            separate_fasta_for=(names[1],))
+    gn = sorted(gffs)
+    tg = (names[0], names[33])
+    strains, table = ir.load_table(csvp)
+    data = ir.load_genomes(gn, [gffs[n] for n in gn], [fas[n] for n in gn])
+    recs = list(ir.iter_gene_clusters(strains, table, data, up, down, dsc))
+    run = po.OracleRun(klength=k, canon=canon, stroi=set(tg), consider_missing=cm)
+    run.feed(recs)
+    ek, ekh, ehp = run.texts()
+    eng = Engine(klength=k, canon=canon, max_strains=96, stroi=set(tg), consider_missing=cm)
+    with ni.Pangenome(csvp, None, None, up, down, dsc, targets=tg, genome_names=gn, gff_paths=[gffs[n] for n in gn],
+                      fasta_paths=[fas[n] for n in gn]) as pg:
+        outs = list(eng.run_pangenome(pg, batch_clusters=9))
+    assert len(outs) == 5
+    assert "".join(o.kmers_to_hashes for o in outs) == ekh
+    assert "".join(o.hashes_to_patterns for o in outs) == ehp
+    assert "".join(o.kmers_tsv for o in outs) == ek
+    eng.close()

@@ -1,0 +1,121 @@
+"""Row N1: the native reader (csrc/pf_input.cpp) against the Python restatement of
+/root/reference/panfeed/input.py:274-468 (oracle/input_restatement.py) on a synthetic on-disk pangenome.
+PARITY UNPINNED at the pyfaidx boundary -- both sides restate the same reading of input.py."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import input_restatement as ir
+from panfeed_amd import native_input as ni
+from panfeed_amd import packing, synth
+
+
+@pytest.fixture(scope="module")
+def pangenome(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("pangenome"))
+    cl = synth.generate(30, 12, flank=0, mean_len=300, min_len=40, max_len=900, n_rate=0.05, paralog_rate=0.1,
+                        shuffle_columns=3)
+    names = cl[0].names
+    csvp, gffs, fas = synth.write_pangenome(d, cl, drop_gff_for=(names[2],), separate_fasta_for=(names[4], names[5]))
+    gn = sorted(gffs)
+    return dict(dir=d, csv=csvp, names=names, genomes=gn, gff=[gffs[n] for n in gn], fasta=[fas[n] for n in gn])
+
+
+def _expected(p, up, down, dsc, genes=None, log=None):
+    strains, table = ir.load_table(p["csv"])
+    data = ir.load_genomes(p["genomes"], p["gff"], p["fasta"])
+    return strains, list(ir.iter_gene_clusters(strains, table, data, up, down, dsc, gene_list=genes, log=log))
+
+
+def _open(p, up=0, down=0, dsc=False, **kw):
+    return ni.Pangenome(p["csv"], None, None, up, down, dsc, genome_names=p["genomes"], gff_paths=p["gff"],
+                        fasta_paths=p["fasta"], **kw)
+
+
+@pytest.mark.parametrize("up,down,dsc", [(0, 0, False), (50, 30, False), (200, 200, False), (20, 40, True),
+                                         (0, 10, True)])
+def test_records_equal_restatement(pangenome, up, down, dsc):
+    log = []
+    strains, exp = _expected(pangenome, up, down, dsc, log=log)
+    with _open(pangenome, up, down, dsc) as pg:
+        assert pg.strains == strains and pg.sorted_strains == sorted(strains)
+        assert pg.n_clusters == len(exp)
+        got = list(pg.records(7))
+        nlog = pg.take_log()
+    assert len(got) == len(exp)
+    nseq = 0
+    for (g, gi, gp), (e, ei, ep) in zip(got, exp):
+        assert gi == ei
+        assert gp.dtype == ep.dtype and (gp == ep).all()
+        assert list(g.keys()) == list(e.keys())        # dict order: present strains in table order, absent sorted
+        for s in g:
+            assert g[s] == e[s], (gi, s)
+            nseq += len(g[s])
+    assert nseq > 200
+    assert nlog.strip().split("\n") == log and len(log) >= 2      # the missing-GFF warning + the dropped CDS lines
+
+
+def test_gene_list_filter(pangenome):
+    strains, table = ir.load_table(pangenome["csv"])
+    genes = [table[3][0], table[17][0], "not_a_cluster"]
+    _s, exp = _expected(pangenome, 10, 10, False, genes=set(genes))
+    with _open(pangenome, 10, 10, genes=genes) as pg:
+        got = list(pg.records(4))
+    assert [g[1] for g in got] == [e[1] for e in exp] == genes[:2]
+    assert all(g[0] == e[0] for g, e in zip(got, exp))
+
+
+@pytest.mark.parametrize("k,canon,ntg", [(31, True, 0), (15, False, 2), (40, True, 1)])
+def test_batches_equal_packer_over_restated_records(pangenome, k, canon, ntg):
+    """reader -> pf_pack_records by pointer == the numpy packer over the restated records"""
+    tg = tuple(pangenome["names"][i] for i in (0, 7)[:ntg])
+    _s, exp = _expected(pangenome, 40, 25, False)
+    W = 1
+    with _open(pangenome, 40, 25, targets=tg) as pg:
+        hbs = list(pg.batches(k, canon, W, max_clusters=11, first_ordinal=5))
+    pos = 0
+    for hb in hbs:
+        n = len(hb.idx)
+        ref = packing.build_batch(exp[pos:pos + n], k, canon, W, stroi=tg, first_ordinal=5 + pos)
+        for f in ("packed", "seg_word_off", "seg_len", "seg_sample", "seg_ord_base", "seg_strand_off",
+                  "cluster_seg_off", "extra_cluster", "extra_ord", "extra_bits", "cluster_nstrains",
+                  "cluster_npresab", "cluster_presab", "cluster_ordinal"):
+            assert np.array_equal(np.asarray(getattr(hb, f)), np.asarray(getattr(ref, f))), f
+        assert hb.extra_keys == ref.extra_keys and hb.idx == ref.idx and hb.sorted_strains == ref.sorted_strains
+        assert hb.n_instances == ref.n_instances and hb.n_strand_words == ref.n_strand_words
+        assert all((x == y).all() for x, y in zip(hb.presab, ref.presab))
+        assert [(x.cluster, x.strain, x.seq, x.segs, x.ambig) for x in hb.targets] == \
+               [(y.cluster, y.strain, y.seq, y.segs, y.ambig) for y in ref.targets]
+        pos += n
+    assert pos == len(exp)
+
+
+def test_discovery_and_directory_open(pangenome, tmp_path):
+    """what_are_my_inputfiles (input.py:16-64): directory and file-of-files listings, .gff only, fasta needs a gff"""
+    gffdir = os.path.join(pangenome["dir"], "gffs")
+    names, with_fa, gffs, fastas = ni.what_are_my_inputfiles(gffdir, gffdir)
+    assert names == pangenome["genomes"]
+    assert with_fa == sorted(n for n, f in zip(pangenome["genomes"], pangenome["fasta"]) if f)
+    fof = tmp_path / "gffs.txt"
+    fof.write_text("\n".join(pangenome["gff"] + ["/x/readme.txt"]) + "\n")
+    names2, _fa, gffs2, _ = ni.what_are_my_inputfiles(str(fof))
+    assert names2 == names and gffs2 == gffs
+    with pytest.raises(FileNotFoundError):
+        ni.what_are_my_inputfiles(str(tmp_path))
+    _s, exp = _expected(pangenome, 5, 5, False)
+    with ni.Pangenome(pangenome["csv"], gffdir, gffdir, 5, 5) as pg:
+        got = list(pg.records(100))
+    assert all(g[0] == e[0] and g[1] == e[1] for g, e in zip(got, exp)) and len(got) == len(exp)
+
+
+def test_reader_errors(pangenome, tmp_path):
+    from panfeed_amd._lib import PanfeedHipError
+    with pytest.raises(PanfeedHipError):
+        ni.Pangenome(str(tmp_path / "nope.csv"), None, genome_names=["a"], gff_paths=[pangenome["gff"][0]])
+    with pytest.raises(PanfeedHipError):
+        ni.Pangenome(pangenome["csv"], None, genome_names=["a"], gff_paths=[str(tmp_path / "nope.gff")])
+    bad = tmp_path / "nofasta.gff"
+    bad.write_text("##gff-version 3\nc1\tx\tCDS\t1\t9\t.\t+\t0\tID=g1\n")
+    with pytest.raises(PanfeedHipError):        # the reference's .split("##FASTA")[1] IndexError (input.py:104-107)
+        ni.Pangenome(pangenome["csv"], None, genome_names=["a"], gff_paths=[str(bad)])
