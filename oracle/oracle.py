@@ -133,6 +133,11 @@ class OracleRun:
                                    int(s.start), int(s.end), int(s.strand), 0, int(s.offset))
                     j += 1
             pa = np.ascontiguousarray(np.asarray(presab), dtype=np.int64)
+            if self.opts.consider_missing and len(pa) != n:
+                # init_presabs_vector's `v[clusterpresab == 0] = np.nan` (panfeed.py:19): numpy refuses a boolean
+                # mask of another length -- e.g. a strain of the table without a GFF under --consider-missing-cluster
+                raise IndexError(f"boolean index did not match indexed array along axis 0; size of axis is {n} "
+                                 f"but size of corresponding boolean axis is {len(pa)}")
             keep += [c_names, tgt, seqs, pa]
             arr[ci] = _Cluster(_b(idx), n, nseq, c_names, tgt, seqs, len(pa), 0,
                                pa.ctypes.data_as(C.POINTER(C.c_int64)))

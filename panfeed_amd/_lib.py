@@ -138,6 +138,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build the HIP extension first "
                           "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+    try:
+        # one HIP runtime per process: PyTorch ships its own libamdhip64; if this library pulled in the system copy
+        # first, a later `import torch` (device tensors for the RCCL merge) would bring a second runtime that finds
+        # no GPU.  Importing torch first makes both resolve to the same loaded runtime.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here means header and library disagree

@@ -482,6 +482,10 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
                 return fail(PF_ERR_ARG, "cluster_seg_off not monotone / out of range at %u", i);
             if (b->cluster_nstrains[i] > c->o.max_strains || b->cluster_npresab[i] > c->o.max_strains)
                 return fail(PF_ERR_ARG, "cluster %u has more strains than max_strains", i);
+            // init_presabs_vector, panfeed.py:19: a boolean mask must have the vector's length (numpy IndexError)
+            if (c->o.consider_missing && b->cluster_nstrains[i] != b->cluster_npresab[i])
+                return fail(PF_ERR_ARG, "cluster %u: consider_missing needs len(clusterpresab) == number of strains "
+                            "(%u != %u)", i, b->cluster_npresab[i], b->cluster_nstrains[i]);
         }
         if (C && b->cluster_seg_off[0] != 0) return fail(PF_ERR_ARG, "cluster_seg_off[0] must be 0");
         for (uint32_t s = 0; s < NSEG; s++) {

@@ -514,20 +514,29 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     return x;
 }
 
-constexpr uint32_t DEDUP_THREADS = 1024;
+constexpr uint32_t DEDUP_THREADS = 512;
+constexpr uint32_t DEDUP_GTAB = 256;          // hash groups table (mode 1 needs <= DEDUP_MAX_D groups)
+constexpr uint32_t DEDUP_POOL = 6144;         // u64 words of LDS holding one copy of every distinct sequence
+constexpr uint32_t DEDUP_CH = 4;              // 16-byte chunks per lane kept in registers (CH * GL * 64 bases per segment)
+constexpr uint32_t DEDUP_U = 2;               // segments in flight per 16-lane group
+constexpr uint32_t DEDUP_GL = 8;              // lanes that share one segment
+constexpr uint32_t DEDUP_UNSET = 0xFFFFFFFFu;
+constexpr uint32_t DEDUP_INGLOBAL = 0x80000000u;
 
 __global__ __launch_bounds__(DEDUP_THREADS) void cluster_dedup_kernel(DedupParams p) {
-    // 64 KiB in all: two workgroups per CU
-    __shared__ uint64_t s_hash[DEDUP_MAX_SEGS];
-    __shared__ uint64_t t_val[DEDUP_TAB];      // per hash group: min of (ord_base << 32 | local index); the group's
-                                               // hash is s_hash[] of whichever member currently holds the minimum
+    // ~78 KiB in all: two workgroups per CU
+    __shared__ uint64_t t_key[DEDUP_GTAB];     // content hash of the group
+    __shared__ uint64_t t_val[DEDUP_GTAB];     // min over the group's members of (ord_base << 32 | local index)
+    __shared__ uint32_t t_pool[DEDUP_GTAB];    // where the group's sequence sits: pool word offset, or INGLOBAL | index
+    __shared__ uint32_t t_len[DEDUP_GTAB];     // its length in bases
+    __shared__ uint64_t s_pool[DEDUP_POOL];
     __shared__ uint32_t s_rep[DEDUP_MAX_SEGS]; // low 16 bits: local index of the representative; a representative
                                                // also carries its distinct index in the high 16 bits
     __shared__ uint32_t s_woff[DEDUP_MAX_SEGS];// word offset relative to the cluster's first segment
     __shared__ uint32_t s_len[DEDUP_MAX_SEGS];
     __shared__ uint32_t r_list[DEDUP_MAX_D];   // representatives (local indices), unordered
     __shared__ uint32_t r_ord0[DEDUP_MAX_D], r_ninst[DEDUP_MAX_D], r_dense[DEDUP_MAX_D];   // by distinct index
-    __shared__ uint32_t sh_bad, sh_nrep, sh_total;
+    __shared__ uint32_t sh_bad, sh_nrep, sh_total, sh_ngroups, sh_pool_used;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t c = blockIdx.x;
@@ -539,9 +548,9 @@ __global__ __launch_bounds__(DEDUP_THREADS) void cluster_dedup_kernel(DedupParam
     const uint32_t Wp = (p.W + 3) & ~3u;
 
     bool mode1 = p.enable && n >= 4 && n <= DEDUP_MAX_SEGS;
-    if (tid == 0) { sh_bad = 0; sh_nrep = 0; sh_total = 0; }
+    if (tid == 0) { sh_bad = 0; sh_nrep = 0; sh_total = 0; sh_ngroups = 0; sh_pool_used = 0; }
     if (mode1) {
-        for (uint32_t i = tid; i < DEDUP_TAB; i += DEDUP_THREADS) t_val[i] = EMPTY64;
+        for (uint32_t i = tid; i < DEDUP_GTAB; i += DEDUP_THREADS) { t_key[i] = EMPTY64; t_val[i] = EMPTY64; t_pool[i] = DEDUP_UNSET; }
     }
     __syncthreads();
     if (mode1) {
@@ -556,99 +565,151 @@ __global__ __launch_bounds__(DEDUP_THREADS) void cluster_dedup_kernel(DedupParam
         if (wspan >= 0xFFFFFFFFull) mode1 = false;      // uniform; a cluster this large is not worth it anyway
     }
     if (mode1) {
-        // ---- 1. 64-bit content hash per segment: 16 lanes per segment, four segments in flight per group
+        // ---- 1. one pass over the packed bytes: DEDUP_GL lanes per segment, DEDUP_U segments in flight per group.  A segment is
+        // read once into registers, hashed (64 bits), looked up in the group table; the first segment of a group
+        // leaves its words in the LDS pool, every later one is compared with the pool word for word (exact).
+        // Per wave the steps run in lockstep -- claim, publish, then wait -- so a waiting group never sits in front
+        // of the group it waits for.
         const ulonglong2* cbase = reinterpret_cast<const ulonglong2*>(p.packed + p.seg_word_off[seg0]);
-        const uint32_t grp = tid >> 4, gl = tid & 15, ngrp = DEDUP_THREADS >> 4;
-        for (uint32_t s = grp; s < n; s += 4 * ngrp) {
-            uint32_t len[4], pc[4], pmax = 0;
-            const ulonglong2* w[4];
-            uint64_t acc[4] = {0, 0, 0, 0};
+        const uint32_t grp = tid / DEDUP_GL, gl = tid % DEDUP_GL, ngrp = DEDUP_THREADS / DEDUP_GL;
+        const uint32_t wave_grp0 = (tid >> 6) * (64 / DEDUP_GL);
+        for (uint32_t sw = wave_grp0; sw < n; sw += DEDUP_U * ngrp) {
+            const uint32_t s = sw + (grp - wave_grp0);
+            uint32_t len[DEDUP_U], pc[DEDUP_U], si[DEDUP_U], slot[DEDUP_U];
+            bool has[DEDUP_U], registrar[DEDUP_U];
+            const ulonglong2* w[DEDUP_U];
+            ulonglong2 v[DEDUP_U][DEDUP_CH];
+            uint64_t acc[DEDUP_U] = {};
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t si = s + u * ngrp;
-                const bool has = si < n;
-                len[u] = has ? s_len[si] : 0;
+            for (int u = 0; u < (int)DEDUP_U; u++) {
+                si[u] = s + u * ngrp;
+                has[u] = si[u] < n;
+                len[u] = has[u] ? s_len[si[u]] : 0;
                 pc[u] = (len[u] + 63) >> 6;
-                w[u] = cbase + ((has ? s_woff[si] : 0) >> 1);
-                pmax = max(pmax, pc[u]);
+                w[u] = cbase + ((has[u] ? s_woff[si[u]] : 0) >> 1);
             }
-            for (uint32_t j = gl; j < pmax; j += 16) {
-                ulonglong2 v[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) v[u] = j < pc[u] ? w[u][j] : make_ulonglong2(0, 0);
+            for (int u = 0; u < (int)DEDUP_U; u++)
 #pragma unroll
-                for (int u = 0; u < 4; u++)
+                for (uint32_t q = 0; q < DEDUP_CH; q++) {
+                    const uint32_t j = gl + DEDUP_GL * q;
+                    v[u][q] = j < pc[u] ? w[u][j] : make_ulonglong2(0, 0);
+                }
+#pragma unroll
+            for (int u = 0; u < (int)DEDUP_U; u++) {
+#pragma unroll
+                for (uint32_t q = 0; q < DEDUP_CH; q++) {
+                    const uint32_t j = gl + DEDUP_GL * q;
                     if (j < pc[u])
-                        acc[u] += mix64(v[u].x + 0x9E3779B97F4A7C15ull * (2 * j + 1)) ^
-                                  mix64(v[u].y + 0xC2B2AE3D27D4EB4Full * (2 * j + 2));
+                        acc[u] += mix64(v[u][q].x + 0x9E3779B97F4A7C15ull * (2 * j + 1)) ^
+                                  mix64(v[u][q].y + 0xC2B2AE3D27D4EB4Full * (2 * j + 2));
+                }
+                for (uint32_t j = gl + DEDUP_GL * DEDUP_CH; j < pc[u]; j += DEDUP_GL) {      // longer than the registers hold
+                    const ulonglong2 x = w[u][j];
+                    acc[u] += mix64(x.x + 0x9E3779B97F4A7C15ull * (2 * j + 1)) ^ mix64(x.y + 0xC2B2AE3D27D4EB4Full * (2 * j + 2));
+                }
             }
+            // claim: lane 0 of the group finds or opens the hash group
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < (int)DEDUP_U; u++) {
                 uint64_t a = acc[u];
-                for (int d = 1; d < 16; d <<= 1) a += __shfl_xor(a, d);
+                for (int d = 1; d < (int)DEDUP_GL; d <<= 1) a += __shfl_xor(a, d);
                 uint64_t h = mix64(a ^ ((uint64_t)len[u] << 40));
                 if (h == EMPTY64) h = EMPTY64 - 1;
-                const uint32_t si = s + u * ngrp;
-                if (gl == 0 && si < n) s_hash[si] = h;
-            }
-        }
-        __syncthreads();
-        // ---- 2. group by hash; the group's representative is the copy with the lowest ordinal
-        for (uint32_t s = tid; s < n; s += DEDUP_THREADS) {
-            const uint64_t h = s_hash[s];
-            const uint64_t mine = ((uint64_t)p.seg_ord_base[seg0 + s] << 32) | s;
-            uint32_t slot = (uint32_t)h & (DEDUP_TAB - 1);
-            for (;;) {
-                uint64_t cur = __hip_atomic_load(&t_val[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (cur == EMPTY64) {
-                    cur = atomicCAS((unsigned long long*)&t_val[slot], (unsigned long long)EMPTY64, (unsigned long long)mine);
-                    if (cur == EMPTY64) break;                       // first member of a new group
-                }
-                if (s_hash[(uint32_t)cur] == h) {                    // any holder of the slot is a member of its group
-                    atomicMin((unsigned long long*)&t_val[slot], (unsigned long long)mine);
-                    break;
-                }
-                slot = (slot + 1) & (DEDUP_TAB - 1);
-            }
-            s_rep[s] = slot;     // table slot for now
-        }
-        __syncthreads();
-        for (uint32_t s = tid; s < n; s += DEDUP_THREADS) s_rep[s] = (uint32_t)t_val[s_rep[s]];
-        __syncthreads();
-        // ---- 3. verify every copy against its representative, word for word (two copies in flight per group)
-        for (uint32_t s = grp; s < n; s += 2 * ngrp) {
-            bool diff = false;
-            uint32_t pc[2];
-            const ulonglong2 *a[2], *b[2];
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const uint32_t si = s + u * ngrp;
-                pc[u] = 0; a[u] = cbase; b[u] = cbase;
-                if (si < n) {
-                    const uint32_t r = s_rep[si];
-                    if (r != si) {
-                        const uint32_t len = s_len[si];
-                        diff = diff || len != s_len[r];
-                        pc[u] = (len + 63) >> 6;
-                        a[u] = cbase + (s_woff[si] >> 1);
-                        b[u] = cbase + (s_woff[r] >> 1);
+                uint32_t sl = 0, reg = 0;
+                if (gl == 0 && has[u]) {
+                    sl = (uint32_t)h & (DEDUP_GTAB - 1);
+                    for (uint32_t probes = 0;; probes++) {
+                        uint64_t cur = __hip_atomic_load(&t_key[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (cur == EMPTY64) {
+                            cur = atomicCAS((unsigned long long*)&t_key[sl], (unsigned long long)EMPTY64, (unsigned long long)h);
+                            if (cur == EMPTY64) {
+                                reg = 1;
+                                if (atomicAdd(&sh_ngroups, 1u) >= DEDUP_MAX_D) sh_bad = 1;    // too many distinct sequences
+                                break;
+                            }
+                        }
+                        if (cur == h) break;
+                        sl = (sl + 1) & (DEDUP_GTAB - 1);
+                        if (probes >= DEDUP_GTAB) { sh_bad = 1; sl = DEDUP_GTAB; break; }
                     }
+                    if (sl < DEDUP_GTAB)
+                        atomicMin((unsigned long long*)&t_val[sl],
+                                  (unsigned long long)(((uint64_t)p.seg_ord_base[seg0 + si[u]] << 32) | si[u]));
+                    s_rep[si[u]] = sl;       // table slot for now
                 }
+                slot[u] = __shfl(sl, lane & ~(DEDUP_GL - 1));
+                registrar[u] = __shfl(reg, lane & ~(DEDUP_GL - 1)) != 0;
+                if (slot[u] >= DEDUP_GTAB) has[u] = false;      // cluster given up (mode 0)
             }
-            if (!diff) {
-                for (uint32_t j = gl; j < max(pc[0], pc[1]); j += 16) {
-                    ulonglong2 x[2], y[2];
+            // publish: the first segment of a group leaves its words in the pool
 #pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        x[u] = j < pc[u] ? a[u][j] : make_ulonglong2(0, 0);
-                        y[u] = j < pc[u] ? b[u][j] : make_ulonglong2(0, 0);
+            for (int u = 0; u < (int)DEDUP_U; u++) {
+                if (has[u] && registrar[u]) {
+                    uint32_t off = 0;
+                    if (gl == 0) off = atomicAdd(&sh_pool_used, 2 * pc[u]);
+                    off = __shfl(off, lane & ~(DEDUP_GL - 1));
+                    const bool fits = off + 2 * pc[u] <= DEDUP_POOL;
+                    if (fits) {
+#pragma unroll
+                        for (uint32_t q = 0; q < DEDUP_CH; q++) {
+                            const uint32_t j = gl + DEDUP_GL * q;
+                            if (j < pc[u]) { s_pool[off + 2 * j] = v[u][q].x; s_pool[off + 2 * j + 1] = v[u][q].y; }
+                        }
+                        for (uint32_t j = gl + DEDUP_GL * DEDUP_CH; j < pc[u]; j += DEDUP_GL) {
+                            const ulonglong2 x = w[u][j];
+                            s_pool[off + 2 * j] = x.x; s_pool[off + 2 * j + 1] = x.y;
+                        }
                     }
-#pragma unroll
-                    for (int u = 0; u < 2; u++) diff = diff || x[u].x != y[u].x || x[u].y != y[u].y;
+                    if (gl == 0) t_len[slot[u]] = len[u];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    // all the group's stores are ahead of the offset: a wave's LDS stores complete in program order
+                    if (gl == 0)
+                        __hip_atomic_store(&t_pool[slot[u]], fits ? off : (DEDUP_INGLOBAL | si[u]), __ATOMIC_RELEASE,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
-            if (diff) sh_bad = 1;     // a 64-bit hash collision: give up on this cluster (mode 0), stay exact
+            // compare: every other segment of the group against the pool (or against the first one's global words)
+#pragma unroll
+            for (int u = 0; u < (int)DEDUP_U; u++) {
+                if (has[u] && !registrar[u]) {
+                    uint32_t pp;
+                    while ((pp = __hip_atomic_load(&t_pool[slot[u]], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == DEDUP_UNSET)
+                        __builtin_amdgcn_s_sleep(1);
+                    bool diff = t_len[slot[u]] != len[u];
+                    if (diff) {
+                    } else if (pp & DEDUP_INGLOBAL) {
+                        const uint32_t r = pp & ~DEDUP_INGLOBAL;
+                        const ulonglong2* b = cbase + (s_woff[r] >> 1);
+                        {
+#pragma unroll
+                            for (uint32_t q = 0; q < DEDUP_CH; q++) {
+                                const uint32_t j = gl + DEDUP_GL * q;
+                                if (j < pc[u]) { const ulonglong2 y = b[j]; diff = diff || y.x != v[u][q].x || y.y != v[u][q].y; }
+                            }
+                            for (uint32_t j = gl + DEDUP_GL * DEDUP_CH; j < pc[u]; j += DEDUP_GL) {
+                                const ulonglong2 x = w[u][j], y = b[j];
+                                diff = diff || x.x != y.x || x.y != y.y;
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (uint32_t q = 0; q < DEDUP_CH; q++) {
+                            const uint32_t j = gl + DEDUP_GL * q;
+                            if (j < pc[u]) diff = diff || s_pool[pp + 2 * j] != v[u][q].x || s_pool[pp + 2 * j + 1] != v[u][q].y;
+                        }
+                        for (uint32_t j = gl + DEDUP_GL * DEDUP_CH; j < pc[u]; j += DEDUP_GL) {
+                            const ulonglong2 x = w[u][j];
+                            diff = diff || s_pool[pp + 2 * j] != x.x || s_pool[pp + 2 * j + 1] != x.y;
+                        }
+                    }
+                    if (diff) sh_bad = 1;     // a 64-bit hash collision: give up on this cluster (mode 0), stay exact
+                }
+            }
         }
+        __syncthreads();
+        if (!sh_bad)
+            for (uint32_t s = tid; s < n; s += DEDUP_THREADS) s_rep[s] = (uint32_t)t_val[s_rep[s]];
         __syncthreads();
         // ---- 4. representatives -> distinct indices in ordinal order
         for (uint32_t s = tid; s < n; s += DEDUP_THREADS)

@@ -81,6 +81,12 @@ class Engine:
 
     # ------------------------------------------------------------------ device calls
     def submit_host_batch(self, hb):
+        if self.consider_missing and not np.array_equal(hb.cluster_nstrains, hb.cluster_npresab):
+            # the reference stops in init_presabs_vector (panfeed.py:19): a boolean mask of another length
+            ci = int(np.flatnonzero(np.asarray(hb.cluster_nstrains) != np.asarray(hb.cluster_npresab))[0])
+            raise IndexError(f"cluster {hb.idx[ci]}: boolean index did not match indexed array along axis 0; size of "
+                             f"axis is {int(hb.cluster_nstrains[ci])} but size of corresponding boolean axis is "
+                             f"{int(hb.cluster_npresab[ci])}")
         b = _lib.Batch()
         b.n_clusters = hb.n_clusters
         b.n_segs = len(hb.seg_len)

@@ -138,7 +138,7 @@ def generate(n_clusters, n_samples, first=0, shuffle_columns=None, **kw):
 
 def write_pangenome(outdir, clusters, seed=1, wrap=60, drop_gff_for=(), missing_gene_rate=0.01, lower_rate=0.02,
                     separate_fasta_for=()):
-    """Write `clusters` (flank=0) as an on-disk pangenome the way panfeed reads it: one Prokka-style GFF3 per sample
+    """Write `clusters` as an on-disk pangenome the way panfeed reads it: one Prokka-style GFF3 per sample
     (CDS features, ##FASTA section) and a panaroo gene_presence_absence.csv.  Genes sit on 1-3 contigs per sample with
     random spacers, some flush against a contig edge (offset clipping), - strand genes stored reverse-complemented.
     Returns (csv_path, {sample: gff_path}, {sample: fasta_path or None})."""
@@ -155,7 +155,7 @@ def write_pangenome(outdir, clusters, seed=1, wrap=60, drop_gff_for=(), missing_
             k = copies.get(nm, 0)
             copies[nm] = k + 1
             gid = f"{nm}_{cl.index:05d}_{k}"
-            per_sample[nm].append((gid, cl.seq_string(q).encode(), int(cl.seq_strand[q])))
+            per_sample[nm].append((gid, cl.seq_string(q).encode(), int(cl.seq_strand[q]), int(cl.up)))
             cells[ci].setdefault(nm, []).append(gid)
     os.makedirs(os.path.join(outdir, "gffs"), exist_ok=True)
     gffs, fastas = {}, {}
@@ -171,13 +171,13 @@ def write_pangenome(outdir, clusters, seed=1, wrap=60, drop_gff_for=(), missing_
             cname = f"{nm}_contig{c + 1}"
             seq = bytearray()
             first = True
-            for gid, s, strand in glist:
+            for gid, s, strand, inset in glist:
                 spacer = 0 if (first and rng.random() < 0.3) else int(rng.integers(3, 180))
                 first = False
                 seq += np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, spacer)].tobytes()
-                start = len(seq) + 1
+                start = len(seq) + 1 + inset          # clusters made with flank=F: the CDS is the inner part, so
                 seq += s if strand > 0 else s[::-1].translate(comp)
-                end = len(seq)
+                end = len(seq) - inset                # reading with upstream=downstream=F returns the whole allele
                 if rng.random() >= missing_gene_rate:
                     gff_lines.append(f"{cname}\tProdigal\tCDS\t{start}\t{end}\t.\t{'+' if strand > 0 else '-'}\t0\t"
                                      f"ID={gid};Parent={gid}_gene;product=hypothetical protein")

@@ -110,6 +110,41 @@ def test_seeded_vs_oracle(k, canon, S, flank, dedup):
     eng.close()
 
 
+def test_dedup_single_pass_paths():
+    """cluster_dedup_kernel's one-pass grouping: segments longer than its registers hold, more distinct bytes than
+    its LDS pool holds (compare against the first copy's global words), sequences that differ only in the last
+    base or only by trailing A's (identical packed words, different lengths)"""
+    from panfeed_amd.classes import Seqinfo
+    from panfeed_amd.engine import Engine
+    rng = np.random.default_rng(11)
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    names = [f"q{i:03d}" for i in range(90)]
+
+    def mk(seq, i, j=0):
+        return Seqinfo(seq.decode(), seq.translate(comp).decode(), f"g{i}_{j}", "ctg", 5, 5 + len(seq) - 1, 1, 0)
+
+    def rnd(L):
+        return np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, L)].tobytes()
+    ones = np.ones(90, dtype=np.int64)
+    recs = []
+    a = [rnd(5500), rnd(5500), rnd(4100)]
+    a.append(a[0][:-1] + (b"C" if a[0][-1:] != b"C" else b"G"))         # differs in the very last base
+    recs.append(({nm: [mk(a[i % 4], i)] for i, nm in enumerate(names)}, "long", ones))
+    b = [rnd(5000) for _ in range(40)]                                   # 40 x 1250 B > the 48 KiB pool
+    recs.append(({nm: [mk(b[i % 40], i)] for i, nm in enumerate(names)}, "poolover", ones))
+    x = rnd(250)[:-1] + b"C"
+    c = [x, x + b"A", x + b"AA", x + b"A" * 70, x[:-1] + b"A"]          # same words, other lengths
+    recs.append(({nm: [mk(c[i % 5], i)] for i, nm in enumerate(names)}, "trailingA", ones))
+    eng = Engine(klength=31, max_strains=96)
+    out = eng.run(recs)
+    assert out.timing["n_dedup_clusters"] == 3
+    (ek, ekh, ehp), st = _oracle_texts(recs, klength=31)
+    assert out.kmers_to_hashes == ekh
+    assert out.hashes_to_patterns == ehp
+    assert out.stats["unique_kmers"] == st["unique_kmers"]
+    eng.close()
+
+
 def _diverse_records(n_samples, length, seed, n_clusters=2):
     """every sample carries its own random sequence: unique k-mers ~ instances (table overflow path)"""
     from panfeed_amd.classes import Seqinfo

@@ -119,3 +119,13 @@ def test_reader_errors(pangenome, tmp_path):
     bad.write_text("##gff-version 3\nc1\tx\tCDS\t1\t9\t.\t+\t0\tID=g1\n")
     with pytest.raises(PanfeedHipError):        # the reference's .split("##FASTA")[1] IndexError (input.py:104-107)
         ni.Pangenome(pangenome["csv"], None, genome_names=["a"], gff_paths=[str(bad)])
+
+
+def test_oracle_refuses_mask_of_other_length():
+    """panfeed.py:19 `v[clusterpresab == 0] = np.nan` with len(clusterpresab) != len(cluster): numpy IndexError"""
+    from oracle import oracle as po
+    from panfeed_amd.classes import Seqinfo
+    gs = {"a": [Seqinfo("ACGTACGTAA", "TGCATGCATT", "g", "c", 1, 10, 1, 0)], "b": []}
+    with pytest.raises(IndexError, match="boolean index did not match"):
+        po.OracleRun(klength=5, consider_missing=True).feed([(gs, "x", np.array([1, 0, 1]))])
+    po.OracleRun(klength=5, consider_missing=False).feed([(gs, "x", np.array([1, 0, 1]))])

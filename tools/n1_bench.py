@@ -12,7 +12,7 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 host_only = "--host-only" in sys.argv
 C_, S = (int(args[0]) if args else 300), (int(args[1]) if len(args) > 1 else 1000)
 k, up, down = 31, 100, 100
-cl = synth.generate(C_, S, flank=0)
+cl = synth.generate(C_, S, flank=up)          # BASELINE configs[1] shape: allele-specific 100-base flanks
 d = tempfile.mkdtemp()
 t = time.time(); csvp, gffs, fas = synth.write_pangenome(d, cl, missing_gene_rate=0.0); t_write = time.time() - t
 gn = sorted(gffs)
