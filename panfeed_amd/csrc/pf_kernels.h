@@ -516,14 +516,14 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
 
 constexpr uint32_t DEDUP_THREADS = 512;
 constexpr uint32_t DEDUP_GTAB = 256;          // hash groups table (mode 1 needs <= DEDUP_MAX_D groups)
-constexpr uint32_t DEDUP_POOL = 6144;         // u64 words of LDS holding one copy of every distinct sequence
+constexpr uint32_t DEDUP_POOL = 2048;         // u64 words of LDS holding one copy of every distinct sequence
 constexpr uint32_t DEDUP_CH = 4;              // 16-byte chunks per lane kept in registers (CH * GL * 64 bases per segment)
-constexpr uint32_t DEDUP_U = 2;               // segments in flight per 16-lane group
+constexpr uint32_t DEDUP_U = 1;               // segments in flight per 16-lane group
 constexpr uint32_t DEDUP_GL = 8;              // lanes that share one segment
 constexpr uint32_t DEDUP_UNSET = 0xFFFFFFFFu;
 constexpr uint32_t DEDUP_INGLOBAL = 0x80000000u;
 
-__global__ __launch_bounds__(DEDUP_THREADS) void cluster_dedup_kernel(DedupParams p) {
+__global__ __launch_bounds__(DEDUP_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void cluster_dedup_kernel(DedupParams p) {
     // ~78 KiB in all: two workgroups per CU
     __shared__ uint64_t t_key[DEDUP_GTAB];     // content hash of the group
     __shared__ uint64_t t_val[DEDUP_GTAB];     // min over the group's members of (ord_base << 32 | local index)
