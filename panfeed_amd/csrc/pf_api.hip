@@ -1405,4 +1405,16 @@ int pf_pattern_count(pf_ctx* c, uint64_t* n) {
     return PF_OK;
 }
 
+#ifdef PF_PROF
+/* profiling builds only (not part of the ABI): cycles per kernel phase, see PF_PROF_STAMP in pf_kernels.h */
+int pf_debug_prof(uint64_t* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(pf::pf_prof), sizeof(uint64_t) * 64) != hipSuccess) return PF_ERR_HIP;
+    if (reset) {
+        static const uint64_t zero[64] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(pf::pf_prof), zero, sizeof zero) != hipSuccess) return PF_ERR_HIP;
+    }
+    return PF_OK;
+}
+#endif
+
 }  // extern "C"

@@ -19,6 +19,17 @@
 
 namespace pf {
 
+// phase profiling (build with -DPF_PROF): shader-clock cycles per phase as workgroup thread 0 sees them
+#ifdef PF_PROF
+__device__ unsigned long long pf_prof[64];
+#define PF_PROF_BEGIN() uint64_t prof_t_ = __builtin_readcyclecounter()
+#define PF_PROF_STAMP(k) do { if (threadIdx.x == 0) { const uint64_t n_ = __builtin_readcyclecounter(); \
+    atomicAdd(&pf_prof[k], (unsigned long long)(n_ - prof_t_)); prof_t_ = n_; } } while (0)
+#else
+#define PF_PROF_BEGIN() do { } while (0)
+#define PF_PROF_STAMP(k) do { } while (0)
+#endif
+
 constexpr uint32_t SCAN_THREADS = 1024;
 constexpr uint32_t SCAN_WAVES = SCAN_THREADS / 64;
 constexpr uint32_t LDS_BYTES = 163840;           // 160 KiB, whole CU
@@ -1529,7 +1540,7 @@ __device__ __forceinline__ int pattern_find_or_claim(const PatternTable& t, uint
 }
 
 template <class CFG, bool MULTI>
-__global__ __launch_bounds__(CFG::THREADS) void finish_kernel(FinishParams p) {
+__global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void finish_kernel(FinishParams p) {
     constexpr uint32_t T = CFG::THREADS, DW = CFG::DW, AT = CFG::AT;
     __shared__ __align__(16) uint32_t M[CFG::MR];
     __shared__ uint32_t occ[DW], keepbm[DW];
@@ -1542,10 +1553,11 @@ __global__ __launch_bounds__(CFG::THREADS) void finish_kernel(FinishParams p) {
     constexpr tag_t UNTABLED = (tag_t)(AT - 1);
     __shared__ tag_t slot_at[MULTI ? 1 : 9600];                  // per occupied slot: its mask's table position
     __shared__ uint32_t wave_tot[T / 64 + 1];
-    __shared__ uint32_t sh_npres, at_count;
+    __shared__ uint32_t sh_npres, at_count, wl_count;
     __shared__ uint64_t sh_base;
 
     const uint32_t tid = threadIdx.x;
+    PF_PROF_BEGIN();
     const uint32_t item = p.work[blockIdx.x];
     const uint32_t c = p.item_cluster[item];
     if (p.cluster_overflow[c]) return;
@@ -1585,7 +1597,7 @@ __global__ __launch_bounds__(CFG::THREADS) void finish_kernel(FinishParams p) {
     for (uint32_t i = tid; i < DW; i += T) { occ[i] = 0; keepbm[i] = 0; }
     for (uint32_t i = tid; i < AT; i += T) { at_key[i] = 0; at_minord[i] = NO_ORD; }
     if (tid == 0) {
-        at_count = 0;
+        at_count = 0; wl_count = 0;
         uint32_t np = 0;
         for (uint32_t w = 0; w < W; w++) np += __popc(presab[w]);
         sh_npres = np;
@@ -1598,11 +1610,23 @@ __global__ __launch_bounds__(CFG::THREADS) void finish_kernel(FinishParams p) {
             atomicOr(&M[d * Wp + (smp >> 5)], 1u << (smp & 31));
         }
     }
+    PF_PROF_STAMP(0);
     // phase A: distinct allele masks
     for (uint32_t q = 0; q < nparts; q++) {
     set_part(q);
-    for (uint32_t i = tid; i < ns; i += T) {
-        const uint64_t amask = (uint64_t)mlo[i] | ((uint64_t)mhi[i] << 32);
+    // four slots per thread and trip: their loads are issued together (the loop is latency-, not bandwidth-bound)
+    for (uint32_t i0 = tid; i0 < ns; i0 += 4 * T) {
+      uint32_t ml_[4], mh_[4];
+#pragma unroll
+      for (uint32_t u = 0; u < 4; u++) {
+          const uint32_t i = i0 + u * T;
+          ml_[u] = i < ns ? mlo[i] : 0; mh_[u] = i < ns ? mhi[i] : 0;
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < 4; u++) {
+        const uint32_t i = i0 + u * T;
+        if (i >= ns) break;
+        const uint64_t amask = (uint64_t)ml_[u] | ((uint64_t)mh_[u] << 32);
         tag_t tag = UNTABLED;
         {
             uint32_t a = (uint32_t)mix64(amask) % PROBE;
@@ -1618,9 +1642,11 @@ __global__ __launch_bounds__(CFG::THREADS) void finish_kernel(FinishParams p) {
             }
         }
         if (!MULTI) slot_at[i] = tag;
+      }
     }
     }
     __syncthreads();
+    PF_PROF_STAMP(1);
     const uint32_t npresent = sh_npres;
     const uint32_t n_eff = p.consider_missing ? npresent : nstr;               // panfeed.py:191 / :196
     const uint32_t lo = p.maf_lo[n_eff], hi = p.maf_hi[n_eff];
@@ -1647,7 +1673,7 @@ __global__ __launch_bounds__(CFG::THREADS) void finish_kernel(FinishParams p) {
             row_word4(amask, ch, wv);
 #pragma unroll
             for (int j = 0; j < 4; j++)
-                if (ch + j < nchunks) { cnt += __popc(wv[j]); eq = eq && (wv[j] == presab[ch + j]); }
+                if (ch + j < nchunks) { cnt += __popc(wv[j]); if (same_possible) eq = eq && (wv[j] == presab[ch + j]); }
             mm3_block(s, wv[0], wv[1], wv[2], wv[3]);
         }
         if (p.consider_missing) {
@@ -1684,38 +1710,123 @@ __global__ __launch_bounds__(CFG::THREADS) void finish_kernel(FinishParams p) {
         p.pat_n[pid] = nstr;
     };
 
-    // phase B: one row evaluation per distinct mask
-    for (uint32_t t = tid; t < AT; t += T) {
+    // the same two, eight lanes per mask: lane `sub` gathers words [32 r + 4 sub, +4) of the row; the row hash is
+    // sequential, so all eight run it on the shuffled words; popcount / equality are reduced over the eight lanes
+    auto row_eval8 = [&](uint64_t amask, uint32_t sub, uint4& hout) -> bool {
+        H128 s;
+        s.h1 = 0x9747b28cu ^ nstr; s.h2 = 0x1b873593u; s.h3 = 0xe6546b64u; s.h4 = 0x85ebca6bu;
+        if (p.multiple_files) { s.h2 ^= (uint32_t)ordinal; s.h3 ^= (uint32_t)(ordinal >> 32); }
+        uint32_t cnt = 0;
+        bool eq = true;
+        const uint32_t gbase = (tid & 63u) & ~7u;
+        for (uint32_t ch0 = 0; ch0 < nchunks; ch0 += 32) {
+            const uint32_t ch = ch0 + 4 * sub;
+            uint32_t wv[4] = {0, 0, 0, 0};
+            if (ch < nchunks) {
+                row_word4(amask, ch, wv);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (ch + j < nchunks) { cnt += __popc(wv[j]); if (same_possible) eq = eq && (wv[j] == presab[ch + j]); }
+            }
+            const uint32_t nb = min(8u, (nchunks - ch0 + 3) >> 2);
+            for (uint32_t j = 0; j < nb; j++) {
+                const uint32_t b0 = __shfl(wv[0], gbase + j), b1 = __shfl(wv[1], gbase + j);
+                const uint32_t b2 = __shfl(wv[2], gbase + j), b3 = __shfl(wv[3], gbase + j);
+                mm3_block(s, b0, b1, b2, b3);
+            }
+        }
+        if (p.consider_missing) {
+            for (uint32_t ch = 0; ch < nchunks; ch += 4) {
+                uint32_t wv[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) wv[j] = (ch + j < nchunks) ? ~presab[ch + j] : 0;
+                mm3_block(s, wv[0], wv[1], wv[2], wv[3]);
+            }
+        }
+        mm3_final(s, nchunks * 4);
+        int ne = eq ? 0 : 1;
+        for (int d = 1; d < 8; d <<= 1) { cnt += __shfl_xor(cnt, d); ne |= __shfl_xor(ne, d); }
+        bool keep = cnt >= lo && cnt <= hi;                 // panfeed.py:197-200
+        if (same_possible && !ne) keep = false;             // panfeed.py:202-204
+        hout = make_uint4(s.h1, s.h2, s.h3, s.h4);
+        return keep;
+    };
+    auto write_row8 = [&](uint32_t pid, uint64_t amask, uint32_t sub) {
+        for (uint32_t w0 = 0; w0 < W; w0 += 32) {
+            const uint32_t w = w0 + 4 * sub;
+            if (w >= W) break;
+            uint32_t wv[4] = {0, 0, 0, 0};
+            if (w < nchunks) row_word4(amask, w, wv);
+            for (uint32_t j = 0; j < 4 && w + j < W; j++) {
+                p.pat_bits[(size_t)pid * W + w + j] = (w + j < nchunks) ? wv[j] : 0;
+                if (p.pat_nan) {
+                    uint32_t nn = 0;
+                    if (p.consider_missing && w + j < nchunks) {
+                        nn = ~presab[w + j];
+                        const uint32_t rem = nstr - ((w + j) << 5);
+                        if (rem < 32) nn &= (1u << rem) - 1;
+                    }
+                    p.pat_nan[(size_t)pid * W + w + j] = nn;
+                }
+            }
+        }
+        if (sub == 0) p.pat_n[pid] = nstr;
+    };
+
+    // phase B: one row evaluation per distinct mask (eight lanes each)
+    for (uint32_t t = tid >> 3; t < AT; t += T >> 3) {
         const uint64_t key = at_key[t];
         if (!key) continue;
         uint4 h;
-        at_keep[t] = row_eval(key, h) ? 1u : 0u;
-        at_hash[t] = h;
+        const bool kp = row_eval8(key, tid & 7u, h);
+        if ((tid & 7u) == 0) { at_keep[t] = kp ? 1u : 0u; at_hash[t] = h; }
     }
     __syncthreads();
-    // phase C: ordinal bitmaps, lowest ordinal per mask
+    PF_PROF_STAMP(2);
+    // phase C: ordinal bitmaps, lowest ordinal per mask.  Slots whose mask did not fit the table (rare) are left to
+    // a second, plain loop so that the batched one stays small.
+    bool saw_untabled = false;
     for (uint32_t q = 0; q < nparts; q++) {
     set_part(q);
-    for (uint32_t i = tid; i < ns; i += T) {
-        const uint32_t o = ordp[i];
-        if ((o >> 5) >= dense_words) continue;
-        uint64_t amask = 0;
-        if (MULTI) amask = (uint64_t)mlo[i] | ((uint64_t)mhi[i] << 32);
-        const tag_t tag = MULTI ? find_tag(amask) : slot_at[i];
-        bool keep;
-        if (tag == UNTABLED) {
-            if (!MULTI) amask = (uint64_t)mlo[i] | ((uint64_t)mhi[i] << 32);
-            uint4 h;
-            keep = row_eval(amask, h);
-        } else {
-            keep = at_keep[tag] != 0;
-            if (keep) atomicMin(&at_minord[tag], o);
-        }
+    for (uint32_t i0 = tid; i0 < ns; i0 += 4 * T) {
+      uint32_t o_[4], ml_[4], mh_[4];
+#pragma unroll
+      for (uint32_t u = 0; u < 4; u++) {
+          const uint32_t i = i0 + u * T;
+          o_[u] = i < ns ? ordp[i] : 0xFFFFFFFFu;
+          if (MULTI) { ml_[u] = i < ns ? mlo[i] : 0; mh_[u] = i < ns ? mhi[i] : 0; }
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < 4; u++) {
+        const uint32_t i = i0 + u * T;
+        const uint32_t o = o_[u];
+        if (i >= ns || (o >> 5) >= dense_words) continue;
+        const tag_t tag = MULTI ? find_tag((uint64_t)ml_[u] | ((uint64_t)mh_[u] << 32)) : slot_at[i];
         atomicOr(&occ[o >> 5], 1u << (o & 31));
-        if (keep) atomicOr(&keepbm[o >> 5], 1u << (o & 31));
+        if (tag == UNTABLED) { saw_untabled = true; continue; }
+        if (at_keep[tag] != 0) {
+            atomicMin(&at_minord[tag], o);
+            atomicOr(&keepbm[o >> 5], 1u << (o & 31));
+        }
+      }
     }
+    }
+    if (saw_untabled) {
+        for (uint32_t q = 0; q < nparts; q++) {
+            set_part(q);
+#pragma unroll 1
+            for (uint32_t i = tid; i < ns; i += T) {
+                const uint32_t o = ordp[i];
+                if ((o >> 5) >= dense_words) continue;
+                const uint64_t amask = (uint64_t)mlo[i] | ((uint64_t)mhi[i] << 32);
+                if ((MULTI ? find_tag(amask) : slot_at[i]) != UNTABLED) continue;
+                uint4 h;
+                if (row_eval(amask, h)) atomicOr(&keepbm[o >> 5], 1u << (o & 31));
+            }
+        }
     }
     __syncthreads();
+    PF_PROF_STAMP(3);
     // prefix popcounts over the bitmap words
     uint32_t tot_o, tot_k;
     {
@@ -1734,6 +1845,7 @@ __global__ __launch_bounds__(CFG::THREADS) void finish_kernel(FinishParams p) {
     }
     if (tid == 0) at_count = 0;      // from here on: number of pattern-table slots this workgroup claims
     __syncthreads();
+    PF_PROF_STAMP(4);
     auto rank_of = [&](uint32_t o) -> uint32_t { return pocc[o >> 5] + __popc(occ[o >> 5] & ((1u << (o & 31)) - 1)); };
     auto kept_before = [&](uint32_t o) -> uint32_t { return pkeep[o >> 5] + __popc(keepbm[o >> 5] & ((1u << (o & 31)) - 1)); };
     // ---- run-global pattern table, bulk protocol.  Entry AT-1 of the mask table (never a hash position) stands
@@ -1787,6 +1899,7 @@ __global__ __launch_bounds__(CFG::THREADS) void finish_kernel(FinishParams p) {
         if (e_state == 1) e_newidx = atomicAdd(&at_count, 1u);     // at_count: claims of this workgroup (reused)
     }
     __syncthreads();
+    PF_PROF_STAMP(5);
     if (tid == 0) {
         const uint32_t nnew = at_count;
         uint32_t base = 0;
@@ -1821,40 +1934,81 @@ __global__ __launch_bounds__(CFG::THREADS) void finish_kernel(FinishParams p) {
             }
         } else {
             at_pid[tid] = e_pid;
-            if (lowered && e_pid < p.pt.pool) write_row(e_pid, e_key);
+            if (lowered && e_pid < p.pt.pool) at_minord[atomicAdd(&wl_count, 1u)] = tid;   // row written below, 8 lanes each
         }
     }
     __syncthreads();
+    PF_PROF_STAMP(6);
     const uint64_t obase = sh_base - p.out_base;
+    // rows of the patterns whose first_seen this workgroup lowered (at_minord is free by now: the list of their
+    // mask-table positions)
+    for (uint32_t g = tid >> 3, nw = wl_count; g < nw; g += T >> 3) {
+        const uint32_t t = at_minord[g];
+        write_row8(at_pid[t], at_key[t], tid & 7u);
+    }
     // outputs: key + pattern id per kept k-mer, in first-occurrence order
     for (uint32_t q = 0; q < nparts; q++) {
     set_part(q);
-    for (uint32_t i = tid; i < ns; i += T) {
-        const uint32_t o = ordp[i];
-        if ((o >> 5) >= dense_words || !((keepbm[o >> 5] >> (o & 31)) & 1)) continue;
-        uint64_t amask = 0;
-        if (MULTI) amask = (uint64_t)mlo[i] | ((uint64_t)mhi[i] << 32);
-        const tag_t tag = MULTI ? find_tag(amask) : slot_at[i];
-        uint32_t pid;
-        if (tag == UNTABLED) {
-            // mask table was full: this slot goes to the run-global table on its own
-            if (!MULTI) amask = (uint64_t)mlo[i] | ((uint64_t)mhi[i] << 32);
-            uint4 h;
-            row_eval(amask, h);
-            bool lowered;
-            pid = pattern_insert_lower(p.pt, ((uint64_t)h.x << 32) | h.y, h.z,
-                                       (ordinal << 32) | (uint64_t)(rank_of(o) + 1), &lowered);
-            if (lowered && pid < p.pt.pool) write_row(pid, amask);
-        } else {
-            pid = at_pid[tag];
-        }
+    for (uint32_t i0 = tid; i0 < ns; i0 += 4 * T) {
+      uint32_t o_[4], ml_[4], mh_[4];
+      uint64_t k0_[4];
+      bool kp_[4];
+#pragma unroll
+      for (uint32_t u = 0; u < 4; u++) {
+          const uint32_t i = i0 + u * T;
+          o_[u] = i < ns ? ordp[i] : 0xFFFFFFFFu;
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < 4; u++) {
+          const uint32_t i = i0 + u * T, o = o_[u];
+          kp_[u] = (o >> 5) < dense_words && ((keepbm[o >> 5] >> (o & 31)) & 1);
+          k0_[u] = kp_[u] ? p.tab_key[((size_t)slice * KW) * NS + i] : 0;
+          if (MULTI) { ml_[u] = kp_[u] ? mlo[i] : 0; mh_[u] = kp_[u] ? mhi[i] : 0; }
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < 4; u++) {
+        const uint32_t i = i0 + u * T;
+        if (!kp_[u]) continue;
+        const uint32_t o = o_[u];
+        const tag_t tag = MULTI ? find_tag((uint64_t)ml_[u] | ((uint64_t)mh_[u] << 32)) : slot_at[i];
+        if (tag == UNTABLED) continue;           // second loop below
         const uint64_t oi = obase + kept_before(o);
         if (oi >= p.out_cap) { p.pt.counters[1] = 2; continue; }
-        p.out_key[oi * KW] = p.tab_key[((size_t)slice * KW) * NS + i];
+        p.out_key[oi * KW] = k0_[u];
         if (KW == 2) p.out_key[oi * KW + 1] = p.tab_key[((size_t)slice * KW + 1) * NS + i];
-        p.out_pid[oi] = pid;
+        p.out_pid[oi] = at_pid[tag];
+      }
     }
     }
+    if (saw_untabled) {
+        // mask table was full: these slots go to the run-global table on their own
+        for (uint32_t q = 0; q < nparts; q++) {
+            set_part(q);
+#pragma unroll 1
+            for (uint32_t i = tid; i < ns; i += T) {
+                const uint32_t o = ordp[i];
+                if ((o >> 5) >= dense_words || !((keepbm[o >> 5] >> (o & 31)) & 1)) continue;
+                const uint64_t amask = (uint64_t)mlo[i] | ((uint64_t)mhi[i] << 32);
+                if ((MULTI ? find_tag(amask) : slot_at[i]) != UNTABLED) continue;
+                uint4 h;
+                row_eval(amask, h);
+                bool lw;
+                const uint32_t pid = pattern_insert_lower(p.pt, ((uint64_t)h.x << 32) | h.y, h.z,
+                                                          (ordinal << 32) | (uint64_t)(rank_of(o) + 1), &lw);
+                if (lw && pid < p.pt.pool) write_row(pid, amask);
+                const uint64_t oi = obase + kept_before(o);
+                if (oi >= p.out_cap) { p.pt.counters[1] = 2; continue; }
+                p.out_key[oi * KW] = p.tab_key[((size_t)slice * KW) * NS + i];
+                if (KW == 2) p.out_key[oi * KW + 1] = p.tab_key[((size_t)slice * KW + 1) * NS + i];
+                p.out_pid[oi] = pid;
+            }
+        }
+    }
+    __syncthreads();
+    PF_PROF_STAMP(7);
+#ifdef PF_PROF
+    if (tid == 0) atomicAdd(&pf_prof[8], 1ull);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

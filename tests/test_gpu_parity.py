@@ -135,9 +135,17 @@ def test_dedup_single_pass_paths():
     x = rnd(250)[:-1] + b"C"
     c = [x, x + b"A", x + b"AA", x + b"A" * 70, x[:-1] + b"A"]          # same words, other lengths
     recs.append(({nm: [mk(c[i % 5], i)] for i, nm in enumerate(names)}, "trailingA", ones))
+    anc = np.frombuffer(rnd(1500), np.uint8)
+    d = []
+    for _ in range(30):                                                  # far more distinct allele masks than the
+        m = anc.copy()                                                   # fused kernel's mask table holds
+        hit = rng.random(len(m)) < 0.02
+        m[hit] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(hit.sum()))]
+        d.append(m.tobytes())
+    recs.append(({nm: [mk(d[i % 30], i)] for i, nm in enumerate(names)}, "manymasks", ones))
     eng = Engine(klength=31, max_strains=96)
     out = eng.run(recs)
-    assert out.timing["n_dedup_clusters"] == 3
+    assert out.timing["n_dedup_clusters"] == 4
     (ek, ekh, ehp), st = _oracle_texts(recs, klength=31)
     assert out.kmers_to_hashes == ekh
     assert out.hashes_to_patterns == ehp

@@ -1,0 +1,30 @@
+"""Cycles per phase inside the fused kernels (PF_PROF build).  On the GPU box:
+    PF_PROF=1 python -c "import __graft_entry__ as g; g.build(force=True)" && python tools/phase_prof.py [clusters]
+then rebuild without PF_PROF."""
+import ctypes as C
+import sys
+
+sys.path.insert(0, ".")
+from panfeed_amd import devbatch, synth  # noqa: E402
+from panfeed_amd.engine import Engine  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
+S, k = 1000, 31
+eng = Engine(klength=k, max_strains=1024, max_items=8192, pattern_capacity=1 << 23)
+cl = synth.generate(n, S, flank=100, n_rate=0.0)
+db = devbatch.from_synth(eng, cl, k)
+db.submit()
+eng.L.pf_reset_patterns(eng.ctx)
+buf = (C.c_uint64 * 64)()
+eng.L.pf_debug_prof(buf, 1)
+db.submit()
+eng.L.pf_debug_prof(buf, 0)
+v = list(buf)
+names = {0: "finish: init + M", 1: "finish: A masks", 2: "finish: B row eval", 3: "finish: C bitmaps", 4: "finish: prefix",
+         5: "finish: find/claim", 6: "finish: publish+rows", 7: "finish: outputs", 8: "finish: workgroups"}
+tot = sum(v[0:8])
+for i in range(64):
+    if v[i]:
+        print(f"{i:2d} {names.get(i, ''):24s} {v[i]:14d} {100.0 * v[i] / tot if i < 8 else 0:6.1f}%"
+              + (f"  {v[i] / v[8]:9.0f} cyc/wg" if i < 8 and v[8] else ""))
+print(eng.timing())
