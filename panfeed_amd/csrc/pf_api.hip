@@ -105,7 +105,8 @@ struct pf_ctx {
     // scan view built by cluster_dedup_kernel
     DevBuf v_word_off, v_len, v_sample, v_ord, seg_distinct, v_nseg, v_nstr, v_mode, v_dense, extra_off, extra_dense;
     DevBuf bm_occ, bm_keep, pre_occ, pre_keep, mrows, slot_out, it_is_extra, cmask_lo, cmask_hi, it_compact;
-    DevBuf strand_bits;
+    DevBuf strand_bits, scan_desc;
+    int n_cu = 256;
     DevBuf it_cluster, it_part, it_nparts, it_nslots, it_slice, it_sib0, it_nsib, it_extra_first, it_count,
         it_unique, it_kept, work_scan, work_extra, work_fin, work_fin2, work_fin3, work_rows, sub_cluster, sub_item0, sub_nitems;
     std::vector<Arena*> arenas;
@@ -222,7 +223,15 @@ int launch_scan_t(pf_ctx* c, const pf::ScanParams& sp, uint32_t n) {
                                    (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(n), dim3(pf::SCAN_THREADS), lds, c->stream, sp);
+    // descriptors first (one thread per work entry), then one persistent workgroup per CU
+    PFCHK(c->scan_desc.ensure((size_t)n * sizeof(pf::ScanDesc)));
+    pf::ScanParams q = sp;
+    q.n_work = n;
+    q.desc = c->scan_desc.as<pf::ScanDesc>();
+    hipLaunchKernelGGL(pf::scan_desc_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, q, c->scan_desc.as<pf::ScanDesc>());
+    HIPCHK(hipGetLastError());
+    const uint32_t grid = n < (uint32_t)c->n_cu ? n : (uint32_t)c->n_cu;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(pf::SCAN_THREADS), lds, c->stream, q);
     HIPCHK(hipGetLastError());
     return PF_OK;
 }
@@ -290,7 +299,7 @@ void pf_destroy(pf_ctx* c) {
     for (auto& e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->stage_pin) (void)hipHostFree(c->stage_pin);
-    c->stage_dev.release();
+    c->stage_dev.release(); c->scan_desc.release();
     c->mg_lo.release(); c->mg_hi.release(); c->mg_min.release(); c->mg_cnt.release();
     if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
     if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
@@ -317,6 +326,7 @@ int pf_create(pf_ctx** out, int device, const pf_opts* o) {
 
     pf_ctx* c = new pf_ctx();
     c->device = device;
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->o = *o;
     c->KW = o->klength <= 31 ? 1 : 2;
     c->NS = pf::nslots_max(c->KW);

@@ -141,11 +141,32 @@ struct ScanParams {
     uint32_t* chunkmask;              // [slice][8]  bit ch set: chunk ch was flushed
     uint32_t* item_count;             // [item] unique keys in the item's table
     uint32_t* cluster_overflow;       // [cluster] |= 1 when any partition overflowed
-    const uint32_t* work;             // [gridDim.x] item ids of this launch
+    const uint32_t* work;             // [n_work] item ids of this launch
+    const struct ScanDesc* desc;      // [n_work] what a workgroup needs to start on work[i] (scan_desc_kernel)
+    uint32_t n_work;
     uint32_t k;
     uint32_t W;
     uint32_t NS;                      // slots per scratch slice (= nslots_max(KW))
 };
+
+// One 64-byte record per work entry, so that a workgroup starts an item with one load instead of a chain of
+// four dependent ones (work -> item arrays -> cluster arrays); the scan kernel requests the next one while it
+// works on the current item.
+struct ScanDesc { uint32_t item, c, part, nparts, ns, slice, seg0, nseg, nstr, compact, pad[6]; };
+static_assert(sizeof(ScanDesc) == 64, "ScanDesc is read as 16 words");
+
+__global__ __launch_bounds__(256) void scan_desc_kernel(ScanParams p, ScanDesc* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n_work) return;
+    ScanDesc d{};
+    d.item = p.work[i];
+    d.c = p.item_cluster[d.item];
+    d.part = p.item_part[d.item]; d.nparts = p.item_nparts[d.item];
+    d.ns = p.item_nslots[d.item]; d.slice = p.item_scratch[d.item];
+    d.compact = p.item_compact[d.item];
+    d.seg0 = p.cluster_seg_off[d.c]; d.nseg = p.cluster_vnseg[d.c]; d.nstr = p.cluster_vnstr[d.c];
+    out[i] = d;
+}
 
 // lower bound of `v` in seg_sample[a..b)
 __device__ __forceinline__ uint32_t seg_lower_bound(const uint32_t* seg_sample, uint32_t a, uint32_t b, uint32_t v) {
@@ -274,8 +295,14 @@ constexpr uint32_t M_ORDB = M_NINST + SEG_TILE;
 constexpr uint32_t M_SAMPLE = M_ORDB + SEG_TILE;
 constexpr uint32_t M_UPREF = M_SAMPLE + SEG_TILE;                        // [SEG_TILE + 1] unit prefix
 constexpr uint32_t M_TMP = M_UPREF + SEG_TILE + 2;                       // one scratch word
-static_assert(M_TMP + 1 <= MISC_WORDS, "misc area too small");
+constexpr uint32_t M_DESC = M_TMP + 2;                                   // [16] the current item's ScanDesc
+constexpr uint32_t M_NDESC = M_DESC + 16;                                // [16] the next item's
+static_assert(M_NDESC + 16 <= MISC_WORDS, "misc area too small");
 
+// Persistent: gridDim.x workgroups (one per CU: the table takes the whole LDS) walk work entries
+// blockIdx.x, blockIdx.x + gridDim.x, ...  With one workgroup per CU nothing else hides the dependent global
+// loads an item starts with, so the next item's descriptor is requested at the start of the current one and its
+// first tile of segment metadata before the current table is dumped.
 template <int KW, bool CANON>
 __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -286,16 +313,37 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
     uint32_t* misc = bits + NS;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t item = p.work[blockIdx.x];
-    const uint32_t c = p.item_cluster[item];
-    const uint32_t part = p.item_part[item], nparts = p.item_nparts[item];
-    const uint32_t ns = p.item_nslots[item];
-    const uint32_t slice = p.item_scratch[item];
-    const uint32_t seg0 = p.cluster_seg_off[c], seg1 = seg0 + p.cluster_vnseg[c];
-    const uint32_t nstr = p.cluster_vnstr[c];
-    const uint32_t nchunks = (nstr + 31) >> 5;
     const uint32_t k = p.k;
+
+    // first-tile metadata of the item about to start, one segment per thread (tid < SEG_TILE)
+    uint32_t pm_len = 0, pm_ordb = 0, pm_sample = 0;
+    uint64_t pm_wo = 0;
+    auto fetch_tile0 = [&](uint32_t seg0, uint32_t nseg) {
+        if (tid < min(nseg, SEG_TILE)) {
+            const uint32_t s = seg0 + tid;
+            pm_len = p.seg_len[s]; pm_wo = p.seg_word_off[s]; pm_ordb = p.seg_ord_base[s]; pm_sample = p.seg_sample[s];
+        }
+    };
+    if (blockIdx.x < p.n_work) {
+        if (tid < 16) misc[M_DESC + tid] = reinterpret_cast<const uint32_t*>(p.desc + blockIdx.x)[tid];
+        __syncthreads();
+        fetch_tile0(misc[M_DESC + 6], misc[M_DESC + 7]);
+    }
+
+    for (uint32_t wi = blockIdx.x; wi < p.n_work; wi += gridDim.x) {
+    // ---- the current item (M_DESC was written before the barrier that ended the previous trip)
+    const uint32_t item = misc[M_DESC + 0], c = misc[M_DESC + 1];
+    const uint32_t part = misc[M_DESC + 2], nparts = misc[M_DESC + 3];
+    const uint32_t ns = misc[M_DESC + 4], slice = misc[M_DESC + 5];
+    const uint32_t seg0 = misc[M_DESC + 6], seg1 = seg0 + misc[M_DESC + 7];
+    const uint32_t nstr = misc[M_DESC + 8];
+    const bool compact = misc[M_DESC + 9] != 0;  // view has <= 64 columns: at most chunks 0 and 1
+    const uint32_t nchunks = (nstr + 31) >> 5;
     const uint32_t limit = insert_limit(ns);
+    // request the next item's descriptor now; it is looked at after the scan loop
+    const uint32_t wn = wi + gridDim.x;
+    uint32_t nd_word = 0;
+    if (wn < p.n_work && tid < 16) nd_word = reinterpret_cast<const uint32_t*>(p.desc + wn)[tid];
 
     for (uint32_t i = tid; i < ns; i += SCAN_THREADS) {
         keys[i] = EMPTY64;
@@ -304,9 +352,32 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
         bits[i] = 0;
     }
     if (tid < 2) misc[tid] = 0;
-    for (uint32_t ch = tid; ch <= nchunks; ch += SCAN_THREADS)
-        misc[M_CHUNK + ch] = seg_lower_bound(p.seg_sample, seg0, seg1, ch << 5);
+    const bool one_tile = seg1 - seg0 <= SEG_TILE;
+    if (!one_tile) {
+        for (uint32_t ch = tid; ch <= nchunks; ch += SCAN_THREADS)
+            misc[M_CHUNK + ch] = seg_lower_bound(p.seg_sample, seg0, seg1, ch << 5);
+    }
+    {   // tile 0 from the registers filled during the previous item
+        const uint32_t nseg = min(SEG_TILE, seg1 - seg0);
+        if (tid < nseg) {
+            misc[M_WOFF + 2 * tid] = (uint32_t)pm_wo;
+            misc[M_WOFF + 2 * tid + 1] = (uint32_t)(pm_wo >> 32);
+            misc[M_NINST + tid] = pm_len >= k ? pm_len - k + 1 : 0;
+            misc[M_ORDB + tid] = pm_ordb;
+            misc[M_SAMPLE + tid] = pm_sample;
+        }
+    }
     __syncthreads();
+    if (one_tile) {
+        // chunk boundaries from the staged sample columns (sorted): no global search
+        const uint32_t nseg = seg1 - seg0;
+        for (uint32_t ch = tid; ch <= nchunks; ch += SCAN_THREADS) {
+            uint32_t a = 0, b = nseg;
+            const uint32_t v = ch << 5;
+            while (a < b) { const uint32_t m = (a + b) >> 1; if (misc[M_SAMPLE + m] < v) a = m + 1; else b = m; }
+            misc[M_CHUNK + ch] = seg0 + a;
+        }
+    }
 
     uint32_t mask_word = 0;   // thread t < 8 accumulates chunkmask word t
     bool overflow = false;
@@ -325,8 +396,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
 
     for (uint32_t t0 = seg0; t0 < seg1 && !overflow; t0 += SEG_TILE) {
         const uint32_t nseg = min(SEG_TILE, seg1 - t0);
-        // ---- stage this tile's segment metadata (coalesced), then unit prefix by wave 0
-        if (tid < nseg) {
+        // ---- stage this tile's segment metadata (coalesced; tile 0 is there already), then unit prefix by wave 0
+        if (t0 != seg0 && tid < nseg) {
             const uint32_t s = t0 + tid;
             const uint32_t len = p.seg_len[s];
             const uint64_t wo = p.seg_word_off[s];
@@ -424,14 +495,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
         }
         // the next tile overwrites the staged metadata: everyone is past the barrier above
     }
-    const bool compact = p.item_compact[item] != 0;      // view has <= 64 columns: at most chunks 0 and 1
-    if (!overflow && chunk_dirty && !compact) { flush_chunk(); __syncthreads(); }
+    if (!overflow && chunk_dirty && !compact) { flush_chunk(); }
+    // ---- the next item: descriptor to LDS, first tile of its segment metadata into registers (in flight
+    // while this item's table is written out)
+    if (tid < 16) misc[M_NDESC + tid] = nd_word;
+    __syncthreads();
+    if (wn < p.n_work) fetch_tile0(misc[M_NDESC + 6], misc[M_NDESC + 7]);
 
     if (overflow) {
         if (tid == 0) { atomicOr(&p.cluster_overflow[c], 1u); p.item_count[item] = 0; }
-        return;
-    }
-    if (compact) {
+    } else if (compact) {
         // chunk 0 words were flushed to global memory iff a chunk 1 followed; the last chunk is still in bits[]
         const bool last_live = chunk_dirty;
         const bool c0_flushed = (mask_word_any(mask_word, tid) & 1u) != 0;
@@ -455,15 +528,19 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
         }
         __syncthreads();
         if (tid == 0) p.item_count[item] = misc[M_COUNT];
-        return;
+    } else {
+        for (uint32_t i = tid; i < ns; i += SCAN_THREADS) {
+            p.tab_key[((size_t)slice * KW) * NS + i] = keys[i];
+            if (KW == 2) p.tab_key[((size_t)slice * KW + 1) * NS + i] = keys[NS + i];
+            p.tab_ord[(size_t)slice * NS + i] = ord[i];
+        }
+        if (tid < 8) p.chunkmask[slice * 8 + tid] = mask_word;
+        if (tid == 0) p.item_count[item] = misc[M_COUNT];
     }
-    for (uint32_t i = tid; i < ns; i += SCAN_THREADS) {
-        p.tab_key[((size_t)slice * KW) * NS + i] = keys[i];
-        if (KW == 2) p.tab_key[((size_t)slice * KW + 1) * NS + i] = keys[NS + i];
-        p.tab_ord[(size_t)slice * NS + i] = ord[i];
+    __syncthreads();                               // the table and misc[] are free again
+    if (tid < 16) misc[M_DESC + tid] = misc[M_NDESC + tid];
+    __syncthreads();
     }
-    if (tid < 8) p.chunkmask[slice * 8 + tid] = mask_word;
-    if (tid == 0) p.item_count[item] = misc[M_COUNT];
 }
 
 // ---------------------------------------------------------------------------------------------
