@@ -186,14 +186,22 @@ __device__ __forceinline__ void table_update(uint64_t* keys, uint32_t* ord, uint
     bool inserted = false;
     while (active) {
         if (KW == 1) {
-            uint64_t cur = __hip_atomic_load(&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (cur == EMPTY64) {
-                cur = atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)EMPTY64,
-                                (unsigned long long)key.w[0]);
-                if (cur == EMPTY64) { inserted = true; cur = key.w[0]; }
+            // two-slot buckets: `home` is a bucket index (ns / 2 buckets), both keys come with one 128-bit read,
+            // a new key takes the first empty slot of the first bucket that has one.  Half the probe steps of
+            // slot-by-slot probing -- the loop runs as long as the slowest of the 64 lanes.
+            const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(&keys[2 * slot]);
+            const bool hit0 = kk.x == key.w[0], hit1 = kk.y == key.w[0];
+            if (hit0 || hit1) { slot = 2 * slot + (hit0 ? 0u : 1u); break; }
+            const bool e0 = kk.x == EMPTY64, e1 = kk.y == EMPTY64;
+            if (e0 || e1) {
+                const uint32_t s2 = 2 * slot + (e0 ? 0u : 1u);
+                const uint64_t cur = atomicCAS((unsigned long long*)&keys[s2], (unsigned long long)EMPTY64,
+                                               (unsigned long long)key.w[0]);
+                if (cur == EMPTY64) { inserted = true; slot = s2; break; }
+                if (cur == key.w[0]) { slot = s2; break; }
+                continue;                                   // the bucket changed under us: look at it again
             }
-            if (cur == key.w[0]) break;
-            slot = slot + 1 == ns ? 0 : slot + 1;
+            slot = slot + 1 == (ns >> 1) ? 0 : slot + 1;
         } else {
             // word 0 is claimed by CAS, word 1 published right after; a reader that sees word 0 match but
             // word 1 still EMPTY re-reads the same slot on its next iteration.
@@ -269,16 +277,16 @@ __device__ __forceinline__ void scan_unit(uint64_t* keys, uint32_t* ord, uint32_
         Key<KW> key = rc_smaller ? rc : fwd;          // specseq <= revspecseq -> forward (panfeed.py:70)
         const uint32_t h = key_hash<KW>(key);
         const bool mine = nparts == 1 || (((h & 0xFFFFu) * nparts) >> 16) == part;
-        table_update<KW>(keys, ord, bits, misc, NS, ns, limit, valid && mine, key, __umulhi(h, ns), ordb + pos, bit);
+        table_update<KW>(keys, ord, bits, misc, NS, ns, limit, valid && mine, key, __umulhi(h, KW == 1 ? ns >> 1 : ns), ordb + pos, bit);
     } else {
         // forward then reverse complement, both inserted (panfeed.py:82-88)
         uint32_t h = key_hash<KW>(fwd);
         bool mine = nparts == 1 || (((h & 0xFFFFu) * nparts) >> 16) == part;
-        table_update<KW>(keys, ord, bits, misc, NS, ns, limit, valid && mine, fwd, __umulhi(h, ns),
+        table_update<KW>(keys, ord, bits, misc, NS, ns, limit, valid && mine, fwd, __umulhi(h, KW == 1 ? ns >> 1 : ns),
                          2 * (ordb + pos), bit);
         h = key_hash<KW>(rc);
         mine = nparts == 1 || (((h & 0xFFFFu) * nparts) >> 16) == part;
-        table_update<KW>(keys, ord, bits, misc, NS, ns, limit, valid && mine, rc, __umulhi(h, ns),
+        table_update<KW>(keys, ord, bits, misc, NS, ns, limit, valid && mine, rc, __umulhi(h, KW == 1 ? ns >> 1 : ns),
                          2 * (ordb + pos) + 1, bit);
     }
 }
@@ -330,6 +338,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
         fetch_tile0(misc[M_DESC + 6], misc[M_DESC + 7]);
     }
 
+    PF_PROF_BEGIN();
     for (uint32_t wi = blockIdx.x; wi < p.n_work; wi += gridDim.x) {
     // ---- the current item (M_DESC was written before the barrier that ended the previous trip)
     const uint32_t item = misc[M_DESC + 0], c = misc[M_DESC + 1];
@@ -379,6 +388,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
         }
     }
 
+    PF_PROF_STAMP(16);
     uint32_t mask_word = 0;   // thread t < 8 accumulates chunkmask word t
     bool overflow = false;
     uint32_t ch = 0;          // current sample chunk (32 columns); its bits[] words are live in LDS
@@ -431,6 +441,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
             if (lane == 63) misc[M_UPREF + SEG_TILE] = x;   // total (index 256 is not covered above)
         }
         __syncthreads();
+        PF_PROF_STAMP(17);
 
         // ---- walk the chunks that intersect this tile
         uint32_t lo = 0;   // local segment index
@@ -491,6 +502,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
             chunk_dirty = true;
             lo = hi;
             __syncthreads();                       // the chunk part is complete in LDS
+            PF_PROF_STAMP(18);
             if (misc[M_OVERFLOW]) { overflow = true; break; }
         }
         // the next tile overwrites the staged metadata: everyone is past the barrier above
@@ -501,6 +513,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
     if (tid < 16) misc[M_NDESC + tid] = nd_word;
     __syncthreads();
     if (wn < p.n_work) fetch_tile0(misc[M_NDESC + 6], misc[M_NDESC + 7]);
+    PF_PROF_STAMP(19);
 
     if (overflow) {
         if (tid == 0) { atomicOr(&p.cluster_overflow[c], 1u); p.item_count[item] = 0; }
@@ -538,8 +551,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
         if (tid == 0) p.item_count[item] = misc[M_COUNT];
     }
     __syncthreads();                               // the table and misc[] are free again
+    PF_PROF_STAMP(20);
     if (tid < 16) misc[M_DESC + tid] = misc[M_NDESC + tid];
     __syncthreads();
+    PF_PROF_STAMP(21);
+#ifdef PF_PROF
+    if (tid == 0) atomicAdd(&pf_prof[24], 1ull);
+#endif
     }
 }
 

@@ -409,8 +409,9 @@ def test_merge_kernel_matches_sort_merge():
     dup = torch.randperm(P, generator=g)[: P // 2].to(dev)
     rank1 = rows[dup].clone()
     rank1[:, 2] += (1 << 40)                                   # a later rank saw half of them again
-    early = rows[dup[: P // 8]].clone()
-    early[:, 2] -= 1                                           # ... and a few of them earlier than rank 0
+    # ... and a few of them earlier than rank 0 (first_seen is unsigned on the device: leave the row with 0 alone)
+    early = rows[dup[rows[dup, 2] > 0][: P // 8]].clone()
+    early[:, 2] -= 1
     rank2 = torch.cat([early, torch.randint(-2**62, 2**62, (P // 3, 3), generator=g).to(dev)])
     allpay = torch.cat([rows, rank1, rank2])
     # single-process torch merge over the concatenation: which rows are the global firsts

@@ -21,10 +21,13 @@ db.submit()
 eng.L.pf_debug_prof(buf, 0)
 v = list(buf)
 names = {0: "finish: init + M", 1: "finish: A masks", 2: "finish: B row eval", 3: "finish: C bitmaps", 4: "finish: prefix",
-         5: "finish: find/claim", 6: "finish: publish+rows", 7: "finish: outputs", 8: "finish: workgroups"}
-tot = sum(v[0:8])
-for i in range(64):
-    if v[i]:
-        print(f"{i:2d} {names.get(i, ''):24s} {v[i]:14d} {100.0 * v[i] / tot if i < 8 else 0:6.1f}%"
-              + (f"  {v[i] / v[8]:9.0f} cyc/wg" if i < 8 and v[8] else ""))
+         5: "finish: find/claim", 6: "finish: publish+rows", 7: "finish: outputs", 8: "finish: workgroups",
+         16: "scan: clear + tile0", 17: "scan: unit prefix", 18: "scan: windows", 19: "scan: next desc/tile",
+         20: "scan: table dump", 21: "scan: desc swap", 24: "scan: items"}
+for lo, hi, cnt in ((0, 8, 8), (16, 24, 24)):
+    tot = sum(v[lo:hi])
+    for i in list(range(lo, hi)) + [cnt]:
+        if v[i]:
+            print(f"{i:2d} {names.get(i, ''):24s} {v[i]:14d} {100.0 * v[i] / tot if i < hi else 0:6.1f}%"
+                  + (f"  {v[i] / v[cnt]:9.0f} cyc/item" if i < hi and v[cnt] else ""))
 print(eng.timing())
