@@ -168,6 +168,23 @@ int pf_reset_patterns(pf_ctx* ctx);
 int pf_submit(pf_ctx* ctx, const pf_batch* batch, pf_result* counters);
 
 /* Copy the arrays of the last batch's result to host memory owned by the context. */
+/*
+ * Genomes resident in HBM (SURVEY 8f N1 on the device).  pf_genomes_upload packs the contigs (A/C/G/T in either
+ * case -> 2 bits, anything else -> an arbitrary code the caller must never ask for) into the context's genome
+ * store and returns each contig's word offset.  pf_submit_gather is pf_submit for a batch whose packed input is
+ * produced on the device: segment s is the range [src_start, src_start + seg_len) of the source at src_off --
+ * the genome store, or (flag bit 0) b->packed, the words the host packed itself -- copied, or (flag bit 1)
+ * reverse-complemented (what `-seq` of input.py:431,443 yields), to b->seg_word_off[s] of a device buffer of
+ * g->n_words words.  Replaces the per-base host work of input.py:413-446 + the packing of the boundary.
+ */
+typedef struct {
+    uint64_t n_words;
+    const uint64_t* src_off; const uint32_t* src_start; const uint32_t* src_flags;   /* [b->n_segs] */
+} pf_gather;
+int pf_genomes_upload(pf_ctx* ctx, uint32_t n_contigs, const char* const* ascii, const uint64_t* len,
+                      uint64_t* word_off_out);
+int pf_genomes_clear(pf_ctx* ctx);
+int pf_submit_gather(pf_ctx* ctx, const pf_batch* b, const pf_gather* g, pf_result* counters);
 int pf_fetch(pf_ctx* ctx, pf_result* res);
 
 int pf_get_timing(pf_ctx* ctx, pf_timing* t);
@@ -227,6 +244,12 @@ typedef struct {
     const uint8_t* seq_target;        /* [n_seqs] `strain in stroi` (panfeed.py:90), may be NULL */
     const uint32_t* cluster_seq_off;  /* [n_clusters+1] */
     uint32_t klength, canon, W, want_strand;
+    /* optional (NULL = every sequence is given as text): sequences that are ranges of the genomes resident in HBM
+     * (pf_genomes_upload).  seq_flags bit 0: by reference -- seq/comp of that sequence are not read, the range is
+     * pure A/C/G/T and not a target strain's; bit 1: the sequence is the reverse complement of the range. */
+    const uint64_t* seq_src_off;      /* [n_seqs] word offset of the contig in the genome store */
+    const uint32_t* seq_src_start;    /* [n_seqs] lowest base coordinate of the range in the contig */
+    const uint32_t* seq_flags;        /* [n_seqs] */
 } pf_pack_in;
 
 typedef struct pf_packed pf_packed;
@@ -245,6 +268,11 @@ typedef struct {
     const uint32_t* target_seg_start; const uint32_t* target_seg_nwin;
     const uint32_t* target_ambig_off; const uint32_t* target_ambig_pos; const int8_t* target_ambig_used;
     const char* target_ambig_keys;    /* klength bytes per slow-path window */
+    /* with by-reference sequences: `packed` / n_words hold only the segments packed on the host ("literal"),
+     * seg_word_off are offsets in the DEVICE buffer of n_words_dev words that pf_submit_gather fills; NULL / 0
+     * when every sequence was given as text */
+    uint64_t n_words_dev;
+    const uint64_t* gather_src_off; const uint32_t* gather_src_start; const uint32_t* gather_src_flags;
 } pf_packed_view_t;
 
 int pf_pack_records(const pf_pack_in* in, pf_packed** out);
@@ -288,6 +316,9 @@ typedef struct {
     const uint32_t* cluster_presab;         /* [n_clusters * W] bits over sorted(strains) */
     const uint32_t* cluster_strain_off;     /* [n_clusters+1] into cluster_strain: the dict keys in insertion order */
     const char* const* cluster_strain;
+    /* after pf_pangenome_set_store: sequences given as ranges of the resident genomes (seq/comp NULL for those);
+     * same meaning as the fields of pf_pack_in; NULL before */
+    const uint64_t* seq_src_off; const uint32_t* seq_src_start; const uint32_t* seq_flags;
 } pf_records_view_t;
 
 int pf_pangenome_open(const pf_pangenome_opts* opts, pf_pangenome** out);
@@ -297,6 +328,10 @@ const char* pf_pangenome_strain(pf_pangenome* p, uint32_t i, int sorted);
 const char* pf_pangenome_take_log(pf_pangenome* p);   /* warnings the reference sends to logger.warning */
 /* Records of the next (at most) max_clusters rows of the table; n_clusters == 0 at the end. */
 int pf_pangenome_next(pf_pangenome* p, uint32_t max_clusters, pf_records** out, pf_records_view_t* view);
+/* Contigs of all genomes in one flat order (upper-cased text), for pf_genomes_upload; then the word offsets it
+ * returned: from here on pf_pangenome_next hands out non-target, pure-ACGT sequences by reference. */
+int pf_pangenome_contigs(pf_pangenome* p, uint32_t* n, const char* const** ascii, const uint64_t** len);
+int pf_pangenome_set_store(pf_pangenome* p, const uint64_t* contig_word_off, uint32_t n);
 void pf_records_free(pf_records* r);
 
 /* Host helper: md5 + base64 of a digest -- panfeed.py:175-176 -- for writers. */

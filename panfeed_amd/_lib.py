@@ -62,7 +62,12 @@ class PackIn(C.Structure):
     _fields_ = [("n_clusters", C.c_uint32), ("n_seqs", C.c_uint32),
                 ("seq", C.POINTER(C.c_char_p)), ("comp", C.POINTER(C.c_char_p)), ("seq_len", C.c_void_p),
                 ("seq_col", C.c_void_p), ("seq_target", C.c_void_p), ("cluster_seq_off", C.c_void_p),
-                ("klength", C.c_uint32), ("canon", C.c_uint32), ("W", C.c_uint32), ("want_strand", C.c_uint32)]
+                ("klength", C.c_uint32), ("canon", C.c_uint32), ("W", C.c_uint32), ("want_strand", C.c_uint32),
+                ("seq_src_off", C.c_void_p), ("seq_src_start", C.c_void_p), ("seq_flags", C.c_void_p)]
+
+
+class Gather(C.Structure):
+    _fields_ = [("n_words", C.c_uint64), ("src_off", C.c_void_p), ("src_start", C.c_void_p), ("src_flags", C.c_void_p)]
 
 
 class PackedView(C.Structure):
@@ -78,7 +83,9 @@ class PackedView(C.Structure):
                 ("target_seg_index", C.POINTER(C.c_uint32)), ("target_seg_start", C.POINTER(C.c_uint32)),
                 ("target_seg_nwin", C.POINTER(C.c_uint32)), ("target_ambig_off", C.POINTER(C.c_uint32)),
                 ("target_ambig_pos", C.POINTER(C.c_uint32)), ("target_ambig_used", C.POINTER(C.c_int8)),
-                ("target_ambig_keys", C.POINTER(C.c_char))]
+                ("target_ambig_keys", C.POINTER(C.c_char)),
+                ("n_words_dev", C.c_uint64), ("gather_src_off", C.POINTER(C.c_uint64)),
+                ("gather_src_start", C.POINTER(C.c_uint32)), ("gather_src_flags", C.POINTER(C.c_uint32))]
 
 
 class PangenomeOpts(C.Structure):
@@ -105,7 +112,9 @@ class RecordsView(C.Structure):
                 ("cluster_seq_off", C.POINTER(C.c_uint32)), ("cluster_name", C.POINTER(C.c_char_p)),
                 ("cluster_nstrains", C.POINTER(C.c_uint32)), ("cluster_npresab", C.POINTER(C.c_uint32)),
                 ("cluster_presab", C.POINTER(C.c_uint32)), ("cluster_strain_off", C.POINTER(C.c_uint32)),
-                ("cluster_strain", C.POINTER(C.c_char_p))]
+                ("cluster_strain", C.POINTER(C.c_char_p)),
+                ("seq_src_off", C.POINTER(C.c_uint64)), ("seq_src_start", C.POINTER(C.c_uint32)),
+                ("seq_flags", C.POINTER(C.c_uint32))]
 
 
 class Timing(C.Structure):
@@ -125,7 +134,8 @@ EXPORTS = ["pf_last_error", "pf_version", "pf_device_count", "pf_create", "pf_de
            "pf_render_kmers_to_hashes", "pf_render_hashes_to_patterns", "pf_render_kmers_tsv", "pf_free_text",
            "pf_pack_records", "pf_packed_view", "pf_packed_free",
            "pf_pangenome_open", "pf_pangenome_close", "pf_pangenome_info", "pf_pangenome_strain",
-           "pf_pangenome_take_log", "pf_pangenome_next", "pf_records_free"]
+           "pf_pangenome_take_log", "pf_pangenome_next", "pf_records_free", "pf_pangenome_contigs",
+           "pf_pangenome_set_store", "pf_genomes_upload", "pf_genomes_clear", "pf_submit_gather"]
 
 _lib = None
 
@@ -193,6 +203,13 @@ def load():
     L.pf_pangenome_take_log.argtypes = [C.c_void_p]
     L.pf_pangenome_take_log.restype = C.c_char_p
     L.pf_pangenome_next.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(RecordsView)]
+    L.pf_pangenome_contigs.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_char_p)),
+                                       C.POINTER(C.POINTER(C.c_uint64))]
+    L.pf_pangenome_set_store.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32]
+    L.pf_genomes_upload.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64),
+                                    C.POINTER(C.c_uint64)]
+    L.pf_genomes_clear.argtypes = [C.c_void_p]
+    L.pf_submit_gather.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(Gather), C.POINTER(Result)]
     L.pf_records_free.argtypes = [C.c_void_p]
     L.pf_records_free.restype = None
     L.pf_free_text.argtypes = [C.c_void_p]

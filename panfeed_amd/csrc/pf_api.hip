@@ -106,6 +106,9 @@ struct pf_ctx {
     DevBuf v_word_off, v_len, v_sample, v_ord, seg_distinct, v_nseg, v_nstr, v_mode, v_dense, extra_off, extra_dense;
     DevBuf bm_occ, bm_keep, pre_occ, pre_keep, mrows, slot_out, it_is_extra, cmask_lo, cmask_hi, it_compact;
     DevBuf strand_bits, scan_desc;
+    DevBuf g_store, b_literal, g_src_off, g_src_start, g_src_flags;   // genomes resident in HBM + per-batch gather lists
+    uint64_t g_words = 0;
+    const pf_gather* pending_gather = nullptr;
     int n_cu = 256;
     DevBuf it_cluster, it_part, it_nparts, it_nslots, it_slice, it_sib0, it_nsib, it_extra_first, it_count,
         it_unique, it_kept, work_scan, work_extra, work_fin, work_fin2, work_fin3, work_rows, sub_cluster, sub_item0, sub_nitems;
@@ -300,6 +303,7 @@ void pf_destroy(pf_ctx* c) {
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->stage_pin) (void)hipHostFree(c->stage_pin);
     c->stage_dev.release(); c->scan_desc.release();
+    c->g_store.release(); c->b_literal.release(); c->g_src_off.release(); c->g_src_start.release(); c->g_src_flags.release();
     c->mg_lo.release(); c->mg_hi.release(); c->mg_min.release(); c->mg_cnt.release();
     if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
     if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
@@ -485,6 +489,10 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
     // ---- batch arrays on the device
     pf_batch d = *b;
     std::vector<uint32_t> h_extra_cluster;
+    const pf_gather* gth = c->pending_gather;
+    c->pending_gather = nullptr;
+    if (gth && b->on_device) return fail(PF_ERR_ARG, "pf_submit_gather takes host arrays");
+    const uint64_t total_words = gth ? gth->n_words : b->n_words;
     if (!b->on_device) {
         // validate what the kernels index with (host copies are at hand)
         for (uint32_t i = 0; i < C; i++) {
@@ -500,7 +508,7 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
         if (C && b->cluster_seg_off[0] != 0) return fail(PF_ERR_ARG, "cluster_seg_off[0] must be 0");
         for (uint32_t s = 0; s < NSEG; s++) {
             const uint64_t nw = 2ull * ((b->seg_len[s] + 63) / 64);
-            if ((b->seg_word_off[s] & 1) || b->seg_word_off[s] + nw + 2 > b->n_words)
+            if ((b->seg_word_off[s] & 1) || b->seg_word_off[s] + nw + 2 > total_words)
                 return fail(PF_ERR_ARG, "segment %u: misaligned or outside packed[] (needs 2 words of tail padding)", s);
         }
         for (uint32_t i = 0; i < C; i++)
@@ -511,9 +519,40 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
                 if (s > b->cluster_seg_off[i] && b->seg_sample[s] < b->seg_sample[s - 1])
                     return fail(PF_ERR_ARG, "segments of cluster %u are not sorted by sample", i);
             }
-        PFCHK(upload(c, c->b_packed, b->packed, (size_t)b->n_words, &d.packed));
+        if (!gth) PFCHK(upload(c, c->b_packed, b->packed, (size_t)b->n_words, &d.packed));
         PFCHK(upload(c, c->b_seg_word_off, b->seg_word_off, NSEG, &d.seg_word_off));
         PFCHK(upload(c, c->b_seg_len, b->seg_len, NSEG, &d.seg_len));
+        if (gth) {
+            // the packed input is produced on the device: segments copied (or reverse-complemented) out of the
+            // resident genomes, plus the few the host packed itself (b->packed = the literal words)
+            if (NSEG && (!gth->src_off || !gth->src_start || !gth->src_flags)) return fail(PF_ERR_ARG, "gather arrays missing");
+            for (uint32_t s = 0; s < NSEG; s++) {
+                const uint64_t nw = 2ull * ((b->seg_len[s] + 63) / 64);
+                const uint64_t last = (uint64_t)gth->src_start[s] + b->seg_len[s];         // bases
+                if (gth->src_flags[s] & 1u) {
+                    if (gth->src_off[s] + nw + 1 > b->n_words || gth->src_start[s] != 0 || (gth->src_flags[s] & 2u))
+                        return fail(PF_ERR_ARG, "segment %u: literal source outside packed[]", s);
+                } else if (gth->src_off[s] + (last + 31) / 32 + 1 > c->g_words) {
+                    return fail(PF_ERR_ARG, "segment %u: source range outside the resident genomes", s);
+                }
+            }
+            PFCHK(c->b_packed.ensure((size_t)std::max<uint64_t>(total_words, 2) * 8));
+            d.packed = c->b_packed.as<uint64_t>();
+            const uint64_t* lit; const uint64_t* so; const uint32_t* ss; const uint32_t* sf;
+            PFCHK(upload(c, c->b_literal, b->packed, (size_t)b->n_words, &lit));
+            PFCHK(upload(c, c->g_src_off, gth->src_off, NSEG, &so));
+            PFCHK(upload(c, c->g_src_start, gth->src_start, NSEG, &ss));
+            PFCHK(upload(c, c->g_src_flags, gth->src_flags, NSEG, &sf));
+            if (total_words >= 2)
+                HIPCHK(hipMemsetAsync(c->b_packed.as<uint64_t>() + (total_words - 2), 0, 16, c->stream));
+            if (NSEG) {
+                pf::GatherParams gp{};
+                gp.store = c->g_store.as<uint64_t>(); gp.literal = lit; gp.src_off = so; gp.src_start = ss; gp.src_flags = sf;
+                gp.seg_word_off = d.seg_word_off; gp.seg_len = d.seg_len; gp.packed = c->b_packed.as<uint64_t>(); gp.n_segs = NSEG;
+                hipLaunchKernelGGL(pf::gather_segments_kernel, dim3((NSEG + 15) / 16), dim3(256), 0, c->stream, gp);
+                HIPCHK(hipGetLastError());
+            }
+        }
         PFCHK(upload(c, c->b_seg_sample, b->seg_sample, NSEG, &d.seg_sample));
         PFCHK(upload(c, c->b_seg_ord, b->seg_ord_base, NSEG, &d.seg_ord_base));
         PFCHK(upload(c, c->b_cl_seg_off, b->cluster_seg_off, (size_t)C + 1, &d.cluster_seg_off));
@@ -1413,6 +1452,89 @@ int pf_pattern_count(pf_ctx* c, uint64_t* n) {
     if (!c || !n) return fail(PF_ERR_ARG, "null argument");
     *n = c->n_patterns;
     return PF_OK;
+}
+
+int pf_submit_gather(pf_ctx* c, const pf_batch* b, const pf_gather* g, pf_result* r) {
+    if (!c || !b || !g) return fail(PF_ERR_ARG, "pf_submit_gather: null argument");
+    c->pending_gather = g;
+    const int rc = pf_submit(c, b, r);
+    c->pending_gather = nullptr;
+    return rc;
+}
+
+int pf_genomes_clear(pf_ctx* c) {
+    if (!c) return fail(PF_ERR_ARG, "pf_genomes_clear: null context");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->g_store.release();
+    c->g_words = 0;
+    return PF_OK;
+}
+
+int pf_genomes_upload(pf_ctx* c, uint32_t n, const char* const* ascii, const uint64_t* len, uint64_t* word_off) {
+    if (!c || (n && (!ascii || !len || !word_off))) return fail(PF_ERR_ARG, "pf_genomes_upload: null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (len[i] >= 0xFFFFFF00ull) return fail(PF_ERR_ARG, "contig %u is too long for 32-bit coordinates", i);
+        word_off[i] = total;
+        total += 2 * ((len[i] + 63) / 64) + 2;
+    }
+    c->g_store.release();
+    PFCHK(c->g_store.ensure((size_t)std::max<uint64_t>(total, 2) * 8));
+    c->g_words = total;
+    // staged in blocks: pinned host block -> device ASCII block -> 2-bit words
+    const size_t BLOCK = 64u << 20;
+    char* pin = nullptr;
+    DevBuf dasc, dpieces;
+    int rc = PF_OK;
+    do {
+        if (hipHostMalloc((void**)&pin, BLOCK, hipHostMallocDefault) != hipSuccess) { rc = fail(PF_ERR_OOM, "hipHostMalloc(%zu) failed", BLOCK); break; }
+        if ((rc = dasc.ensure(BLOCK)) != PF_OK) break;
+        std::vector<pf::PackPiece> pieces;
+        size_t fill = 0;
+        uint32_t blocks = 0;
+        auto flush = [&]() -> int {
+            if (pieces.empty()) return PF_OK;
+            PFCHK(dpieces.ensure(pieces.size() * sizeof(pf::PackPiece)));
+            HIPCHK(hipMemcpyAsync(dasc.p, pin, fill, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(dpieces.p, pieces.data(), pieces.size() * sizeof(pf::PackPiece), hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(pf::genome_pack_kernel, dim3(blocks), dim3(256), 0, c->stream, (const uint8_t*)dasc.p,
+                               (const pf::PackPiece*)dpieces.p, (uint32_t)pieces.size(), c->g_store.as<uint64_t>());
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(c->stream));        // the pinned block is reused
+            pieces.clear(); fill = 0; blocks = 0;
+            return PF_OK;
+        };
+        for (uint32_t i = 0; i < n && rc == PF_OK; i++) {
+            uint64_t done = 0;
+            const uint64_t L = len[i];
+            do {
+                if (BLOCK - fill < 64) { if ((rc = flush()) != PF_OK) break; }
+                const uint64_t room = (BLOCK - fill - 32) / 32 * 32;                  // bases this block still takes
+                const uint64_t take = std::min<uint64_t>(L - done, room);
+                const bool last = done + take == L;
+                memcpy(pin + fill, ascii[i] + done, take);
+                const size_t padded = (take + 31) / 32 * 32;
+                memset(pin + fill + take, 'A', padded - take);
+                pf::PackPiece pc{};
+                pc.ascii_off = fill; pc.dst_word = word_off[i] + done / 32; pc.nbases = (uint32_t)take;
+                const uint64_t contig_words = 2 * ((L + 63) / 64) + 2;
+                pc.nwords = (uint32_t)(last ? contig_words - done / 32 : take / 32);
+                pc.block0 = blocks;
+                blocks += (pc.nwords + 255) / 256;
+                if (pc.nwords) pieces.push_back(pc);
+                fill += padded;
+                done += take;
+                if (!last && (rc = flush()) != PF_OK) break;
+            } while (done < L);
+        }
+        if (rc == PF_OK) rc = flush();
+    } while (0);
+    if (pin) (void)hipHostFree(pin);
+    dasc.release(); dpieces.release();
+    return rc;
 }
 
 #ifdef PF_PROF

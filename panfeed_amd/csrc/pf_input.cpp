@@ -11,6 +11,7 @@
 #include "../../include/panfeed_hip.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -29,8 +30,14 @@ int in_fail(int code, const std::string& msg) { pf_set_error_(msg.c_str()); retu
 
 struct Feature { std::string id, chrom; long long start, end; int strand; };
 
+struct Contig {
+    std::string seq;                 // upper case
+    std::vector<uint32_t> bad;       // positions of bytes other than A/C/G/T, ascending
+    uint64_t word_off = 0;           // in the device genome store (pf_pangenome_set_store)
+};
+
 struct Genome {
-    std::unordered_map<std::string, std::string> contigs;       // name -> upper-case sequence
+    std::unordered_map<std::string, Contig> contigs;            // name -> sequence
     std::unordered_map<std::string, Feature> features;          // ID -> feature (later lines overwrite, as a dict)
     std::string warnings;
     std::string error;
@@ -49,7 +56,7 @@ inline bool is_space(char c) { return c == ' ' || c == '\t' || c == '\n' || c ==
 
 // FASTA text -> contigs (pyfaidx: name up to first whitespace, lines joined, upper case)
 void parse_fasta(const char* p, const char* end, Genome& g) {
-    std::string* cur = nullptr;
+    Contig* cur = nullptr;
     while (p < end) {
         const char* nl = (const char*)memchr(p, '\n', end - p);
         const char* le = nl ? nl : end;
@@ -59,15 +66,16 @@ void parse_fasta(const char* p, const char* end, Genome& g) {
             const char* q = p + 1;
             while (q < e && !is_space(*q)) q++;
             std::string name(p + 1, q);
-            auto ins = g.contigs.emplace(name, std::string());
+            auto ins = g.contigs.emplace(name, Contig());
             cur = ins.second ? &ins.first->second : nullptr;      // a repeated name keeps its first record
         } else if (cur) {
-            const size_t o = cur->size();
-            cur->resize(o + (e - p));
+            const size_t o = cur->seq.size();
+            cur->seq.resize(o + (e - p));
             for (const char* q = p; q < e; q++) {
                 char c = *q;
                 if (c >= 'a' && c <= 'z') c = (char)(c - 32);
-                (*cur)[o + (q - p)] = c;
+                cur->seq[o + (q - p)] = c;
+                if (c != 'A' && c != 'C' && c != 'G' && c != 'T') cur->bad.push_back((uint32_t)(o + (q - p)));
             }
         }
         p = nl ? nl + 1 : end;
@@ -194,19 +202,144 @@ struct pf_pangenome {
     size_t next_row = 0;
     std::string log;
     uint32_t W = 0;
+    // genomes resident on the device: flat contig order handed to pf_genomes_upload, by-reference mode
+    std::vector<Contig*> flat;
+    std::vector<const char*> flat_ptr;
+    std::vector<uint64_t> flat_len;
+    bool by_ref = false;
 };
 
 struct pf_records {
     // storage
-    std::vector<std::string> seq_store, comp_store, id_store, chrom_store;
+    std::vector<std::string> seq_store, comp_store;
     std::vector<const char*> seq, comp, ids, chroms, cluster_name_ptr, strain_ptr;
     std::vector<uint32_t> seq_len, seq_col, seq_strain, cluster_seq_off, cluster_nstrains, cluster_npresab, cluster_presab,
         cluster_row, cluster_strain_off, strain_index;
     std::vector<uint8_t> seq_target;
     std::vector<int32_t> seq_strand;
     std::vector<int64_t> seq_start, seq_end, seq_offset;
-    std::vector<std::string> strain_store;     // dict-order strain names of each cluster, concatenated (CSR)
+    std::vector<uint64_t> seq_src_off;
+    std::vector<uint32_t> seq_src_start, seq_flags;
 };
+
+namespace {
+// one row of the table -> its records (thread-safe: reads the pangenome only)
+struct RowOut {
+    std::vector<std::string> seq, comp;
+    std::vector<const char*> ids, chroms;
+    std::vector<uint32_t> seq_len, seq_col, seq_strain, presab, dict, seq_src_start, seq_flags;
+    std::vector<uint64_t> seq_src_off;
+    std::vector<uint8_t> seq_target;
+    std::vector<int32_t> seq_strand;
+    std::vector<int64_t> seq_start, seq_end, seq_offset;
+    std::string log, error;
+};
+
+void build_row(const pf_pangenome* P, size_t row, RowOut& R) {
+    const size_t S = P->strains.size();
+    const std::string& idx = P->cluster_names[row];
+    const auto& cells = P->cells[row];
+    R.presab.assign(P->W, 0);
+    // dict insertion order: present strains with genome data (CSV order), then absent strains (sorted)
+    std::vector<uint32_t>& dict = R.dict;                            // strain indices
+    for (size_t s = 0; s < S; s++)
+        if (!cells[s].empty()) {
+            const uint32_t sp = P->sorted_pos[s];
+            R.presab[sp >> 5] |= 1u << (sp & 31);                    // input.py:375-377
+            if (P->genomes.count(P->strains[s])) dict.push_back((uint32_t)s);   // input.py:384-387
+        }
+    const size_t npresent_dict = dict.size();
+    {
+        std::vector<uint32_t> absent;
+        for (size_t s = 0; s < S; s++) if (cells[s].empty()) absent.push_back((uint32_t)s);
+        std::sort(absent.begin(), absent.end(), [&](uint32_t a, uint32_t b) { return P->sorted_pos[a] < P->sorted_pos[b]; });
+        dict.insert(dict.end(), absent.begin(), absent.end());      // input.py:465-466
+    }
+    // column of each dict strain in sorted(cluster.keys())  (panfeed.py:47-49)
+    std::vector<uint32_t> order(dict.size());
+    for (size_t i = 0; i < dict.size(); i++) order[i] = (uint32_t)i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return P->sorted_pos[dict[a]] < P->sorted_pos[dict[b]]; });
+    std::vector<uint32_t> col(dict.size());
+    for (size_t i = 0; i < order.size(); i++) col[order[i]] = (uint32_t)i;
+
+    for (size_t di = 0; di < npresent_dict; di++) {
+        const std::string& strain = P->strains[dict[di]];
+        const Genome& g = P->genomes.find(strain)->second;
+        const bool is_target = P->targets.count(strain) != 0;
+        const std::string& genes = cells[dict[di]];
+        size_t q0 = 0;
+        for (;;) {                                                   // genes.split(';')  input.py:393
+            size_t t = genes.find(';', q0);
+            std::string gene = genes.substr(q0, t == std::string::npos ? std::string::npos : t - q0);
+            auto fit = g.features.find(gene);
+            if (fit == g.features.end()) {                           // input.py:396-402
+                R.log += "Could not find gene " + gene + " from " + idx + " in " + strain + "\n";
+                if (P->raise_missing) { R.error = "Could not find gene " + gene + " from " + idx + " in " + strain; return; }
+            } else {
+                const Feature& f = fit->second;
+                auto cit = g.contigs.find(f.chrom);
+                if (cit == g.contigs.end()) {                        // input.py:404-411
+                    R.log += "Could not find chromosome " + f.chrom + " in " + strain + "\n";
+                    if (P->raise_missing) { R.error = "Could not find chromosome " + f.chrom + " in " + strain; return; }
+                } else {
+                    const Contig& ctg = cit->second;
+                    const long long up = P->up, down = P->down;
+                    const long long offset = (f.strand > 0 && f.start - 1 - up < 0) ? f.start - 1 : up;        // :415-418
+                    const long long offset_d = (f.strand < 0 && f.start - 1 - down < 0) ? f.start - 1 : down;  // :421-424
+                    long long a, b, seq_start, seq_end;
+                    if (!P->dsc) {                                   // :427-436
+                        if (f.strand > 0) { a = f.start - 1 - offset; b = f.end + offset_d; seq_start = f.start - offset; seq_end = f.end + offset_d; }
+                        else { a = f.start - 1 - offset_d; b = f.end + offset; seq_start = f.start - offset_d; seq_end = f.end + offset; }
+                    } else {                                         // :437-446
+                        if (f.strand > 0) { a = f.start - 1 - offset; b = f.start + offset_d; seq_start = f.start - offset; seq_end = f.start + offset_d; }
+                        else { a = f.end - 1 - offset_d; b = f.end + offset; seq_start = f.end - offset_d; seq_end = f.end + offset; }
+                    }
+                    // Python slice clipping of contig[a:b]
+                    const long long n = (long long)ctg.seq.size();
+                    if (a < 0) a = std::max(0LL, a + n);
+                    if (b < 0) b = std::max(0LL, b + n);
+                    a = std::min(a, n); b = std::min(b, n);
+                    if (b < a) b = a;
+                    // resident genomes: a pure-ACGT range of a non-target strain goes by reference
+                    bool ref = P->by_ref && !is_target;
+                    if (ref) {
+                        auto it = std::lower_bound(ctg.bad.begin(), ctg.bad.end(), (uint32_t)a);
+                        if (it != ctg.bad.end() && (long long)*it < b) ref = false;
+                    }
+                    R.seq_len.push_back((uint32_t)(b - a));
+                    if (ref) {
+                        R.seq.emplace_back(); R.comp.emplace_back();
+                        R.seq_src_off.push_back(ctg.word_off); R.seq_src_start.push_back((uint32_t)a);
+                        R.seq_flags.push_back(1u | (f.strand < 0 ? 2u : 0u));
+                    } else {
+                        std::string seq = ctg.seq.substr((size_t)a, (size_t)(b - a));
+                        if (f.strand < 0) {                          // -sequences[...]: reverse complement
+                            std::reverse(seq.begin(), seq.end());
+                            for (auto& ch : seq) ch = (char)g_comp.t[(unsigned char)ch];
+                        }
+                        std::string comp(seq.size(), 'N');           // revseq = (-seq)[::-1] : the complement (:449-452)
+                        for (size_t i = 0; i < seq.size(); i++) comp[i] = (char)g_comp.t[(unsigned char)seq[i]];
+                        R.seq.push_back(std::move(seq));
+                        R.comp.push_back(std::move(comp));
+                        R.seq_src_off.push_back(0); R.seq_src_start.push_back(0); R.seq_flags.push_back(0);
+                    }
+                    R.ids.push_back(f.id.c_str());
+                    R.chroms.push_back(f.chrom.c_str());
+                    R.seq_col.push_back(col[di]);
+                    R.seq_strain.push_back((uint32_t)di);
+                    R.seq_target.push_back(is_target ? 1 : 0);
+                    R.seq_strand.push_back(f.strand);
+                    R.seq_start.push_back(seq_start);
+                    R.seq_end.push_back(seq_end);
+                    R.seq_offset.push_back(offset);
+                }
+            }
+            if (t == std::string::npos) break;
+            q0 = t + 1;
+        }
+    }
+}
+}  // namespace
 
 extern "C" {
 
@@ -320,115 +453,59 @@ void pf_records_free(pf_records* r) { delete r; }
 int pf_pangenome_next(pf_pangenome* P, uint32_t max_clusters, pf_records** out, pf_records_view_t* v) {
     if (!P || !out || !v) return in_fail(PF_ERR_ARG, "null argument");
     *out = nullptr;
+    // rows of this call
+    std::vector<size_t> rows;
+    while (P->next_row < P->cluster_names.size() && rows.size() < max_clusters) {
+        const size_t row = P->next_row++;
+        if (P->have_genes && !P->genes.count(P->cluster_names[row])) continue;        // input.py:353-355
+        rows.push_back(row);
+    }
+    const uint32_t made = (uint32_t)rows.size();
+    std::vector<RowOut> ro(made);
+    {
+        unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+        if (made < 4) nt = 1;
+        std::atomic<uint32_t> next{0};
+        std::vector<std::thread> th;
+        auto work = [&] { for (uint32_t i; (i = next.fetch_add(1)) < made;) build_row(P, rows[i], ro[i]); };
+        for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
+        work();
+        for (auto& x : th) x.join();
+    }
+    for (uint32_t i = 0; i < made; i++) {
+        P->log += ro[i].log;                                                           // in table order
+        if (!ro[i].error.empty()) return in_fail(PF_ERR_ARG, ro[i].error);
+    }
     pf_records* R = new pf_records();
     R->cluster_seq_off.push_back(0);
     R->cluster_strain_off.push_back(0);
-    const size_t S = P->strains.size();
-    uint32_t made = 0;
-    while (P->next_row < P->cluster_names.size() && made < max_clusters) {
-        const size_t row = P->next_row++;
-        const std::string& idx = P->cluster_names[row];
-        if (P->have_genes && !P->genes.count(idx)) continue;            // input.py:353-355
-        const auto& cells = P->cells[row];
-        std::vector<uint32_t> presab(P->W, 0);
-        // dict insertion order: present strains with genome data (CSV order), then absent strains (sorted)
-        std::vector<uint32_t> dict;                                      // strain indices
-        for (size_t s = 0; s < S; s++)
-            if (!cells[s].empty()) {
-                const uint32_t sp = P->sorted_pos[s];
-                presab[sp >> 5] |= 1u << (sp & 31);                      // input.py:375-377
-                if (P->genomes.count(P->strains[s])) dict.push_back((uint32_t)s);   // input.py:384-387
-            }
-        const size_t npresent_dict = dict.size();
-        {
-            std::vector<uint32_t> absent;
-            for (size_t s = 0; s < S; s++) if (cells[s].empty()) absent.push_back((uint32_t)s);
-            std::sort(absent.begin(), absent.end(), [&](uint32_t a, uint32_t b) { return P->strains[a] < P->strains[b]; });
-            dict.insert(dict.end(), absent.begin(), absent.end());      // input.py:465-466
-        }
-        // column of each dict strain in sorted(cluster.keys())  (panfeed.py:47-49)
-        std::vector<uint32_t> order(dict.size());
-        for (size_t i = 0; i < dict.size(); i++) order[i] = (uint32_t)i;
-        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return P->strains[dict[a]] < P->strains[dict[b]]; });
-        std::vector<uint32_t> col(dict.size());
-        for (size_t i = 0; i < order.size(); i++) col[order[i]] = (uint32_t)i;
-
-        for (size_t di = 0; di < npresent_dict; di++) {
-            const std::string& strain = P->strains[dict[di]];
-            const Genome& g = P->genomes.find(strain)->second;
-            const std::string& genes = cells[dict[di]];
-            size_t q0 = 0;
-            for (;;) {                                                   // genes.split(';')  input.py:393
-                size_t t = genes.find(';', q0);
-                std::string gene = genes.substr(q0, t == std::string::npos ? std::string::npos : t - q0);
-                auto fit = g.features.find(gene);
-                if (fit == g.features.end()) {                           // input.py:396-402
-                    P->log += "Could not find gene " + gene + " from " + idx + " in " + strain + "\n";
-                    if (P->raise_missing) { delete R; return in_fail(PF_ERR_ARG, "Could not find gene " + gene + " from " + idx + " in " + strain); }
-                } else {
-                    const Feature& f = fit->second;
-                    auto cit = g.contigs.find(f.chrom);
-                    if (cit == g.contigs.end()) {                        // input.py:404-411
-                        P->log += "Could not find chromosome " + f.chrom + " in " + strain + "\n";
-                        if (P->raise_missing) { delete R; return in_fail(PF_ERR_ARG, "Could not find chromosome " + f.chrom + " in " + strain); }
-                    } else {
-                        const std::string& ctg = cit->second;
-                        const long long up = P->up, down = P->down;
-                        const long long offset = (f.strand > 0 && f.start - 1 - up < 0) ? f.start - 1 : up;        // :415-418
-                        const long long offset_d = (f.strand < 0 && f.start - 1 - down < 0) ? f.start - 1 : down;  // :421-424
-                        long long a, b, seq_start, seq_end;
-                        if (!P->dsc) {                                   // :427-436
-                            if (f.strand > 0) { a = f.start - 1 - offset; b = f.end + offset_d; seq_start = f.start - offset; seq_end = f.end + offset_d; }
-                            else { a = f.start - 1 - offset_d; b = f.end + offset; seq_start = f.start - offset_d; seq_end = f.end + offset; }
-                        } else {                                         // :437-446
-                            if (f.strand > 0) { a = f.start - 1 - offset; b = f.start + offset_d; seq_start = f.start - offset; seq_end = f.start + offset_d; }
-                            else { a = f.end - 1 - offset_d; b = f.end + offset; seq_start = f.end - offset_d; seq_end = f.end + offset; }
-                        }
-                        // Python slice clipping of contig[a:b]
-                        const long long n = (long long)ctg.size();
-                        if (a < 0) a = std::max(0LL, a + n);
-                        if (b < 0) b = std::max(0LL, b + n);
-                        a = std::min(a, n); b = std::min(b, n);
-                        if (b < a) b = a;
-                        std::string seq = ctg.substr((size_t)a, (size_t)(b - a));
-                        if (f.strand < 0) {                              // -sequences[...]: reverse complement
-                            std::reverse(seq.begin(), seq.end());
-                            for (auto& ch : seq) ch = (char)g_comp.t[(unsigned char)ch];
-                        }
-                        std::string comp(seq.size(), 'N');               // revseq = (-seq)[::-1] : the complement (:449-452)
-                        for (size_t i = 0; i < seq.size(); i++) comp[i] = (char)g_comp.t[(unsigned char)seq[i]];
-                        R->seq_len.push_back((uint32_t)seq.size());
-                        R->seq_store.push_back(std::move(seq));
-                        R->comp_store.push_back(std::move(comp));
-                        R->id_store.push_back(f.id);
-                        R->chrom_store.push_back(f.chrom);
-                        R->seq_col.push_back(col[di]);
-                        R->seq_strain.push_back((uint32_t)di);
-                        R->seq_target.push_back(P->targets.count(strain) ? 1 : 0);
-                        R->seq_strand.push_back(f.strand);
-                        R->seq_start.push_back(seq_start);
-                        R->seq_end.push_back(seq_end);
-                        R->seq_offset.push_back(offset);
-                    }
-                }
-                if (t == std::string::npos) break;
-                q0 = t + 1;
-            }
-        }
+    size_t nseq = 0;
+    for (auto& r : ro) nseq += r.seq_len.size();
+    R->seq_store.reserve(nseq); R->comp_store.reserve(nseq);
+    auto app = [](auto& dst, const auto& src) { dst.insert(dst.end(), src.begin(), src.end()); };
+    for (uint32_t i = 0; i < made; i++) {
+        RowOut& r = ro[i];
+        for (auto& x : r.seq) R->seq_store.push_back(std::move(x));
+        for (auto& x : r.comp) R->comp_store.push_back(std::move(x));
+        app(R->ids, r.ids); app(R->chroms, r.chroms);
+        app(R->seq_len, r.seq_len); app(R->seq_col, r.seq_col); app(R->seq_strain, r.seq_strain);
+        app(R->seq_target, r.seq_target); app(R->seq_strand, r.seq_strand);
+        app(R->seq_start, r.seq_start); app(R->seq_end, r.seq_end); app(R->seq_offset, r.seq_offset);
+        app(R->seq_src_off, r.seq_src_off); app(R->seq_src_start, r.seq_src_start); app(R->seq_flags, r.seq_flags);
         R->cluster_seq_off.push_back((uint32_t)R->seq_len.size());
-        R->cluster_nstrains.push_back((uint32_t)dict.size());
-        R->cluster_npresab.push_back((uint32_t)S);
-        R->cluster_presab.insert(R->cluster_presab.end(), presab.begin(), presab.end());
-        R->cluster_row.push_back((uint32_t)row);
-        for (uint32_t s : dict) R->strain_index.push_back(s);
+        R->cluster_nstrains.push_back((uint32_t)r.dict.size());
+        R->cluster_npresab.push_back((uint32_t)P->strains.size());
+        app(R->cluster_presab, r.presab);
+        R->cluster_row.push_back((uint32_t)rows[i]);
+        app(R->strain_index, r.dict);
         R->cluster_strain_off.push_back((uint32_t)R->strain_index.size());
-        made++;
     }
     const size_t n = R->seq_len.size();
-    R->seq.resize(n); R->comp.resize(n); R->ids.resize(n); R->chroms.resize(n);
+    R->seq.resize(n); R->comp.resize(n);
     for (size_t i = 0; i < n; i++) {
-        R->seq[i] = R->seq_store[i].c_str(); R->comp[i] = R->comp_store[i].c_str();
-        R->ids[i] = R->id_store[i].c_str(); R->chroms[i] = R->chrom_store[i].c_str();
+        const bool ref = (R->seq_flags[i] & 1u) != 0;
+        R->seq[i] = ref ? nullptr : R->seq_store[i].c_str();
+        R->comp[i] = ref ? nullptr : R->comp_store[i].c_str();
     }
     R->cluster_name_ptr.resize(made);
     for (uint32_t i = 0; i < made; i++) R->cluster_name_ptr[i] = P->cluster_names[R->cluster_row[i]].c_str();
@@ -443,7 +520,40 @@ int pf_pangenome_next(pf_pangenome* P, uint32_t max_clusters, pf_records** out, 
     v->cluster_nstrains = R->cluster_nstrains.data(); v->cluster_npresab = R->cluster_npresab.data();
     v->cluster_presab = R->cluster_presab.data(); v->cluster_strain_off = R->cluster_strain_off.data();
     v->cluster_strain = R->strain_ptr.data();
+    v->seq_src_off = P->by_ref ? R->seq_src_off.data() : nullptr;
+    v->seq_src_start = P->by_ref ? R->seq_src_start.data() : nullptr;
+    v->seq_flags = P->by_ref ? R->seq_flags.data() : nullptr;
     *out = R;
+    return PF_OK;
+}
+
+int pf_pangenome_contigs(pf_pangenome* P, uint32_t* n, const char* const** ascii, const uint64_t** len) {
+    if (!P || !n || !ascii || !len) return in_fail(PF_ERR_ARG, "pf_pangenome_contigs: null argument");
+    if (P->flat.empty()) {
+        // any fixed order will do; keep it deterministic: genomes by name, contigs by name
+        std::vector<std::string> gnames;
+        for (auto& kv : P->genomes) gnames.push_back(kv.first);
+        std::sort(gnames.begin(), gnames.end());
+        for (auto& gn : gnames) {
+            Genome& g = P->genomes.find(gn)->second;
+            std::vector<std::string> cn;
+            for (auto& kv : g.contigs) cn.push_back(kv.first);
+            std::sort(cn.begin(), cn.end());
+            for (auto& c : cn) P->flat.push_back(&g.contigs.find(c)->second);
+        }
+        for (Contig* c : P->flat) { P->flat_ptr.push_back(c->seq.data()); P->flat_len.push_back(c->seq.size()); }
+    }
+    *n = (uint32_t)P->flat.size();
+    *ascii = P->flat_ptr.data();
+    *len = P->flat_len.data();
+    return PF_OK;
+}
+
+int pf_pangenome_set_store(pf_pangenome* P, const uint64_t* contig_word_off, uint32_t n) {
+    if (!P || (n && !contig_word_off)) return in_fail(PF_ERR_ARG, "pf_pangenome_set_store: null argument");
+    if (n != P->flat.size()) return in_fail(PF_ERR_ARG, "pf_pangenome_set_store: call pf_pangenome_contigs first (contig count differs)");
+    for (uint32_t i = 0; i < n; i++) P->flat[i]->word_off = contig_word_off[i];
+    P->by_ref = true;
     return PF_OK;
 }
 

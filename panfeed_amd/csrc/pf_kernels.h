@@ -2519,6 +2519,96 @@ __global__ __launch_bounds__(256) void cluster_ninst_kernel(const uint32_t* clus
     if (lane == 0) { cluster_ninst[c] = n; cluster_vinst[c] = nv; cluster_vwords[c] = wv; }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Genomes resident in HBM (row N1 on the device): contigs as 2 bits per base, segments gathered from them
+// ---------------------------------------------------------------------------------------------
+// A contig sits at an even word offset of the store, 32 bases per word (first base in bits 63:62), followed by at
+// least two zero words.  Non-ACGT bytes get an arbitrary code: the host knows where they are and never asks for a
+// range that contains one.
+struct PackPiece {
+    uint64_t ascii_off;      // byte offset of the piece in the staged ASCII block (multiple of 32)
+    uint64_t dst_word;       // first word of the piece in the store
+    uint32_t nbases;         // bases of the piece (a multiple of 32 unless it ends its contig)
+    uint32_t nwords;         // words to write: ceil(nbases / 32) plus the contig's zero padding behind its last piece
+    uint32_t block0;         // first 256-thread block of the piece
+    uint32_t pad;
+};
+
+__device__ __forceinline__ uint32_t codes16(uint64_t b) {
+    // eight ASCII bytes -> eight 2-bit codes, first byte most significant: A 0, C 1, G 2, T 3 = ((c >> 1) ^ (c >> 2)) & 3
+    const uint64_t x = ((b >> 1) ^ (b >> 2)) & 0x0303030303030303ull;
+    uint32_t r = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) r |= (uint32_t)((x >> (8 * j)) & 3u) << (14 - 2 * j);
+    return r;
+}
+
+__global__ __launch_bounds__(256) void genome_pack_kernel(const uint8_t* ascii, const PackPiece* pieces, uint32_t npieces,
+                                                          uint64_t* store) {
+    uint32_t a = 0, b = npieces;                         // last piece with block0 <= blockIdx.x
+    while (b - a > 1) { const uint32_t m = (a + b) >> 1; if (pieces[m].block0 <= blockIdx.x) a = m; else b = m; }
+    const PackPiece pc = pieces[a];
+    const uint32_t w = (blockIdx.x - pc.block0) * 256 + threadIdx.x;
+    if (w >= pc.nwords) return;
+    uint64_t out = 0;
+    const uint64_t base = (uint64_t)w * 32;
+    if (base < pc.nbases) {
+        const ulonglong2* src = reinterpret_cast<const ulonglong2*>(ascii + pc.ascii_off + base);
+        const ulonglong2 lo = src[0], hi = src[1];
+        out = ((uint64_t)codes16(lo.x) << 48) | ((uint64_t)codes16(lo.y) << 32) | ((uint64_t)codes16(hi.x) << 16) |
+              (uint64_t)codes16(hi.y);
+        const uint32_t nb = (uint32_t)min((uint64_t)32, pc.nbases - base);
+        if (nb < 32) out &= ~0ull << (2 * (32 - nb));
+    }
+    store[pc.dst_word + w] = out;
+}
+
+struct GatherParams {
+    const uint64_t* store;        // genome store
+    const uint64_t* literal;      // packed words the host prepared itself (sequences with non-ACGT bases, target strains)
+    const uint64_t* src_off;      // [n_segs] word offset of the source inside its buffer
+    const uint32_t* src_start;    // [n_segs] lowest base coordinate of the range inside the source
+    const uint32_t* src_flags;    // [n_segs] bit 0: source is `literal`; bit 1: reverse complement
+    const uint64_t* seg_word_off; const uint32_t* seg_len;
+    uint64_t* packed;
+    uint32_t n_segs;
+};
+
+// 16 lanes per segment, one destination word per lane and trip
+__global__ __launch_bounds__(256) void gather_segments_kernel(GatherParams p) {
+    const uint32_t seg = blockIdx.x * 16 + (threadIdx.x >> 4), gl = threadIdx.x & 15;
+    if (seg >= p.n_segs) return;
+    const uint32_t len = p.seg_len[seg], flags = p.src_flags[seg], start = p.src_start[seg];
+    const uint64_t* src = ((flags & 1u) ? p.literal : p.store) + p.src_off[seg];
+    uint64_t* dst = p.packed + p.seg_word_off[seg];
+    const uint32_t nw = 2 * ((len + 63) >> 6);
+    for (uint32_t w = gl; w < nw; w += 16) {
+        uint64_t out = 0;
+        if (w * 32 < len) {
+            const uint32_t nb = min(32u, len - w * 32);
+            if (!(flags & 2u)) {
+                const uint32_t pos = start + w * 32, i = pos >> 5, sh = (pos & 31) << 1;
+                out = src[i] << sh;
+                if (sh) out |= src[i + 1] >> (64 - sh);
+            } else {
+                // destination base j = complement of source base start + len - 1 - j
+                const int64_t qhi = (int64_t)start + len - 1 - (int64_t)w * 32, ws = qhi - 31;
+                uint64_t y;
+                if (ws >= 0) {
+                    const uint32_t i = (uint32_t)(ws >> 5), sh = ((uint32_t)ws & 31) << 1;
+                    y = src[i] << sh;
+                    if (sh) y |= src[i + 1] >> (64 - sh);
+                } else {
+                    y = src[0] >> (2 * (uint32_t)(-ws));
+                }
+                out = rev_groups(~y);
+            }
+            if (nb < 32) out &= ~0ull << (2 * (32 - nb));
+        }
+        dst[w] = out;
+    }
+}
+
 __global__ void fill_u64_kernel(uint64_t* p, uint64_t v, uint64_t n) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
         p[i] = v;

@@ -32,7 +32,12 @@ struct Extra { uint32_t ord; std::vector<uint32_t> bits; std::string key; };
 
 struct ClusterOut {
     std::vector<uint64_t> words;                 // packed segments of the cluster, in final (sorted) order
-    std::vector<uint32_t> seg_woff, seg_len, seg_sample, seg_ord, seg_strand_nw;   // woff: words into `words`
+    std::vector<uint32_t> seg_woff, seg_len, seg_sample, seg_ord, seg_strand_nw;   // woff: words into the cluster's
+                                                 // share of the device buffer
+    std::vector<uint32_t> seg_lit;               // literal segments: words into `words`; by reference: 0xFFFFFFFF
+    std::vector<uint64_t> seg_src_off;           // by reference: the range in the resident genomes
+    std::vector<uint32_t> seg_src_start, seg_src_flags;
+    uint32_t dev_words = 0;
     std::vector<uint8_t> seg_wants_strand;
     std::vector<Extra> extras;
     // per target sequence (iteration order)
@@ -67,9 +72,12 @@ void pack_cluster(const pf_pack_in* in, uint32_t ci, ClusterOut& o) {
         const uint32_t col = in->seq_col[q];
         const bool target = in->seq_target && in->seq_target[q];
         const uint64_t num_kmer = L >= k ? (uint64_t)L - k + 1 : 0;              // panfeed.py:59,64
-        codes.resize(L);
+        const bool byref = in->seq_flags && (in->seq_flags[q] & 1u);
+        if (byref && target) { o.error = "a target strain's sequence cannot be given by reference"; return; }
+        if (!byref && (!seq || !comp)) { o.error = "sequence text missing"; return; }
+        codes.resize(byref ? 0 : L);
         std::vector<uint32_t> bad;
-        for (uint32_t i = 0; i < L; i++) {
+        for (uint32_t i = 0; i < L && !byref; i++) {
             codes[i] = (int8_t)code_of((unsigned char)seq[i]);
             if (codes[i] < 0) bad.push_back(i);
             else if (code_of((unsigned char)comp[i]) != 3 - codes[i]) {
@@ -146,6 +154,23 @@ void pack_cluster(const pf_pack_in* in, uint32_t ci, ClusterOut& o) {
         where[g.order] = (uint32_t)j;
         const uint32_t nw = 2 * ((g.len + 63) / 64);
         const uint32_t w0 = (uint32_t)o.words.size();
+        const bool byref = in->seq_flags && (in->seq_flags[g.seq] & 1u);
+        o.seg_woff.push_back(o.dev_words);
+        o.dev_words += nw;
+        o.seg_len.push_back(g.len);
+        o.seg_sample.push_back(g.col);
+        o.seg_ord.push_back(g.ord);
+        o.seg_wants_strand.push_back(g.strand ? 1 : 0);
+        o.seg_strand_nw.push_back(g.strand ? (g.len - k + 1 + 63) / 64 : 0);
+        if (byref) {                 // the whole sequence is one segment (pure A/C/G/T): gathered on the device
+            o.seg_lit.push_back(0xFFFFFFFFu);
+            o.seg_src_off.push_back(in->seq_src_off[g.seq]);
+            o.seg_src_start.push_back(in->seq_src_start[g.seq]);
+            o.seg_src_flags.push_back(in->seq_flags[g.seq] & 2u);
+            continue;
+        }
+        o.seg_lit.push_back(w0);
+        o.seg_src_off.push_back(0); o.seg_src_start.push_back(0); o.seg_src_flags.push_back(1u);
         o.words.resize(w0 + nw, 0);
         const char* seq = in->seq[g.seq] + g.a;
         for (uint32_t i0 = 0; i0 < g.len; i0 += 32) {
@@ -154,12 +179,6 @@ void pack_cluster(const pf_pack_in* in, uint32_t ci, ClusterOut& o) {
             for (uint32_t i = 0; i < m; i++) w = (w << 2) | (uint64_t)code_of((unsigned char)seq[i0 + i]);
             o.words[w0 + (i0 >> 5)] = w << (2 * (32 - m));
         }
-        o.seg_woff.push_back(w0);
-        o.seg_len.push_back(g.len);
-        o.seg_sample.push_back(g.col);
-        o.seg_ord.push_back(g.ord);
-        o.seg_wants_strand.push_back(g.strand ? 1 : 0);
-        o.seg_strand_nw.push_back(g.strand ? (g.len - k + 1 + 63) / 64 : 0);
     }
     for (auto& x : o.t_seg_local) x = where[x];
 }
@@ -177,6 +196,10 @@ struct pf_packed {
     std::string t_amb_keys;
     std::vector<uint64_t> cluster_ninst;
     uint64_t n_strand_words = 0, n_instances = 0;
+    bool gather = false;
+    uint64_t n_words_dev = 0;
+    std::vector<uint64_t> g_src_off;
+    std::vector<uint32_t> g_src_start, g_src_flags;
 };
 
 extern "C" {
@@ -199,12 +222,19 @@ int pf_pack_records(const pf_pack_in* in, pf_packed** out) {
         if (!outs[ci].error.empty()) return pk_fail(PF_ERR_ARG, "cluster %u: %s", ci, outs[ci].error.c_str());
     pf_packed* p = new pf_packed();
     p->cluster_seg_off.assign(1, 0);
-    uint64_t woff = 0, strand_words = 0;
+    p->gather = in->seq_flags != nullptr;
+    if (p->gather && (!in->seq_src_off || !in->seq_src_start)) { delete p; return pk_fail(PF_ERR_ARG, "pf_pack_records: seq_src arrays missing"); }
+    uint64_t woff = 0, strand_words = 0, lit_off = 0;
     for (uint32_t ci = 0; ci < C; ci++) {
         ClusterOut& o = outs[ci];
         const uint32_t seg_base = (uint32_t)p->seg_len.size();
         for (size_t j = 0; j < o.seg_len.size(); j++) {
             p->seg_word_off.push_back(woff + o.seg_woff[j]);
+            if (p->gather) {
+                p->g_src_off.push_back(o.seg_lit[j] != 0xFFFFFFFFu ? lit_off + o.seg_lit[j] : o.seg_src_off[j]);
+                p->g_src_start.push_back(o.seg_src_start[j]);
+                p->g_src_flags.push_back(o.seg_src_flags[j]);
+            }
             p->seg_len.push_back(o.seg_len[j]);
             p->seg_sample.push_back(o.seg_sample[j]);
             p->seg_ord_base.push_back(o.seg_ord[j]);
@@ -221,7 +251,8 @@ int pf_pack_records(const pf_pack_in* in, pf_packed** out) {
         }
         p->seg_strand_off.insert(p->seg_strand_off.end(), soff.begin(), soff.end());
         p->packed.insert(p->packed.end(), o.words.begin(), o.words.end());
-        woff += o.words.size();
+        woff += o.dev_words;
+        lit_off += o.words.size();
         p->cluster_seg_off.push_back((uint32_t)p->seg_len.size());
         for (auto& e : o.extras) {
             p->extra_cluster.push_back(ci);
@@ -250,6 +281,7 @@ int pf_pack_records(const pf_pack_in* in, pf_packed** out) {
     p->t_amb_off.push_back((uint32_t)p->t_amb_pos.size());
     p->packed.push_back(0);
     p->packed.push_back(0);                       // 16 bytes of tail padding
+    p->n_words_dev = p->gather ? woff + 2 : 0;
     p->n_strand_words = strand_words;
     *out = p;
     return PF_OK;
@@ -286,6 +318,10 @@ int pf_packed_view(const pf_packed* p, pf_packed_view_t* v) {
     v->cluster_ninst = p->cluster_ninst.data();
     v->n_strand_words = p->n_strand_words;
     v->n_instances = p->n_instances;
+    v->n_words_dev = p->n_words_dev;
+    v->gather_src_off = p->gather ? p->g_src_off.data() : nullptr;
+    v->gather_src_start = p->gather ? p->g_src_start.data() : nullptr;
+    v->gather_src_flags = p->gather ? p->g_src_flags.data() : nullptr;
     return PF_OK;
 }
 

@@ -110,7 +110,13 @@ class Engine:
             b.seg_strand_off = _ptr(hb.seg_strand_off)
             b.n_strand_words = hb.n_strand_words
         res = _lib.Result()
-        _lib.check(self.L.pf_submit(self.ctx, C.byref(b), C.byref(res)))
+        if hb.gather_src_off is not None:
+            # segments are ranges of the genomes resident in HBM; b.packed = the few the host packed itself
+            g = _lib.Gather(int(hb.n_words_dev), hb.gather_src_off.ctypes.data, hb.gather_src_start.ctypes.data,
+                            hb.gather_src_flags.ctypes.data)
+            _lib.check(self.L.pf_submit_gather(self.ctx, C.byref(b), C.byref(g), C.byref(res)))
+        else:
+            _lib.check(self.L.pf_submit(self.ctx, C.byref(b), C.byref(res)))
         return res
 
     def fetch(self):

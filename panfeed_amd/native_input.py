@@ -88,6 +88,24 @@ class Pangenome:
         self.n_clusters, self.n_strains = int(info.n_clusters), int(info.n_strains)
         self.strains = [self.L.pf_pangenome_strain(self.h, i, 0).decode() for i in range(self.n_strains)]
         self.sorted_strains = [self.L.pf_pangenome_strain(self.h, i, 1).decode() for i in range(self.n_strains)]
+        self.resident = False
+
+    def make_resident(self, engine):
+        """Upload every contig to `engine`'s GPU (2 bits per base, pf_genomes_upload) and switch the reader to
+        by-reference records: a sequence that is pure A/C/G/T and not a target strain's is handed on as (contig,
+        start, length, strand) and cut out -- or reverse-complemented -- by the device (pf_submit_gather); the host
+        then does no per-base work for it.  Target strains and sequences with other letters stay text."""
+        n = C.c_uint32()
+        ptrs = C.POINTER(C.c_char_p)()
+        lens = C.POINTER(C.c_uint64)()
+        _lib.check(self.L.pf_pangenome_contigs(self.h, C.byref(n), C.byref(ptrs), C.byref(lens)))
+        off = (C.c_uint64 * max(n.value, 1))()
+        _lib.check(self.L.pf_genomes_upload(engine.ctx, n.value, ptrs, lens, off))
+        _lib.check(self.L.pf_pangenome_set_store(self.h, off, n.value))
+        self.resident = True
+        self.n_contigs = int(n.value)
+        self.genome_bases = int(sum(lens[i] for i in range(n.value)))
+        return self
 
     def close(self):
         if self.h:
@@ -123,6 +141,8 @@ class Pangenome:
     def records(self, max_clusters=64):
         """Reference-shaped records `(gene_sequences, idx, clusterpresab)` (input.py:468) -- for tests and for
         callers that want the mirror API; the batch path below never builds them."""
+        if self.resident:
+            raise RuntimeError("records() yields text; after make_resident() use batches()")
         while True:
             got = self.next_records(max_clusters)
             if got is None:
@@ -153,7 +173,10 @@ class Pangenome:
                                   C.cast(v.seq_col, C.c_void_p),
                                   C.cast(v.seq_target, C.c_void_p) if self.targets else None,
                                   C.cast(v.cluster_seq_off, C.c_void_p), k, int(bool(canon)), W,
-                                  int(bool(want_strand)))
+                                  int(bool(want_strand)),
+                                  C.cast(v.seq_src_off, C.c_void_p) if self.resident else None,
+                                  C.cast(v.seq_src_start, C.c_void_p) if self.resident else None,
+                                  C.cast(v.seq_flags, C.c_void_p) if self.resident else None)
                 ph = C.c_void_p()
                 _lib.check(L.pf_pack_records(C.byref(pin), C.byref(ph)))
                 try:

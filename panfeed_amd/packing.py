@@ -93,6 +93,12 @@ class HostBatch:
     extra_keys: list = field(default_factory=list)        # k-mer strings of the slow-path rows
     targets: list = field(default_factory=list)           # SeqMeta of sequences in target strains
     n_instances: int = 0                                  # trip count of panfeed.py:64 (x2 non-canonical)
+    # with genomes resident in HBM (pf_submit_gather): `packed` holds only the host-packed ("literal") segments,
+    # seg_word_off are offsets in the device buffer of n_words_dev words the gather fills
+    n_words_dev: int = 0
+    gather_src_off: np.ndarray = None
+    gather_src_start: np.ndarray = None
+    gather_src_flags: np.ndarray = None
 
     @property
     def n_clusters(self):
@@ -290,6 +296,11 @@ def _fill_from_packed(L, hb, handle, n_clusters, seq_ref):
     keys = C.string_at(v.extra_keys, v.n_extra * k) if v.n_extra else b""
     hb.extra_keys = [keys[i * k:(i + 1) * k].decode("latin-1") for i in range(v.n_extra)]
     hb.n_instances = int(v.n_instances)
+    if v.n_words_dev:
+        hb.n_words_dev = int(v.n_words_dev)
+        hb.gather_src_off = arr(v.gather_src_off, v.n_segs, np.uint64)
+        hb.gather_src_start = arr(v.gather_src_start, v.n_segs, np.uint32)
+        hb.gather_src_flags = arr(v.gather_src_flags, v.n_segs, np.uint32)
     nt = v.n_targets
     t_seq = arr(v.target_seq, nt, np.uint32)
     t_so = arr(v.target_seg_off, nt + 1, np.uint32)

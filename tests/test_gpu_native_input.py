@@ -6,9 +6,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("resident", [False, True], ids=["text", "resident"])
 @pytest.mark.parametrize("k,canon,up,down,dsc,cm", [(31, True, 0, 0, False, False), (21, False, 60, 40, False, True),
-                                                  (25, True, 30, 50, True, False)])
-def test_files_to_tsv(tmp_path, k, canon, up, down, dsc, cm):
+                                                  (25, True, 30, 50, True, False), (40, True, 300, 300, False, False)])
+def test_files_to_tsv(tmp_path, k, canon, up, down, dsc, cm, resident):
+    """resident: contigs live on the GPU as 2 bits per base (pf_genomes_upload) and the segments are cut out of them
+    -- or reverse-complemented -- by gather_segments_kernel; the host sends coordinates, not bases"""
     from oracle import input_restatement as ir
     from oracle import oracle as po
     from panfeed_amd import native_input as ni
@@ -32,6 +35,9 @@ def test_files_to_tsv(tmp_path, k, canon, up, down, dsc, cm):
     eng = Engine(klength=k, canon=canon, max_strains=96, stroi=set(tg), consider_missing=cm)
     with ni.Pangenome(csvp, None, None, up, down, dsc, targets=tg, genome_names=gn, gff_paths=[gffs[n] for n in gn],
                       fasta_paths=[fas[n] for n in gn]) as pg:
+        if resident:
+            pg.make_resident(eng)
+            assert pg.n_contigs >= 69 and pg.genome_bases > 100000
         outs = list(eng.run_pangenome(pg, batch_clusters=9))
     assert len(outs) == 5
     assert "".join(o.kmers_to_hashes for o in outs) == ekh

@@ -129,3 +129,59 @@ def test_oracle_refuses_mask_of_other_length():
     with pytest.raises(IndexError, match="boolean index did not match"):
         po.OracleRun(klength=5, consider_missing=True).feed([(gs, "x", np.array([1, 0, 1]))])
     po.OracleRun(klength=5, consider_missing=False).feed([(gs, "x", np.array([1, 0, 1]))])
+
+
+def test_by_reference_batches_describe_the_same_input(pangenome):
+    """resident-genome mode without a GPU: the reader hands out (contig, start, length, strand) instead of text for
+    pure-ACGT sequences of non-target strains; cutting those ranges out of the contigs (what gather_segments_kernel
+    does on the device) must rebuild, word for word, the packed buffer of the text mode; all other arrays equal"""
+    import ctypes as C
+    from panfeed_amd import _lib
+    L = _lib.load()
+    k, W = 21, 1
+    tg = (pangenome["names"][0],)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    with _open(pangenome, 40, 25, targets=tg) as pg:
+        text = list(pg.batches(k, True, W, max_clusters=11))
+    with _open(pangenome, 40, 25, targets=tg) as pg:
+        n, ptrs, lens = C.c_uint32(), C.POINTER(C.c_char_p)(), C.POINTER(C.c_uint64)()
+        _lib.check(L.pf_pangenome_contigs(pg.h, C.byref(n), C.byref(ptrs), C.byref(lens)))
+        off = (C.c_uint64 * n.value)()
+        contig_at, tot = {}, 0
+        for i in range(n.value):                       # the layout pf_genomes_upload assigns
+            off[i] = tot
+            contig_at[tot] = C.string_at(ptrs[i], lens[i])
+            tot += 2 * ((lens[i] + 63) // 64) + 2
+        _lib.check(L.pf_pangenome_set_store(pg.h, off, n.value))
+        pg.resident = True
+        refd = list(pg.batches(k, True, W, max_clusters=11))
+    assert len(text) == len(refd)
+    n_ref = n_rev = n_lit = 0
+    for a, b in zip(text, refd):
+        for f in ("seg_word_off", "seg_len", "seg_sample", "seg_ord_base", "seg_strand_off", "cluster_seg_off",
+                  "extra_cluster", "extra_ord", "extra_bits", "cluster_nstrains", "cluster_npresab", "cluster_presab"):
+            assert np.array_equal(getattr(a, f), getattr(b, f)), f
+        assert a.extra_keys == b.extra_keys and a.n_instances == b.n_instances and a.n_strand_words == b.n_strand_words
+        assert [(x.cluster, x.strain, x.seq, x.segs, x.ambig) for x in a.targets] == \
+               [(y.cluster, y.strain, y.seq, y.segs, y.ambig) for y in b.targets]
+        assert b.n_words_dev == len(a.packed)
+        rebuilt = np.zeros(b.n_words_dev, dtype=np.uint64)
+        for s in range(len(b.seg_len)):
+            ln, wo = int(b.seg_len[s]), int(b.seg_word_off[s])
+            nw = 2 * ((ln + 63) // 64)
+            fl, so, st = int(b.gather_src_flags[s]), int(b.gather_src_off[s]), int(b.gather_src_start[s])
+            if fl & 1:
+                rebuilt[wo:wo + nw] = b.packed[so:so + nw]
+                n_lit += 1
+                continue
+            seq = contig_at[so][st:st + ln]
+            assert len(seq) == ln
+            if fl & 2:
+                seq = seq[::-1].translate(comp)
+                n_rev += 1
+            buf = (C.c_uint64 * max(nw, 1))()
+            assert L.pf_pack_acgt(seq, ln, buf) == nw
+            rebuilt[wo:wo + nw] = np.ctypeslib.as_array(buf)[:nw]
+            n_ref += 1
+        assert np.array_equal(rebuilt, a.packed)
+    assert n_ref > 150 and n_rev > 50 and n_lit > 10          # text stays for the target strain and the N-carrying ones
