@@ -12,6 +12,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -28,7 +30,8 @@ namespace {
 
 int in_fail(int code, const std::string& msg) { pf_set_error_(msg.c_str()); return code; }
 
-struct Feature { std::string id, chrom; long long start, end; int strand; };
+struct Contig;
+struct Feature { std::string id, chrom; long long start, end; int strand; const Contig* ctg = nullptr; };
 
 struct Contig {
     std::string seq;                 // upper case
@@ -203,6 +206,8 @@ struct pf_pangenome {
     std::string log;
     uint32_t W = 0;
     // genomes resident on the device: flat contig order handed to pf_genomes_upload, by-reference mode
+    std::vector<const Genome*> strain_genome;  // per table strain: its genome data or null (input.py:384-387)
+    std::vector<uint8_t> strain_target;
     std::vector<Contig*> flat;
     std::vector<const char*> flat_ptr;
     std::vector<uint64_t> flat_len;
@@ -225,7 +230,7 @@ struct pf_records {
 namespace {
 // one row of the table -> its records (thread-safe: reads the pangenome only)
 struct RowOut {
-    std::vector<std::string> seq, comp;
+    std::vector<std::string> seq, comp;          // literal sequences only (seq_flags bit 0 clear), in order
     std::vector<const char*> ids, chroms;
     std::vector<uint32_t> seq_len, seq_col, seq_strain, presab, dict, seq_src_start, seq_flags;
     std::vector<uint64_t> seq_src_off;
@@ -246,7 +251,7 @@ void build_row(const pf_pangenome* P, size_t row, RowOut& R) {
         if (!cells[s].empty()) {
             const uint32_t sp = P->sorted_pos[s];
             R.presab[sp >> 5] |= 1u << (sp & 31);                    // input.py:375-377
-            if (P->genomes.count(P->strains[s])) dict.push_back((uint32_t)s);   // input.py:384-387
+            if (P->strain_genome[s]) dict.push_back((uint32_t)s);   // input.py:384-387
         }
     const size_t npresent_dict = dict.size();
     {
@@ -262,27 +267,33 @@ void build_row(const pf_pangenome* P, size_t row, RowOut& R) {
     std::vector<uint32_t> col(dict.size());
     for (size_t i = 0; i < order.size(); i++) col[order[i]] = (uint32_t)i;
 
+    {
+        const size_t est = npresent_dict + npresent_dict / 16 + 4;
+        R.ids.reserve(est); R.chroms.reserve(est); R.seq_len.reserve(est); R.seq_col.reserve(est); R.seq_strain.reserve(est);
+        R.seq_src_start.reserve(est); R.seq_flags.reserve(est); R.seq_src_off.reserve(est); R.seq_target.reserve(est);
+        R.seq_strand.reserve(est); R.seq_start.reserve(est); R.seq_end.reserve(est); R.seq_offset.reserve(est);
+    }
+    std::string gene;
     for (size_t di = 0; di < npresent_dict; di++) {
         const std::string& strain = P->strains[dict[di]];
-        const Genome& g = P->genomes.find(strain)->second;
-        const bool is_target = P->targets.count(strain) != 0;
+        const Genome& g = *P->strain_genome[dict[di]];
+        const bool is_target = P->strain_target[dict[di]] != 0;
         const std::string& genes = cells[dict[di]];
         size_t q0 = 0;
         for (;;) {                                                   // genes.split(';')  input.py:393
             size_t t = genes.find(';', q0);
-            std::string gene = genes.substr(q0, t == std::string::npos ? std::string::npos : t - q0);
+            gene.assign(genes, q0, t == std::string::npos ? std::string::npos : t - q0);
             auto fit = g.features.find(gene);
             if (fit == g.features.end()) {                           // input.py:396-402
                 R.log += "Could not find gene " + gene + " from " + idx + " in " + strain + "\n";
                 if (P->raise_missing) { R.error = "Could not find gene " + gene + " from " + idx + " in " + strain; return; }
             } else {
                 const Feature& f = fit->second;
-                auto cit = g.contigs.find(f.chrom);
-                if (cit == g.contigs.end()) {                        // input.py:404-411
+                if (!f.ctg) {                                        // input.py:404-411
                     R.log += "Could not find chromosome " + f.chrom + " in " + strain + "\n";
                     if (P->raise_missing) { R.error = "Could not find chromosome " + f.chrom + " in " + strain; return; }
                 } else {
-                    const Contig& ctg = cit->second;
+                    const Contig& ctg = *f.ctg;
                     const long long up = P->up, down = P->down;
                     const long long offset = (f.strand > 0 && f.start - 1 - up < 0) ? f.start - 1 : up;        // :415-418
                     const long long offset_d = (f.strand < 0 && f.start - 1 - down < 0) ? f.start - 1 : down;  // :421-424
@@ -308,7 +319,6 @@ void build_row(const pf_pangenome* P, size_t row, RowOut& R) {
                     }
                     R.seq_len.push_back((uint32_t)(b - a));
                     if (ref) {
-                        R.seq.emplace_back(); R.comp.emplace_back();
                         R.seq_src_off.push_back(ctg.word_off); R.seq_src_start.push_back((uint32_t)a);
                         R.seq_flags.push_back(1u | (f.strand < 0 ? 2u : 0u));
                     } else {
@@ -412,6 +422,16 @@ int pf_pangenome_open(const pf_pangenome_opts* o, pf_pangenome** out) {
         P->log += gs[i].warnings;
         P->genomes.emplace(o->genome_names[i], std::move(gs[i]));
     }
+    for (auto& kv : P->genomes)                                    // feature -> contig, once
+        for (auto& fv : kv.second.features) {
+            auto cit = kv.second.contigs.find(fv.second.chrom);
+            fv.second.ctg = cit == kv.second.contigs.end() ? nullptr : &cit->second;
+        }
+    for (auto& st : P->strains) {
+        auto git = P->genomes.find(st);
+        P->strain_genome.push_back(git == P->genomes.end() ? nullptr : &git->second);
+        P->strain_target.push_back(P->targets.count(st) ? 1 : 0);
+    }
     // input.py:338-348
     size_t missing = 0;
     for (auto& s : P->strains) if (!P->genomes.count(s)) missing++;
@@ -462,6 +482,14 @@ int pf_pangenome_next(pf_pangenome* P, uint32_t max_clusters, pf_records** out, 
     }
     const uint32_t made = (uint32_t)rows.size();
     std::vector<RowOut> ro(made);
+    const bool dbg = getenv("PF_DEBUG_TIMING") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!dbg) return;
+        auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[pf_pangenome_next] %-12s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t0).count());
+        t0 = t;
+    };
     {
         unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
         if (made < 4) nt = 1;
@@ -472,6 +500,7 @@ int pf_pangenome_next(pf_pangenome* P, uint32_t max_clusters, pf_records** out, 
         work();
         for (auto& x : th) x.join();
     }
+    lap("rows");
     for (uint32_t i = 0; i < made; i++) {
         P->log += ro[i].log;                                                           // in table order
         if (!ro[i].error.empty()) return in_fail(PF_ERR_ARG, ro[i].error);
@@ -479,9 +508,9 @@ int pf_pangenome_next(pf_pangenome* P, uint32_t max_clusters, pf_records** out, 
     pf_records* R = new pf_records();
     R->cluster_seq_off.push_back(0);
     R->cluster_strain_off.push_back(0);
-    size_t nseq = 0;
-    for (auto& r : ro) nseq += r.seq_len.size();
-    R->seq_store.reserve(nseq); R->comp_store.reserve(nseq);
+    size_t nlit = 0;
+    for (auto& r : ro) nlit += r.seq.size();
+    R->seq_store.reserve(nlit); R->comp_store.reserve(nlit);
     auto app = [](auto& dst, const auto& src) { dst.insert(dst.end(), src.begin(), src.end()); };
     for (uint32_t i = 0; i < made; i++) {
         RowOut& r = ro[i];
@@ -500,12 +529,14 @@ int pf_pangenome_next(pf_pangenome* P, uint32_t max_clusters, pf_records** out, 
         app(R->strain_index, r.dict);
         R->cluster_strain_off.push_back((uint32_t)R->strain_index.size());
     }
+    lap("merge");
     const size_t n = R->seq_len.size();
     R->seq.resize(n); R->comp.resize(n);
-    for (size_t i = 0; i < n; i++) {
+    for (size_t i = 0, li = 0; i < n; i++) {
         const bool ref = (R->seq_flags[i] & 1u) != 0;
-        R->seq[i] = ref ? nullptr : R->seq_store[i].c_str();
-        R->comp[i] = ref ? nullptr : R->comp_store[i].c_str();
+        R->seq[i] = ref ? nullptr : R->seq_store[li].c_str();
+        R->comp[i] = ref ? nullptr : R->comp_store[li].c_str();
+        if (!ref) li++;
     }
     R->cluster_name_ptr.resize(made);
     for (uint32_t i = 0; i < made; i++) R->cluster_name_ptr[i] = P->cluster_names[R->cluster_row[i]].c_str();

@@ -154,8 +154,9 @@ class Pangenome:
             finally:
                 self.free_records(h)
 
-    def batches(self, klength, canon, W, max_clusters=256, want_strand=True, first_ordinal=0):
-        """HostBatch per `max_clusters` rows of the table, packed by the library straight from the reader's buffers."""
+    def batches(self, klength, canon, W, max_clusters=256, want_strand=True, first_ordinal=0, with_names=False):
+        """HostBatch per `max_clusters` rows of the table, packed by the library straight from the reader's buffers.
+        with_names: also fill hb.sorted_strains / hb.presab (Python lists per cluster; nothing on the GPU path reads them)."""
         L = self.L
         k = int(klength)
         ordinal = int(first_ordinal)
@@ -198,6 +199,8 @@ class Pangenome:
                 ordinal += nc
                 for ci in range(nc):
                     hb.idx.append(v.cluster_name[ci].decode())
+                    if not with_names:
+                        continue
                     a, b = int(v.cluster_strain_off[ci]), int(v.cluster_strain_off[ci + 1])
                     hb.sorted_strains.append(sorted(v.cluster_strain[j].decode() for j in range(a, b)))
                     npres = int(v.cluster_npresab[ci])

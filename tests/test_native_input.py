@@ -73,7 +73,7 @@ def test_batches_equal_packer_over_restated_records(pangenome, k, canon, ntg):
     _s, exp = _expected(pangenome, 40, 25, False)
     W = 1
     with _open(pangenome, 40, 25, targets=tg) as pg:
-        hbs = list(pg.batches(k, canon, W, max_clusters=11, first_ordinal=5))
+        hbs = list(pg.batches(k, canon, W, max_clusters=11, first_ordinal=5, with_names=True))
     pos = 0
     for hb in hbs:
         n = len(hb.idx)
