@@ -370,6 +370,12 @@ int pf_render_kmers_tsv(pf_ctx* ctx, const pf_target_seq* seqs, uint32_t n, cons
                         char** out, uint64_t* nbytes);
 void pf_free_text(char* p);
 
+/* Parallel gzip of a block of output text (the reference: gzip.open(..., "wt", compresslevel=9),
+ * /root/reference/panfeed/input.py:239-241,255-258 -- one core).  `data` is cut at line ends into chunks of about
+ * chunk_bytes, each deflated as its own gzip member on its own host thread; *out (pf_free_text) is the members
+ * concatenated, to be appended to the .gz file.  Decompresses to exactly `data`. */
+int pf_gzip_members(const char* data, uint64_t n, int level, uint64_t chunk_bytes, char** out, uint64_t* out_n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -178,3 +178,34 @@ def test_device_md5_block_source_on_host(tmp_path):
     subprocess.check_call(["g++", "-O1", "-o", str(exe), str(cpp)])
     out = subprocess.check_output([str(exe)]).decode().split()
     assert out == [hashlib.md5(m).hexdigest() for m in msgs]
+
+
+def test_parallel_gzip_writer_roundtrip(tmp_path):
+    """N2: the .gz files are multi-member gzip written by the library's threads; any gzip reader gets the text back
+    (the reference: gzip.open(..., "wt", compresslevel=9), input.py:239-241,255-258)"""
+    import gzip
+    import subprocess
+    from panfeed_amd.output import ParallelGzipWriter
+    rng = np.random.default_rng(3)
+    lines = ["group_%05d\t%s\t%s\n" % (i, "".join("ACGT"[c] for c in rng.integers(0, 4, 31)), "x" * 24) for i in range(40000)]
+    text = "".join(lines)
+    p = str(tmp_path / "a.tsv.gz")
+    with ParallelGzipWriter(p, buffer_bytes=1 << 20, chunk_bytes=1 << 16) as w:      # many members, several emits
+        w.write("header\tline\n")
+        w.flush()
+        for i in range(0, len(lines), 1000):
+            w.write("".join(lines[i:i + 1000]))
+    with gzip.open(p, "rt") as fh:
+        assert fh.read() == "header\tline\n" + text
+    raw = open(p, "rb").read()
+    assert raw.count(b"\x1f\x8b\x08") >= 10 and len(raw) < len(text) // 2
+    assert subprocess.run(["gzip", "-t", p]).returncode == 0
+    # every member holds whole lines
+    import zlib
+    d = zlib.decompressobj(31)
+    first = d.decompress(raw)
+    assert first.endswith(b"\n") and d.unused_data.startswith(b"\x1f\x8b")
+    q = str(tmp_path / "empty.tsv.gz")
+    ParallelGzipWriter(q).close()
+    with gzip.open(q, "rt") as fh:
+        assert fh.read() == ""
