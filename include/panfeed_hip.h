@@ -51,7 +51,8 @@ typedef struct {
     const uint32_t* maf_lo;
     const uint32_t* maf_hi;
     uint64_t pattern_capacity; /* slots of the run-global pattern table; 0 = default (2^24) */
-    uint32_t max_items;        /* clusters in flight per internal sub-batch; 0 = default */
+    uint32_t max_items;        /* work items (cluster x key partition) in flight per internal sub-batch; 0 = default;
+                                  clamped so that their scratch slices take at most half of the free device memory */
     uint32_t flags;            /* PF_FLAG_* */
 } pf_opts;
 

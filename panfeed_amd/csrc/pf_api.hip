@@ -10,6 +10,7 @@
 #include "../../include/panfeed_hip.h"
 
 #include <algorithm>
+#include <cmath>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -336,6 +337,16 @@ int pf_create(pf_ctx** out, int device, const pf_opts* o) {
     c->NS = pf::nslots_max(c->KW);
     c->W = (o->max_strains + 31) / 32;
     c->max_items = o->max_items ? o->max_items : 2048;
+    {
+        // work items of one launch = scratch slices resident at once; keep them within half of the free HBM
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b) {
+            const uint64_t slice_bytes = (uint64_t)c->NS * (8ull * c->KW + 4 + 4ull * c->W + 16 + 8 + 4 + 4 + 4 + 4) +
+                                         (uint64_t)pf::DENSE_WORDS * 16 + (uint64_t)pf::DEDUP_MROWS * 4 + 64;
+            const uint64_t fit = (free_b / 2) / slice_bytes;
+            if (c->max_items > fit) c->max_items = (uint32_t)std::max<uint64_t>(fit, 64);
+        }
+    }
     c->maf_lo.assign(o->maf_lo, o->maf_lo + o->max_strains + 1);
     c->maf_hi.assign(o->maf_hi, o->maf_hi + o->max_strains + 1);
     c->o.maf_lo = c->maf_lo.data();
@@ -670,8 +681,17 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
     // a deduplicated cluster whose distinct sequences alone carry far more windows than one table holds will
     // overflow it: start it with two key partitions instead of paying for a failed first scan (a wrong guess
     // only costs time: an overflow still triggers the doubling retry)
+    // Estimate of the distinct windows of D near-identical sequences of average length L = vinst / D: the first
+    // contributes all of its windows, every further one the share a 1 % divergence touches (1 - 0.99^k: 27 % of the
+    // 31-mers, 40 % of the 51-mers) plus a margin.
+    const double share = 1.0 - std::pow(0.99, (double)c->o.klength) + 0.06;
     for (uint32_t i = 0; i < C; i++)
-        if (h_mode[i] == 1 && vinst[i] * mult * 2 > (uint64_t)pf::insert_limit(NS) * 5) nparts[i] = 2;
+        if (h_mode[i] == 1 && h_vnstr[i]) {
+            const double D = (double)h_vnstr[i], L = (double)(vinst[i] * mult) / D;
+            const double est = L * (1.0 + share * (D - 1.0));
+            const double room = 0.9 * (double)pf::insert_limit(NS);
+            if (est > room) nparts[i] = (uint32_t)std::min<double>(std::ceil(est / room), 64.0);
+        }
     uint32_t pass = 0;
     const uint32_t lim_full = pf::insert_limit(NS);
     uint64_t arena_base = 0;

@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256) void strand_bits_kernel(const uint64_t* packed
 // scan sets "distinct-sequence" bits instead of sample bits, and rows_kernel expands them through
 // M[d] = set of samples that carry distinct sequence d.  Output is identical to scanning every copy.
 // A cluster stays in mode 0 (scan everything) when dedup does not pay or does not fit.
-constexpr uint32_t DEDUP_MAX_SEGS = 2048;     // segments of a cluster the LDS tables hold
+constexpr uint32_t DEDUP_MAX_SEGS = 16384;    // segments of a cluster (one byte of LDS each)
 constexpr uint32_t DEDUP_TAB = 4096;          // hash table slots (power of two, 2x segments)
 constexpr uint32_t DEDUP_MAX_D = 64;          // distinct sequences (two 32-bit presence words)
 constexpr uint32_t DEDUP_MROWS = 4096;        // words of the M matrix: D * ceil4(W) <= this
@@ -630,17 +630,17 @@ constexpr uint32_t DEDUP_UNSET = 0xFFFFFFFFu;
 constexpr uint32_t DEDUP_INGLOBAL = 0x80000000u;
 
 __global__ __launch_bounds__(DEDUP_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void cluster_dedup_kernel(DedupParams p) {
-    // ~78 KiB in all: two workgroups per CU
+    // ~42 KiB in all and 80 VGPRs: three workgroups per CU
     __shared__ uint64_t t_key[DEDUP_GTAB];     // content hash of the group
     __shared__ uint64_t t_val[DEDUP_GTAB];     // min over the group's members of (ord_base << 32 | local index)
     __shared__ uint32_t t_pool[DEDUP_GTAB];    // where the group's sequence sits: pool word offset, or INGLOBAL | index
     __shared__ uint32_t t_len[DEDUP_GTAB];     // its length in bases
     __shared__ uint64_t s_pool[DEDUP_POOL];
-    __shared__ uint32_t s_rep[DEDUP_MAX_SEGS]; // low 16 bits: local index of the representative; a representative
-                                               // also carries its distinct index in the high 16 bits
-    __shared__ uint32_t s_woff[DEDUP_MAX_SEGS];// word offset relative to the cluster's first segment
-    __shared__ uint32_t s_len[DEDUP_MAX_SEGS];
-    __shared__ uint32_t r_list[DEDUP_MAX_D];   // representatives (local indices), unordered
+    __shared__ uint32_t t_woff[DEDUP_GTAB];    // word offset (relative to the cluster's first segment) of its first member
+    __shared__ uint32_t t_rank[DEDUP_GTAB];    // distinct index of the group (representatives in ordinal order)
+    __shared__ uint8_t s_slot[DEDUP_MAX_SEGS]; // hash group (table slot) of every segment
+    __shared__ uint32_t r_list[DEDUP_MAX_D];   // occupied table slots, unordered
+    __shared__ uint32_t r_rep[DEDUP_MAX_D];    // by distinct index: local index of the representative
     __shared__ uint32_t r_ord0[DEDUP_MAX_D], r_ninst[DEDUP_MAX_D], r_dense[DEDUP_MAX_D];   // by distinct index
     __shared__ uint32_t sh_bad, sh_nrep, sh_total, sh_ngroups, sh_pool_used;
 
@@ -660,14 +660,7 @@ __global__ __launch_bounds__(DEDUP_THREADS) __attribute__((amdgpu_waves_per_eu(6
     }
     __syncthreads();
     if (mode1) {
-        // ---- 0. segment metadata into LDS (coalesced) so that the data loads below are not behind it
-        const uint64_t wbase = p.seg_word_off[seg0];
-        const uint64_t wspan = p.seg_word_off[seg1 - 1] - wbase;
-        for (uint32_t s = tid; s < n; s += DEDUP_THREADS) {
-            s_woff[s] = (uint32_t)(p.seg_word_off[seg0 + s] - wbase);
-            s_len[s] = p.seg_len[seg0 + s];
-        }
-        __syncthreads();
+        const uint64_t wspan = p.seg_word_off[seg1 - 1] - p.seg_word_off[seg0];
         if (wspan >= 0xFFFFFFFFull) mode1 = false;      // uniform; a cluster this large is not worth it anyway
     }
     if (mode1) {
@@ -676,9 +669,19 @@ __global__ __launch_bounds__(DEDUP_THREADS) __attribute__((amdgpu_waves_per_eu(6
         // leaves its words in the LDS pool, every later one is compared with the pool word for word (exact).
         // Per wave the steps run in lockstep -- claim, publish, then wait -- so a waiting group never sits in front
         // of the group it waits for.
-        const ulonglong2* cbase = reinterpret_cast<const ulonglong2*>(p.packed + p.seg_word_off[seg0]);
+        const uint64_t wbase = p.seg_word_off[seg0];
+        const ulonglong2* cbase = reinterpret_cast<const ulonglong2*>(p.packed + wbase);
         const uint32_t grp = tid / DEDUP_GL, gl = tid % DEDUP_GL, ngrp = DEDUP_THREADS / DEDUP_GL;
         const uint32_t wave_grp0 = (tid >> 6) * (64 / DEDUP_GL);
+        // segment metadata is read from global memory one trip ahead (no LDS copy: clusters of thousands of samples
+        // have thousands of segments)
+        uint32_t nx_len[DEDUP_U], nx_woff[DEDUP_U];
+#pragma unroll
+        for (int u = 0; u < (int)DEDUP_U; u++) {
+            const uint32_t sn = grp + u * ngrp;
+            nx_len[u] = sn < n ? p.seg_len[seg0 + sn] : 0;
+            nx_woff[u] = sn < n ? (uint32_t)(p.seg_word_off[seg0 + sn] - wbase) : 0;
+        }
         for (uint32_t sw = wave_grp0; sw < n; sw += DEDUP_U * ngrp) {
             const uint32_t s = sw + (grp - wave_grp0);
             uint32_t len[DEDUP_U], pc[DEDUP_U], si[DEDUP_U], slot[DEDUP_U];
@@ -690,10 +693,13 @@ __global__ __launch_bounds__(DEDUP_THREADS) __attribute__((amdgpu_waves_per_eu(6
             for (int u = 0; u < (int)DEDUP_U; u++) {
                 si[u] = s + u * ngrp;
                 has[u] = si[u] < n;
-                len[u] = has[u] ? s_len[si[u]] : 0;
+                len[u] = nx_len[u];
                 pc[u] = (len[u] + 63) >> 6;
-                w[u] = cbase + ((has[u] ? s_woff[si[u]] : 0) >> 1);
+                w[u] = cbase + (nx_woff[u] >> 1);
             }
+            uint32_t my_woff[DEDUP_U];
+#pragma unroll
+            for (int u = 0; u < (int)DEDUP_U; u++) my_woff[u] = nx_woff[u];
 #pragma unroll
             for (int u = 0; u < (int)DEDUP_U; u++)
 #pragma unroll
@@ -701,6 +707,12 @@ __global__ __launch_bounds__(DEDUP_THREADS) __attribute__((amdgpu_waves_per_eu(6
                     const uint32_t j = gl + DEDUP_GL * q;
                     v[u][q] = j < pc[u] ? w[u][j] : make_ulonglong2(0, 0);
                 }
+#pragma unroll
+            for (int u = 0; u < (int)DEDUP_U; u++) {          // the next trip's metadata, behind this trip's data
+                const uint32_t sn = si[u] + DEDUP_U * ngrp;
+                nx_len[u] = sn < n ? p.seg_len[seg0 + sn] : 0;
+                nx_woff[u] = sn < n ? (uint32_t)(p.seg_word_off[seg0 + sn] - wbase) : 0;
+            }
 #pragma unroll
             for (int u = 0; u < (int)DEDUP_U; u++) {
 #pragma unroll
@@ -742,7 +754,7 @@ __global__ __launch_bounds__(DEDUP_THREADS) __attribute__((amdgpu_waves_per_eu(6
                     if (sl < DEDUP_GTAB)
                         atomicMin((unsigned long long*)&t_val[sl],
                                   (unsigned long long)(((uint64_t)p.seg_ord_base[seg0 + si[u]] << 32) | si[u]));
-                    s_rep[si[u]] = sl;       // table slot for now
+                    s_slot[si[u]] = (uint8_t)sl;
                 }
                 slot[u] = __shfl(sl, lane & ~(DEDUP_GL - 1));
                 registrar[u] = __shfl(reg, lane & ~(DEDUP_GL - 1)) != 0;
@@ -767,11 +779,11 @@ __global__ __launch_bounds__(DEDUP_THREADS) __attribute__((amdgpu_waves_per_eu(6
                             s_pool[off + 2 * j] = x.x; s_pool[off + 2 * j + 1] = x.y;
                         }
                     }
-                    if (gl == 0) t_len[slot[u]] = len[u];
+                    if (gl == 0) { t_len[slot[u]] = len[u]; t_woff[slot[u]] = my_woff[u]; }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     // all the group's stores are ahead of the offset: a wave's LDS stores complete in program order
                     if (gl == 0)
-                        __hip_atomic_store(&t_pool[slot[u]], fits ? off : (DEDUP_INGLOBAL | si[u]), __ATOMIC_RELEASE,
+                        __hip_atomic_store(&t_pool[slot[u]], fits ? off : DEDUP_INGLOBAL, __ATOMIC_RELEASE,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
@@ -785,8 +797,7 @@ __global__ __launch_bounds__(DEDUP_THREADS) __attribute__((amdgpu_waves_per_eu(6
                     bool diff = t_len[slot[u]] != len[u];
                     if (diff) {
                     } else if (pp & DEDUP_INGLOBAL) {
-                        const uint32_t r = pp & ~DEDUP_INGLOBAL;
-                        const ulonglong2* b = cbase + (s_woff[r] >> 1);
+                        const ulonglong2* b = cbase + (t_woff[slot[u]] >> 1);
                         {
 #pragma unroll
                             for (uint32_t q = 0; q < DEDUP_CH; q++) {
@@ -814,27 +825,25 @@ __global__ __launch_bounds__(DEDUP_THREADS) __attribute__((amdgpu_waves_per_eu(6
             }
         }
         __syncthreads();
-        if (!sh_bad)
-            for (uint32_t s = tid; s < n; s += DEDUP_THREADS) s_rep[s] = (uint32_t)t_val[s_rep[s]];
-        __syncthreads();
-        // ---- 4. representatives -> distinct indices in ordinal order
-        for (uint32_t s = tid; s < n; s += DEDUP_THREADS)
-            if ((s_rep[s] & 0xFFFFu) == s) {
+        // ---- 4. hash groups -> distinct indices in the ordinal order of their representatives
+        for (uint32_t t = tid; t < DEDUP_GTAB; t += DEDUP_THREADS)
+            if (t_key[t] != EMPTY64) {
                 const uint32_t at = atomicAdd(&sh_nrep, 1u);
-                if (at < DEDUP_MAX_D) r_list[at] = s;
+                if (at < DEDUP_MAX_D) r_list[at] = t;
             }
         __syncthreads();
         const uint32_t D = sh_nrep;
         mode1 = !sh_bad && D <= DEDUP_MAX_D && D * Wp <= DEDUP_MROWS && 2 * D <= n;
         if (mode1) {
             if (tid < D) {
-                const uint32_t s = r_list[tid];
-                const uint32_t o = p.seg_ord_base[seg0 + s];
+                const uint32_t slot = r_list[tid];
+                const uint64_t val = t_val[slot];            // (ord_base << 32 | local index) of the representative
                 uint32_t rank = 0;
-                for (uint32_t j = 0; j < D; j++) rank += p.seg_ord_base[seg0 + r_list[j]] < o ? 1u : 0u;
-                s_rep[s] = s | (rank << 16);
-                const uint32_t len = s_len[s];
-                r_ord0[rank] = o;
+                for (uint32_t j = 0; j < D; j++) rank += t_val[r_list[j]] < val ? 1u : 0u;
+                t_rank[slot] = rank;
+                r_rep[rank] = (uint32_t)val;
+                const uint32_t len = t_len[slot];
+                r_ord0[rank] = (uint32_t)(val >> 32);
                 r_ninst[rank] = len >= k ? len - k + 1 : 0;
             }
             __syncthreads();
@@ -853,9 +862,9 @@ __global__ __launch_bounds__(DEDUP_THREADS) __attribute__((amdgpu_waves_per_eu(6
             const uint64_t dense_bits = ((uint64_t)sh_total + (ex1 - ex0)) * mult;
             mode1 = dense_bits <= (uint64_t)DENSE_WORDS * 32;
             if (mode1) {
-                for (uint32_t s = tid; s < n; s += DEDUP_THREADS) p.seg_distinct[seg0 + s] = s_rep[s_rep[s] & 0xFFFFu] >> 16;
+                for (uint32_t s = tid; s < n; s += DEDUP_THREADS) p.seg_distinct[seg0 + s] = t_rank[s_slot[s]];
                 if (tid < D) {
-                    const uint32_t s = r_list[tid], d = s_rep[s] >> 16;
+                    const uint32_t d = tid, s = r_rep[d];
                     p.v_word_off[seg0 + d] = p.seg_word_off[seg0 + s];
                     p.v_len[seg0 + d] = p.seg_len[seg0 + s];
                     p.v_sample[seg0 + d] = d;

@@ -153,6 +153,43 @@ def test_dedup_single_pass_paths():
     eng.close()
 
 
+def test_dedup_thousands_of_segments():
+    """clusters with more segments than samples fit one LDS tile of the old kernel (2 600 samples, paralogs): the
+    one-pass grouping keeps one byte per segment and reads the metadata from global memory one trip ahead"""
+    from panfeed_amd.classes import Seqinfo
+    from panfeed_amd.engine import Engine
+    rng = np.random.default_rng(21)
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    S = 2600
+    names = [f"z{i:05d}" for i in range(S)]
+
+    def mk(seq, i, j=0):
+        return Seqinfo(seq.decode(), seq.translate(comp).decode(), f"g{i}_{j}", "ctg", 5, 5 + len(seq) - 1, 1, 0)
+
+    def rnd(L):
+        return np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, L)].tobytes()
+    recs = []
+    for ci, (nall, L) in enumerate(((5, 90), (11, 140))):
+        al = [rnd(L) for _ in range(nall)]
+        al[1] = al[0][:L // 2] + (b"C" if al[0][L // 2:L // 2 + 1] != b"C" else b"G") + al[0][L // 2 + 1:]   # near copy
+        pres = np.ones(S, dtype=np.int64)
+        pres[ci::17] = 0
+        gs = {}
+        for i, nm in enumerate(names):
+            if pres[i]:
+                gs[nm] = [mk(al[(i * 7 + ci) % nall], i)] + ([mk(al[(i + 1) % nall], i, 1)] if i % 9 == 0 else [])
+            else:
+                gs[nm] = []
+        recs.append((gs, f"wide{ci}", pres))
+    eng = Engine(klength=15, max_strains=2624)
+    out = eng.run(recs)
+    assert out.timing["n_dedup_clusters"] == 2
+    (ek, ekh, ehp), st = _oracle_texts(recs, klength=15)
+    assert out.kmers_to_hashes == ekh
+    assert out.hashes_to_patterns == ehp
+    eng.close()
+
+
 def _diverse_records(n_samples, length, seed, n_clusters=2):
     """every sample carries its own random sequence: unique k-mers ~ instances (table overflow path)"""
     from panfeed_amd.classes import Seqinfo
