@@ -106,7 +106,7 @@ struct pf_ctx {
     // scan view built by cluster_dedup_kernel
     DevBuf v_word_off, v_len, v_sample, v_ord, seg_distinct, v_nseg, v_nstr, v_mode, v_dense, extra_off, extra_dense;
     DevBuf bm_occ, bm_keep, pre_occ, pre_keep, mrows, slot_out, it_is_extra, cmask_lo, cmask_hi, it_compact;
-    DevBuf strand_bits, scan_desc;
+    DevBuf strand_bits, scan_desc, md5_list;
     DevBuf g_store, b_literal, g_src_off, g_src_start, g_src_flags;   // genomes resident in HBM + per-batch gather lists
     uint64_t g_words = 0;
     const pf_gather* pending_gather = nullptr;
@@ -303,7 +303,7 @@ void pf_destroy(pf_ctx* c) {
     for (auto& e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->stage_pin) (void)hipHostFree(c->stage_pin);
-    c->stage_dev.release(); c->scan_desc.release();
+    c->stage_dev.release(); c->scan_desc.release(); c->md5_list.release();
     c->g_store.release(); c->b_literal.release(); c->g_src_off.release(); c->g_src_start.release(); c->g_src_flags.release();
     c->mg_lo.release(); c->mg_hi.release(); c->mg_min.release(); c->mg_cnt.release();
     if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
@@ -1049,9 +1049,16 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
         mp.pat_nan = c->o.consider_missing ? c->pat_nan.as<uint32_t>() : nullptr;
         mp.pat_n = c->pat_n.as<uint32_t>(); mp.pat_md5 = c->pat_md5.as<uint8_t>();
         mp.pid0 = c->pid0; mp.pid1 = pid1; mp.W = W;
+        // int64 rows (the clusters' own rows) are listed by the float pass and hashed by a second, small one
+        PFCHK(c->md5_list.ensure(((size_t)C + 2) * 4));
+        HIPCHK(hipMemsetAsync(c->md5_list.p, 0, 4, c->stream));
+        mp.int_list = c->md5_list.as<uint32_t>();
         PFCHK(mark_begin(c, 5));
         const uint32_t md5_lds = pf::MD5_THREADS * (pf::MD5_TILE + 1) * 4 * (c->o.consider_missing ? 2 : 1);
-        hipLaunchKernelGGL(pf::md5_kernel, dim3((pid1 - c->pid0 + pf::MD5_THREADS - 1) / pf::MD5_THREADS), dim3(pf::MD5_THREADS),
+        hipLaunchKernelGGL(pf::md5_kernel<true>, dim3((pid1 - c->pid0 + pf::MD5_THREADS - 1) / pf::MD5_THREADS), dim3(pf::MD5_THREADS),
+                           md5_lds, c->stream, mp);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(pf::md5_kernel<false>, dim3((C + pf::MD5_THREADS - 1) / pf::MD5_THREADS), dim3(pf::MD5_THREADS),
                            md5_lds, c->stream, mp);
         HIPCHK(hipGetLastError());
         PFCHK(mark_end(c));

@@ -2342,33 +2342,51 @@ __device__ __forceinline__ void md5_block(uint32_t st[4], const uint32_t m[16]) 
 struct Md5Params {
     const uint32_t* pat_bits; const uint32_t* pat_nan; const uint32_t* pat_n;
     uint8_t* pat_md5;
+    uint32_t* int_list;      // [0] = count, [1..] = pattern ids of int64 rows (cluster rows) met by the float pass
     uint32_t pid0, pid1, W;
 };
 constexpr uint32_t MD5_THREADS = 256;
 constexpr uint32_t MD5_TILE = 16;     // row words staged per round (512 vector elements = 64 MD5 blocks)
 
+// FLOAT_ROWS: the pass over all new patterns, specialised for the float64 image of k-mer rows (98 % of the patterns):
+// the low word of every element is zero, which the inlined md5_block folds away (32 of its 64 message additions);
+// the few int64 rows (one per cluster at most) are only listed.  !FLOAT_ROWS: the listed int64 rows.
+template <bool FLOAT_ROWS>
 __global__ __launch_bounds__(MD5_THREADS) void md5_kernel(Md5Params p) {
-    // The rows of a block's 256 patterns are contiguous in the pool: they are loaded coalesced into LDS, 32 words
-    // per row and round (odd row stride: conflict-free), and every lane then walks its own row.  (row stride 17 words)
+    // The rows of a block's 256 patterns are loaded coalesced into LDS, 16 words per row and round (odd row stride:
+    // conflict-free), and every lane then walks its own row.
     extern __shared__ uint32_t md5_lds[];            // 17 KiB (+17 KiB with a NaN mask): 8 waves per SIMD stay resident
+    __shared__ uint32_t row_pid[MD5_THREADS];
     uint32_t* t_bits = md5_lds;
     uint32_t* t_nan = md5_lds + MD5_THREADS * (MD5_TILE + 1);
     const uint32_t tid = threadIdx.x;
-    const uint32_t pbase = p.pid0 + blockIdx.x * MD5_THREADS;
-    const uint32_t pid = pbase + tid;
-    const bool live = pid < p.pid1;
-    const uint32_t rows = min(MD5_THREADS, p.pid1 - pbase);
+    uint32_t pid, rows;
+    bool live;
+    if (FLOAT_ROWS) {
+        const uint32_t pbase = p.pid0 + blockIdx.x * MD5_THREADS;
+        pid = pbase + tid;
+        live = pid < p.pid1;
+        rows = min(MD5_THREADS, p.pid1 - pbase);
+    } else {
+        const uint32_t cnt = p.int_list[0], i0 = blockIdx.x * MD5_THREADS;
+        if (i0 >= cnt) return;
+        rows = min(MD5_THREADS, cnt - i0);
+        live = tid < rows;
+        pid = live ? p.int_list[1 + i0 + tid] : 0;
+    }
+    row_pid[tid] = pid;
     const uint32_t nk = live ? p.pat_n[pid] : 0;
     const bool is_int = (nk >> 31) != 0;
+    if (FLOAT_ROWS && live && is_int) {                       // left to the second pass
+        p.int_list[1 + atomicAdd(&p.int_list[0], 1u)] = pid;
+        live = false;
+    }
     const uint32_t n = nk & 0x7FFFFFFFu;
     const bool has_nan = p.pat_nan != nullptr;
     uint32_t st[4] = {0x67452301u, 0xefcdab89u, 0x98badcfeu, 0x10325476u};
     const uint64_t nbytes = (uint64_t)n * 8;
     const uint32_t full = n >> 3;             // whole 64-byte blocks = 8 elements each
     const uint32_t rem = n & 7;
-    const uint32_t c_even = is_int ? 1u : 0u;                 // low word of a set element
-    const uint32_t c_odd = is_int ? 0u : 0x3FF00000u;         // high word of a set element
-    const uint32_t c_nan = is_int ? 0u : 0x7FF80000u;         // high word of a NaN element (never also set)
     uint32_t m[16];
     uint32_t tail_bw = 0, tail_nw = 0;
     const uint32_t W = p.W;
@@ -2377,8 +2395,8 @@ __global__ __launch_bounds__(MD5_THREADS) void md5_kernel(Md5Params p) {
         __syncthreads();
         for (uint32_t i = tid; i < rows * tw; i += MD5_THREADS) {
             const uint32_t r = i / tw, w = i - r * tw;
-            t_bits[r * (MD5_TILE + 1) + w] = p.pat_bits[(size_t)(pbase + r) * W + w0 + w];
-            if (has_nan) t_nan[r * (MD5_TILE + 1) + w] = p.pat_nan[(size_t)(pbase + r) * W + w0 + w];
+            t_bits[r * (MD5_TILE + 1) + w] = p.pat_bits[(size_t)row_pid[r] * W + w0 + w];
+            if (has_nan) t_nan[r * (MD5_TILE + 1) + w] = p.pat_nan[(size_t)row_pid[r] * W + w0 + w];
         }
         __syncthreads();
         if (!live) continue;
@@ -2393,10 +2411,15 @@ __global__ __launch_bounds__(MD5_THREADS) void md5_kernel(Md5Params p) {
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 // int64 LE: 01 00.. ; float64 LE: 1.0 = 0x3FF00000:00000000, NaN = 0x7FF80000:00000000 (np.nan);
-                // branch-free: masks of the element's bit / NaN flag ANDed with per-lane constants
+                // branch-free: masks of the element's bit / NaN flag ANDed with constants
                 const uint32_t bm = 0u - ((bw >> j) & 1), nm = 0u - ((nw >> j) & 1);
-                m[2 * j] = bm & c_even;
-                m[2 * j + 1] = (bm & c_odd) | (nm & c_nan);
+                if (FLOAT_ROWS) {
+                    m[2 * j] = 0;
+                    m[2 * j + 1] = (bm & 0x3FF00000u) | (nm & 0x7FF80000u);
+                } else {
+                    m[2 * j] = bm & 1u;
+                    m[2 * j + 1] = 0;
+                }
             }
             md5_block(st, m);
         }
@@ -2415,8 +2438,8 @@ __global__ __launch_bounds__(MD5_THREADS) void md5_kernel(Md5Params p) {
     for (int j = 0; j < 8; j++) {
         const uint32_t bit = (tail_bw >> j) & 1, isn = (tail_nw >> j) & 1;
         if ((uint32_t)j < rem) {
-            m[2 * j] = is_int ? bit : 0;
-            m[2 * j + 1] = is_int ? 0 : (bit ? 0x3FF00000u : (isn ? 0x7FF80000u : 0));
+            m[2 * j] = FLOAT_ROWS ? 0 : bit;
+            m[2 * j + 1] = FLOAT_ROWS ? (bit ? 0x3FF00000u : (isn ? 0x7FF80000u : 0)) : 0;
         } else if ((uint32_t)j == rem) {
             m[2 * j] = 0x80;              // first pad byte right after the data
         }
