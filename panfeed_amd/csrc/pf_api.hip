@@ -110,6 +110,10 @@ struct pf_ctx {
     DevBuf g_store, b_literal, g_src_off, g_src_start, g_src_flags;   // genomes resident in HBM + per-batch gather lists
     uint64_t g_words = 0;
     const pf_gather* pending_gather = nullptr;
+    // host scratch of pf_submit, kept between calls (capacity persists: no allocation / page faults in steady state)
+    std::vector<Item> hs_items;
+    std::vector<uint8_t> hs_fused;
+    std::vector<uint32_t> hs_v[10], hs_w[6], hs_sub[3];
     int n_cu = 256;
     DevBuf it_cluster, it_part, it_nparts, it_nslots, it_slice, it_sib0, it_nsib, it_extra_first, it_count,
         it_unique, it_kept, work_scan, work_extra, work_fin, work_fin2, work_fin3, work_rows, sub_cluster, sub_item0, sub_nitems;
@@ -698,11 +702,14 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
 
     while (!todo.empty()) {
         // ---- items of this pass
-        std::vector<Item> items;
-        std::vector<uint8_t> item_fused;      // 0 unfused, 1 fused small class, 2 fused large class
+        std::vector<Item>& items = c->hs_items;
+        std::vector<uint8_t>& item_fused = c->hs_fused;      // 0 unfused, 1 fused small class, 2 fused large class
+        items.clear(); item_fused.clear();
+        items.reserve(todo.size() + 64); item_fused.reserve(todo.size() + 64);
         struct Sub { uint32_t item0, nitems, cl0, ncl; };
         std::vector<Sub> subs;
-        std::vector<uint32_t> sub_cluster, sub_item0, sub_nitems;
+        std::vector<uint32_t>&sub_cluster = c->hs_sub[0], &sub_item0 = c->hs_sub[1], &sub_nitems = c->hs_sub[2];
+        sub_cluster.clear(); sub_item0.clear(); sub_nitems.clear();
         uint64_t arena_cap = 0;
         Sub cur{0, 0, 0, 0};
         for (uint32_t ci : todo) {
@@ -767,8 +774,12 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
 
         // ---- item arrays
         const size_t NI = items.size();
-        std::vector<uint32_t> v_cluster(NI), v_part(NI), v_nparts(NI), v_nslots(NI), v_slice(NI), v_sib0(NI), v_nsib(NI),
-            v_exfirst(NI), v_isex(NI), v_compact(NI), w_scan, w_extra, w_fin, w_fin2, w_fin3, w_rows;
+        std::vector<uint32_t>&v_cluster = c->hs_v[0], &v_part = c->hs_v[1], &v_nparts = c->hs_v[2], &v_nslots = c->hs_v[3],
+            &v_slice = c->hs_v[4], &v_sib0 = c->hs_v[5], &v_nsib = c->hs_v[6], &v_exfirst = c->hs_v[7], &v_isex = c->hs_v[8],
+            &v_compact = c->hs_v[9], &w_scan = c->hs_w[0], &w_extra = c->hs_w[1], &w_fin = c->hs_w[2], &w_fin2 = c->hs_w[3],
+            &w_fin3 = c->hs_w[4], &w_rows = c->hs_w[5];
+        for (auto& v : c->hs_v) v.resize(NI);
+        for (auto& v : c->hs_w) { v.clear(); v.reserve(NI); }
         for (size_t i = 0; i < NI; i++) {
             v_cluster[i] = items[i].cluster; v_part[i] = items[i].part; v_nparts[i] = items[i].nparts;
             v_nslots[i] = items[i].nslots; v_slice[i] = items[i].slice; v_sib0[i] = items[i].sib0;
