@@ -358,18 +358,21 @@ def test_run_stream_equals_one_batch():
         eng.close()
 
 
-def test_config1_scale_properties():
-    """BASELINE configs[1] shape (200 samples, no flanks) at a size the oracle cannot cover in seconds:
+@pytest.mark.parametrize("S,n,flank,k,head", [(200, 1500, 0, 31, 25), (1000, 600, 100, 31, 3), (1000, 300, 100, 51, 2)],
+                         ids=["cfg1_200s", "cfg2_1000s_flank", "cfg2_k51"])
+def test_config1_scale_properties(S, n, flank, k, head):
+    """BASELINE configs[1] shape (200 samples, no flanks) and configs[2] shape (1 000 samples, +-100 bp: 32-word rows,
+    both finish classes, key partitions; k = 51: two-word keys) at sizes the oracle cannot cover in seconds:
     the whole pipeline with and without the identical-sequence shortcut must agree k-mer for k-mer and digest
     for digest; totals must add up; first_seen must be a strict order; the head of the run equals the oracle."""
     import ctypes as C
     from panfeed_amd import devbatch, synth
     from panfeed_amd.engine import Engine
-    S, k, n = 200, 31, 1500
-    cl = synth.generate(n, S, first=0, flank=0, n_rate=0.0)
+    ms = (S + 31) // 32 * 32
+    cl = synth.generate(n, S, first=0, flank=flank, n_rate=0.0)
     res = {}
     for dedup in (True, False):
-        eng = Engine(klength=k, max_strains=224, dedup=dedup, max_items=512)
+        eng = Engine(klength=k, max_strains=ms, dedup=dedup, max_items=512)
         db = devbatch.from_synth(eng, cl, k)
         r = db.submit()
         f = eng.fetch()
@@ -379,7 +382,8 @@ def test_config1_scale_properties():
         uniq = np.ctypeslib.as_array(f.cluster_unique, shape=(C_,)).copy()
         cpat = np.ctypeslib.as_array(f.cluster_pattern, shape=(C_,)).copy()
         tot = int(cnt.sum())
-        keys = np.ctypeslib.as_array(f.kmer_key, shape=(tot,)).copy()
+        KW = 1 if k <= 31 else 2
+        keys = np.ctypeslib.as_array(f.kmer_key, shape=(tot * KW,)).reshape(tot, KW).copy()
         pids = np.ctypeslib.as_array(f.kmer_pattern, shape=(tot,)).copy()
         P = int(f.n_patterns)
         md5 = np.ctypeslib.as_array(f.pattern_md5, shape=(P * 16,)).reshape(P, 16).copy()
@@ -392,13 +396,13 @@ def test_config1_scale_properties():
         res[dedup] = (cnt, uniq, keys[order], md5[pids[order]], md5[cpat], np.sort(fs))
         if dedup:
             assert eng.timing()["n_dedup_clusters"] > n * 0.9
-            hb_head = [c.record() for c in cl[:25]]
+            hb_head = [c.record() for c in cl[:head]]
         db.free()
         eng.close()
     for a, b in zip(res[True], res[False]):
         assert np.array_equal(a, b)
-    # the first 25 clusters against the oracle, text for text
-    eng = Engine(klength=k, max_strains=224)
+    # the first clusters against the oracle, text for text
+    eng = Engine(klength=k, max_strains=ms)
     out = eng.run(hb_head)
     (ek, ekh, ehp), st = _oracle_texts(hb_head, klength=k)
     assert out.kmers_to_hashes == ekh and out.hashes_to_patterns == ehp
