@@ -1,17 +1,19 @@
 // pf_kernels.h -- HIP kernels of the panfeed hot path for gfx950 (MI355X, wave64, 160 KiB LDS/CU).
 //
-// Pipeline per sub-batch of gene clusters (DESIGN.md has the full picture):
-//   cluster_dedup_kernel  per cluster: identical segments -> one representative per distinct sequence (exact).
-//   kmer_scan_kernel   one 1024-thread workgroup per (cluster, key partition): slides the k window over
-//                      the 2-bit packed segments, canonicalises (panfeed.py:65-75), and groups k-mers in
-//                      an LDS hash table {key, first-occurrence ordinal, 32-sample presence word};
-//                      samples are swept in chunks of 32 columns, each chunk's words flushed coalesced.
-//   rows_kernel        per item: popcount / MAF + same-as-cluster filter (panfeed.py:190-204), 128-bit row
-//                      hash, LDS bitonic sort by first-occurrence ordinal (dict insertion order, :189).
-//   cluster_base_kernel  output offsets per cluster.
-//   emit_kernel        per item: merged rank over the cluster's partitions, run-global pattern table
-//                      (first-seen rule, panfeed.py:179-187, 210-223), k-mer -> pattern id output.
-//   pattern_rows_kernel  representative rows of new patterns -> pattern pool.
+// Pipeline per batch of gene clusters (DESIGN.md has the full picture):
+//   gather_segments_kernel  (optional) segments cut out of / reverse-complemented from genomes resident in HBM.
+//   cluster_dedup_kernel  per cluster: identical segments -> one representative per distinct sequence (exact,
+//                      one pass over the packed bytes).
+//   scan_desc_kernel + kmer_scan_kernel   persistent 1024-thread workgroups, one (cluster, key partition) at a
+//                      time: slide the k window over the 2-bit packed segments, canonicalise (panfeed.py:65-75),
+//                      group k-mers in an LDS hash table {key, first-occurrence ordinal, 32-column presence word};
+//                      columns are swept in chunks of 32, each chunk's words flushed coalesced.
+//   finish_kernel      deduplicated clusters: everything after the scan in one workgroup (sample sets, allele-mask
+//                      table, MAF / same-as-cluster filter, ranks from ordinal bitmaps, run-global pattern table,
+//                      outputs).
+//   rows_kernel -> cluster_base_kernel -> emit_kernel -> pattern_rows_kernel   the general path: popcount / MAF +
+//                      same-as-cluster filter (panfeed.py:190-204), 128-bit row hash, ordinal order (dict insertion
+//                      order, :189), run-global pattern table (first-seen rule, :179-187, 210-223), pattern rows.
 //   md5_kernel         MD5 of the int64 / float64 image of each new pattern (panfeed.py:175, 206).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -588,7 +590,7 @@ __global__ __launch_bounds__(256) void strand_bits_kernel(const uint64_t* packed
 }
 
 // ---------------------------------------------------------------------------------------------
-// cluster_dedup_kernel: find identical segments inside a cluster (exact: hash, then word compare)
+// cluster_dedup_kernel: find identical segments inside a cluster (exact: hash, then word compare, one pass)
 // ---------------------------------------------------------------------------------------------
 // Samples that carry the same allele contribute the same k-mers at the same relative positions, so
 // only one representative per distinct sequence has to be scanned: the representative is the copy
@@ -597,7 +599,6 @@ __global__ __launch_bounds__(256) void strand_bits_kernel(const uint64_t* packed
 // M[d] = set of samples that carry distinct sequence d.  Output is identical to scanning every copy.
 // A cluster stays in mode 0 (scan everything) when dedup does not pay or does not fit.
 constexpr uint32_t DEDUP_MAX_SEGS = 16384;    // segments of a cluster (one byte of LDS each)
-constexpr uint32_t DEDUP_TAB = 4096;          // hash table slots (power of two, 2x segments)
 constexpr uint32_t DEDUP_MAX_D = 64;          // distinct sequences (two 32-bit presence words)
 constexpr uint32_t DEDUP_MROWS = 4096;        // words of the M matrix: D * ceil4(W) <= this
 constexpr uint32_t DENSE_WORDS = 8192;        // ordinal bitmap words (262144 dense ordinals)
