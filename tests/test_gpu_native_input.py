@@ -1,6 +1,7 @@
 """Row N1 end to end on the GPU: files on disk -> native reader -> packer -> HIP path -> the three TSV texts,
 against the oracle run over the Python restatement's records (oracle/input_restatement.py; parity unpinned at
 the pyfaidx boundary)."""
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -64,4 +65,35 @@ def test_missing_gff_under_consider_missing_raises(tmp_path):
     with ni.Pangenome(csvp, None, genome_names=gn, gff_paths=[gffs[n] for n in gn]) as pg:
         with pytest.raises(IndexError, match="boolean index did not match"):
             list(eng.run_pangenome(pg))
+    eng.close()
+
+
+def test_gather_argument_checks(tmp_path):
+    """pf_submit_gather refuses ranges outside the resident genomes / literal buffer instead of reading them"""
+    from panfeed_amd import native_input as ni
+    from panfeed_amd import synth
+    from panfeed_amd._lib import PanfeedHipError
+    from panfeed_amd.engine import Engine
+    cl = synth.generate(4, 12, first=1, flank=0, mean_len=150, min_len=60, max_len=300, n_rate=0.0)
+    csvp, gffs, fas = synth.write_pangenome(str(tmp_path), cl, missing_gene_rate=0.0, lower_rate=0.0)
+    gn = sorted(gffs)
+    eng = Engine(klength=15, max_strains=32)
+    with ni.Pangenome(csvp, None, genome_names=gn, gff_paths=[gffs[n] for n in gn]) as pg:
+        pg.make_resident(eng)
+        hb = next(pg.batches(15, True, eng.W))
+    assert hb.gather_src_off is not None and (hb.gather_src_flags & 1).sum() == 0      # everything by reference
+    eng.submit_host_batch(hb)                                                            # fine
+    bad = hb.gather_src_off.copy()
+    hb.gather_src_off = bad + np.uint64(1 << 40)
+    with pytest.raises(PanfeedHipError, match="outside the resident genomes"):
+        eng.submit_host_batch(hb)
+    hb.gather_src_off = bad
+    fl = hb.gather_src_flags.copy()
+    hb.gather_src_flags = fl | np.uint32(1)                                              # claims a literal source
+    with pytest.raises(PanfeedHipError, match="literal source"):
+        eng.submit_host_batch(hb)
+    hb.gather_src_flags = fl
+    assert eng.L.pf_genomes_clear(eng.ctx) == 0
+    with pytest.raises(PanfeedHipError, match="outside the resident genomes"):
+        eng.submit_host_batch(hb)
     eng.close()
