@@ -266,7 +266,7 @@ class Engine:
         out.kmers_to_hashes = kh_all
         out.hashes_to_patterns = hp_all
         out.kmers_tsv = "".join("".join(x) for x in kt_by_cluster)
-        out.stats = {"instances": int(hb.n_instances),
+        out.stats = {"clusters": int(hb.n_clusters), "instances": int(hb.n_instances),
                      "device_instances": int(res.n_instances),
                      "unique_kmers": int(res.n_unique), "kept_kmers": int(res.n_kept),
                      "new_patterns": int(res.n_new_patterns), "patterns": int(res.n_patterns)}

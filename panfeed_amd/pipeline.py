@@ -1,0 +1,85 @@
+"""Host pipeline of a whole run: files on disk -> the three output files.
+
+Stands where the reference's reader / worker / writer processes do (/root/reference/panfeed/__main__.py:39-81 and the
+serial loop :350-356): the native reader hands out table rows (host threads), the next batch is packed while the GPU
+works on the current one (`Engine.run_batches`), the texts of a finished batch are written -- and, under `compress`,
+deflated on all host threads -- by a writer thread while the GPU has the next batch.  Output order is the table order
+(the reference's --cores 1 order) whatever finishes first."""
+import os
+import queue
+import threading
+
+from .engine import Engine
+from .native_input import Pangenome
+from .output import create_hash_files, create_kmer_stroi, write_headers
+
+
+class _Columns:
+    """what write_headers needs of the reference's `genepres` (panfeed.py:116-129)"""
+
+    def __init__(self, columns):
+        self.columns = list(columns)
+
+
+def run_files(presence_absence, gffdir, output, fastadir=None, klength=31, canon=True, consider_missing=False,
+              patfilt=True, maf=0.01, upstream=0, downstream=0, downstream_start_codon=False, targets=(), genes=None,
+              compress=False, batch_clusters=256, resident=True, device=0, max_items=0, pattern_capacity=0):
+    """One directory of outputs (`kmers.tsv`, `kmers_to_hashes.tsv`, `hashes_to_patterns.tsv`, `.gz` under
+    `compress`) from a panaroo table and a directory (or file of files) of GFFs.  Option names and meaning follow
+    the reference's (`__main__.py:86-186`); `patfilt` is what `pattern_hasher` receives (`--no-filter` inverted,
+    `__main__.py:283-297`).  Returns a dict of counters."""
+    os.makedirs(output, exist_ok=True)
+    targets = tuple(targets or ())
+    pg = Pangenome(presence_absence, gffdir, fastadir, upstream, downstream, downstream_start_codon, targets=targets,
+                   genes=genes)
+    eng = None
+    stats = {"clusters": 0, "instances": 0, "kept_kmers": 0, "patterns": 0, "device_ms": 0.0, "bytes": 0}
+    try:
+        eng = Engine(klength=klength, canon=canon, consider_missing=consider_missing, patfilt=patfilt, maf=maf,
+                     max_strains=max(32, (pg.n_strains + 31) // 32 * 32), stroi=set(targets), device=device,
+                     max_items=max_items, pattern_capacity=pattern_capacity)
+        if resident:
+            pg.make_resident(eng)
+        kmer_stroi = create_kmer_stroi(output, compress)
+        hash_pat, kmer_hash = create_hash_files(output, compress)
+        write_headers(hash_pat, kmer_hash, _Columns(pg.strains))
+        q = queue.Queue(maxsize=4)
+        failed = []
+
+        def writer():
+            while True:
+                o = q.get()
+                if o is None:
+                    return
+                try:
+                    if not failed:
+                        kmer_stroi.write(o.kmers_tsv)
+                        kmer_hash.write(o.kmers_to_hashes)
+                        hash_pat.write(o.hashes_to_patterns)
+                except Exception as e:          # keep draining so that the producer never blocks on a dead writer
+                    failed.append(e)
+
+        wt = threading.Thread(target=writer, name="panfeed-writer")
+        wt.start()
+        try:
+            for o in eng.run_pangenome(pg, batch_clusters=batch_clusters):
+                stats["clusters"] += o.stats.get("clusters", 0)
+                stats["instances"] += o.stats.get("instances", 0)
+                stats["kept_kmers"] += o.stats.get("kept_kmers", 0)
+                stats["patterns"] = o.stats.get("patterns", stats["patterns"])
+                stats["device_ms"] += o.timing.get("total_ms", 0.0)
+                stats["bytes"] += len(o.kmers_tsv) + len(o.kmers_to_hashes) + len(o.hashes_to_patterns)
+                q.put(o)
+        finally:
+            q.put(None)
+            wt.join()
+            for fh in (kmer_stroi, kmer_hash, hash_pat):
+                fh.close()
+        if failed:
+            raise failed[0]
+        stats["log"] = pg.take_log()
+        return stats
+    finally:
+        pg.close()
+        if eng is not None:
+            eng.close()

@@ -97,3 +97,41 @@ def test_gather_argument_checks(tmp_path):
     with pytest.raises(PanfeedHipError, match="outside the resident genomes"):
         eng.submit_host_batch(hb)
     eng.close()
+
+
+@pytest.mark.parametrize("compress", [False, True], ids=["plain", "gzip"])
+def test_run_files_pipeline(tmp_path, compress):
+    """row N3: one call from the files on disk to the three output files (writer thread, parallel gzip), headers
+    included, against the oracle over the restated records"""
+    import gzip
+    import os
+    from oracle import input_restatement as ir
+    from oracle import oracle as po
+    from panfeed_amd import synth
+    from panfeed_amd.engine import KMERS_TO_HASHES_HEADER, KMERS_TSV_HEADER, hashes_to_patterns_header
+    from panfeed_amd.pipeline import run_files
+    cl = synth.generate(30, 50, first=300, flank=0, mean_len=300, min_len=50, max_len=900, n_rate=0.03, paralog_rate=0.05)
+    names = cl[0].names
+    src = tmp_path / "in"
+    csvp, gffs, fas = synth.write_pangenome(str(src), cl)
+    gn = sorted(gffs)
+    tg = (names[3],)
+    out = str(tmp_path / "out")
+    st = run_files(csvp, str(src / "gffs"), out, klength=23, upstream=40, downstream=20, targets=tg, compress=compress,
+                   batch_clusters=7)
+    strains, table = ir.load_table(csvp)
+    recs = list(ir.iter_gene_clusters(strains, table, ir.load_genomes(gn, [gffs[n] for n in gn]), 40, 20, False))
+    run = po.OracleRun(klength=23, stroi=set(tg))
+    run.feed(recs)
+    ek, ekh, ehp = run.texts()
+    assert st["clusters"] == 30 and st["instances"] == run.stats()["instances"]
+
+    def rd(name):
+        if compress:
+            with gzip.open(os.path.join(out, name + ".gz"), "rt") as fh:
+                return fh.read()
+        with open(os.path.join(out, name)) as fh:
+            return fh.read()
+    assert rd("kmers_to_hashes.tsv") == KMERS_TO_HASHES_HEADER + ekh
+    assert rd("hashes_to_patterns.tsv") == hashes_to_patterns_header(strains) + ehp
+    assert rd("kmers.tsv") == KMERS_TSV_HEADER + ek

@@ -50,4 +50,18 @@ if not host_only:
         out[mode] = dict(e2e_s=round(t_e2e, 3), e2e_inst_per_s=inst / t_e2e, device_ms=round(dev, 1), text_bytes=nb,
                          genome_upload_s=round(t_up, 3))
         pg.close(); eng.close()
+if not host_only:
+    # files -> files through pipeline.run_files (writer thread; gzip = level 9 members on all host threads)
+    import os, shutil
+    from panfeed_amd.pipeline import run_files
+    for compress in (False, True):
+        od = tempfile.mkdtemp()
+        t = time.time()
+        st = run_files(csvp, os.path.join(d, "gffs"), od, klength=k, upstream=up, downstream=down, compress=compress,
+                       batch_clusters=64)
+        dt = time.time() - t
+        size = sum(os.path.getsize(os.path.join(od, f)) for f in os.listdir(od))
+        out["files_to_files_gzip" if compress else "files_to_files"] = dict(
+            seconds=round(dt, 3), inst_per_s=st["instances"] / dt, text_bytes=st["bytes"], file_bytes=size)
+        shutil.rmtree(od)
 print(json.dumps(out))
