@@ -119,9 +119,16 @@ struct pf_ctx {
         it_unique, it_kept, work_scan, work_extra, work_fin, work_fin2, work_fin3, work_rows, sub_cluster, sub_item0, sub_nitems;
     std::vector<Arena*> arenas;
     DevBuf mg_lo, mg_hi, mg_min, mg_cnt;   // pf_merge_patterns scratch table
-    DevBuf stage_dev;              // one device block for the small per-pass arrays
-    void* stage_pin = nullptr;     // pinned host mirror of it
-    size_t stage_pin_cap = 0;
+    // the small per-pass arrays: one device block + its pinned host mirror, two of each because the two halves of a
+    // batch's first pass are in flight together (stage_slot picks the pair)
+    DevBuf stage_devs[2];
+    void* stage_pins[2] = {nullptr, nullptr};
+    size_t stage_pin_caps[2] = {0, 0};
+    int stage_slot = 0;
+    void* pin_dedup = nullptr;     // pinned host copies of the per-cluster arrays the dedup kernel leaves
+    size_t pin_dedup_cap = 0;
+    uint64_t* pin_small = nullptr; // pinned scratch: cursor values going up, cursor read-backs of a deferred pass
+    hipEvent_t ev_half[2] = {nullptr, nullptr};
     // last batch bookkeeping
     bool have_batch = false;
     uint32_t n_clusters = 0;
@@ -201,23 +208,26 @@ int staged_upload(pf_ctx* c, std::vector<std::pair<DevBuf*, const std::vector<ui
         total += (std::max<size_t>(arrs[i].second->size(), 1) * 4 + 255) & ~(size_t)255;
     }
     for (auto& a : arrs) if (!a.first->view) a.first->release();
-    PFCHK(c->stage_dev.ensure(total));
-    if (total > c->stage_pin_cap) {
-        if (c->stage_pin) (void)hipHostFree(c->stage_pin);
-        c->stage_pin = nullptr; c->stage_pin_cap = 0;
+    DevBuf& stage_dev = c->stage_devs[c->stage_slot];
+    void*& stage_pin = c->stage_pins[c->stage_slot];
+    size_t& stage_pin_cap = c->stage_pin_caps[c->stage_slot];
+    PFCHK(stage_dev.ensure(total));
+    if (total > stage_pin_cap) {
+        if (stage_pin) (void)hipHostFree(stage_pin);
+        stage_pin = nullptr; stage_pin_cap = 0;
         const size_t want = total + total / 4;
-        hipError_t e = hipHostMalloc(&c->stage_pin, want, hipHostMallocDefault);
+        hipError_t e = hipHostMalloc(&stage_pin, want, hipHostMallocDefault);
         if (e != hipSuccess) return fail(PF_ERR_OOM, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
-        c->stage_pin_cap = want;
+        stage_pin_cap = want;
     }
     for (size_t i = 0; i < arrs.size(); i++) {
         const auto& v = *arrs[i].second;
-        if (!v.empty()) memcpy((char*)c->stage_pin + off[i], v.data(), v.size() * 4);
-        arrs[i].first->p = (char*)c->stage_dev.p + off[i];
+        if (!v.empty()) memcpy((char*)stage_pin + off[i], v.data(), v.size() * 4);
+        arrs[i].first->p = (char*)stage_dev.p + off[i];
         arrs[i].first->cap = 0;
         arrs[i].first->view = true;
     }
-    HIPCHK(hipMemcpyAsync(c->stage_dev.p, c->stage_pin, total, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(stage_dev.p, stage_pin, total, hipMemcpyHostToDevice, c->stream));
     return PF_OK;
 }
 
@@ -306,8 +316,10 @@ void pf_destroy(pf_ctx* c) {
     for (Arena* a : c->arenas) { a->key.release(); a->pid.release(); a->first.release(); delete a; }
     for (auto& e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-    if (c->stage_pin) (void)hipHostFree(c->stage_pin);
-    c->stage_dev.release(); c->scan_desc.release(); c->md5_list.release();
+    for (int i = 0; i < 2; i++) { if (c->stage_pins[i]) (void)hipHostFree(c->stage_pins[i]); c->stage_devs[i].release(); if (c->ev_half[i]) (void)hipEventDestroy(c->ev_half[i]); }
+    if (c->pin_dedup) (void)hipHostFree(c->pin_dedup);
+    if (c->pin_small) (void)hipHostFree(c->pin_small);
+    c->scan_desc.release(); c->md5_list.release();
     c->g_store.release(); c->b_literal.release(); c->g_src_off.release(); c->g_src_start.release(); c->g_src_flags.release();
     c->mg_lo.release(); c->mg_hi.release(); c->mg_min.release(); c->mg_cnt.release();
     if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
@@ -360,7 +372,9 @@ int pf_create(pf_ctx** out, int device, const pf_opts* o) {
     do {
         hipError_t e = hipStreamCreate(&c->stream);
         if (e != hipSuccess) { rc = fail(PF_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); break; }
-        if (hipEventCreate(&c->ev_t0) != hipSuccess || hipEventCreate(&c->ev_t1) != hipSuccess) {
+        if (hipEventCreate(&c->ev_half[0]) != hipSuccess || hipEventCreate(&c->ev_half[1]) != hipSuccess ||
+            hipHostMalloc((void**)&c->pin_small, 256, hipHostMallocDefault) != hipSuccess ||
+            hipEventCreate(&c->ev_t0) != hipSuccess || hipEventCreate(&c->ev_t1) != hipSuccess) {
             rc = fail(PF_ERR_HIP, "hipEventCreate failed"); break;
         }
         if (!guard(upload_vec(c, c->d_maf_lo, c->maf_lo))) break;
@@ -621,8 +635,28 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
     HIPCHK(hipMemsetAsync(c->cursor.p, 0, 64, c->stream));
 
     // ---- identical segments -> scan view (mode 1) or the caller's list as it is (mode 0)
-    std::vector<uint64_t> ninst(C), vinst(C), words(C);
-    std::vector<uint32_t> h_mode(C), h_dense(C), h_vnstr(C);
+    // The dedup kernel's per-cluster results come back into pinned memory, in two halves for a large batch: the
+    // host builds and launches the first half's work items while the GPU is still on the second half's dedup, and the
+    // second half's while the first half's scan runs -- otherwise the GPU idles for the ~1.2 ms that takes.
+    const size_t C8 = ((size_t)C + 1) & ~(size_t)1;
+    {
+        const size_t need = C8 * 36 + 64;
+        if (need > c->pin_dedup_cap) {
+            if (c->pin_dedup) (void)hipHostFree(c->pin_dedup);
+            c->pin_dedup = nullptr; c->pin_dedup_cap = 0;
+            hipError_t e = hipHostMalloc(&c->pin_dedup, need + need / 4, hipHostMallocDefault);
+            if (e != hipSuccess) return fail(PF_ERR_OOM, "hipHostMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+            c->pin_dedup_cap = need + need / 4;
+        }
+    }
+    uint64_t* ninst = reinterpret_cast<uint64_t*>(c->pin_dedup);
+    uint64_t* vinst = ninst + C8;
+    uint64_t* words = vinst + C8;
+    uint32_t* h_mode = reinterpret_cast<uint32_t*>(words + C8);
+    uint32_t* h_dense = h_mode + C8;
+    uint32_t* h_vnstr = h_dense + C8;
+    const bool split = C >= 8192;                  // two halves in flight
+    const uint32_t half_end[2] = {split ? C / 4 : C, C};   // a quarter first: enough GPU work to hide building the rest
     if (C) {
         pf::DedupParams dp{};
         dp.packed = d.packed; dp.seg_word_off = d.seg_word_off; dp.seg_len = d.seg_len;
@@ -637,20 +671,27 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
         dp.extra_dense = c->extra_dense.as<uint32_t>();
         dp.k = c->o.klength; dp.W = W; dp.canon = c->o.canon;
         dp.enable = (c->o.flags & PF_FLAG_NO_DEDUP) ? 0u : 1u;
-        PFCHK(mark_begin(c, 3));
-        hipLaunchKernelGGL(pf::cluster_dedup_kernel, dim3(C), dim3(pf::DEDUP_THREADS), 0, c->stream, dp);
-        HIPCHK(hipGetLastError());
-        PFCHK(mark_end(c));
-        hipLaunchKernelGGL(pf::cluster_ninst_kernel, dim3((C + 3) / 4), dim3(256), 0, c->stream, d.cluster_seg_off,
-                           d.seg_len, c->v_len.as<uint32_t>(), c->v_nseg.as<uint32_t>(), c->o.klength, C,
-                           c->cl_ninst.as<uint64_t>(), c->cl_vinst.as<uint64_t>(), c->cl_vwords.as<uint64_t>());
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(ninst.data(), c->cl_ninst.p, (size_t)C * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(vinst.data(), c->cl_vinst.p, (size_t)C * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(words.data(), c->cl_vwords.p, (size_t)C * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(h_mode.data(), c->v_mode.p, (size_t)C * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(h_dense.data(), c->v_dense.p, (size_t)C * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(h_vnstr.data(), c->v_nstr.p, (size_t)C * 4, hipMemcpyDeviceToHost, c->stream));
+        for (int h = 0; h < 2; h++) {
+            const uint32_t c0 = h ? half_end[0] : 0, c1 = half_end[h], n = c1 - c0;
+            if (n) {
+                dp.cluster_base = c0;
+                PFCHK(mark_begin(c, 3));
+                hipLaunchKernelGGL(pf::cluster_dedup_kernel, dim3(n), dim3(pf::DEDUP_THREADS), 0, c->stream, dp);
+                HIPCHK(hipGetLastError());
+                PFCHK(mark_end(c));
+                hipLaunchKernelGGL(pf::cluster_ninst_kernel, dim3((n + 3) / 4), dim3(256), 0, c->stream, d.cluster_seg_off,
+                                   d.seg_len, c->v_len.as<uint32_t>(), c->v_nseg.as<uint32_t>(), c->o.klength, c0, c1,
+                                   c->cl_ninst.as<uint64_t>(), c->cl_vinst.as<uint64_t>(), c->cl_vwords.as<uint64_t>());
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipMemcpyAsync(ninst + c0, c->cl_ninst.as<uint64_t>() + c0, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(hipMemcpyAsync(vinst + c0, c->cl_vinst.as<uint64_t>() + c0, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(hipMemcpyAsync(words + c0, c->cl_vwords.as<uint64_t>() + c0, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(hipMemcpyAsync(h_mode + c0, c->v_mode.as<uint32_t>() + c0, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(hipMemcpyAsync(h_dense + c0, c->v_dense.as<uint32_t>() + c0, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(hipMemcpyAsync(h_vnstr + c0, c->v_nstr.as<uint32_t>() + c0, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+            }
+            HIPCHK(hipEventRecord(c->ev_half[h], c->stream));
+        }
     }
     // ---- strand bits of target-strain segments (canonical mode)
     c->n_strand_words = (b->seg_strand_off && c->o.canon) ? b->n_strand_words : 0;
@@ -667,21 +708,16 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
         HIPCHK(hipGetLastError());
     }
     lap("upload+dedup launch");
-    HIPCHK(hipStreamSynchronize(c->stream));
-    lap("sync after dedup");
     const uint64_t mult = c->o.canon ? 1 : 2;
     uint64_t total_inst = 0;
-    for (uint32_t i = 0; i < C; i++) {
-        if (ninst[i] * mult >= 0xFFFFFFF0ull) return fail(PF_ERR_ARG, "cluster %u has too many k-mer instances", i);
-        total_inst += ninst[i] * mult;
-        c->timing.n_dedup_clusters += h_mode[i];
-    }
 
     c->pid0 = c->n_patterns;
     c->cluster_arena.assign(C, 0);
 
-    std::vector<uint32_t> todo(C), nparts(C, 1);
+    std::vector<uint32_t> nparts(C, 1);
+    std::vector<uint32_t> todo(half_end[0]), todo_second(C - half_end[0]), todo_first;
     std::iota(todo.begin(), todo.end(), 0u);
+    std::iota(todo_second.begin(), todo_second.end(), half_end[0]);
     // a deduplicated cluster whose distinct sequences alone carry far more windows than one table holds will
     // overflow it: start it with two key partitions instead of paying for a failed first scan (a wrong guess
     // only costs time: an overflow still triggers the doubling retry)
@@ -689,18 +725,37 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
     // contributes all of its windows, every further one the share a 1 % divergence touches (1 - 0.99^k: 27 % of the
     // 31-mers, 40 % of the 51-mers) plus a margin.
     const double share = 1.0 - std::pow(0.99, (double)c->o.klength) + 0.06;
-    for (uint32_t i = 0; i < C; i++)
-        if (h_mode[i] == 1 && h_vnstr[i]) {
-            const double D = (double)h_vnstr[i], L = (double)(vinst[i] * mult) / D;
-            const double est = L * (1.0 + share * (D - 1.0));
-            const double room = 0.9 * (double)pf::insert_limit(NS);
-            if (est > room) nparts[i] = (uint32_t)std::min<double>(std::ceil(est / room), 64.0);
+    // what the host does with a half's dedup results once they have arrived (ev_half[h])
+    auto prep_half = [&](int h) -> int {
+        for (uint32_t i = h ? half_end[0] : 0; i < half_end[h]; i++) {
+            if (ninst[i] * mult >= 0xFFFFFFF0ull) return fail(PF_ERR_ARG, "cluster %u has too many k-mer instances", i);
+            total_inst += ninst[i] * mult;
+            c->timing.n_dedup_clusters += h_mode[i];
+            if (h_mode[i] == 1 && h_vnstr[i]) {
+                const double D = (double)h_vnstr[i], L = (double)(vinst[i] * mult) / D;
+                const double est = L * (1.0 + share * (D - 1.0));
+                const double room = 0.9 * (double)pf::insert_limit(NS);
+                if (est > room) nparts[i] = (uint32_t)std::min<double>(std::ceil(est / room), 64.0);
+            }
         }
+        return PF_OK;
+    };
     uint32_t pass = 0;
     const uint32_t lim_full = pf::insert_limit(NS);
     uint64_t arena_base = 0;
+    Arena* deferred_ar = nullptr;          // the first half's pass, launched and not yet waited for
+    if (C) {
+        HIPCHK(hipEventSynchronize(c->ev_half[0]));
+        lap("first half's dedup results");
+        PFCHK(prep_half(0));
+    }
 
     while (!todo.empty()) {
+        c->stage_slot = (int)(pass & 1);
+        if (split && pass == 1 && deferred_ar) {
+            HIPCHK(hipEventSynchronize(c->ev_half[1]));
+            PFCHK(prep_half(1));
+        }
         // ---- items of this pass
         std::vector<Item>& items = c->hs_items;
         std::vector<uint8_t>& item_fused = c->hs_fused;      // 0 unfused, 1 fused small class, 2 fused large class
@@ -842,8 +897,8 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
         }
         // the cursor's next free index restarts at this arena's base
         {
-            uint64_t cur0 = arena_base;
-            HIPCHK(hipMemcpyAsync(c->cursor.p, &cur0, 8, hipMemcpyHostToDevice, c->stream));
+            c->pin_small[pass & 1] = arena_base;
+            HIPCHK(hipMemcpyAsync(c->cursor.p, &c->pin_small[pass & 1], 8, hipMemcpyHostToDevice, c->stream));
         }
 
         lap("upload items");
@@ -1020,6 +1075,16 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
         for (uint32_t ci : todo) c->timing.scan_packed_bytes += words[ci] * 8 * nparts[ci];
 
         lap("launch pass");
+        if (split && pass == 0 && !todo_second.empty()) {
+            // no wait: the second half's pass is built now and goes in behind this one
+            HIPCHK(hipMemcpyAsync(&c->pin_small[8], c->cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
+            deferred_ar = ar;
+            arena_base += ar->cap;
+            todo_first.swap(todo);
+            todo.swap(todo_second);
+            pass++;
+            continue;
+        }
         // ---- who overflowed?
         std::vector<uint32_t> ovf(C);
         uint64_t cur3[3];
@@ -1031,6 +1096,15 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
         if (ar->used > ar->cap) return fail(PF_ERR_CAPACITY, "output arena overflow (%llu > %llu)",
                                             (unsigned long long)ar->used, (unsigned long long)ar->cap);
         arena_base += ar->cap;
+        if (deferred_ar) {                         // the first half's pass finished before this one started
+            deferred_ar->used = c->pin_small[8] - deferred_ar->base;
+            if (deferred_ar->used > deferred_ar->cap)
+                return fail(PF_ERR_CAPACITY, "output arena overflow (%llu > %llu)", (unsigned long long)deferred_ar->used,
+                            (unsigned long long)deferred_ar->cap);
+            deferred_ar = nullptr;
+            todo.insert(todo.begin(), todo_first.begin(), todo_first.end());
+            todo_first.clear();
+        }
         std::vector<uint32_t> next;
         for (uint32_t ci : todo)
             if (ovf[ci]) {

@@ -614,6 +614,7 @@ struct DedupParams {
     uint32_t* v_nseg; uint32_t* v_nstr; uint32_t* v_mode; uint32_t* v_dense;       // [C]
     uint32_t* extra_dense;            // [n_extra] ordinal of the extra row in the cluster's (dense) numbering
     uint32_t k, W, canon, enable;
+    uint32_t cluster_base;            // first cluster of this launch (the batch's clusters may be launched in two halves)
 };
 
 __device__ __forceinline__ uint64_t mix64(uint64_t x) {
@@ -646,7 +647,7 @@ __global__ __launch_bounds__(DEDUP_THREADS) __attribute__((amdgpu_waves_per_eu(6
     __shared__ uint32_t sh_bad, sh_nrep, sh_total, sh_ngroups, sh_pool_used;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint32_t c = blockIdx.x;
+    const uint32_t c = blockIdx.x + p.cluster_base;
     const uint32_t seg0 = p.cluster_seg_off[c], seg1 = p.cluster_seg_off[c + 1];
     const uint32_t n = seg1 - seg0;
     const uint32_t ex0 = p.extra_off[c], ex1 = p.extra_off[c + 1];
@@ -2530,11 +2531,11 @@ __global__ __launch_bounds__(256) void merge_lookup_kernel(MergeParams p) {
 // instances / packed words the scan will actually visit (the view); one wave per cluster
 __global__ __launch_bounds__(256) void cluster_ninst_kernel(const uint32_t* cluster_seg_off, const uint32_t* seg_len,
                                                             const uint32_t* v_len, const uint32_t* v_nseg, uint32_t k,
-                                                            uint32_t n_clusters, uint64_t* cluster_ninst,
+                                                            uint32_t c_first, uint32_t c_end, uint64_t* cluster_ninst,
                                                             uint64_t* cluster_vinst, uint64_t* cluster_vwords) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (c >= n_clusters) return;
+    const uint32_t c = c_first + ((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (c >= c_end) return;
     const uint32_t s0 = cluster_seg_off[c], s1 = cluster_seg_off[c + 1], sv = s0 + v_nseg[c];
     uint64_t n = 0, nv = 0, wv = 0;
     for (uint32_t s = s0 + lane; s < s1; s += 64) {
