@@ -190,6 +190,26 @@ def test_dedup_thousands_of_segments():
     eng.close()
 
 
+def test_large_batch_two_part_first_pass():
+    """>= 8192 clusters: the first pass is launched in two parts (a quarter of the clusters while the GPU is still on
+    the dedup of the rest); same texts as the oracle, overflow retries from both parts included"""
+    from panfeed_amd import synth
+    from panfeed_amd.engine import Engine
+    cl = synth.generate(9000, 12, first=40000, flank=5, mean_len=70, min_len=40, max_len=160, n_rate=0.01, paralog_rate=0.05)
+    recs = [c.record() for c in cl]
+    # two clusters whose tables overflow, one in each part
+    for pos, seed in ((100, 1), (8000, 2)):
+        recs[pos] = _diverse_records(24, 900, seed, n_clusters=1)[0][0]
+    eng = Engine(klength=21, max_strains=32, max_items=4096)          # several sub-batches per part as well
+    out = eng.run(recs)
+    assert out.timing["n_retried"] >= 2 and out.timing["n_dedup_clusters"] > 4000
+    (ek, ekh, ehp), st = _oracle_texts(recs, klength=21)
+    assert out.kmers_to_hashes == ekh
+    assert out.hashes_to_patterns == ehp
+    assert out.stats["unique_kmers"] == st["unique_kmers"]
+    eng.close()
+
+
 def _diverse_records(n_samples, length, seed, n_clusters=2):
     """every sample carries its own random sequence: unique k-mers ~ instances (table overflow path)"""
     from panfeed_amd.classes import Seqinfo
