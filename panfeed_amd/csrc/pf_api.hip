@@ -494,6 +494,9 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
     if (!c || !b) return fail(PF_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(c->device));
     c->have_batch = false;
+    // whatever way this call ends, nothing it queued is still reading the caller's arrays or the pinned staging
+    // blocks afterwards (the successful path has waited already; an error return may come with work in flight)
+    struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{c->stream};
     const uint32_t C = b->n_clusters, NSEG = b->n_segs, W = c->W, NS = c->NS, KW = (uint32_t)c->KW;
     if (b->n_segs && (!b->packed || !b->seg_word_off || !b->seg_len || !b->seg_sample || !b->seg_ord_base))
         return fail(PF_ERR_ARG, "segment arrays missing");
