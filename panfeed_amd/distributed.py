@@ -2,12 +2,19 @@
 processing order); the only cross-rank state of the path is the run-global `patterns` set and its
 first-seen rule (/root/reference/panfeed/panfeed.py:149-150, 179-180, 210-212).
 
-Every rank dedups its own clusters on its GPU; at the end (or per super-batch) the ranks all-gather
-{md5 digest (16 B), first_seen (8 B)} of their patterns over RCCL -- an all-gather, not a ring
-all-reduce: the payload is a set union, and on xGMI it spreads over all seven links -- and each
-rank keeps a pattern row iff its first_seen is the minimum for that digest.  first_seen =
-(global cluster ordinal << 32 | rank inside the cluster) is monotone in the reference's --cores 1
-order, so the surviving rows, sorted by first_seen, are exactly hashes_to_patterns.tsv.
+Every rank dedups its own clusters on its GPU; at the end (or per super-batch) the ranks exchange
+{md5 digest (16 B), first_seen (8 B)} of their patterns over RCCL and each rank keeps a pattern row iff its
+first_seen is the minimum for that digest.  first_seen = (global cluster ordinal << 32 | rank inside the
+cluster) is monotone in the reference's --cores 1 order, so the surviving rows, sorted by first_seen, are
+exactly hashes_to_patterns.tsv.
+
+Two forms of the exchange (same result):
+  "owner"     (default) every digest has an owner rank (a few of its bits mod world); rows go to their owners with
+              one all-to-all, the owner marks the first of every digest (device hash table), the marks go back
+              with a second all-to-all of one byte per row.  A rank sends and receives its own volume once: on the
+              point-to-point xGMI links that is 1/world of what an all-gather moves, and the merge kernel sees
+              1/world of the rows.
+  "allgather" every rank gathers every row and marks its own.
 """
 import ctypes as C
 
@@ -34,16 +41,78 @@ def shard_range(n_clusters, rank, world, weights=None):
     return cuts[rank], cuts[rank + 1]
 
 
-def merge_pattern_tensors(md5, first_seen, dist=None, engine=None):
+def _pack_rows(md5, first_seen):
+    n = md5.shape[0]
+    pay = torch.empty((n, 3), dtype=torch.int64, device=md5.device)
+    if n:
+        pay[:, :2] = md5.contiguous().view(torch.int64).view(n, 2)
+        pay[:, 2] = first_seen
+    return pay
+
+
+def _first_per_digest(rows, engine=None):
+    """rows: int64 [m,3] {md5 lo, md5 hi, first_seen}.  (keep bool [m]: the row holds the minimum first_seen of its
+    digest, number of distinct digests).  On the GPU by the library's hash-table kernels, else a torch sort."""
+    m = rows.shape[0]
+    dev = rows.device
+    if m == 0:
+        return torch.zeros(0, dtype=torch.bool, device=dev), 0
+    if engine is not None and rows.is_cuda:
+        return _merge_on_device(engine, rows, 0, m)
+    # lexicographic sort by (digest hi, digest lo): two stable passes
+    order = torch.argsort(rows[:, 1], stable=True)
+    order = order[torch.argsort(rows[order, 0], stable=True)]
+    sp = rows[order]
+    new_group = torch.ones(m, dtype=torch.bool, device=dev)
+    new_group[1:] = (sp[1:, 0] != sp[:-1, 0]) | (sp[1:, 1] != sp[:-1, 1])
+    gid = torch.cumsum(new_group.to(torch.int64), 0) - 1
+    n_distinct = int(gid[-1].item()) + 1
+    gmin = torch.full((n_distinct,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=dev)
+    gmin.scatter_reduce_(0, gid, sp[:, 2], reduce="amin")
+    keep = torch.empty(m, dtype=torch.bool, device=dev)
+    keep[order] = sp[:, 2] == gmin[gid]
+    return keep, n_distinct
+
+
+def _merge_owner(md5, first_seen, dist, engine):
+    world = dist.get_world_size()
+    dev = md5.device
+    n = md5.shape[0]
+    pay = _pack_rows(md5, first_seen)
+    owner = ((pay[:, 0] >> 17) & 0x7FFFFFFF) % world            # any fixed function of the digest
+    order = torch.argsort(owner, stable=True)
+    send = pay[order].contiguous()
+    send_counts = torch.bincount(owner, minlength=world).to(torch.int64)
+    recv_counts = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_to_all_single(recv_counts, send_counts)
+    sc, rc = send_counts.tolist(), recv_counts.tolist()
+    recv = torch.empty((sum(rc), 3), dtype=torch.int64, device=dev)
+    dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=sc)
+    if recv.is_cuda:
+        torch.cuda.synchronize(dev)                             # the library runs on its own stream
+    keep_recv, n_owned = _first_per_digest(recv, engine)
+    keep_back = torch.empty(n, dtype=torch.uint8, device=dev)
+    dist.all_to_all_single(keep_back, keep_recv.to(torch.uint8).contiguous(), output_split_sizes=sc, input_split_sizes=rc)
+    keep = torch.empty(n, dtype=torch.bool, device=dev)
+    keep[order] = keep_back.bool()
+    tot = torch.tensor([n_owned], dtype=torch.int64, device=dev)
+    dist.all_reduce(tot)
+    return keep, int(tot.item())
+
+
+def merge_pattern_tensors(md5, first_seen, dist=None, engine=None, method="owner"):
     """md5: uint8 [n,16], first_seen: int64 [n] (this rank's patterns, any device).
     Returns (keep_mask [n] bool: this rank's row is the global first for its digest,
              n_global: number of distinct digests over all ranks).
-    With CUDA tensors and an `engine`, the dedup after the all-gather runs in the library's hash-table kernels
-    (pf_merge_patterns, O(rows) atomics); otherwise (CPU / gloo tests) by a lexicographic sort in torch."""
+    With CUDA tensors and an `engine`, the marking runs in the library's hash-table kernels (pf_merge_patterns,
+    O(rows) atomics); otherwise (CPU / gloo tests) by a lexicographic sort in torch."""
     dev = md5.device
     n = md5.shape[0]
     use_kernel = engine is not None and md5.is_cuda
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    multi = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
+    if multi and method == "owner":
+        return _merge_owner(md5, first_seen, dist, engine)
+    if multi:
         world, rank = dist.get_world_size(), dist.get_rank()
         counts = torch.zeros(world, dtype=torch.int64, device=dev)
         mine = torch.tensor([n], dtype=torch.int64, device=dev)
@@ -52,8 +121,7 @@ def merge_pattern_tensors(md5, first_seen, dist=None, engine=None):
         nmax = max(max(cl), 1)
         pay = torch.zeros((nmax, 3), dtype=torch.int64, device=dev)
         if n:
-            pay[:n, :2] = md5.contiguous().view(torch.int64).view(n, 2)
-            pay[:n, 2] = first_seen
+            pay[:n] = _pack_rows(md5, first_seen)
         allpay = torch.empty((world * nmax, 3), dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(allpay, pay)
         if use_kernel:
@@ -67,38 +135,12 @@ def merge_pattern_tensors(md5, first_seen, dist=None, engine=None):
             return keep[:n].bool(), int(n_global.value)
         valid = (torch.arange(nmax, device=dev)[None, :] < counts[:, None]).reshape(-1)
         allpay = allpay[valid]
-        owner = torch.arange(world, device=dev).repeat_interleave(nmax)[valid]
+        my_first = sum(cl[:rank])
     else:
-        rank = 0
-        allpay = torch.empty((n, 3), dtype=torch.int64, device=dev)
-        if n:
-            allpay[:, :2] = md5.contiguous().view(torch.int64).view(n, 2)
-            allpay[:, 2] = first_seen
-        if use_kernel:
-            return _merge_on_device(engine, allpay, 0, n)
-        owner = torch.zeros(n, dtype=torch.int64, device=dev)
-    m = allpay.shape[0]
-    if m == 0:
-        return torch.zeros(0, dtype=torch.bool, device=dev), 0
-    # lexicographic sort by (digest hi, digest lo): two stable passes
-    order = torch.argsort(allpay[:, 1], stable=True)
-    order = order[torch.argsort(allpay[order, 0], stable=True)]
-    sp = allpay[order]
-    new_group = torch.ones(m, dtype=torch.bool, device=dev)
-    new_group[1:] = (sp[1:, 0] != sp[:-1, 0]) | (sp[1:, 1] != sp[:-1, 1])
-    gid = torch.cumsum(new_group.to(torch.int64), 0) - 1
-    n_global = int(gid[-1].item()) + 1
-    gmin = torch.full((n_global,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=dev)
-    gmin.scatter_reduce_(0, gid, sp[:, 2], reduce="amin")
-    is_first = sp[:, 2] == gmin[gid]
-    # map back to this rank's rows (they sit at the start of its all-gather slot, in order)
-    mine_sorted = owner[order] == rank
-    keep = torch.zeros(n, dtype=torch.bool, device=dev)
-    if n:
-        # position of each of my rows inside my slot = index among my rows in gathered order
-        my_pos = torch.cumsum((owner == rank).to(torch.int64), 0) - 1
-        keep[my_pos[order][mine_sorted]] = is_first[mine_sorted]
-    return keep, n_global
+        allpay = _pack_rows(md5, first_seen)
+        my_first = 0
+    keep_all, n_global = _first_per_digest(allpay, engine if use_kernel else None)
+    return keep_all[my_first:my_first + n], n_global
 
 
 def _merge_on_device(engine, allpay, my_first, my_count):
@@ -142,8 +184,8 @@ def engine_n_patterns(engine):
     return n.value
 
 
-def merge_patterns(engine, dist, device):
-    """All-gather the engine's pattern digests and return the number of run-global unique patterns."""
+def merge_patterns(engine, dist, device, method="owner"):
+    """Exchange the engine's pattern digests and return the number of run-global unique patterns."""
     md5, fs = export_patterns(engine, device)
-    _keep, n_global = merge_pattern_tensors(md5, fs, dist, engine=engine)
+    _keep, n_global = merge_pattern_tensors(md5, fs, dist, engine=engine, method=method)
     return n_global

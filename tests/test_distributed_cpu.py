@@ -23,25 +23,27 @@ def _make(rank, world, seed=3):
     return per
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, method="owner"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     per = _make(rank, world)
     md5 = torch.from_numpy(per[rank][0].copy())
     fs = torch.from_numpy(per[rank][1].copy())
-    keep, n_global = merge_pattern_tensors(md5, fs, dist)
+    keep, n_global = merge_pattern_tensors(md5, fs, dist, method=method)
     q.put((rank, keep.numpy().tolist(), n_global))
     dist.barrier()
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("method", ["owner", "allgather"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_merge_patterns_gloo(world):
+def test_merge_patterns_gloo(world, method):
+    """both forms of the exchange (all-to-all to the digest's owner and back / all-gather) mark the same rows"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + world
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    port = 29500 + (os.getpid() % 2000) + world + (10 if method == "owner" else 0)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, method)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}

@@ -482,6 +482,11 @@ def test_merge_kernel_matches_sort_merge():
         keep, n_glob = _merge_on_device(eng, allpay, first, cnt)
         assert n_glob == n_ref
         assert torch.equal(keep.cpu(), keep_all[first:first + cnt])
+    # what the owner rank of the all-to-all form computes: a mark for every row it received
+    from panfeed_amd.distributed import _first_per_digest
+    k_dev, n_dev = _first_per_digest(allpay, eng)
+    k_cpu, n_cpu = _first_per_digest(allpay.cpu())
+    assert n_dev == n_cpu == n_ref and torch.equal(k_dev.cpu(), k_cpu) and torch.equal(k_cpu, keep_all)
     # the padded layout all_gather_into_tensor leaves (equal slots per rank, garbage behind the real rows)
     import ctypes as C
     from panfeed_amd import _lib
