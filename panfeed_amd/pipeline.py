@@ -23,9 +23,11 @@ class _Columns:
 
 def run_files(presence_absence, gffdir, output, fastadir=None, klength=31, canon=True, consider_missing=False,
               patfilt=True, maf=0.01, upstream=0, downstream=0, downstream_start_codon=False, targets=(), genes=None,
-              compress=False, batch_clusters=256, resident=True, device=0, max_items=0, pattern_capacity=0):
+              compress=False, multiple_files=False, batch_clusters=256, resident=True, device=0, max_items=0,
+              pattern_capacity=0):
     """One directory of outputs (`kmers.tsv`, `kmers_to_hashes.tsv`, `hashes_to_patterns.tsv`, `.gz` under
-    `compress`) from a panaroo table and a directory (or file of files) of GFFs.  Option names and meaning follow
+    `compress`; under `multiple_files` one such directory per gene cluster, `<output>/<cluster>/`, the pattern set
+    starting empty in each: `panfeed.py:35-43,153-167`) from a panaroo table and a directory (or file of files) of GFFs.  Option names and meaning follow
     the reference's (`__main__.py:86-186`); `patfilt` is what `pattern_hasher` receives (`--no-filter` inverted,
     `__main__.py:283-297`).  Returns a dict of counters."""
     os.makedirs(output, exist_ok=True)
@@ -36,15 +38,39 @@ def run_files(presence_absence, gffdir, output, fastadir=None, klength=31, canon
     stats = {"clusters": 0, "instances": 0, "kept_kmers": 0, "patterns": 0, "device_ms": 0.0, "bytes": 0}
     try:
         eng = Engine(klength=klength, canon=canon, consider_missing=consider_missing, patfilt=patfilt, maf=maf,
-                     max_strains=max(32, (pg.n_strains + 31) // 32 * 32), stroi=set(targets), device=device,
+                     multiple_files=multiple_files, max_strains=max(32, (pg.n_strains + 31) // 32 * 32),
+                     stroi=set(targets), device=device,
                      max_items=max_items, pattern_capacity=pattern_capacity)
         if resident:
             pg.make_resident(eng)
-        kmer_stroi = create_kmer_stroi(output, compress)
-        hash_pat, kmer_hash = create_hash_files(output, compress)
-        write_headers(hash_pat, kmer_hash, _Columns(pg.strains))
+        cols = _Columns(pg.strains)
+        if multiple_files:
+            kmer_stroi = hash_pat = kmer_hash = None
+        else:
+            kmer_stroi = create_kmer_stroi(output, compress)
+            hash_pat, kmer_hash = create_hash_files(output, compress)
+            write_headers(hash_pat, kmer_hash, cols)
         q = queue.Queue(maxsize=4)
         failed = []
+
+        def write_one(o):
+            if not multiple_files:
+                kmer_stroi.write(o.kmers_tsv)
+                kmer_hash.write(o.kmers_to_hashes)
+                hash_pat.write(o.hashes_to_patterns)
+                return
+            for idx, kt, kh, hp in o.per_cluster:
+                path = os.path.join(output, idx)
+                os.makedirs(path, exist_ok=True)
+                ks = create_kmer_stroi(path, compress)
+                ks.write(kt)
+                ks.close()
+                f_hp, f_kh = create_hash_files(path, compress)
+                write_headers(f_hp, f_kh, cols)
+                f_hp.write(hp)
+                f_kh.write(kh)
+                f_hp.close()
+                f_kh.close()
 
         def writer():
             while True:
@@ -53,9 +79,7 @@ def run_files(presence_absence, gffdir, output, fastadir=None, klength=31, canon
                     return
                 try:
                     if not failed:
-                        kmer_stroi.write(o.kmers_tsv)
-                        kmer_hash.write(o.kmers_to_hashes)
-                        hash_pat.write(o.hashes_to_patterns)
+                        write_one(o)
                 except Exception as e:          # keep draining so that the producer never blocks on a dead writer
                     failed.append(e)
 
@@ -74,7 +98,8 @@ def run_files(presence_absence, gffdir, output, fastadir=None, klength=31, canon
             q.put(None)
             wt.join()
             for fh in (kmer_stroi, kmer_hash, hash_pat):
-                fh.close()
+                if fh is not None:
+                    fh.close()
         if failed:
             raise failed[0]
         stats["log"] = pg.take_log()

@@ -135,3 +135,32 @@ def test_run_files_pipeline(tmp_path, compress):
     assert rd("kmers_to_hashes.tsv") == KMERS_TO_HASHES_HEADER + ekh
     assert rd("hashes_to_patterns.tsv") == hashes_to_patterns_header(strains) + ehp
     assert rd("kmers.tsv") == KMERS_TSV_HEADER + ek
+
+
+def test_run_files_multiple_files(tmp_path):
+    """--multiple-files through the pipeline: one directory per cluster, patterns start empty in each"""
+    import os
+    from oracle import input_restatement as ir
+    from oracle import oracle as po
+    from panfeed_amd import synth
+    from panfeed_amd.engine import KMERS_TO_HASHES_HEADER, KMERS_TSV_HEADER, hashes_to_patterns_header
+    from panfeed_amd.pipeline import run_files
+    cl = synth.generate(9, 30, first=900, flank=0, mean_len=200, min_len=50, max_len=500, n_rate=0.03, paralog_rate=0.05)
+    names = cl[0].names
+    src = tmp_path / "in"
+    csvp, gffs, fas = synth.write_pangenome(str(src), cl)
+    gn = sorted(gffs)
+    tg = (names[5],)
+    out = str(tmp_path / "out")
+    run_files(csvp, str(src / "gffs"), out, klength=19, targets=tg, multiple_files=True, batch_clusters=4)
+    strains, table = ir.load_table(csvp)
+    recs = list(ir.iter_gene_clusters(strains, table, ir.load_genomes(gn, [gffs[n] for n in gn]), 0, 0, False))
+    assert sorted(os.listdir(out)) == sorted(r[1] for r in recs)
+    for rec in recs:
+        run = po.OracleRun(klength=19, stroi=set(tg), multiple_files=True)
+        run.feed([rec])
+        ek, ekh, ehp = run.texts()
+        d = os.path.join(out, rec[1])
+        assert open(os.path.join(d, "kmers_to_hashes.tsv")).read() == KMERS_TO_HASHES_HEADER + ekh
+        assert open(os.path.join(d, "hashes_to_patterns.tsv")).read() == hashes_to_patterns_header(strains) + ehp
+        assert open(os.path.join(d, "kmers.tsv")).read() == KMERS_TSV_HEADER + ek
