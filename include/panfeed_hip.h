@@ -371,6 +371,15 @@ int pf_render_kmers_tsv(pf_ctx* ctx, const pf_target_seq* seqs, uint32_t n, cons
                         char** out, uint64_t* nbytes);
 void pf_free_text(char* p);
 
+/* The bodies of kmers_to_hashes.tsv and hashes_to_patterns.tsv of the last pf_submit written ON THE DEVICE
+ * (panfeed.py:177,208 and :181-187,217-223): rows assembled in LDS, coalesced stores, one copy to pinned host memory.
+ * No pf_fetch needed; the k-mer keys and pattern rows never cross PCIe, only the text does.  names: cluster names in
+ * batch order; extra_keys: n_extra * klength bytes, the k-mer text of the batch's slow-path rows (NULL if none).
+ * *kh / *hp point into pinned memory owned by the context (two blocks used alternately): valid until the call after
+ * the next one, so that a writer thread can still be on the previous batch.  Not under multiple_files. */
+int pf_render_device(pf_ctx* ctx, const char* const* names, const char* extra_keys, uint64_t n_extra,
+                     const char** kh, uint64_t* kh_bytes, const char** hp, uint64_t* hp_bytes);
+
 /* Parallel gzip of a block of output text (the reference: gzip.open(..., "wt", compresslevel=9),
  * /root/reference/panfeed/input.py:239-241,255-258 -- one core).  `data` is cut at line ends into chunks of about
  * chunk_bytes, each deflated as its own gzip member on its own host thread; *out (pf_free_text) is the members

@@ -107,6 +107,11 @@ struct pf_ctx {
     DevBuf v_word_off, v_len, v_sample, v_ord, seg_distinct, v_nseg, v_nstr, v_mode, v_dense, extra_off, extra_dense;
     DevBuf bm_occ, bm_keep, pre_occ, pre_keep, mrows, slot_out, it_is_extra, cmask_lo, cmask_hi, it_compact;
     DevBuf strand_bits, scan_desc, md5_list;
+    DevBuf pat_b64, txt_dev, txt_meta;   // device-side rendering: base64 of every digest, the text, its per-row tables
+    uint32_t b64_done = 0;               // patterns whose base64 is in pat_b64
+    char* txt_pins[2] = {nullptr, nullptr};   // pinned host copies of the rendered text, used alternately so that a
+    size_t txt_pin_caps[2] = {0, 0};          // writer thread may still be on the previous batch's
+    int txt_slot = 0;
     DevBuf g_store, b_literal, g_src_off, g_src_start, g_src_flags;   // genomes resident in HBM + per-batch gather lists
     uint64_t g_words = 0;
     const pf_gather* pending_gather = nullptr;
@@ -194,6 +199,7 @@ int reset_patterns(pf_ctx* c) {
     HIPCHK(hipMemsetAsync(c->pt_counters.p, 0, 16, c->stream));
     c->n_patterns = 0;
     c->pid0 = 0;
+    c->b64_done = 0;
     c->h_pat_bits.clear(); c->h_pat_nan.clear(); c->h_pat_n.clear(); c->h_pat_md5.clear(); c->h_first_seen.clear();
     c->h_b64.clear();
     return PF_OK;
@@ -319,7 +325,8 @@ void pf_destroy(pf_ctx* c) {
     for (int i = 0; i < 2; i++) { if (c->stage_pins[i]) (void)hipHostFree(c->stage_pins[i]); c->stage_devs[i].release(); if (c->ev_half[i]) (void)hipEventDestroy(c->ev_half[i]); }
     if (c->pin_dedup) (void)hipHostFree(c->pin_dedup);
     if (c->pin_small) (void)hipHostFree(c->pin_small);
-    c->scan_desc.release(); c->md5_list.release();
+    c->scan_desc.release(); c->pat_b64.release(); c->txt_dev.release(); c->txt_meta.release();
+    for (int i = 0; i < 2; i++) if (c->txt_pins[i]) (void)hipHostFree(c->txt_pins[i]); c->md5_list.release();
     c->g_store.release(); c->b_literal.release(); c->g_src_off.release(); c->g_src_start.release(); c->g_src_flags.release();
     c->mg_lo.release(); c->mg_hi.release(); c->mg_min.release(); c->mg_cnt.release();
     if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
@@ -1650,6 +1657,144 @@ int pf_genomes_upload(pf_ctx* c, uint32_t n, const char* const* ascii, const uin
     if (pin) (void)hipHostFree(pin);
     dasc.release(); dpieces.release();
     return rc;
+}
+
+int pf_render_device(pf_ctx* c, const char* const* names, const char* extra_keys, uint64_t n_extra,
+                     const char** kh, uint64_t* kh_bytes, const char** hp, uint64_t* hp_bytes) {
+    if (!c || !kh || !kh_bytes || !hp || !hp_bytes) return fail(PF_ERR_ARG, "pf_render_device: null argument");
+    if (!c->have_batch) return fail(PF_ERR_STATE, "pf_render_device needs a successful pf_submit");
+    if (c->o.multiple_files) return fail(PF_ERR_ARG, "pf_render_device writes one pair of texts per batch; use the host renderers under multiple_files");
+    HIPCHK(hipSetDevice(c->device));
+    const uint32_t C = c->n_clusters, W = c->W, KW = (uint32_t)c->KW, k = c->o.klength;
+    if (C && !names) return fail(PF_ERR_ARG, "pf_render_device: cluster names missing");
+    if (c->arenas.size() > pf::TEXT_MAX_ARENAS) return fail(PF_ERR_CAPACITY, "pf_render_device: too many passes (%zu)", c->arenas.size());
+    hipStream_t st = c->stream;
+    // ---- small per-cluster / per-pattern arrays to the host: counts and the first-seen order
+    std::vector<uint64_t> koff(C);
+    std::vector<uint32_t> kcnt(C);
+    if (C) {
+        HIPCHK(hipMemcpyAsync(koff.data(), c->cl_kmer_off.p, (size_t)C * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(kcnt.data(), c->cl_kmer_cnt.p, (size_t)C * 4, hipMemcpyDeviceToHost, st));
+    }
+    const uint32_t p0 = c->pid0, p1 = c->n_patterns, P = p1 - p0;
+    std::vector<uint64_t> fs(P);
+    std::vector<uint32_t> rlen(P);
+    DevBuf d_rlen;
+    if (P) {
+        PFCHK(d_rlen.ensure((size_t)P * 4));
+        hipLaunchKernelGGL(pf::hp_rowlen_kernel, dim3((P + 255) / 256), dim3(256), 0, st, c->pat_n.as<uint32_t>(),
+                           c->o.consider_missing ? c->pat_nan.as<uint32_t>() : (const uint32_t*)nullptr, W, p0, P,
+                           d_rlen.as<uint32_t>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(fs.data(), c->pt.first_seen + p0, (size_t)P * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(rlen.data(), d_rlen.p, (size_t)P * 4, hipMemcpyDeviceToHost, st));
+        // base64 of the digests not yet converted
+        PFCHK(c->pat_b64.ensure((size_t)c->pt.pool * 24));
+        if (c->b64_done < p1) {
+            hipLaunchKernelGGL(pf::b64_kernel, dim3((p1 - c->b64_done + 255) / 256), dim3(256), 0, st,
+                               c->pat_md5.as<uint8_t>(), c->b64_done, p1, c->pat_b64.as<char>());
+            HIPCHK(hipGetLastError());
+            c->b64_done = p1;
+        }
+    } else if (!c->pat_b64.p) {
+        PFCHK(c->pat_b64.ensure((size_t)c->pt.pool * 24));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    d_rlen.release();
+    // ---- kmers_to_hashes layout: rows per cluster, workgroups per cluster
+    std::vector<uint64_t> text_off(C + 1, 0);
+    std::vector<uint32_t> name_off(C + 1, 0), arena_of(C), blk_cluster, blk_row0;
+    std::string blob;
+    uint32_t rows_per_block = 256;
+    for (uint32_t i = 0; i < C; i++) {
+        const uint32_t L = (uint32_t)strlen(names[i]);
+        blob.append(names[i], L);
+        name_off[i + 1] = (uint32_t)blob.size();
+        const uint64_t head = L + 2 + 24 + 1, rowlen = (uint64_t)L + 1 + k + 1 + 24 + 1;
+        if (head + rowlen > pf::TEXT_TILE) return fail(PF_ERR_ARG, "cluster name too long for the text kernel (%u bytes)", L);
+        rows_per_block = std::min<uint32_t>(rows_per_block, (uint32_t)((pf::TEXT_TILE - head) / rowlen));
+        text_off[i + 1] = text_off[i] + head + (uint64_t)kcnt[i] * rowlen;
+        const uint32_t a = c->cluster_arena[i];
+        arena_of[i] = a;
+        koff[i] = kcnt[i] ? koff[i] - c->arenas[a]->base : 0;
+    }
+    for (uint32_t i = 0; i < C; i++)
+        for (uint32_t r = 0; r < kcnt[i] + 1; r += rows_per_block) { blk_cluster.push_back(i); blk_row0.push_back(r); }
+    // ---- hashes_to_patterns layout: new patterns in first-seen order
+    std::vector<uint32_t> order(P);
+    std::iota(order.begin(), order.end(), 0u);
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return fs[x] < fs[y]; });
+    std::vector<uint64_t> row_off(P + 1, 0);
+    for (uint32_t i = 0; i < P; i++) { row_off[i + 1] = row_off[i] + rlen[order[i]]; order[i] += p0; }
+    const uint64_t kh_n = text_off[C], hp_n = row_off[P];
+    const uint64_t hp_at = (kh_n + 255) & ~(uint64_t)255;          // the second text starts 256-byte aligned
+    const uint64_t total = hp_at + hp_n + 16;
+    PFCHK(c->txt_dev.ensure(total));
+    c->txt_slot ^= 1;
+    char*& txt_pin = c->txt_pins[c->txt_slot];
+    size_t& txt_pin_cap = c->txt_pin_caps[c->txt_slot];
+    if (total > txt_pin_cap) {
+        if (txt_pin) (void)hipHostFree(txt_pin);
+        txt_pin = nullptr; txt_pin_cap = 0;
+        const size_t want = total + total / 4;
+        if (hipHostMalloc((void**)&txt_pin, want, hipHostMallocDefault) != hipSuccess) return fail(PF_ERR_OOM, "hipHostMalloc(%zu) failed", want);
+        txt_pin_cap = want;
+    }
+    // ---- one block of tables for both kernels
+    auto pad8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
+    size_t o = 0;
+    const size_t o_text = o; o += pad8((size_t)(C + 1) * 8);
+    const size_t o_koff = o; o += pad8((size_t)C * 8);
+    const size_t o_rowoff = o; o += pad8((size_t)(P + 1) * 8);
+    const size_t o_name = o; o += pad8((size_t)(C + 1) * 4);
+    const size_t o_kcnt = o; o += pad8((size_t)C * 4);
+    const size_t o_arena = o; o += pad8((size_t)C * 4);
+    const size_t o_bc = o; o += pad8(blk_cluster.size() * 4);
+    const size_t o_br = o; o += pad8(blk_row0.size() * 4);
+    const size_t o_order = o; o += pad8((size_t)P * 4);
+    const size_t o_blob = o; o += pad8(blob.size() + 1);
+    const size_t o_extra = o; o += pad8((size_t)n_extra * k + 1);
+    std::vector<char> meta(o, 0);
+    memcpy(&meta[o_text], text_off.data(), (size_t)(C + 1) * 8);
+    if (C) memcpy(&meta[o_koff], koff.data(), (size_t)C * 8);
+    memcpy(&meta[o_rowoff], row_off.data(), (size_t)(P + 1) * 8);
+    memcpy(&meta[o_name], name_off.data(), (size_t)(C + 1) * 4);
+    if (C) { memcpy(&meta[o_kcnt], kcnt.data(), (size_t)C * 4); memcpy(&meta[o_arena], arena_of.data(), (size_t)C * 4); }
+    if (!blk_cluster.empty()) { memcpy(&meta[o_bc], blk_cluster.data(), blk_cluster.size() * 4); memcpy(&meta[o_br], blk_row0.data(), blk_row0.size() * 4); }
+    if (P) memcpy(&meta[o_order], order.data(), (size_t)P * 4);
+    if (!blob.empty()) memcpy(&meta[o_blob], blob.data(), blob.size());
+    if (n_extra && extra_keys) memcpy(&meta[o_extra], extra_keys, (size_t)n_extra * k);
+    PFCHK(c->txt_meta.ensure(o));
+    HIPCHK(hipMemcpyAsync(c->txt_meta.p, meta.data(), o, hipMemcpyHostToDevice, st));
+    const char* dm = c->txt_meta.as<char>();
+    if (!blk_cluster.empty()) {
+        pf::KhTextParams kp{};
+        kp.text_off = (const uint64_t*)(dm + o_text); kp.name_off = (const uint32_t*)(dm + o_name); kp.names = dm + o_blob;
+        kp.kmer_off = (const uint64_t*)(dm + o_koff); kp.kmer_cnt = (const uint32_t*)(dm + o_kcnt);
+        kp.cluster_pattern = c->cl_pattern.as<uint32_t>(); kp.cluster_arena = (const uint32_t*)(dm + o_arena);
+        kp.block_cluster = (const uint32_t*)(dm + o_bc); kp.block_row0 = (const uint32_t*)(dm + o_br);
+        for (size_t a = 0; a < c->arenas.size(); a++) { kp.arena_key[a] = c->arenas[a]->key.as<uint64_t>(); kp.arena_pid[a] = c->arenas[a]->pid.as<uint32_t>(); }
+        kp.b64 = c->pat_b64.as<char>(); kp.extra_keys = dm + o_extra; kp.text = c->txt_dev.as<char>();
+        kp.k = k; kp.KW = KW; kp.rows_per_block = rows_per_block;
+        hipLaunchKernelGGL(pf::kh_text_kernel, dim3((uint32_t)blk_cluster.size()), dim3(256), 0, st, kp);
+        HIPCHK(hipGetLastError());
+    }
+    if (P) {
+        pf::HpTextParams hpp{};
+        hpp.order = (const uint32_t*)(dm + o_order); hpp.row_off = (const uint64_t*)(dm + o_rowoff);
+        hpp.pat_bits = c->pat_bits.as<uint32_t>();
+        hpp.pat_nan = c->o.consider_missing ? c->pat_nan.as<uint32_t>() : nullptr;
+        hpp.pat_n = c->pat_n.as<uint32_t>(); hpp.b64 = c->pat_b64.as<char>();
+        hpp.text = c->txt_dev.as<char>() + hp_at; hpp.n = P; hpp.W = W;
+        hipLaunchKernelGGL(pf::hp_text_kernel, dim3(P), dim3(256), 0, st, hpp);
+        HIPCHK(hipGetLastError());
+    }
+    if (kh_n) HIPCHK(hipMemcpyAsync(txt_pin, c->txt_dev.p, kh_n, hipMemcpyDeviceToHost, st));
+    if (hp_n) HIPCHK(hipMemcpyAsync(txt_pin + hp_at, c->txt_dev.as<char>() + hp_at, hp_n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    *kh = txt_pin; *kh_bytes = kh_n;
+    *hp = txt_pin + hp_at; *hp_bytes = hp_n;
+    return PF_OK;
 }
 
 #ifdef PF_PROF

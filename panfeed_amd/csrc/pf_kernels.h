@@ -2554,6 +2554,160 @@ __global__ __launch_bounds__(256) void cluster_ninst_kernel(const uint32_t* clus
 }
 
 // ---------------------------------------------------------------------------------------------
+// Text of the output files, written on the device (row N2): the rows are assembled in LDS, one row per thread,
+// and leave the workgroup as coalesced 16-byte stores.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ char b64_char(uint32_t v) {
+    v &= 63;
+    return (char)(v < 26 ? 'A' + v : v < 52 ? 'a' + (v - 26) : v < 62 ? '0' + (v - 52) : v == 62 ? '+' : '/');
+}
+// binascii.b2a_base64(digest)[:24] for patterns [pid0, pid1)  (panfeed.py:176, 207)
+__global__ __launch_bounds__(256) void b64_kernel(const uint8_t* md5, uint32_t pid0, uint32_t pid1, char* out) {
+    const uint32_t pid = pid0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (pid >= pid1) return;
+    const uint8_t* d = md5 + (size_t)pid * 16;
+    char* o = out + (size_t)pid * 24;
+    for (int i = 0, q = 0; i < 15; i += 3, q += 4) {
+        const uint32_t v = ((uint32_t)d[i] << 16) | ((uint32_t)d[i + 1] << 8) | d[i + 2];
+        o[q] = b64_char(v >> 18); o[q + 1] = b64_char(v >> 12); o[q + 2] = b64_char(v >> 6); o[q + 3] = b64_char(v);
+    }
+    const uint32_t v = (uint32_t)d[15] << 16;
+    o[20] = b64_char(v >> 18); o[21] = b64_char(v >> 12); o[22] = '='; o[23] = '=';
+}
+
+constexpr uint32_t TEXT_TILE = 24576;        // bytes of text a workgroup assembles at a time
+constexpr uint32_t TEXT_MAX_ARENAS = 16;
+struct KhTextParams {
+    // per cluster
+    const uint64_t* text_off;        // [C+1] byte offset of the cluster's rows in the text
+    const uint32_t* name_off;        // [C+1] into names
+    const char* names;
+    const uint64_t* kmer_off;        // [C] index of the cluster's first kept k-mer inside its arena
+    const uint32_t* kmer_cnt; const uint32_t* cluster_pattern; const uint32_t* cluster_arena;
+    const uint32_t* block_cluster;   // [gridDim.x] cluster of the workgroup
+    const uint32_t* block_row0;      // [gridDim.x] its first row (0 = the cluster's own row)
+    const uint64_t* arena_key[TEXT_MAX_ARENAS]; const uint32_t* arena_pid[TEXT_MAX_ARENAS];
+    const char* b64; const char* extra_keys;   // extra_keys: k bytes per slow-path row of the batch
+    char* text;
+    uint32_t k, KW, rows_per_block;
+};
+
+// kmers_to_hashes.tsv: "<idx>\t\t<hash>\n" then "<idx>\t<k-mer>\t<hash>\n" per kept k-mer  (panfeed.py:177, 208)
+__global__ __launch_bounds__(256) void kh_text_kernel(KhTextParams p) {
+    __shared__ __align__(16) char tile[TEXT_TILE + 32];
+    const uint32_t c = p.block_cluster[blockIdx.x], row0 = p.block_row0[blockIdx.x];
+    const uint32_t n0 = p.name_off[c], L = p.name_off[c + 1] - n0;
+    const uint32_t k = p.k, cnt = p.kmer_cnt[c];
+    const uint32_t head = L + 2 + 24 + 1, rowlen = L + 1 + k + 1 + 24 + 1;
+    const uint32_t nrows_total = cnt + 1;                                   // row 0 is the cluster's own row
+    const uint32_t nrows = min(p.rows_per_block, nrows_total - row0);
+    // byte range of these rows inside the cluster's text
+    const uint64_t b0 = row0 == 0 ? 0 : head + (uint64_t)(row0 - 1) * rowlen;
+    const uint64_t b1 = head + (uint64_t)(row0 + nrows - 1) * rowlen;
+    const uint64_t gbase = p.text_off[c] + b0;
+    const uint32_t mis = (uint32_t)(gbase & 15);                            // tile[mis + i] <-> text[gbase + i]
+    const uint32_t a = p.cluster_arena[c];
+    const uint64_t* keys = p.arena_key[a];
+    const uint32_t* pids = p.arena_pid[a];
+    const uint64_t koff = p.kmer_off[c];
+    for (uint32_t r = threadIdx.x; r < nrows; r += blockDim.x) {
+        const uint32_t row = row0 + r;
+        char* w = tile + mis + (row == 0 ? 0 : head + (uint64_t)(row - 1) * rowlen - b0);
+        for (uint32_t i = 0; i < L; i++) w[i] = p.names[n0 + i];
+        w += L;
+        *w++ = '\t';
+        uint32_t pid;
+        if (row == 0) {
+            pid = p.cluster_pattern[c];
+        } else {
+            const uint64_t j = koff + (row - 1);
+            const uint64_t k0 = keys[j * p.KW];
+            if (k0 >> 63) {                                                  // a slow-path row: its text is at hand
+                const char* e = p.extra_keys + (size_t)(uint32_t)k0 * k;
+                for (uint32_t q = 0; q < k; q++) w[q] = e[q];
+            } else {
+                uint64_t hi = 0, lo = k0;
+                if (p.KW == 2) { const uint64_t k1 = keys[j * 2 + 1]; hi = k0 >> 1; lo = ((k0 & 1) << 63) | k1; }
+                for (uint32_t q = 0; q < k; q++) {
+                    const uint32_t bit = 2 * (k - 1 - q);
+                    const uint32_t code = bit >= 64 ? (uint32_t)(hi >> (bit - 64)) & 3 : (uint32_t)(lo >> bit) & 3;
+                    w[q] = (char)(0x54474341u >> (8 * code));               // "ACGT"
+                }
+            }
+            w += k;
+            pid = pids[j];
+        }
+        *w++ = '\t';
+        const char* h = p.b64 + (size_t)pid * 24;
+        for (uint32_t i = 0; i < 24; i++) w[i] = h[i];
+        w[24] = '\n';
+    }
+    __syncthreads();
+    // out: the unaligned head and tail byte by byte, the middle as 16-byte pieces
+    const uint32_t nbytes = (uint32_t)(b1 - b0);
+    char* g = p.text + gbase;
+    const uint32_t lead = min(nbytes, (16 - mis) & 15);
+    for (uint32_t i = threadIdx.x; i < lead; i += blockDim.x) g[i] = tile[mis + i];
+    const uint32_t mid = (nbytes - lead) >> 4;
+    const uint4* src = reinterpret_cast<const uint4*>(tile + mis + lead);
+    uint4* dst = reinterpret_cast<uint4*>(g + lead);
+    for (uint32_t i = threadIdx.x; i < mid; i += blockDim.x) dst[i] = src[i];
+    for (uint32_t i = lead + (mid << 4) + threadIdx.x; i < nbytes; i += blockDim.x) g[i] = tile[mis + i];
+}
+
+struct HpTextParams {
+    const uint32_t* order;           // [n] new pattern ids in first-seen order
+    const uint64_t* row_off;         // [n+1] byte offsets of the rows
+    const uint32_t* pat_bits; const uint32_t* pat_nan; const uint32_t* pat_n;
+    const char* b64;
+    char* text;
+    uint32_t n, W;
+};
+// bytes of a hashes_to_patterns row: 24 + one tab per cell + one digit per non-NaN cell + newline
+__global__ __launch_bounds__(256) void hp_rowlen_kernel(const uint32_t* pat_n, const uint32_t* pat_nan, uint32_t W,
+                                                        uint32_t pid0, uint32_t n, uint32_t* len) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t pid = pid0 + i, nk = pat_n[pid], cells = nk & 0x7FFFFFFFu;
+    uint32_t nn = 0;
+    if (pat_nan && !(nk >> 31))
+        for (uint32_t w = 0; w < W; w++) nn += __popc(pat_nan[(size_t)pid * W + w]);
+    len[i] = 24 + cells + (cells - nn) + 1;
+}
+// hashes_to_patterns.tsv: "<hash>\t0\t1...\n", '' for a NaN cell  (panfeed.py:181-187, 217-223); one workgroup per row
+__global__ __launch_bounds__(256) void hp_text_kernel(HpTextParams p) {
+    __shared__ uint32_t pre[257];
+    const uint32_t i = blockIdx.x;
+    const uint32_t pid = p.order[i], nk = p.pat_n[pid], cells = nk & 0x7FFFFFFFu;
+    const bool use_nan = p.pat_nan && !(nk >> 31);
+    const uint32_t* bits = p.pat_bits + (size_t)pid * p.W;
+    const uint32_t* nan = use_nan ? p.pat_nan + (size_t)pid * p.W : nullptr;
+    char* g = p.text + p.row_off[i];
+    if (threadIdx.x < 24) g[threadIdx.x] = p.b64[(size_t)pid * 24 + threadIdx.x];
+    // NaN cells before each 32-cell word (only with a NaN mask)
+    const uint32_t nwords = (cells + 31) >> 5;
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t w = 0; w < nwords && w < 256; w++) { pre[w] = run; run += nan ? __popc(nan[w]) : 0; }
+    }
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < cells; e += blockDim.x) {
+        const uint32_t w = e >> 5, b = e & 31;
+        uint32_t before = 0;
+        bool isn = false;
+        if (nan) {
+            const uint32_t nw = nan[w];
+            before = (w < 256 ? pre[w] : 0) + __popc(nw & ((1u << b) - 1));
+            isn = (nw >> b) & 1;
+        }
+        char* q = g + 24 + 2 * (size_t)e - before;                          // every earlier NaN cell is one byte shorter
+        q[0] = '\t';
+        if (!isn) q[1] = ((bits[w] >> b) & 1) ? '1' : '0';
+    }
+    if (threadIdx.x == 0) g[p.row_off[i + 1] - p.row_off[i] - 1] = '\n';
+}
+
+// ---------------------------------------------------------------------------------------------
 // Genomes resident in HBM (row N1 on the device): contigs as 2 bits per base, segments gathered from them
 // ---------------------------------------------------------------------------------------------
 // A contig sits at an even word offset of the store, 32 bases per word (first base in bits 63:62), followed by at

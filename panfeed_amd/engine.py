@@ -158,16 +158,19 @@ class Engine:
                 ordinal += len(chunk)
         return self.run_batches(host_batches(), prefetch)
 
-    def run_pangenome(self, pangenome, batch_clusters=256, prefetch=2):
+    def run_pangenome(self, pangenome, batch_clusters=256, prefetch=2, device_text=False):
         """run_stream fed by the native reader (native_input.Pangenome): table rows -> records -> packed batches
         without leaving the library, then the GPU; yields BatchOutput in table order."""
         if tuple(sorted(pangenome.targets)) != tuple(sorted(self.stroi or ())):
             raise ValueError("the pangenome reader and the engine were given different target strains")
         return self.run_batches(pangenome.batches(self.k, self.canon, self.W, max_clusters=batch_clusters,
-                                                  first_ordinal=self.next_ordinal), prefetch)
+                                                  first_ordinal=self.next_ordinal), prefetch, device_text)
 
-    def run_batches(self, host_batches, prefetch=2):
-        """GPU over an iterator of HostBatch, the next ones being prepared on one host thread meanwhile."""
+    def run_batches(self, host_batches, prefetch=2, device_text=False):
+        """GPU over an iterator of HostBatch, the next ones being prepared on one host thread meanwhile.
+        device_text: kmers_to_hashes / hashes_to_patterns of a batch without target-strain rows come back as
+        memoryviews of text the GPU wrote (render_device; valid until the batch after the next one has been rendered)
+        instead of str; batches with kmers.tsv rows and --multiple-files runs keep the host renderers."""
         from concurrent.futures import ThreadPoolExecutor
         it = iter(host_batches)
 
@@ -182,9 +185,24 @@ class Engine:
                     break
                 pending.append(pool.submit(pack_next))
                 self.next_ordinal = int(hb.cluster_ordinal[-1]) + 1 if hb.n_clusters else self.next_ordinal
-                self.submit_host_batch(hb)
-                res = self.fetch()
-                yield self._render(hb, res)
+                res = self.submit_host_batch(hb)
+                if device_text and not hb.targets and not self.multiple_files:
+                    out = BatchOutput()
+                    out.kmers_to_hashes, out.hashes_to_patterns = self.render_device(hb)
+                    out.kmers_tsv = b""
+                    out.stats = {"clusters": int(hb.n_clusters), "instances": int(hb.n_instances),
+                                 "device_instances": int(res.n_instances), "unique_kmers": int(res.n_unique),
+                                 "kept_kmers": int(res.n_kept), "new_patterns": int(res.n_new_patterns),
+                                 "patterns": self.pattern_count()}
+                    out.timing = self.timing()
+                    yield out
+                    continue
+                yield self._render(hb, self.fetch())
+
+    def pattern_count(self):
+        n = C.c_uint64()
+        _lib.check(self.L.pf_pattern_count(self.ctx, C.byref(n)))
+        return int(n.value)
 
     def _hash_strings(self, res):
         p0, p1 = self.n_patterns, int(res.n_patterns)
@@ -272,6 +290,19 @@ class Engine:
                      "new_patterns": int(res.n_new_patterns), "patterns": int(res.n_patterns)}
         out.timing = self.timing()
         return out
+
+    def render_device(self, hb):
+        """(kmers_to_hashes body, hashes_to_patterns body) of the last submit as memoryviews over pinned host memory,
+        the text having been written by the GPU (pf_render_device): no pf_fetch, no bytes -> str; valid until the
+        render after the next one.  kmers.tsv rows (target strains) still come from `_render` / `_render_targets`."""
+        C_ = hb.n_clusters
+        names = (C.c_char_p * max(C_, 1))(*[s.encode() for s in hb.idx])
+        extra = "".join(hb.extra_keys).encode("latin-1") if hb.extra_keys else None
+        kh, kn, hp, hn = C.c_void_p(), C.c_uint64(), C.c_void_p(), C.c_uint64()
+        _lib.check(self.L.pf_render_device(self.ctx, names, extra, len(hb.extra_keys), C.byref(kh), C.byref(kn),
+                                           C.byref(hp), C.byref(hn)))
+        mk = (lambda p, n: memoryview((C.c_char * n).from_address(p)).cast("B") if n else memoryview(b""))
+        return mk(kh.value, kn.value), mk(hp.value, hn.value)
 
     def _render_targets(self, hb, metas):
         """kmers.tsv rows of `metas` (packing.SeqMeta, in order) through pf_render_kmers_tsv"""

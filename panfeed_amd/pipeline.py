@@ -23,8 +23,8 @@ class _Columns:
 
 def run_files(presence_absence, gffdir, output, fastadir=None, klength=31, canon=True, consider_missing=False,
               patfilt=True, maf=0.01, upstream=0, downstream=0, downstream_start_codon=False, targets=(), genes=None,
-              compress=False, multiple_files=False, batch_clusters=256, resident=True, device=0, max_items=0,
-              pattern_capacity=0):
+              compress=False, multiple_files=False, batch_clusters=256, resident=True, device_text=True, device=0,
+              max_items=0, pattern_capacity=0):
     """One directory of outputs (`kmers.tsv`, `kmers_to_hashes.tsv`, `hashes_to_patterns.tsv`, `.gz` under
     `compress`; under `multiple_files` one such directory per gene cluster, `<output>/<cluster>/`, the pattern set
     starting empty in each: `panfeed.py:35-43,153-167`) from a panaroo table and a directory (or file of files) of GFFs.  Option names and meaning follow
@@ -51,13 +51,28 @@ def run_files(presence_absence, gffdir, output, fastadir=None, klength=31, canon
             hash_pat, kmer_hash = create_hash_files(output, compress)
             write_headers(hash_pat, kmer_hash, cols)
         q = queue.Queue(maxsize=4)
+        # text the GPU wrote lives in two pinned blocks used alternately: a batch may only be rendered once the batch
+        # before the previous one has been written out
+        slots = threading.Semaphore(2)
         failed = []
+
+        def put(fh, data):
+            # text the GPU wrote arrives as bytes: straight into the file's binary layer (or the gzip writer)
+            if isinstance(data, str):
+                fh.write(data)
+            elif len(data):
+                raw = getattr(fh, "buffer", None)
+                if raw is not None:
+                    fh.flush()
+                    raw.write(data)
+                else:
+                    fh.write(data)
 
         def write_one(o):
             if not multiple_files:
-                kmer_stroi.write(o.kmers_tsv)
-                kmer_hash.write(o.kmers_to_hashes)
-                hash_pat.write(o.hashes_to_patterns)
+                put(kmer_stroi, o.kmers_tsv)
+                put(kmer_hash, o.kmers_to_hashes)
+                put(hash_pat, o.hashes_to_patterns)
                 return
             for idx, kt, kh, hp in o.per_cluster:
                 path = os.path.join(output, idx)
@@ -82,11 +97,18 @@ def run_files(presence_absence, gffdir, output, fastadir=None, klength=31, canon
                         write_one(o)
                 except Exception as e:          # keep draining so that the producer never blocks on a dead writer
                     failed.append(e)
+                finally:
+                    slots.release()
 
         wt = threading.Thread(target=writer, name="panfeed-writer")
         wt.start()
         try:
-            for o in eng.run_pangenome(pg, batch_clusters=batch_clusters):
+            batches = eng.run_pangenome(pg, batch_clusters=batch_clusters, device_text=device_text)
+            while True:
+                slots.acquire()
+                o = next(batches, None)
+                if o is None:
+                    break
                 stats["clusters"] += o.stats.get("clusters", 0)
                 stats["instances"] += o.stats.get("instances", 0)
                 stats["kept_kmers"] += o.stats.get("kept_kmers", 0)

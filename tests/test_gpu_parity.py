@@ -508,3 +508,30 @@ def test_merge_kernel_matches_sort_merge():
         assert torch.equal(keep.bool().cpu(), keep_all[first:first + x.shape[0]])
         first += x.shape[0]
     eng.close()
+
+
+@pytest.mark.parametrize("kw", [dict(klength=31), dict(klength=47, canon=False), dict(klength=21, consider_missing=True),
+                                dict(klength=15, patfilt=False, maf=0.0)])
+def test_device_rendered_text_equals_host_rendered(kw):
+    """row N2 on the device: kh_text_kernel / hp_text_kernel write the same bytes as the host renderers (slow-path
+    rows with 'N' k-mers, NaN cells, two-word keys, several calls with the pattern pool growing)"""
+    from panfeed_amd import synth
+    from panfeed_amd.engine import Engine
+    from panfeed_amd.packing import build_batch_native
+    cm = kw.get("consider_missing", False)
+    cl = synth.generate(30, 70, first=500, flank=10, mean_len=260, min_len=50, max_len=900, n_rate=0.05, paralog_rate=0.05)
+    recs = [c.record() for c in cl]
+    eng = Engine(max_strains=96, **kw)
+    for lo in (0, 11, 19):
+        part = recs[lo:lo + 11]
+        hb = build_batch_native(part, eng.k, eng.canon, eng.W, first_ordinal=lo)
+        eng.submit_host_batch(hb)
+        kh, hp = eng.render_device(hb)
+        kh, hp = bytes(kh), bytes(hp)
+        out = eng._render(hb, eng.fetch())
+        assert kh.decode() == out.kmers_to_hashes
+        assert hp.decode() == out.hashes_to_patterns
+        assert (b"N" in kh) or not hb.extra_keys
+        if cm:
+            assert b"\t\t" in hp or b"\t\n" in hp
+    eng.close()

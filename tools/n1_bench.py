@@ -29,10 +29,12 @@ out = dict(clusters=C_, samples=S, instances=inst, write_s=round(t_write, 2), op
            read_pack_s=round(t_pack, 3), read_pack_inst_per_s=inst / t_pack)
 if not host_only:
     from panfeed_amd.engine import Engine
-    for mode in ("text", "resident"):
+    for mode in ("text", "resident", "resident_device_text"):
         eng = Engine(klength=k, max_strains=W * 32)
         pg = ni.Pangenome(csvp, None, None, up, down, genome_names=gn, gff_paths=[gffs[n] for n in gn])
         t_up = 0.0
+        if mode == "resident_device_text":
+            pg.make_resident(eng)
         if mode == "resident":
             t = time.time(); pg.make_resident(eng); t_up = time.time() - t
             t = time.time(); ninst2 = 0
@@ -44,7 +46,7 @@ if not host_only:
             pg = ni.Pangenome(csvp, None, None, up, down, genome_names=gn, gff_paths=[gffs[n] for n in gn])
             pg.make_resident(eng)
         t = time.time(); nb = 0; dev = 0.0
-        for o in eng.run_pangenome(pg, batch_clusters=64):
+        for o in eng.run_pangenome(pg, batch_clusters=64, device_text=mode.endswith("device_text")):
             nb += len(o.kmers_to_hashes); dev += o.timing["total_ms"]
         t_e2e = time.time() - t
         out[mode] = dict(e2e_s=round(t_e2e, 3), e2e_inst_per_s=inst / t_e2e, device_ms=round(dev, 1), text_bytes=nb,
