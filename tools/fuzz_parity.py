@@ -1,0 +1,54 @@
+"""Randomised differential test on the GPU: random options and cluster shapes, HIP path vs the oracle, text for text.
+usage: python tools/fuzz_parity.py [n_cases] [seed]   (test infrastructure: imports oracle/)"""
+import sys, time
+import numpy as np
+sys.path.insert(0, ".")
+from oracle import oracle as po
+from panfeed_amd import synth
+from panfeed_amd.engine import Engine
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+fails = 0
+t0 = time.time()
+for case in range(n_cases):
+    rng = np.random.default_rng(seed0 * 100003 + case)
+    k = int(rng.choice([3, 7, 15, 21, 31, 32, 33, 47, 63]))
+    S = int(rng.choice([5, 17, 33, 64, 90, 130, 260]))
+    ncl = int(rng.integers(1, 9))
+    kw = dict(klength=k, canon=bool(rng.random() < 0.7), consider_missing=bool(rng.random() < 0.3),
+              patfilt=bool(rng.random() < 0.8), maf=float(rng.choice([0.0, 0.01, 0.05, 0.2])))
+    gen = dict(flank=int(rng.choice([0, 0, 10, 60])), mean_len=int(rng.choice([60, 150, 400, 1500])), min_len=int(rng.choice([5, 40])),
+               max_len=int(rng.choice([300, 2500])), n_rate=float(rng.choice([0.0, 0.02, 0.2])),
+               paralog_rate=float(rng.choice([0.0, 0.05, 0.3])), sub_rate=float(rng.choice([0.0, 0.01, 0.1])),
+               mean_alleles=float(rng.choice([1.0, 7.0, 40.0])))
+    if gen["min_len"] > gen["max_len"]:
+        gen["min_len"] = gen["max_len"]
+    shuffle = int(rng.integers(0, 99)) if rng.random() < 0.5 else None
+    cl = synth.generate(ncl, S, first=int(rng.integers(0, 10**6)), shuffle_columns=shuffle, **gen)
+    recs = [c.record() for c in cl]
+    names = cl[0].names
+    stroi = set(rng.choice(names, size=min(len(names), int(rng.integers(0, 3))), replace=False).tolist())
+    dedup = bool(rng.random() < 0.8)
+    try:
+        eng = Engine(max_strains=(S + 31) // 32 * 32, stroi=stroi, dedup=dedup, max_items=int(rng.choice([64, 2048])), **kw)
+        cut = int(rng.integers(0, ncl + 1))
+        outs = [eng.run(recs[:cut])] if cut else []
+        if cut < ncl:
+            outs.append(eng.run(recs[cut:]))
+        eng.close()
+        run = po.OracleRun(stroi=stroi, **kw)
+        run.feed(recs)
+        ek, ekh, ehp = run.texts()
+        got = ("".join(o.kmers_tsv for o in outs), "".join(o.kmers_to_hashes for o in outs), "".join(o.hashes_to_patterns for o in outs))
+        ok = got == (ek, ekh, ehp)
+    except Exception as e:  # noqa: BLE001
+        ok = False
+        print("EXC", repr(e)[:200])
+    if not ok:
+        fails += 1
+        print("FAIL case", case, kw, gen, "S", S, "ncl", ncl, "dedup", dedup, "stroi", len(stroi), "shuffle", shuffle, flush=True)
+    if case % 20 == 19:
+        print(f"{case + 1} cases, {fails} failures, {time.time() - t0:.0f} s", flush=True)
+print("DONE", n_cases, "cases", fails, "failures")
+sys.exit(1 if fails else 0)
