@@ -1,5 +1,5 @@
 """Randomised differential test on the GPU: random options and cluster shapes, HIP path vs the oracle, text for text.
-usage: python tools/fuzz_parity.py [n_cases] [seed]   (test infrastructure: imports oracle/)"""
+usage: python tests/fuzz_parity.py [n_cases] [seed]   (test infrastructure: imports oracle/)"""
 import sys, time
 import numpy as np
 sys.path.insert(0, ".")
