@@ -38,6 +38,11 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(root, f)).read()
                 assert "oracle" not in src.replace("# oracle", ""), f
+    # the helper scripts are not checkers either: only tests/, smoke() and bench.py's cpu_baseline leg use oracle/
+    for f in os.listdir(os.path.join(REPO, "tools")):
+        if f.endswith(".py"):
+            src = open(os.path.join(REPO, "tools", f)).read()
+            assert "import oracle" not in src and "from oracle" not in src, f
 
 
 def test_maf_tables_match_reference_arithmetic():
