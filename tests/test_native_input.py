@@ -185,3 +185,38 @@ def test_by_reference_batches_describe_the_same_input(pangenome):
             n_ref += 1
         assert np.array_equal(rebuilt, a.packed)
     assert n_ref > 150 and n_rev > 50 and n_lit > 10          # text stays for the target strain and the N-carrying ones
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_reader_fuzz_against_restatement(tmp_path, seed):
+    """random small pangenomes and options: native reader == Python restatement, record for record"""
+    rng = np.random.default_rng(1000 + seed)
+    S = int(rng.integers(3, 20))
+    cl = synth.generate(int(rng.integers(1, 12)), S, first=int(rng.integers(0, 10**5)), flank=0,
+                        mean_len=int(rng.choice([30, 120, 600])), min_len=int(rng.choice([3, 20])), max_len=900,
+                        n_rate=float(rng.choice([0.0, 0.1, 0.5])), paralog_rate=float(rng.choice([0.0, 0.2])),
+                        shuffle_columns=int(rng.integers(0, 50)) if rng.random() < 0.5 else None)
+    names = cl[0].names
+    drop = tuple(rng.choice(names, size=int(rng.integers(0, 2)), replace=False).tolist())
+    sep = tuple(n for n in names if rng.random() < 0.3 and n not in drop)
+    csvp, gffs, fas = synth.write_pangenome(str(tmp_path), cl, seed=seed, wrap=int(rng.choice([10, 60, 1000])), drop_gff_for=drop,
+                                            missing_gene_rate=float(rng.choice([0.0, 0.05])),
+                                            lower_rate=float(rng.choice([0.0, 0.3])), separate_fasta_for=sep)
+    gn = sorted(gffs)
+    p = dict(csv=csvp, genomes=gn, gff=[gffs[n] for n in gn], fasta=[fas[n] for n in gn])
+    up, down, dsc = int(rng.choice([0, 7, 150, 5000])), int(rng.choice([0, 3, 90, 5000])), bool(rng.random() < 0.3)
+    genes = None
+    if rng.random() < 0.3:
+        _s, table = ir.load_table(csvp)
+        genes = [t[0] for t in table if rng.random() < 0.5] + ["absent_cluster"]
+    log = []
+    strains, exp = _expected(p, up, down, dsc, genes=set(genes) if genes is not None else None, log=log)
+    with _open(p, up, down, dsc, genes=genes) as pg:
+        got = list(pg.records(int(rng.integers(1, 6))))
+        nlog = pg.take_log()
+    assert len(got) == len(exp)
+    for (g, gi, gp), (e, ei, ep) in zip(got, exp):
+        assert gi == ei and (gp == ep).all() and list(g.keys()) == list(e.keys())
+        for s in g:
+            assert g[s] == e[s], (gi, s)
+    assert [x for x in nlog.strip().split("\n") if x] == log
