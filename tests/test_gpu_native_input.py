@@ -99,8 +99,10 @@ def test_gather_argument_checks(tmp_path):
     eng.close()
 
 
+@pytest.mark.parametrize("resident,device_text", [(True, True), (False, True), (True, False)],
+                         ids=["resident_devtext", "text_devtext", "resident_hosttext"])
 @pytest.mark.parametrize("compress", [False, True], ids=["plain", "gzip"])
-def test_run_files_pipeline(tmp_path, compress):
+def test_run_files_pipeline(tmp_path, compress, resident, device_text):
     """row N3: one call from the files on disk to the three output files (writer thread, parallel gzip), headers
     included, against the oracle over the restated records"""
     import gzip
@@ -117,8 +119,9 @@ def test_run_files_pipeline(tmp_path, compress):
     gn = sorted(gffs)
     tg = (names[3],)
     out = str(tmp_path / "out")
+    tg = tg if compress else ()         # with and without kmers.tsv rows (batches with them use the host renderers)
     st = run_files(csvp, str(src / "gffs"), out, klength=23, upstream=40, downstream=20, targets=tg, compress=compress,
-                   batch_clusters=7)
+                   batch_clusters=7, resident=resident, device_text=device_text)
     strains, table = ir.load_table(csvp)
     recs = list(ir.iter_gene_clusters(strains, table, ir.load_genomes(gn, [gffs[n] for n in gn]), 40, 20, False))
     run = po.OracleRun(klength=23, stroi=set(tg))
