@@ -1,5 +1,5 @@
 """Randomised differential test on the GPU: random options and cluster shapes, HIP path vs the oracle, text for text.
-usage: python tests/fuzz_parity.py [n_cases] [seed]   (test infrastructure: imports oracle/)"""
+usage: python tests/fuzz_parity.py [n_cases] [seed] [big]   (test infrastructure: imports oracle/)"""
 import sys, time
 import numpy as np
 sys.path.insert(0, ".")
@@ -9,13 +9,14 @@ from panfeed_amd.engine import Engine
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+big = len(sys.argv) > 3 and sys.argv[3] == "big"        # BASELINE-sized clusters: hundreds to 1 000 samples
 fails = 0
 t0 = time.time()
 for case in range(n_cases):
     rng = np.random.default_rng(seed0 * 100003 + case)
     k = int(rng.choice([3, 7, 15, 21, 31, 32, 33, 47, 63]))
-    S = int(rng.choice([5, 17, 33, 64, 90, 130, 260]))
-    ncl = int(rng.integers(1, 9))
+    S = int(rng.choice([300, 640, 1000, 1100])) if big else int(rng.choice([5, 17, 33, 64, 90, 130, 260]))
+    ncl = int(rng.integers(1, 5 if big else 9))
     kw = dict(klength=k, canon=bool(rng.random() < 0.7), consider_missing=bool(rng.random() < 0.3),
               patfilt=bool(rng.random() < 0.8), maf=float(rng.choice([0.0, 0.01, 0.05, 0.2])))
     gen = dict(flank=int(rng.choice([0, 0, 10, 60])), mean_len=int(rng.choice([60, 150, 400, 1500])), min_len=int(rng.choice([5, 40])),
@@ -37,7 +38,7 @@ for case in range(n_cases):
         if cut < ncl:
             outs.append(eng.run(recs[cut:]))
         eng.close()
-        run = po.OracleRun(stroi=stroi, **kw)
+        run = po.OracleRun(stroi=stroi, threads=16, **kw)
         run.feed(recs)
         ek, ekh, ehp = run.texts()
         got = ("".join(o.kmers_tsv for o in outs), "".join(o.kmers_to_hashes for o in outs), "".join(o.hashes_to_patterns for o in outs))
