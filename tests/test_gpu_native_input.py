@@ -167,3 +167,20 @@ def test_run_files_multiple_files(tmp_path):
         assert open(os.path.join(d, "kmers_to_hashes.tsv")).read() == KMERS_TO_HASHES_HEADER + ekh
         assert open(os.path.join(d, "hashes_to_patterns.tsv")).read() == hashes_to_patterns_header(strains) + ehp
         assert open(os.path.join(d, "kmers.tsv")).read() == KMERS_TSV_HEADER + ek
+
+
+def test_run_files_no_cluster_selected(tmp_path):
+    """--genes naming no cluster of the table: the three files exist and hold their headers only"""
+    import os
+    from panfeed_amd import synth
+    from panfeed_amd.engine import KMERS_TO_HASHES_HEADER, KMERS_TSV_HEADER, hashes_to_patterns_header
+    from panfeed_amd.pipeline import run_files
+    cl = synth.generate(3, 8, first=1, flank=0, mean_len=100, min_len=40, max_len=200)
+    src = tmp_path / "in"
+    csvp, gffs, fas = synth.write_pangenome(str(src), cl)
+    out = str(tmp_path / "out")
+    st = run_files(csvp, str(src / "gffs"), out, klength=11, genes=["not_in_the_table"])
+    assert st["clusters"] == 0 and st["bytes"] == 0
+    assert open(os.path.join(out, "kmers.tsv")).read() == KMERS_TSV_HEADER
+    assert open(os.path.join(out, "kmers_to_hashes.tsv")).read() == KMERS_TO_HASHES_HEADER
+    assert open(os.path.join(out, "hashes_to_patterns.tsv")).read() == hashes_to_patterns_header(cl[0].names)
