@@ -79,10 +79,11 @@ def _merge_owner(md5, first_seen, dist, engine):
     dev = md5.device
     n = md5.shape[0]
     pay = _pack_rows(md5, first_seen)
-    owner = ((pay[:, 0] >> 17) & 0x7FFFFFFF) % world            # any fixed function of the digest
-    order = torch.argsort(owner, stable=True)
-    send = pay[order].contiguous()
-    send_counts = torch.bincount(owner, minlength=world).to(torch.int64)
+    owner = (((pay[:, 0] >> 17) & 0x7FFFFFFF) % world).to(torch.int16)    # any fixed function of the digest
+    order = torch.argsort(owner, stable=True)                    # 16-bit keys: a two-pass radix sort
+    send = pay.index_select(0, order)
+    edges = torch.searchsorted(owner.index_select(0, order), torch.arange(world + 1, device=dev, dtype=torch.int16))
+    send_counts = (edges[1:] - edges[:-1]).to(torch.int64)
     recv_counts = torch.empty(world, dtype=torch.int64, device=dev)
     dist.all_to_all_single(recv_counts, send_counts)
     sc, rc = send_counts.tolist(), recv_counts.tolist()
