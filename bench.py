@@ -4,18 +4,23 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of cluster_cutter + pattern_hasher (device path: pf_submit) over the
-whole synthetic pangenome, packed input already resident in HBM, results left in HBM.
-Workload at every N: BASELINE.json configs[2] -- 50k clusters x 1k samples, k=31, +-100 bp
-flanks (SURVEY 8d generator, pure-ACGT variant) -- PER GPU ("weak" scaling: gene clusters are
-independent, each rank owns a contiguous range; the only exchange is the all-gather of
-(md5, first_seen) pairs for the run-global pattern dedup, inside the timed region).
+One "step" = one pass of cluster_cutter + pattern_hasher (device path: pf_submit) over the rank's synthetic
+pangenome, packed input already resident in HBM, results left in HBM, followed (N > 1) by the exchange of
+{md5, first_seen} for the run-global pattern dedup (inside the timed region).
+
+Workload (default): BASELINE.json configs[2] -- 50k clusters x 1k samples, k=31, +-100 bp flanks (SURVEY 8d generator,
+pure-ACGT variant) -- PER GPU: "weak" scaling, every rank owns a contiguous range of the processing order.
+`--total-clusters T` splits T clusters over the ranks instead (BASELINE configs[3] as written: 50k x 1k sharded over
+8 GPUs, "strong" scaling); kernels and the merge are then timed separately as well.
+`--samples 5000 --k 21|51` is BASELINE configs[4]'s shape; `--targets-clusters M` adds its --targets second pass
+(positional rows of kmers.tsv for M clusters with every sample a target strain), timed on its own.
+`--sweep-alleles` runs a 5 000-cluster pass for several numbers of distinct sequences per cluster.
 
 Prints ONE JSON line on rank 0.  `value` = k-mer instances/s over all ranks (trip count of
-/root/reference/panfeed/panfeed.py:64); `patterns_per_s` = unique patterns/s (rows of
-hashes_to_patterns.tsv).  `roofline` prices the dominant kernel (kmer_scan_kernel) against HBM
-with SURVEY 8(d)'s algorithmic bytes; `cpu_baseline` is the CPU oracle (a port, not the
-reference) on a bounded sample of the same workload, rank 0 at N=1 only.
+/root/reference/panfeed/panfeed.py:64); `patterns_per_s` = unique patterns/s (rows of hashes_to_patterns.tsv).
+`roofline` prices the chain of kernels one pf_submit runs (dedup -> scan -> finish -> md5) against HBM with SURVEY
+8(d)'s algorithmic bytes, and lists every kernel with the roof that actually bounds it; `cpu_baseline` is the CPU
+oracle (a port, not the reference) on a bounded sample of the same workload, rank 0 at N=1 only.
 """
 import argparse
 import json
@@ -29,7 +34,9 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s HBM3E peak (6.3 TB/s measured achievable)
+# vector issue: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles per SIMD, 2.4 GHz
+VALU_PEAK_WAVE_INSTS = 256 * 4 * 0.5 * 2.4e9
 
 
 def parse():
@@ -37,31 +44,41 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--clusters", type=int, default=50000, help="gene clusters per GPU")
+    ap.add_argument("--clusters", type=int, default=50000, help="gene clusters per GPU (weak scaling)")
+    ap.add_argument("--total-clusters", type=int, default=0, help="gene clusters over ALL GPUs (strong scaling)")
     ap.add_argument("--samples", type=int, default=1000)
     ap.add_argument("--flank", type=int, default=100)
     ap.add_argument("--k", type=int, default=31)
+    ap.add_argument("--mean-alleles", type=float, default=7.0)
+    ap.add_argument("--allele-decay", type=float, default=0.5, help="allele weights decay^i (1.0: uniform)")
     ap.add_argument("--max-items", type=int, default=65536)
     ap.add_argument("--cpu-clusters", type=int, default=0, help="clusters in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dedup", action="store_true", help="scan every copy of identical sequences (PF_FLAG_NO_DEDUP)")
     ap.add_argument("--no-every-copy-leg", action="store_true", help="skip the extra scan-every-copy step")
+    ap.add_argument("--targets-clusters", type=int, default=0, help="clusters of the --targets second pass leg")
+    ap.add_argument("--sweep-alleles", action="store_true", help="extra leg: throughput vs distinct sequences per cluster")
+    ap.add_argument("--merge-method", default="owner", choices=["owner", "allgather"])
     return ap.parse_args()
 
 
 def algorithmic_bytes(packed_bytes, n_kept, n_new_patterns, S, k):
-    """sum ceil(len/4) + U*(Kb+16) + U*W8 + P_new*W8."""
+    """sum ceil(len/4) + U*(Kb+16) + U*W8 + P_new*W8; also the part of it this design must move
+    (the U*W8 bit-row term is never materialised: a k-mer carries a pattern id instead)."""
     kb = 8 if k <= 32 else 16
     w8 = (S + 7) // 8
-    return packed_bytes + n_kept * (kb + 16) + n_kept * w8 + n_new_patterns * w8
+    full = packed_bytes + n_kept * (kb + 16) + n_kept * w8 + n_new_patterns * w8
+    return full, full - n_kept * w8
 
 
 def cpu_baseline(args, threads):
     """the CPU oracle on the first clusters of the same workload, ~10-30 s of CPU work"""
     from oracle import oracle as po
     from panfeed_amd import synth
-    n = args.cpu_clusters or max(8, min(args.clusters, 80 * threads))   # ~15-25 s at ~5e6 instances/s/thread
-    cl = synth.generate(n, args.samples, first=0, flank=args.flank, n_rate=0.0)
+    per_cluster = max(1, args.samples // 1000)
+    n = args.cpu_clusters or max(8, min(args.clusters, 80 * threads // per_cluster))   # ~15-25 s at ~5e6 instances/s/thread
+    cl = synth.generate(n, args.samples, first=0, flank=args.flank, n_rate=0.0, mean_alleles=args.mean_alleles,
+                        allele_decay=args.allele_decay)
     recs = [c.record() for c in cl]
     ninst = sum(c.n_instances(args.k) for c in cl)
     run = po.OracleRun(klength=args.k, want_kmers_tsv=False, threads=threads)
@@ -74,6 +91,127 @@ def cpu_baseline(args, threads):
     return {"value": ninst / dt, "unit": "kmer_instances/s", "cores": threads, "kind": "port",
             "sample": f"first {n} clusters of the workload ({ninst} instances, {st['patterns']} patterns) in {dt:.1f} s",
             "patterns_per_s": st["patterns"] / dt}
+
+
+def load_pmc():
+    """committed rocprofv3 --pmc summary of the default command (tools/profile_round.sh): HBM bytes and SQ counters"""
+    for rel in ("profiles/r02/final_pmc_summary.json", "profiles/r01/final_pmc_traffic.json"):
+        path = os.path.join(REPO, rel)
+        if os.path.exists(path):
+            with open(path) as fh:
+                return json.load(fh), rel
+    return None, None
+
+
+# which roof bounds which kernel, and why (DESIGN.md section 4)
+KERNEL_BOUND = {"cluster_dedup_kernel": "hbm", "kmer_scan_kernel": "valu", "md5_kernel": "valu",
+                "finish_kernel": "latency", "rows_kernel": "latency", "emit_kernel": "latency",
+                "pattern_rows_kernel": "latency"}
+
+
+def make_step(eng, dbs, world, dist, dev, method):
+    import torch
+    from panfeed_amd import _lib
+    from panfeed_amd.distributed import merge_patterns
+
+    def step(eng=eng):
+        _lib.check(eng.L.pf_reset_patterns(eng.ctx))
+        tot = {"kept": 0, "new": 0, "scan_ms": 0.0, "rows_ms": 0.0, "emit_ms": 0.0, "total_ms": 0.0, "dedup_ms": 0.0,
+               "patrows_ms": 0.0, "md5_ms": 0.0, "finish_ms": 0.0, "merge_ms": 0.0,
+               "launches": 0, "items": 0, "retried": 0, "unique": 0, "dedup_clusters": 0, "scan_bytes": 0}
+        for d in dbs:
+            res = d.submit(eng)
+            tm = eng.timing()
+            for key in ("dedup_ms", "patrows_ms", "md5_ms", "finish_ms", "scan_ms", "rows_ms", "emit_ms", "total_ms"):
+                tot[key] += tm[key]
+            tot["dedup_clusters"] += tm["n_dedup_clusters"]
+            tot["scan_bytes"] += tm["scan_packed_bytes"]
+            tot["kept"] += int(res.n_kept)
+            tot["new"] += int(res.n_new_patterns)
+            tot["unique"] += int(res.n_unique)
+            tot["launches"] += tm["scan_launches"]
+            tot["items"] += tm["n_items"]
+            tot["retried"] += tm["n_retried"]
+        n_global = tot["new"]
+        if world > 1:
+            t0 = time.time()
+            n_global = merge_patterns(eng, dist, dev, method=method)
+            if dev.type == "cuda":
+                torch.cuda.synchronize()
+            tot["merge_ms"] = (time.time() - t0) * 1e3
+        tot["global_patterns"] = n_global
+        return tot
+    return step
+
+
+def targets_pass(args, local):
+    """BASELINE configs[4]'s second pass: `--targets` with every sample a target strain on a few clusters: one row of
+    kmers.tsv per k-mer instance (panfeed.py:90-107).  Host strings -> the kmers.tsv text, timed end to end and split."""
+    from panfeed_amd import synth
+    from panfeed_amd.engine import Engine
+    from panfeed_amd.packing import build_batch_native
+    S, k = args.samples, args.k
+    cl = synth.generate(args.targets_clusters, S, first=10 ** 6, flank=args.flank, n_rate=0.0,
+                        mean_alleles=args.mean_alleles, allele_decay=args.allele_decay)
+    recs = [c.record() for c in cl]
+    stroi = set(cl[0].names)
+    eng = Engine(klength=k, max_strains=(S + 31) // 32 * 32, stroi=stroi, device=local)
+    t0 = time.time()
+    hb = build_batch_native(recs, k, True, eng.W, stroi=stroi, first_ordinal=0)
+    t_pack = time.time() - t0
+    t0 = time.time()
+    eng.submit_host_batch(hb)
+    t_submit = time.time() - t0
+    t0 = time.time()
+    res = eng.fetch()
+    t_fetch = time.time() - t0
+    t0 = time.time()
+    text = eng._render_targets(hb, hb.targets)
+    t_render = time.time() - t0
+    rows = text.count("\n")
+    eng.close()
+    return {"clusters": args.targets_clusters, "target_strains": S, "rows": rows, "bytes": len(text),
+            "pack_s": t_pack, "submit_s": t_submit, "fetch_s": t_fetch, "render_s": t_render,
+            "rows_per_s_render": rows / t_render if t_render else None,
+            "rows_per_s_end_to_end": rows / (t_pack + t_submit + t_fetch + t_render),
+            "note": "kmers.tsv rows for every sample of the clusters (all strains are targets): strand bits on the "
+                    "device (strand_bits_kernel, inside submit), text by pf_render_kmers_tsv on the host threads"}
+
+
+def allele_sweep(args, local):
+    """throughput against the number of distinct sequences per cluster (5 000 clusters x --samples, uniform allele
+    weights): where the identical-sequence shortcut changes regime"""
+    import torch
+    from panfeed_amd import _lib, devbatch, synth
+    from panfeed_amd.engine import Engine
+    S, k = args.samples, args.k
+    rows = []
+    n = 5000
+    for mean_alleles in (7, 30, 60, 70, 150, 500):
+        eng = Engine(klength=k, max_strains=(S + 31) // 32 * 32, device=local, max_items=32768, pattern_capacity=1 << 24)
+        cl = synth.generate(n, S, first=0, flank=args.flank, n_rate=0.0, mean_alleles=mean_alleles, allele_decay=1.0)
+        distinct = float(np.mean([len(np.unique(c.seq_allele)) for c in cl]))
+        db = devbatch.from_synth(eng, cl, k)
+        del cl
+        best = None
+        for rep in range(3):
+            _lib.check(eng.L.pf_reset_patterns(eng.ctx))
+            torch.cuda.synchronize()
+            t0 = time.time()
+            res = db.submit(eng)
+            torch.cuda.synchronize()
+            dt = time.time() - t0
+            best = dt if best is None or dt < best else best
+        tm = eng.timing()
+        rows.append({"mean_alleles": mean_alleles, "distinct_per_cluster": distinct, "instances": db.n_instances,
+                     "value": db.n_instances / best, "ms": best * 1e3, "clusters_mode1_or_2": tm["n_dedup_clusters"],
+                     "clusters_mode0": n - tm["n_dedup_clusters"], "scan_ms": tm["scan_ms"], "dedup_ms": tm["dedup_ms"],
+                     "finish_ms": tm["finish_ms"], "rows_ms": tm["rows_ms"], "emit_ms": tm["emit_ms"],
+                     "patrows_ms": tm["patrows_ms"], "md5_ms": tm["md5_ms"], "kept": int(res.n_kept),
+                     "patterns": int(res.n_new_patterns), "repartitioned": tm["n_retried"]})
+        db.free()
+        eng.close()
+    return rows
 
 
 def main():
@@ -97,53 +235,31 @@ def main():
     dev = torch.device("cpu") if shared else torch.device("cuda", local)
 
     from panfeed_amd import devbatch, synth
-    from panfeed_amd.distributed import merge_patterns
+    from panfeed_amd.distributed import shard_range
     from panfeed_amd.engine import Engine
 
     S, k = args.samples, args.k
-    first = rank * args.clusters
+    strong = args.total_clusters > 0
+    if strong:
+        first, stop = shard_range(args.total_clusters, rank, world)
+        n_mine = stop - first
+    else:
+        first, n_mine = rank * args.clusters, args.clusters
     t_gen = time.time()
     eng = Engine(klength=k, max_strains=(S + 31) // 32 * 32, device=local, max_items=args.max_items,
                  pattern_capacity=1 << 25, dedup=not args.no_dedup)
     # generate + upload in slabs so the host never holds more than a slab of cluster objects
-    slab = 50000
+    slab = max(1, 50000 * 1000 // max(S, 1))
     dbs = []
-    for s0 in range(0, args.clusters, slab):
-        cl = synth.generate(min(slab, args.clusters - s0), S, first=first + s0, flank=args.flank, n_rate=0.0)
+    for s0 in range(0, n_mine, slab):
+        cl = synth.generate(min(slab, n_mine - s0), S, first=first + s0, flank=args.flank, n_rate=0.0,
+                            mean_alleles=args.mean_alleles, allele_decay=args.allele_decay)
         dbs.append(devbatch.from_synth(eng, cl, k, first_ordinal=first + s0))
         del cl
     t_gen = time.time() - t_gen
     n_inst = sum(d.n_instances for d in dbs)
     packed_bytes = sum(d.packed_bytes for d in dbs)
-
-    def step(eng=eng):
-        from panfeed_amd import _lib
-        _lib.check(eng.L.pf_reset_patterns(eng.ctx))
-        tot = {"kept": 0, "new": 0, "scan_ms": 0.0, "rows_ms": 0.0, "emit_ms": 0.0, "total_ms": 0.0, "dedup_ms": 0.0,
-               "patrows_ms": 0.0, "md5_ms": 0.0, "finish_ms": 0.0,
-               "launches": 0, "items": 0, "retried": 0, "unique": 0, "dedup_clusters": 0, "scan_bytes": 0}
-        for d in dbs:
-            res = d.submit(eng)
-            tm = eng.timing()
-            tot["dedup_ms"] += tm["dedup_ms"]
-            tot["patrows_ms"] += tm["patrows_ms"]
-            tot["md5_ms"] += tm["md5_ms"]
-            tot["finish_ms"] += tm["finish_ms"]
-            tot["dedup_clusters"] += tm["n_dedup_clusters"]
-            tot["scan_bytes"] += tm["scan_packed_bytes"]
-            tot["kept"] += int(res.n_kept)
-            tot["new"] += int(res.n_new_patterns)
-            tot["unique"] += int(res.n_unique)
-            for a, b in (("scan_ms", "scan_ms"), ("rows_ms", "rows_ms"), ("emit_ms", "emit_ms"), ("total_ms", "total_ms")):
-                tot[a] += tm[b]
-            tot["launches"] += tm["scan_launches"]
-            tot["items"] += tm["n_items"]
-            tot["retried"] += tm["n_retried"]
-        n_global = tot["new"]
-        if world > 1:
-            n_global = merge_patterns(eng, dist, dev)
-        tot["global_patterns"] = n_global
-        return tot
+    step = make_step(eng, dbs, world, dist, dev, args.merge_method)
 
     def fence():
         if world > 1:
@@ -159,12 +275,12 @@ def main():
         last = step()
     fence()
     dt = time.time() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt, last["total_ms"], last["merge_ms"]], dtype=torch.float64, device=dev)
     agg = torch.tensor([float(n_inst), float(last["kept"]), float(packed_bytes)], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-    dt = float(tmax.item())
+    dt, max_kernel_ms, max_merge_ms = (float(x) for x in tmax.tolist())
     tot_inst, tot_kept, tot_packed = (float(x) for x in agg.tolist())
 
     # transparency leg (untimed for `value`): the same pass with the identical-sequence shortcut off
@@ -186,7 +302,7 @@ def main():
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
-        alg = algorithmic_bytes(packed_bytes, last["kept"], last["new"], S, k)   # this rank, one step
+        alg, alg_must = algorithmic_bytes(packed_bytes, last["kept"], last["new"], S, k)   # this rank, one step
         kern_ms = {"cluster_dedup_kernel": last["dedup_ms"], "kmer_scan_kernel": last["scan_ms"],
                    "rows_kernel": last["rows_ms"], "emit_kernel": last["emit_ms"],
                    "pattern_rows_kernel": last["patrows_ms"], "md5_kernel": last["md5_ms"],
@@ -194,58 +310,102 @@ def main():
         # The path is a chain of kernels over the same clusters (dedup -> scan -> finish -> md5), none of which moves
         # all of the algorithmic bytes on its own, so the roofline is taken over the chain: SURVEY 8d's algorithmic
         # bytes of the clusters one pf_submit processes / the device time of the chain, first kernel's start to last
-        # kernel's end (HIP events on the library's stream; idle gaps between its kernels count against it).  Per
-        # kernel: its own summed duration and the HBM bytes the PMC pass measured for it.
-        chain_ms = last["total_ms"]            # first kernel's start to last kernel's end (HIP events), gaps included
+        # kernel's end (HIP events on the library's stream; idle gaps between its kernels count against it).
+        chain_ms = last["total_ms"]
         chain_s = chain_ms / 1e3
         achieved = alg / chain_s / 1e9 if chain_s > 0 else 0.0
         dom = max(kern_ms, key=kern_ms.get)
-        # HBM traffic from the committed PMC summary of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-        # separate passes, gfx950 x2 correction on the read side); per step = per pf_submit chain
-        traffic, traffic_src, per_kernel = None, None, {kn: {"ms": v} for kn, v in kern_ms.items() if v > 0}
-        pmc_path = os.path.join(REPO, "profiles", "r01", "final_pmc_traffic.json")
-        default_cmd = (args.clusters, S, k, args.flank, world, args.no_dedup) == (50000, 1000, 31, 100, 1, False)
-        if default_cmd and os.path.exists(pmc_path):
-            with open(pmc_path) as fh:
-                pmc = json.load(fh)
+        # Per kernel: its own time, the roof that bounds it, and -- for the default command -- what the committed PMC
+        # passes measured (HBM bytes; SQ instruction / wait counters): tools/profile_round.sh, tools/pmc_summary.py
+        traffic, traffic_src = None, None
+        per_kernel = {kn: {"ms": v, "bound": KERNEL_BOUND.get(kn, "latency")} for kn, v in kern_ms.items() if v > 0}
+        if "cluster_dedup_kernel" in per_kernel:
+            pk = per_kernel["cluster_dedup_kernel"]
+            pk["algorithmic_GBps"] = packed_bytes / (pk["ms"] / 1e3) / 1e9     # it has to read the packed input once
+            pk["frac_of_hbm_peak"] = pk["algorithmic_GBps"] / HBM_PEAK_GBS
+        default_cmd = (args.clusters, S, k, args.flank, world, args.no_dedup, strong, args.mean_alleles,
+                       args.allele_decay) == (50000, 1000, 31, 100, 1, False, False, 7.0, 0.5)
+        pmc, pmc_rel = load_pmc() if default_cmd else (None, None)
+        if pmc:
             tot = 0.0
-            for kn in per_kernel:
-                hb = sum(v["hbm_bytes_per_step"] for name, v in pmc["kernels"].items() if name.startswith("pf::" + kn))
+            for name, v in pmc["kernels"].items():
+                tot += v.get("hbm_bytes_per_step", 0.0)          # every pf:: kernel of a step, fills included
+            for kn, pk in per_kernel.items():
+                sel = [v for name, v in pmc["kernels"].items() if name.startswith("pf::" + kn)]
+                hb = sum(v.get("hbm_bytes_per_step", 0.0) for v in sel)
                 if hb:
-                    per_kernel[kn]["hbm_bytes"] = hb
-                    per_kernel[kn]["hbm_GBps"] = hb / (per_kernel[kn]["ms"] / 1e3) / 1e9
-                    tot += hb
+                    pk["hbm_bytes"] = hb
+                    pk["hbm_GBps"] = hb / (pk["ms"] / 1e3) / 1e9
+                    pk["hbm_frac_of_peak"] = pk["hbm_GBps"] / HBM_PEAK_GBS
+                valu = sum(v.get("SQ_INSTS_VALU_per_step", 0.0) for v in sel)
+                if valu:
+                    pk["valu_wave_insts"] = valu
+                    pk["valu_frac_of_issue_peak"] = valu / (pk["ms"] / 1e3) / VALU_PEAK_WAVE_INSTS
+                wc = sum(v.get("SQ_WAVE_CYCLES_per_step", 0.0) for v in sel)
+                if wc:
+                    pk["wave_cycles_waiting_frac"] = sum(v.get("SQ_WAIT_ANY_per_step", 0.0) for v in sel) / wc
+                    pk["wave_cycles_issue_stalled_frac"] = sum(v.get("SQ_WAIT_INST_ANY_per_step", 0.0) for v in sel) / wc
             if tot:
-                traffic = tot
-                traffic_src = "profiles/r01/final_pmc_traffic.json"
+                traffic, traffic_src = tot, pmc_rel
+        workload = (f"synthetic {n_mine} clusters x {S} samples on this GPU"
+                    + (f" ({args.total_clusters} over {world} GPUs)" if strong else " per GPU")
+                    + f", k={k}, +-{args.flank} bp flanks, canonical, maf 0.01")
+        if default_cmd:
+            workload += " (BASELINE.json configs[2], pure-ACGT)"
+        elif strong and (args.total_clusters, S, k, args.flank) == (50000, 1000, 31, 100):
+            workload += " (BASELINE.json configs[3]: configs[2] sharded)"
+        elif S == 5000:
+            workload += " (BASELINE.json configs[4] shape)"
         out = {
             "metric": "k-mer instances/s (+ unique patterns/s), k=31, 50k clusters x 1k samples",
             "value": tot_inst * args.steps / dt,
             "unit": "kmer_instances/s",
             "patterns_per_s": last["global_patterns"] * args.steps / dt,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"synthetic {args.clusters} clusters x {S} samples per GPU, k={k}, "
-                                   f"+-{args.flank} bp flanks, canonical, maf 0.01 (BASELINE.json configs[2], pure-ACGT)",
-                       "clusters_per_gpu": args.clusters, "samples": S, "k": k, "flank": args.flank,
-                       "instances_per_gpu": n_inst, "packed_bytes_per_gpu": packed_bytes,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": workload,
+                       "clusters_this_gpu": n_mine, "samples": S, "k": k, "flank": args.flank,
+                       "mean_alleles": args.mean_alleles, "allele_decay": args.allele_decay,
+                       "instances_this_gpu": n_inst, "packed_bytes_this_gpu": packed_bytes,
                        "unique_kmers": last["unique"], "kept_kmers": last["kept"], "patterns": last["global_patterns"],
-                       "sharding": f"{world} x contiguous cluster ranges" + (", RCCL all-gather of pattern digests" if world > 1 else "")},
+                       "sharding": f"{world} x contiguous cluster ranges" + (
+                           f", pattern digests merged by {'RCCL' if not shared else 'gloo'} "
+                           + ("all-to-all to the digest's owner rank and back" if args.merge_method == "owner" else "all-gather")
+                           if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": "pf_submit kernel chain (dedup+scan+finish+md5)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src, "algorithmic_bytes_per_step": alg,
+                         "must_move_bytes_per_step": alg_must,
+                         "must_move_GBps": alg_must / chain_s / 1e9 if chain_s > 0 else 0.0,
+                         "must_move_frac": alg_must / chain_s / 1e9 / HBM_PEAK_GBS if chain_s > 0 else 0.0,
                          "kernel_ms_per_step": chain_ms, "longest_kernel": dom, "per_kernel": per_kernel,
                          "kernels_ms_summed": sum(kern_ms.values()),
-                         "note": "algorithmic bytes (SURVEY 8d) of the clusters one pf_submit processes / device time of "
-                                 "its kernel chain (first start to last end, HIP events on the library's stream); "
-                                 "traffic = HBM bytes of the same kernels per step (PMC)"},
+                         "note": "achieved = SURVEY 8d algorithmic bytes of the clusters one pf_submit processes / device "
+                                 "time of its kernel chain (first start to last end, HIP events on the library's stream). "
+                                 "U*ceil(S/8) of those bytes (one bit row per kept k-mer) are never materialised by this "
+                                 "design -- a k-mer carries a pattern id -- so must_move_* prices only the bytes the path "
+                                 "has to move (packed input, key + pattern id per kept k-mer, one row per new pattern). "
+                                 "Only cluster_dedup_kernel is HBM-bound; per_kernel gives each kernel its own roof: hbm = "
+                                 "bytes it must read / time vs 8 TB/s, valu = SQ_INSTS_VALU / time vs the chip's vector "
+                                 "issue rate (256 CU x 4 SIMD x 1 wave-instruction / 2 cycles x 2.4 GHz), latency = share "
+                                 "of wave cycles spent waiting (SQ_WAIT_ANY / SQ_WAVE_CYCLES).  traffic = HBM bytes of "
+                                 "every pf:: kernel of a step (FETCH_SIZE x 2 + WRITE_SIZE, fill and count kernels "
+                                 "included) from the committed PMC passes of this same command."},
             "device_ms_per_step": dict(kern_ms, submit_total=last["total_ms"]),
             "work_items": last["items"], "clusters_repartitioned": last["retried"],
             "clusters_deduplicated": last["dedup_clusters"], "scan_packed_bytes": last["scan_bytes"],
             "scan_every_copy": every,
             "setup_s": {"generate_and_upload": t_gen},
         }
+        if world > 1:
+            out["multi_gpu"] = {"max_kernel_chain_ms": max_kernel_ms, "max_merge_ms": max_merge_ms,
+                                "merge_method": args.merge_method,
+                                "note": "slowest rank's device chain and host-timed digest exchange of the last step"}
+        if args.targets_clusters:
+            out["targets_second_pass"] = targets_pass(args, local)
+        if args.sweep_alleles:
+            out["allele_sweep"] = allele_sweep(args, local)
         if world == 1 and not args.no_cpu_baseline:
             threads = min(len(os.sched_getaffinity(0)), 16)   # a 1-GPU box's CPU share
             out["cpu_baseline"] = cpu_baseline(args, threads)

@@ -30,7 +30,7 @@ enum pf_status {
     PF_ERR_ARG = -1,      /* bad argument / unsupported option */
     PF_ERR_OOM = -2,      /* host or device allocation failed */
     PF_ERR_HIP = -3,      /* a HIP runtime call failed */
-    PF_ERR_CAPACITY = -4, /* a fixed-capacity table overflowed (pattern table / output arena) */
+    PF_ERR_CAPACITY = -4, /* a capacity that cannot grow was exceeded (work items per cluster, 2^31 patterns) */
     PF_ERR_STATE = -5     /* call order violated */
 };
 
@@ -50,7 +50,9 @@ typedef struct {
        maf_lo[n] <= count <= maf_hi[n]; arrays of max_strains+1 entries. */
     const uint32_t* maf_lo;
     const uint32_t* maf_hi;
-    uint64_t pattern_capacity; /* slots of the run-global pattern table; 0 = default (2^24) */
+    uint64_t pattern_capacity; /* initial slots of the run-global pattern table; 0 = default (2^24).  The table and
+                                  its pool grow on demand (the reference's `patterns` is an unbounded set,
+                                  panfeed.py:146-150): a batch that runs out of ids is re-run with a larger table */
     uint32_t max_items;        /* work items (cluster x key partition) in flight per internal sub-batch; 0 = default;
                                   clamped so that their scratch slices take at most half of the free device memory */
     uint32_t flags;            /* PF_FLAG_* */
@@ -168,7 +170,6 @@ int pf_reset_patterns(pf_ctx* ctx);
  * pf_fetch; `res` (may be NULL) receives the counters only. */
 int pf_submit(pf_ctx* ctx, const pf_batch* batch, pf_result* counters);
 
-/* Copy the arrays of the last batch's result to host memory owned by the context. */
 /*
  * Genomes resident in HBM (SURVEY 8f N1 on the device).  pf_genomes_upload packs the contigs (A/C/G/T in either
  * case -> 2 bits, anything else -> an arbitrary code the caller must never ask for) into the context's genome
@@ -186,6 +187,8 @@ int pf_genomes_upload(pf_ctx* ctx, uint32_t n_contigs, const char* const* ascii,
                       uint64_t* word_off_out);
 int pf_genomes_clear(pf_ctx* ctx);
 int pf_submit_gather(pf_ctx* ctx, const pf_batch* b, const pf_gather* g, pf_result* counters);
+
+/* Copy the arrays of the last batch's result to host memory owned by the context. */
 int pf_fetch(pf_ctx* ctx, pf_result* res);
 
 int pf_get_timing(pf_ctx* ctx, pf_timing* t);
@@ -329,6 +332,13 @@ const char* pf_pangenome_strain(pf_pangenome* p, uint32_t i, int sorted);
 const char* pf_pangenome_take_log(pf_pangenome* p);   /* warnings the reference sends to logger.warning */
 /* Records of the next (at most) max_clusters rows of the table; n_clusters == 0 at the end. */
 int pf_pangenome_next(pf_pangenome* p, uint32_t max_clusters, pf_records** out, pf_records_view_t* view);
+/* Multi-GPU sharding of the processing order (contiguous ranges of table rows per rank).  The clusters a
+ * run processes are the table rows that pass --genes, in table order (input.py:352-355); pf_pangenome_weights gives
+ * each one's number of gene entries (paralogs counted: the sequences iter_gene_clusters will cut, a proxy for its
+ * k-mer instances) so that ranks can balance their ranges; pf_pangenome_set_range restricts pf_pangenome_next to
+ * processed clusters [first, first + count) and rewinds the reader to `first`. */
+int pf_pangenome_weights(pf_pangenome* p, uint32_t cap, uint32_t* weights, uint32_t* n_processed);
+int pf_pangenome_set_range(pf_pangenome* p, uint32_t first, uint32_t count);
 /* Contigs of all genomes in one flat order (upper-cased text), for pf_genomes_upload; then the word offsets it
  * returned: from here on pf_pangenome_next hands out non-target, pure-ACGT sequences by reference. */
 int pf_pangenome_contigs(pf_pangenome* p, uint32_t* n, const char* const** ascii, const uint64_t** len);
@@ -379,6 +389,18 @@ void pf_free_text(char* p);
  * the next one, so that a writer thread can still be on the previous batch.  Not under multiple_files. */
 int pf_render_device(pf_ctx* ctx, const char* const* names, const char* extra_keys, uint64_t n_extra,
                      const char** kh, uint64_t* kh_bytes, const char** hp, uint64_t* hp_bytes);
+/* Same with flags: PF_RENDER_NO_PATTERN_ROWS leaves hashes_to_patterns.tsv out (*hp_bytes = 0) -- a rank of a
+ * multi-GPU run writes its pattern rows only after the run-global merge has said which ones are its own. */
+#define PF_RENDER_NO_PATTERN_ROWS 1u
+int pf_render_device_ex(pf_ctx* ctx, const char* const* names, const char* extra_keys, uint64_t n_extra, uint32_t flags,
+                        const char** kh, uint64_t* kh_bytes, const char** hp, uint64_t* hp_bytes);
+/* Rows of hashes_to_patterns.tsv ("hash\tv0\tv1...\n", panfeed.py:181-187, 217-223) for ANY patterns of the
+ * run-global pool, in the order given, written on the device: pids[n] are pattern ids (< pf_pattern_count).  The
+ * multi-GPU driver calls it after pf_merge_patterns with the ids whose first_seen is the global minimum of their
+ * digest, sorted by first_seen (rank-ordered concatenation then equals the --cores 1 file; reference writer:
+ * __main__.py:67-81).  *text points into the context's pinned memory, valid until the call after the next one of
+ * this function / pf_render_device. */
+int pf_render_pattern_rows(pf_ctx* ctx, const uint32_t* pids, uint64_t n, const char** text, uint64_t* nbytes);
 
 /* Parallel gzip of a block of output text (the reference: gzip.open(..., "wt", compresslevel=9),
  * /root/reference/panfeed/input.py:239-241,255-258 -- one core).  `data` is cut at line ends into chunks of about

@@ -123,6 +123,9 @@ struct pf_ctx {
     DevBuf it_cluster, it_part, it_nparts, it_nslots, it_slice, it_sib0, it_nsib, it_extra_first, it_count,
         it_unique, it_kept, work_scan, work_extra, work_fin, work_fin2, work_fin3, work_rows, sub_cluster, sub_item0, sub_nitems;
     std::vector<Arena*> arenas;
+    uint32_t n_passes = 0;                 // arenas the last pf_submit used (arenas[] itself only ever grows)
+    DevBuf rp_order, rp_rlen, rp_rowoff;   // pf_render_pattern_rows: the id list, row lengths, row offsets
+    uint32_t n_grown = 0;                  // times the pattern table / pool were enlarged
     DevBuf mg_lo, mg_hi, mg_min, mg_cnt;   // pf_merge_patterns scratch table
     // the small per-pass arrays: one device block + its pinned host mirror, two of each because the two halves of a
     // batch's first pass are in flight together (stage_slot picks the pair)
@@ -237,16 +240,95 @@ int staged_upload(pf_ctx* c, std::vector<std::pair<DevBuf*, const std::vector<ui
     return PF_OK;
 }
 
+// the run-global pattern table (`slots` = power of two) and the pool arrays indexed by pattern id (slots / 2 ids)
+int alloc_patterns(pf_ctx* c, uint64_t slots) {
+    c->pt.cap = slots;
+    c->pt.pool = (uint32_t)std::min<uint64_t>(slots / 2, 0x7FFFFFF0ull);
+    const size_t W = c->W, pool = c->pt.pool;
+    PFCHK(c->pt_lo.ensure(slots * 8));
+    PFCHK(c->pt_val.ensure(slots * 8));
+    PFCHK(c->pt_first.ensure(pool * 8));
+    PFCHK(c->pt_counters.ensure(16));
+    PFCHK(c->pat_bits.ensure(pool * W * 4));
+    PFCHK(c->pat_n.ensure(pool * 4));
+    PFCHK(c->pat_md5.ensure(pool * 16));
+    if (c->o.consider_missing) PFCHK(c->pat_nan.ensure(pool * W * 4));
+    c->pt.lo = c->pt_lo.as<uint64_t>();
+    c->pt.val = c->pt_val.as<uint64_t>();
+    c->pt.first_seen = c->pt_first.as<uint64_t>();
+    c->pt.counters = c->pt_counters.as<uint32_t>();
+    return PF_OK;
+}
+
+// The reference's `patterns` is an unbounded set (panfeed.py:146-150): when a batch runs out of pattern ids (or
+// comes close), the table and the pool are re-made larger, the patterns of earlier batches re-inserted
+// (pattern_rehash_kernel; whatever the failed batch added is dropped) and the batch is run again.
+int grow_patterns(pf_ctx* c, uint64_t min_pool) {
+    uint64_t slots = c->pt.cap * 2;
+    while (slots / 2 < min_pool + min_pool / 4) slots <<= 1;
+    if (slots / 2 > 0x7FFFFFF0ull) return fail(PF_ERR_CAPACITY, "more than 2^31 distinct patterns");
+    const uint32_t keep = c->n_patterns;            // ids of the batches that completed
+    const size_t W = c->W;
+    DevBuf o_lo = c->pt_lo, o_val = c->pt_val, o_first = c->pt_first, o_bits = c->pat_bits, o_nan = c->pat_nan,
+           o_n = c->pat_n, o_md5 = c->pat_md5, o_b64 = c->pat_b64;
+    const uint64_t old_cap = c->pt.cap;
+    c->pt_lo = DevBuf(); c->pt_val = DevBuf(); c->pt_first = DevBuf(); c->pat_bits = DevBuf(); c->pat_nan = DevBuf();
+    c->pat_n = DevBuf(); c->pat_md5 = DevBuf(); c->pat_b64 = DevBuf();
+    int rc = alloc_patterns(c, slots);
+    if (rc == PF_OK && o_b64.p) rc = c->pat_b64.ensure((size_t)c->pt.pool * 24);
+    auto copy = [&](DevBuf& dst, DevBuf& src, size_t bytes) -> int {
+        if (bytes && src.p) HIPCHK(hipMemcpyAsync(dst.p, src.p, bytes, hipMemcpyDeviceToDevice, c->stream));
+        return PF_OK;
+    };
+    if (rc == PF_OK) rc = fill_u64(c, c->pt_lo.p, pf::EMPTY64, slots);
+    if (rc == PF_OK) rc = fill_u64(c, c->pt_val.p, pf::EMPTY64, slots);
+    if (rc == PF_OK) rc = fill_u64(c, c->pt_first.p, pf::EMPTY64, c->pt.pool);
+    if (rc == PF_OK) rc = copy(c->pt_first, o_first, (size_t)keep * 8);
+    if (rc == PF_OK) rc = copy(c->pat_bits, o_bits, (size_t)keep * W * 4);
+    if (rc == PF_OK && c->o.consider_missing) rc = copy(c->pat_nan, o_nan, (size_t)keep * W * 4);
+    if (rc == PF_OK) rc = copy(c->pat_n, o_n, (size_t)keep * 4);
+    if (rc == PF_OK) rc = copy(c->pat_md5, o_md5, (size_t)keep * 16);
+    if (rc == PF_OK && o_b64.p) rc = copy(c->pat_b64, o_b64, (size_t)std::min(c->b64_done, keep) * 24);
+    if (rc == PF_OK) {
+        pf::RehashParams rp{};
+        rp.old_lo = o_lo.as<uint64_t>(); rp.old_val = o_val.as<uint64_t>(); rp.old_cap = old_cap;
+        rp.new_lo = c->pt.lo; rp.new_val = c->pt.val; rp.new_cap = slots; rp.keep_below = keep;
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((old_cap + 255) / 256, 8192);
+        hipLaunchKernelGGL(pf::pattern_rehash_kernel, dim3(blocks), dim3(256), 0, c->stream, rp);
+        if (hipGetLastError() != hipSuccess) rc = fail(PF_ERR_HIP, "pattern_rehash_kernel launch failed");
+    }
+    if (rc == PF_OK) {
+        const uint32_t cnt[4] = {keep, 0, 0, 0};
+        if (hipMemcpyAsync(c->pt_counters.p, cnt, 16, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess)
+            rc = fail(PF_ERR_HIP, "growing the pattern table failed");
+    } else {
+        (void)hipStreamSynchronize(c->stream);
+    }
+    o_lo.release(); o_val.release(); o_first.release(); o_bits.release(); o_nan.release(); o_n.release();
+    o_md5.release(); o_b64.release();
+    c->b64_done = std::min(c->b64_done, keep);
+    c->n_grown++;
+    return rc;
+}
+
+template <int KW, bool CANON>
+int scan_attr_t(pf_ctx* c) {
+    // ~100-160 KB of dynamic LDS: the limit is raised once per context (= per device), at pf_create
+    const uint32_t lds = c->NS * (8u * KW + 8u) + pf::MISC_WORDS * 4;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(pf::kmer_scan_kernel<KW, CANON>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return PF_OK;
+}
+int scan_attr(pf_ctx* c) {
+    if (c->KW == 1) return c->o.canon ? scan_attr_t<1, true>(c) : scan_attr_t<1, false>(c);
+    return c->o.canon ? scan_attr_t<2, true>(c) : scan_attr_t<2, false>(c);
+}
+
 template <int KW, bool CANON>
 int launch_scan_t(pf_ctx* c, const pf::ScanParams& sp, uint32_t n) {
-    static bool attr_done = false;
     auto kern = pf::kmer_scan_kernel<KW, CANON>;
     const uint32_t lds = c->NS * (8u * KW + 8u) + pf::MISC_WORDS * 4;
-    if (!attr_done) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
-        attr_done = true;
-    }
     // descriptors first (one thread per work entry), then one persistent workgroup per CU
     PFCHK(c->scan_desc.ensure((size_t)n * sizeof(pf::ScanDesc)));
     pf::ScanParams q = sp;
@@ -326,6 +408,7 @@ void pf_destroy(pf_ctx* c) {
     if (c->pin_dedup) (void)hipHostFree(c->pin_dedup);
     if (c->pin_small) (void)hipHostFree(c->pin_small);
     c->scan_desc.release(); c->pat_b64.release(); c->txt_dev.release(); c->txt_meta.release();
+    c->rp_order.release(); c->rp_rlen.release(); c->rp_rowoff.release();
     for (int i = 0; i < 2; i++) if (c->txt_pins[i]) (void)hipHostFree(c->txt_pins[i]); c->md5_list.release();
     c->g_store.release(); c->b_literal.release(); c->g_src_off.release(); c->g_src_start.release(); c->g_src_flags.release();
     c->mg_lo.release(); c->mg_hi.release(); c->mg_min.release(); c->mg_cnt.release();
@@ -384,27 +467,16 @@ int pf_create(pf_ctx** out, int device, const pf_opts* o) {
             hipEventCreate(&c->ev_t0) != hipSuccess || hipEventCreate(&c->ev_t1) != hipSuccess) {
             rc = fail(PF_ERR_HIP, "hipEventCreate failed"); break;
         }
+        if (!guard(scan_attr(c))) break;
         if (!guard(upload_vec(c, c->d_maf_lo, c->maf_lo))) break;
         if (!guard(upload_vec(c, c->d_maf_hi, c->maf_hi))) break;
         uint64_t cap = o->pattern_capacity ? o->pattern_capacity : (1ull << 24);
         uint64_t p2 = 1024;
         while (p2 < cap) p2 <<= 1;
-        c->pt.cap = p2;
-        c->pt.pool = (uint32_t)std::min<uint64_t>(p2 / 2, 0x7FFFFFF0ull);
-        const size_t W = c->W;
-        if (!guard(c->pt_lo.ensure(p2 * 8)) || !guard(c->pt_val.ensure(p2 * 8)) ||
-            !guard(c->pt_first.ensure((size_t)c->pt.pool * 8)) || !guard(c->pt_counters.ensure(16)) ||
-            !guard(c->pat_bits.ensure((size_t)c->pt.pool * W * 4)) || !guard(c->pat_n.ensure((size_t)c->pt.pool * 4)) ||
-            !guard(c->pat_md5.ensure((size_t)c->pt.pool * 16)))
-            break;
-        if (o->consider_missing && !guard(c->pat_nan.ensure((size_t)c->pt.pool * W * 4))) break;
-        c->pt.lo = c->pt_lo.as<uint64_t>();
-        c->pt.val = c->pt_val.as<uint64_t>();
-        c->pt.first_seen = c->pt_first.as<uint64_t>();
-        c->pt.counters = c->pt_counters.as<uint32_t>();
+        if (!guard(alloc_patterns(c, p2))) break;
         if (!guard(reset_patterns(c))) break;
         // scratch slices
-        const size_t NS = c->NS, S = c->max_items;
+        const size_t NS = c->NS, S = c->max_items, W = c->W;
         if (!guard(c->tab_key.ensure(S * NS * 8 * c->KW)) || !guard(c->tab_ord.ensure(S * NS * 4)) ||
             !guard(c->chunkbits.ensure(S * NS * W * 4)) || !guard(c->chunkmask.ensure(S * 8 * 4)) ||
             !guard(c->slot_hash.ensure(S * NS * 16)) || !guard(c->sorted_pair.ensure(S * NS * 8)) ||
@@ -497,9 +569,10 @@ void pf_b64_digest(const uint8_t d[16], char out[24]) {
 }
 
 // ---------------------------------------------------------------------------------------------
-int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
-    if (!c || !b) return fail(PF_ERR_ARG, "null argument");
-    HIPCHK(hipSetDevice(c->device));
+namespace {
+constexpr int PF_RETRY_PATTERNS = 1;   // internal: the batch ran out of pattern ids, *need = ids it asked for
+
+int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* counters, uint64_t* need) {
     c->have_batch = false;
     // whatever way this call ends, nothing it queued is still reading the caller's arrays or the pinned staging
     // blocks afterwards (the successful path has waited already; an error return may come with work in flight)
@@ -528,8 +601,6 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
     // ---- batch arrays on the device
     pf_batch d = *b;
     std::vector<uint32_t> h_extra_cluster;
-    const pf_gather* gth = c->pending_gather;
-    c->pending_gather = nullptr;
     if (gth && b->on_device) return fail(PF_ERR_ARG, "pf_submit_gather takes host arrays");
     const uint64_t total_words = gth ? gth->n_words : b->n_words;
     if (!b->on_device) {
@@ -1130,13 +1201,14 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
         pass++;
     }
     for (size_t a = pass; a < c->arenas.size(); a++) c->arenas[a]->used = 0;   // arenas of an earlier, longer batch
+    c->n_passes = pass;
 
     // ---- MD5 of the patterns this batch created
-    uint32_t cnt2[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(cnt2, c->pt_counters.p, 8, hipMemcpyDeviceToHost, c->stream));
+    uint32_t cnt2[3] = {0, 0, 0};
+    HIPCHK(hipMemcpyAsync(cnt2, c->pt_counters.p, 12, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (cnt2[1] || cnt2[0] > c->pt.pool)
-        return fail(PF_ERR_CAPACITY, "pattern table full (%u patterns, pool %u): raise pattern_capacity", cnt2[0], c->pt.pool);
+    if (cnt2[2]) return fail(PF_ERR_CAPACITY, "output arena overflow inside a kernel");
+    if (cnt2[1] || cnt2[0] > c->pt.pool) { *need = cnt2[0]; return PF_RETRY_PATTERNS; }
     const uint32_t pid1 = cnt2[0];
     if (pid1 > c->pid0) {
         pf::Md5Params mp{};
@@ -1191,6 +1263,28 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
     c->have_batch = true;
     if (counters) *counters = c->counters;
     return PF_OK;
+}
+}  // namespace
+
+int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
+    if (!c || !b) return fail(PF_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    const pf_gather* gth = c->pending_gather;
+    c->pending_gather = nullptr;
+    if (c->o.multiple_files) {
+        // the pattern set starts empty in every cluster (panfeed.py:165) and ids are salted by the cluster ordinal:
+        // nothing of an earlier batch can ever be matched again
+        PFCHK(reset_patterns(c));
+    } else if ((uint64_t)c->n_patterns * 2 > c->pt.pool) {
+        PFCHK(grow_patterns(c, (uint64_t)c->n_patterns * 2));     // ahead of need: a re-run costs a whole batch
+    }
+    for (int attempt = 0;; attempt++) {
+        uint64_t need = 0;
+        const int rc = submit_once(c, b, gth, counters, &need);
+        if (rc != PF_RETRY_PATTERNS) return rc;
+        if (attempt >= 8) return fail(PF_ERR_CAPACITY, "pattern table still too small after %d enlargements", attempt);
+        PFCHK(grow_patterns(c, std::max<uint64_t>(need, (uint64_t)c->pt.pool + 1)));
+    }
 }
 
 int pf_get_timing(pf_ctx* c, pf_timing* t) {
@@ -1659,15 +1753,93 @@ int pf_genomes_upload(pf_ctx* c, uint32_t n, const char* const* ascii, const uin
     return rc;
 }
 
+namespace {
+// base64 of every digest up to n_patterns, on the device (incremental)
+int ensure_b64_dev(pf_ctx* c) {
+    if (!c->pat_b64.p) PFCHK(c->pat_b64.ensure((size_t)c->pt.pool * 24));
+    const uint32_t p1 = c->n_patterns;
+    if (c->b64_done < p1) {
+        hipLaunchKernelGGL(pf::b64_kernel, dim3((p1 - c->b64_done + 255) / 256), dim3(256), 0, c->stream,
+                           c->pat_md5.as<uint8_t>(), c->b64_done, p1, c->pat_b64.as<char>());
+        HIPCHK(hipGetLastError());
+        c->b64_done = p1;
+    }
+    return PF_OK;
+}
+// pinned host block `slot` of the rendered text, at least `total` bytes
+int text_pin(pf_ctx* c, size_t total) {
+    c->txt_slot ^= 1;
+    char*& pin = c->txt_pins[c->txt_slot];
+    size_t& cap = c->txt_pin_caps[c->txt_slot];
+    if (total > cap) {
+        if (pin) (void)hipHostFree(pin);
+        pin = nullptr; cap = 0;
+        const size_t want = total + total / 4;
+        if (hipHostMalloc((void**)&pin, want, hipHostMallocDefault) != hipSuccess) return fail(PF_ERR_OOM, "hipHostMalloc(%zu) failed", want);
+        cap = want;
+    }
+    return PF_OK;
+}
+}  // namespace
+
+int pf_render_pattern_rows(pf_ctx* c, const uint32_t* pids, uint64_t n, const char** text, uint64_t* nbytes) {
+    if (!c || !text || !nbytes || (n && !pids)) return fail(PF_ERR_ARG, "pf_render_pattern_rows: null argument");
+    HIPCHK(hipSetDevice(c->device));
+    *text = nullptr; *nbytes = 0;
+    if (!n) return PF_OK;
+    if (n > 0x7FFFFFFFull) return fail(PF_ERR_ARG, "pf_render_pattern_rows: too many rows in one call");
+    for (uint64_t i = 0; i < n; i++)
+        if (pids[i] >= c->n_patterns) return fail(PF_ERR_ARG, "pf_render_pattern_rows: pattern id %u out of range (%u patterns)", pids[i], c->n_patterns);
+    hipStream_t st = c->stream;
+    const uint32_t P = (uint32_t)n, W = c->W;
+    PFCHK(ensure_b64_dev(c));
+    PFCHK(c->rp_order.ensure((size_t)P * 4));
+    PFCHK(c->rp_rlen.ensure((size_t)P * 4));
+    PFCHK(c->rp_rowoff.ensure(((size_t)P + 1) * 8));
+    HIPCHK(hipMemcpyAsync(c->rp_order.p, pids, (size_t)P * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(pf::hp_rowlen_kernel, dim3((P + 255) / 256), dim3(256), 0, st, c->pat_n.as<uint32_t>(),
+                       c->o.consider_missing ? c->pat_nan.as<uint32_t>() : (const uint32_t*)nullptr, W, 0u,
+                       c->rp_order.as<uint32_t>(), P, c->rp_rlen.as<uint32_t>());
+    HIPCHK(hipGetLastError());
+    std::vector<uint32_t> rlen(P);
+    HIPCHK(hipMemcpyAsync(rlen.data(), c->rp_rlen.p, (size_t)P * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<uint64_t> row_off((size_t)P + 1, 0);
+    for (uint32_t i = 0; i < P; i++) row_off[i + 1] = row_off[i] + rlen[i];
+    const uint64_t total = row_off[P];
+    PFCHK(c->txt_dev.ensure(total + 16));
+    PFCHK(text_pin(c, total + 16));
+    HIPCHK(hipMemcpyAsync(c->rp_rowoff.p, row_off.data(), ((size_t)P + 1) * 8, hipMemcpyHostToDevice, st));
+    pf::HpTextParams hpp{};
+    hpp.order = c->rp_order.as<uint32_t>(); hpp.row_off = c->rp_rowoff.as<uint64_t>();
+    hpp.pat_bits = c->pat_bits.as<uint32_t>();
+    hpp.pat_nan = c->o.consider_missing ? c->pat_nan.as<uint32_t>() : nullptr;
+    hpp.pat_n = c->pat_n.as<uint32_t>(); hpp.b64 = c->pat_b64.as<char>();
+    hpp.text = c->txt_dev.as<char>(); hpp.n = P; hpp.W = W;
+    hipLaunchKernelGGL(pf::hp_text_kernel, dim3(P), dim3(256), 0, st, hpp);
+    HIPCHK(hipGetLastError());
+    char* pin = c->txt_pins[c->txt_slot];
+    HIPCHK(hipMemcpyAsync(pin, c->txt_dev.p, total, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    *text = pin; *nbytes = total;
+    return PF_OK;
+}
+
 int pf_render_device(pf_ctx* c, const char* const* names, const char* extra_keys, uint64_t n_extra,
                      const char** kh, uint64_t* kh_bytes, const char** hp, uint64_t* hp_bytes) {
+    return pf_render_device_ex(c, names, extra_keys, n_extra, 0, kh, kh_bytes, hp, hp_bytes);
+}
+
+int pf_render_device_ex(pf_ctx* c, const char* const* names, const char* extra_keys, uint64_t n_extra, uint32_t flags,
+                        const char** kh, uint64_t* kh_bytes, const char** hp, uint64_t* hp_bytes) {
     if (!c || !kh || !kh_bytes || !hp || !hp_bytes) return fail(PF_ERR_ARG, "pf_render_device: null argument");
+    const bool want_hp = !(flags & PF_RENDER_NO_PATTERN_ROWS);
     if (!c->have_batch) return fail(PF_ERR_STATE, "pf_render_device needs a successful pf_submit");
     if (c->o.multiple_files) return fail(PF_ERR_ARG, "pf_render_device writes one pair of texts per batch; use the host renderers under multiple_files");
     HIPCHK(hipSetDevice(c->device));
     const uint32_t C = c->n_clusters, W = c->W, KW = (uint32_t)c->KW, k = c->o.klength;
     if (C && !names) return fail(PF_ERR_ARG, "pf_render_device: cluster names missing");
-    if (c->arenas.size() > pf::TEXT_MAX_ARENAS) return fail(PF_ERR_CAPACITY, "pf_render_device: too many passes (%zu)", c->arenas.size());
+    if (c->n_passes > pf::TEXT_MAX_ARENAS) return fail(PF_ERR_CAPACITY, "pf_render_device: too many passes (%u)", c->n_passes);
     hipStream_t st = c->stream;
     // ---- small per-cluster / per-pattern arrays to the host: counts and the first-seen order
     std::vector<uint64_t> koff(C);
@@ -1676,29 +1848,20 @@ int pf_render_device(pf_ctx* c, const char* const* names, const char* extra_keys
         HIPCHK(hipMemcpyAsync(koff.data(), c->cl_kmer_off.p, (size_t)C * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(kcnt.data(), c->cl_kmer_cnt.p, (size_t)C * 4, hipMemcpyDeviceToHost, st));
     }
-    const uint32_t p0 = c->pid0, p1 = c->n_patterns, P = p1 - p0;
+    const uint32_t p0 = c->pid0, p1 = c->n_patterns, P = want_hp ? p1 - p0 : 0;
     std::vector<uint64_t> fs(P);
     std::vector<uint32_t> rlen(P);
     DevBuf d_rlen;
     if (P) {
         PFCHK(d_rlen.ensure((size_t)P * 4));
         hipLaunchKernelGGL(pf::hp_rowlen_kernel, dim3((P + 255) / 256), dim3(256), 0, st, c->pat_n.as<uint32_t>(),
-                           c->o.consider_missing ? c->pat_nan.as<uint32_t>() : (const uint32_t*)nullptr, W, p0, P,
-                           d_rlen.as<uint32_t>());
+                           c->o.consider_missing ? c->pat_nan.as<uint32_t>() : (const uint32_t*)nullptr, W, p0,
+                           (const uint32_t*)nullptr, P, d_rlen.as<uint32_t>());
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(fs.data(), c->pt.first_seen + p0, (size_t)P * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(rlen.data(), d_rlen.p, (size_t)P * 4, hipMemcpyDeviceToHost, st));
-        // base64 of the digests not yet converted
-        PFCHK(c->pat_b64.ensure((size_t)c->pt.pool * 24));
-        if (c->b64_done < p1) {
-            hipLaunchKernelGGL(pf::b64_kernel, dim3((p1 - c->b64_done + 255) / 256), dim3(256), 0, st,
-                               c->pat_md5.as<uint8_t>(), c->b64_done, p1, c->pat_b64.as<char>());
-            HIPCHK(hipGetLastError());
-            c->b64_done = p1;
-        }
-    } else if (!c->pat_b64.p) {
-        PFCHK(c->pat_b64.ensure((size_t)c->pt.pool * 24));
     }
+    PFCHK(ensure_b64_dev(c));
     HIPCHK(hipStreamSynchronize(st));
     d_rlen.release();
     // ---- kmers_to_hashes layout: rows per cluster, workgroups per cluster
@@ -1730,16 +1893,8 @@ int pf_render_device(pf_ctx* c, const char* const* names, const char* extra_keys
     const uint64_t hp_at = (kh_n + 255) & ~(uint64_t)255;          // the second text starts 256-byte aligned
     const uint64_t total = hp_at + hp_n + 16;
     PFCHK(c->txt_dev.ensure(total));
-    c->txt_slot ^= 1;
-    char*& txt_pin = c->txt_pins[c->txt_slot];
-    size_t& txt_pin_cap = c->txt_pin_caps[c->txt_slot];
-    if (total > txt_pin_cap) {
-        if (txt_pin) (void)hipHostFree(txt_pin);
-        txt_pin = nullptr; txt_pin_cap = 0;
-        const size_t want = total + total / 4;
-        if (hipHostMalloc((void**)&txt_pin, want, hipHostMallocDefault) != hipSuccess) return fail(PF_ERR_OOM, "hipHostMalloc(%zu) failed", want);
-        txt_pin_cap = want;
-    }
+    PFCHK(text_pin(c, total));
+    char* txt_pin = c->txt_pins[c->txt_slot];
     // ---- one block of tables for both kernels
     auto pad8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
     size_t o = 0;
@@ -1773,7 +1928,7 @@ int pf_render_device(pf_ctx* c, const char* const* names, const char* extra_keys
         kp.kmer_off = (const uint64_t*)(dm + o_koff); kp.kmer_cnt = (const uint32_t*)(dm + o_kcnt);
         kp.cluster_pattern = c->cl_pattern.as<uint32_t>(); kp.cluster_arena = (const uint32_t*)(dm + o_arena);
         kp.block_cluster = (const uint32_t*)(dm + o_bc); kp.block_row0 = (const uint32_t*)(dm + o_br);
-        for (size_t a = 0; a < c->arenas.size(); a++) { kp.arena_key[a] = c->arenas[a]->key.as<uint64_t>(); kp.arena_pid[a] = c->arenas[a]->pid.as<uint32_t>(); }
+        for (size_t a = 0; a < c->n_passes; a++) { kp.arena_key[a] = c->arenas[a]->key.as<uint64_t>(); kp.arena_pid[a] = c->arenas[a]->pid.as<uint32_t>(); }
         kp.b64 = c->pat_b64.as<char>(); kp.extra_keys = dm + o_extra; kp.text = c->txt_dev.as<char>();
         kp.k = k; kp.KW = KW; kp.rows_per_block = rows_per_block;
         hipLaunchKernelGGL(pf::kh_text_kernel, dim3((uint32_t)blk_cluster.size()), dim3(256), 0, st, kp);

@@ -203,6 +203,7 @@ struct pf_pangenome {
     long long up = 0, down = 0;
     bool dsc = false, raise_missing = false;
     size_t next_row = 0;
+    size_t end_row = (size_t)-1;               // one past the last table row of this reader's range
     std::string log;
     uint32_t W = 0;
     // genomes resident on the device: flat contig order handed to pf_genomes_upload, by-reference mode
@@ -475,7 +476,7 @@ int pf_pangenome_next(pf_pangenome* P, uint32_t max_clusters, pf_records** out, 
     *out = nullptr;
     // rows of this call
     std::vector<size_t> rows;
-    while (P->next_row < P->cluster_names.size() && rows.size() < max_clusters) {
+    while (P->next_row < P->cluster_names.size() && P->next_row < P->end_row && rows.size() < max_clusters) {
         const size_t row = P->next_row++;
         if (P->have_genes && !P->genes.count(P->cluster_names[row])) continue;        // input.py:353-355
         rows.push_back(row);
@@ -555,6 +556,39 @@ int pf_pangenome_next(pf_pangenome* P, uint32_t max_clusters, pf_records** out, 
     v->seq_src_start = P->by_ref ? R->seq_src_start.data() : nullptr;
     v->seq_flags = P->by_ref ? R->seq_flags.data() : nullptr;
     *out = R;
+    return PF_OK;
+}
+
+int pf_pangenome_weights(pf_pangenome* P, uint32_t cap, uint32_t* weights, uint32_t* n_processed) {
+    if (!P || !n_processed) return in_fail(PF_ERR_ARG, "pf_pangenome_weights: null argument");
+    uint32_t n = 0;
+    for (size_t row = 0; row < P->cluster_names.size(); row++) {
+        if (P->have_genes && !P->genes.count(P->cluster_names[row])) continue;        // input.py:353-355
+        if (weights && n < cap) {
+            uint32_t w = 0;
+            for (auto& cell : P->cells[row])
+                if (!cell.empty()) w += 1 + (uint32_t)std::count(cell.begin(), cell.end(), ';');     // input.py:393
+            weights[n] = w;
+        }
+        n++;
+    }
+    *n_processed = n;
+    return PF_OK;
+}
+
+int pf_pangenome_set_range(pf_pangenome* P, uint32_t first, uint32_t count) {
+    if (!P) return in_fail(PF_ERR_ARG, "pf_pangenome_set_range: null argument");
+    // table rows of processed clusters `first` and `first + count`
+    size_t seen = 0, row_first = P->cluster_names.size(), row_end = P->cluster_names.size();
+    for (size_t row = 0; row < P->cluster_names.size(); row++) {
+        if (P->have_genes && !P->genes.count(P->cluster_names[row])) continue;
+        if (seen == first) row_first = row;
+        if (seen == (size_t)first + count) { row_end = row; break; }
+        seen++;
+    }
+    if (count == 0) row_end = row_first;
+    P->next_row = row_first;
+    P->end_row = row_end;
     return PF_OK;
 }
 

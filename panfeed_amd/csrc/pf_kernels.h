@@ -1301,45 +1301,104 @@ struct PatternTable {
     uint64_t* lo;          // [cap] 64 bits of the row hash, EMPTY64 = free; claimed by CAS
     uint64_t* val;         // [cap] (32 more hash bits) << 32 | pattern id, EMPTY64 until published
     uint64_t* first_seen;  // [pool] by pattern id, atomicMin
-    uint32_t* counters;    // [0] patterns allocated  [1] error flag
+    uint32_t* counters;    // [0] pattern ids asked for  [1] out of ids / table full  [2] output arena overflow
     uint64_t cap;          // power of two
     uint32_t pool;         // pattern ids available
 };
 
-// identity = (lo, hi32) = 96 bits of the 128-bit row hash
-__device__ __forceinline__ uint32_t pattern_insert(const PatternTable& t, uint64_t lo, uint32_t hi32,
-                                                   uint64_t first_seen) {
+// identity = (lo, hi31) = 95 bits of the 128-bit row hash (the top bit of hi32 is dropped so that a published
+// `val` can never equal the EMPTY64 sentinel, whatever the pattern id)
+//
+// First half of an insert: find the pattern or claim a free slot WITHOUT allocating an id and without ever
+// waiting.  Returns 0 = found (*pid), 1 = claimed (*slot is ours, val still unpublished), 2 = some other
+// lane / workgroup has claimed a slot with our `lo` and not published it yet (look again later), 3 = the table is
+// full or the run has already failed (counters[1]): *pid = PID_NONE.
+constexpr uint32_t PID_NONE = 0xFFFFFFFFu;
+__device__ __forceinline__ int pattern_find_or_claim(const PatternTable& t, uint64_t lo, uint32_t hi32,
+                                                     uint64_t* slot_out, uint32_t* pid) {
     if (lo == EMPTY64) lo = EMPTY64 - 1;
+    hi32 &= 0x7FFFFFFFu;
     uint64_t slot = (lo ^ ((uint64_t)hi32 * 0x9E3779B97F4A7C15ull)) & (t.cap - 1);
-    uint32_t pid = 0xFFFFFFFFu;
-    for (uint64_t probes = 0; probes < t.cap; ) {
+    for (uint64_t probes = 0; probes < t.cap; probes++) {
         uint64_t cur = __hip_atomic_load(&t.lo[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur == EMPTY64) {
             cur = atomicCAS((unsigned long long*)&t.lo[slot], (unsigned long long)EMPTY64, (unsigned long long)lo);
-            if (cur == EMPTY64) {
-                const uint32_t id = atomicAdd(&t.counters[0], 1u);
-                if (id >= t.pool) { t.counters[1] = 1; pid = 0xFFFFFFFFu; }
-                else pid = id;
-                // publish even on failure so that readers never spin forever
-                __hip_atomic_store(&t.val[slot], ((uint64_t)hi32 << 32) | pid, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
+            if (cur == EMPTY64) { *slot_out = slot; return 1; }
         }
         if (cur == lo) {
             const uint64_t v = __hip_atomic_load(&t.val[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (v == EMPTY64) continue;                    // claimed, not yet published: look again
-            if ((uint32_t)(v >> 32) == hi32) { pid = (uint32_t)v; break; }
+            if (v == EMPTY64) return 2;
+            if ((uint32_t)(v >> 32) == hi32) { *pid = (uint32_t)v; return 0; }
         }
         slot = (slot + 1) & (t.cap - 1);
-        probes++;
+        // a full pool has been noticed: the batch is re-run with a larger table, nothing inserted now matters
+        if ((probes & 63) == 63 && __hip_atomic_load(&t.counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
     }
-    if (pid == 0xFFFFFFFFu) { t.counters[1] = 1; return pid; }
-    atomicMin((unsigned long long*)&t.first_seen[pid], (unsigned long long)first_seen);
+    t.counters[1] = 1;
+    *pid = PID_NONE;
+    return 3;
+}
+__device__ __forceinline__ void pattern_publish(const PatternTable& t, uint64_t slot, uint32_t hi32, uint32_t pid) {
+    __hip_atomic_store(&t.val[slot], ((uint64_t)(hi32 & 0x7FFFFFFFu) << 32) | pid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Blocking insert; atomicMin on first_seen; *lowered = this call lowered it (the caller then writes the pattern's
+// row).  Claim -> publish is straight-line code inside a loop whose condition is WAVE-UNIFORM: a lane that met an
+// unpublished claim (state 2) goes round again together with the whole wave, so the claimer -- even a lane of the
+// same wave -- has published before the next look, whatever the compiler does with the divergent parts.
+__device__ __forceinline__ uint32_t pattern_insert_lower(const PatternTable& t, uint64_t lo, uint32_t hi32,
+                                                         uint64_t first_seen, bool* lowered) {
+    uint32_t pid = PID_NONE;
+    int st = 2;
+    for (;;) {
+        uint64_t slot = 0;
+        if (st == 2) st = pattern_find_or_claim(t, lo, hi32, &slot, &pid);
+        if (st == 1) {
+            const uint32_t id = atomicAdd(&t.counters[0], 1u);
+            if (id >= t.pool) { t.counters[1] = 1; pid = PID_NONE; } else pid = id;
+            pattern_publish(t, slot, hi32, pid);            // published even on failure: nobody waits for ever
+            st = 0;
+        }
+        if (!__any(st == 2)) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    *lowered = false;
+    if (pid == PID_NONE) { t.counters[1] = 1; return pid; }
+    const uint64_t old = atomicMin((unsigned long long*)&t.first_seen[pid], (unsigned long long)first_seen);
+    *lowered = old > first_seen;
     return pid;
+}
+__device__ __forceinline__ uint32_t pattern_insert(const PatternTable& t, uint64_t lo, uint32_t hi32,
+                                                   uint64_t first_seen) {
+    bool lw;
+    return pattern_insert_lower(t, lo, hi32, first_seen, &lw);
 }
 __device__ __forceinline__ uint32_t pattern_insert(const PatternTable& t, uint4 h, uint64_t first_seen) {
     return pattern_insert(t, ((uint64_t)h.x << 32) | h.y, h.z, first_seen);
+}
+
+// pattern table of a larger capacity: re-insert the entries of the old one whose pattern id is < keep_below (the
+// patterns of earlier batches; whatever a failed batch added is dropped)
+struct RehashParams {
+    const uint64_t* old_lo; const uint64_t* old_val; uint64_t old_cap;
+    uint64_t* new_lo; uint64_t* new_val; uint64_t new_cap;
+    uint32_t keep_below;
+};
+__global__ __launch_bounds__(256) void pattern_rehash_kernel(RehashParams p) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < p.old_cap; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t lo = p.old_lo[i], v = p.old_val[i];
+        if (lo == EMPTY64 || v == EMPTY64 || (uint32_t)v >= p.keep_below) continue;
+        const uint32_t hi32 = (uint32_t)(v >> 32);
+        uint64_t slot = (lo ^ ((uint64_t)hi32 * 0x9E3779B97F4A7C15ull)) & (p.new_cap - 1);
+        for (uint64_t probes = 0; probes < p.new_cap; probes++) {
+            // entries are distinct: claiming a free slot is the whole insert
+            if (atomicCAS((unsigned long long*)&p.new_lo[slot], (unsigned long long)EMPTY64, (unsigned long long)lo) == EMPTY64) {
+                p.new_val[slot] = v;
+                break;
+            }
+            slot = (slot + 1) & (p.new_cap - 1);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1445,7 +1504,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
             const uint4 h = p.slot_hash[(size_t)slice * NS + slot];
             const uint32_t pid = pattern_insert(p.pt, h, fs);
             const uint64_t o = obase + kept_before;
-            if (o >= p.out_cap) { p.pt.counters[1] = 2; continue; }   // cannot happen: the arena holds every item's limit
+            if (o >= p.out_cap) { p.pt.counters[2] = 1; continue; }   // cannot happen: the arena holds every item's limit
             p.out_key[o * KW] = p.tab_key[((size_t)slice * KW) * NS + slot];
             if (KW == 2) p.out_key[o * KW + 1] = p.tab_key[((size_t)slice * KW + 1) * NS + slot];
             p.out_pid[o] = pid;
@@ -1523,7 +1582,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
         const uint32_t kb = sout[i];
         if (kb == 0xFFFFFFFFu) continue;
         const uint64_t o_idx = obase + kb;
-        if (o_idx >= p.out_cap) { p.pt.counters[1] = 2; continue; }
+        if (o_idx >= p.out_cap) { p.pt.counters[2] = 1; continue; }
         const uint4 h = p.slot_hash[(size_t)slice * NS + i];
         uint64_t lo = ((uint64_t)h.x << 32) | h.y, hi = ((uint64_t)h.z << 32) | h.w;
         if (lo == EMPTY64) lo--;
@@ -1583,68 +1642,9 @@ struct FinishParams {
     uint32_t consider_missing, patfilt, multiple_files;
 };
 
-// atomicMin on first_seen; true when this call lowered it (the caller then writes the pattern's row)
-__device__ __forceinline__ uint32_t pattern_insert_lower(const PatternTable& t, uint64_t lo, uint32_t hi32,
-                                                         uint64_t first_seen, bool* lowered) {
-    if (lo == EMPTY64) lo = EMPTY64 - 1;
-    uint64_t slot = (lo ^ ((uint64_t)hi32 * 0x9E3779B97F4A7C15ull)) & (t.cap - 1);
-    uint32_t pid = 0xFFFFFFFFu;
-    for (uint64_t probes = 0; probes < t.cap; ) {
-        uint64_t cur = __hip_atomic_load(&t.lo[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cur == EMPTY64) {
-            cur = atomicCAS((unsigned long long*)&t.lo[slot], (unsigned long long)EMPTY64, (unsigned long long)lo);
-            if (cur == EMPTY64) {
-                const uint32_t id = atomicAdd(&t.counters[0], 1u);
-                if (id >= t.pool) { t.counters[1] = 1; pid = 0xFFFFFFFFu; }
-                else pid = id;
-                __hip_atomic_store(&t.val[slot], ((uint64_t)hi32 << 32) | pid, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-        if (cur == lo) {
-            const uint64_t v = __hip_atomic_load(&t.val[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (v == EMPTY64) continue;
-            if ((uint32_t)(v >> 32) == hi32) { pid = (uint32_t)v; break; }
-        }
-        slot = (slot + 1) & (t.cap - 1);
-        probes++;
-    }
-    *lowered = false;
-    if (pid == 0xFFFFFFFFu) { t.counters[1] = 1; return pid; }
-    const uint64_t old = atomicMin((unsigned long long*)&t.first_seen[pid], (unsigned long long)first_seen);
-    *lowered = old > first_seen;
-    return pid;
-}
-
 // MULTI: the work item is the first of several key partitions of the cluster; the slot loops run over all of
 // them (the mask table, ordinal bitmaps and M are per cluster anyway) and slot tags are looked up again instead
 // of being kept per slot.
-// First half of a bulk insert: find the pattern or claim a free slot WITHOUT allocating an id and without ever
-// waiting.  Returns 0 = found (*pid), 1 = claimed (*slot is ours, val still unpublished), 2 = some other
-// workgroup has claimed a slot with our `lo` and not published it yet (resolve later, after publishing ours).
-__device__ __forceinline__ int pattern_find_or_claim(const PatternTable& t, uint64_t lo, uint32_t hi32,
-                                                     uint64_t* slot_out, uint32_t* pid) {
-    if (lo == EMPTY64) lo = EMPTY64 - 1;
-    uint64_t slot = (lo ^ ((uint64_t)hi32 * 0x9E3779B97F4A7C15ull)) & (t.cap - 1);
-    for (uint64_t probes = 0; probes < t.cap; probes++) {
-        uint64_t cur = __hip_atomic_load(&t.lo[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cur == EMPTY64) {
-            cur = atomicCAS((unsigned long long*)&t.lo[slot], (unsigned long long)EMPTY64, (unsigned long long)lo);
-            if (cur == EMPTY64) { *slot_out = slot; return 1; }
-        }
-        if (cur == lo) {
-            const uint64_t v = __hip_atomic_load(&t.val[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (v == EMPTY64) return 2;
-            if ((uint32_t)(v >> 32) == hi32) { *pid = (uint32_t)v; return 0; }
-        }
-        slot = (slot + 1) & (t.cap - 1);
-    }
-    t.counters[1] = 1;
-    *pid = 0xFFFFFFFFu;
-    return 0;
-}
-
 template <class CFG, bool MULTI>
 __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void finish_kernel(FinishParams p) {
     constexpr uint32_t T = CFG::THREADS, DW = CFG::DW, AT = CFG::AT;
@@ -2002,6 +2002,7 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
     }
     if (e_state == 0) {
         e_state = pattern_find_or_claim(p.pt, e_lo, e_hi, &e_gslot, &e_pid);
+        if (e_state == 3) e_state = 0;                             // table full: e_pid = PID_NONE, the batch is re-run
         if (e_state == 1) e_newidx = atomicAdd(&at_count, 1u);     // at_count: claims of this workgroup (reused)
     }
     __syncthreads();
@@ -2018,8 +2019,8 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
     __syncthreads();
     if (e_state == 1) {
         const uint32_t id = sh_npres + e_newidx;
-        e_pid = id < p.pt.pool ? id : 0xFFFFFFFFu;
-        __hip_atomic_store(&p.pt.val[e_gslot], ((uint64_t)e_hi << 32) | e_pid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        e_pid = id < p.pt.pool ? id : PID_NONE;
+        pattern_publish(p.pt, e_gslot, e_hi, e_pid);
     }
     bool lowered = false;
     if (e_state == 2) {
@@ -2079,7 +2080,7 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
         const tag_t tag = MULTI ? find_tag((uint64_t)ml_[u] | ((uint64_t)mh_[u] << 32)) : slot_at[i];
         if (tag == UNTABLED) continue;           // second loop below
         const uint64_t oi = obase + kept_before(o);
-        if (oi >= p.out_cap) { p.pt.counters[1] = 2; continue; }
+        if (oi >= p.out_cap) { p.pt.counters[2] = 1; continue; }
         p.out_key[oi * KW] = k0_[u];
         if (KW == 2) p.out_key[oi * KW + 1] = p.tab_key[((size_t)slice * KW + 1) * NS + i];
         p.out_pid[oi] = at_pid[tag];
@@ -2103,7 +2104,7 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
                                                           (ordinal << 32) | (uint64_t)(rank_of(o) + 1), &lw);
                 if (lw && pid < p.pt.pool) write_row(pid, amask);
                 const uint64_t oi = obase + kept_before(o);
-                if (oi >= p.out_cap) { p.pt.counters[1] = 2; continue; }
+                if (oi >= p.out_cap) { p.pt.counters[2] = 1; continue; }
                 p.out_key[oi * KW] = p.tab_key[((size_t)slice * KW) * NS + i];
                 if (KW == 2) p.out_key[oi * KW + 1] = p.tab_key[((size_t)slice * KW + 1) * NS + i];
                 p.out_pid[oi] = pid;
@@ -2664,11 +2665,12 @@ struct HpTextParams {
     uint32_t n, W;
 };
 // bytes of a hashes_to_patterns row: 24 + one tab per cell + one digit per non-NaN cell + newline
+// pattern i of the list: order[i], or pid0 + i without a list
 __global__ __launch_bounds__(256) void hp_rowlen_kernel(const uint32_t* pat_n, const uint32_t* pat_nan, uint32_t W,
-                                                        uint32_t pid0, uint32_t n, uint32_t* len) {
+                                                        uint32_t pid0, const uint32_t* order, uint32_t n, uint32_t* len) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t pid = pid0 + i, nk = pat_n[pid], cells = nk & 0x7FFFFFFFu;
+    const uint32_t pid = order ? order[i] : pid0 + i, nk = pat_n[pid], cells = nk & 0x7FFFFFFFu;
     uint32_t nn = 0;
     if (pat_nan && !(nk >> 31))
         for (uint32_t w = 0; w < W; w++) nn += __popc(pat_nan[(size_t)pid * W + w]);

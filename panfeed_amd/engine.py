@@ -87,6 +87,10 @@ class Engine:
             raise IndexError(f"cluster {hb.idx[ci]}: boolean index did not match indexed array along axis 0; size of "
                              f"axis is {int(hb.cluster_nstrains[ci])} but size of corresponding boolean axis is "
                              f"{int(hb.cluster_npresab[ci])}")
+        if self.multiple_files:
+            # the library starts every batch with an empty pattern pool (ids are cluster-local, panfeed.py:165)
+            self._md5_b64 = {}
+            self.n_patterns = 0
         b = _lib.Batch()
         b.n_clusters = hb.n_clusters
         b.n_segs = len(hb.seg_len)
@@ -140,7 +144,7 @@ class Engine:
         res = self.fetch()
         return self._render(hb, res)
 
-    def run_stream(self, records, batch_clusters=256, prefetch=2):
+    def run_stream(self, records, batch_clusters=256, prefetch=2, defer_patterns=False):
         """Generator over BatchOutput: packs batch i+1 (host threads, pf_pack_records) while the GPU works on
         batch i and the caller writes batch i-1 -- the reference's reader / workers / writer pipeline
         (__main__.py:39-81,299-344) with the GPU in the workers' place and a deterministic order
@@ -156,21 +160,24 @@ class Engine:
                     return
                 yield build_batch_native(chunk, self.k, self.canon, self.W, stroi=self.stroi, first_ordinal=ordinal)
                 ordinal += len(chunk)
-        return self.run_batches(host_batches(), prefetch)
+        return self.run_batches(host_batches(), prefetch, defer_patterns=defer_patterns)
 
-    def run_pangenome(self, pangenome, batch_clusters=256, prefetch=2, device_text=False):
+    def run_pangenome(self, pangenome, batch_clusters=256, prefetch=2, device_text=False, defer_patterns=False):
         """run_stream fed by the native reader (native_input.Pangenome): table rows -> records -> packed batches
         without leaving the library, then the GPU; yields BatchOutput in table order."""
         if tuple(sorted(pangenome.targets)) != tuple(sorted(self.stroi or ())):
             raise ValueError("the pangenome reader and the engine were given different target strains")
         return self.run_batches(pangenome.batches(self.k, self.canon, self.W, max_clusters=batch_clusters,
-                                                  first_ordinal=self.next_ordinal), prefetch, device_text)
+                                                  first_ordinal=self.next_ordinal), prefetch, device_text,
+                                defer_patterns=defer_patterns)
 
-    def run_batches(self, host_batches, prefetch=2, device_text=False):
+    def run_batches(self, host_batches, prefetch=2, device_text=False, defer_patterns=False):
         """GPU over an iterator of HostBatch, the next ones being prepared on one host thread meanwhile.
         device_text: kmers_to_hashes / hashes_to_patterns of a batch without target-strain rows come back as
         memoryviews of text the GPU wrote (render_device; valid until the batch after the next one has been rendered)
-        instead of str; batches with kmers.tsv rows and --multiple-files runs keep the host renderers."""
+        instead of str; batches with kmers.tsv rows and --multiple-files runs keep the host renderers.
+        defer_patterns: leave hashes_to_patterns empty -- a rank of a sharded run renders its pattern rows after the
+        run-global merge (`render_pattern_rows`)."""
         from concurrent.futures import ThreadPoolExecutor
         it = iter(host_batches)
 
@@ -186,9 +193,18 @@ class Engine:
                 pending.append(pool.submit(pack_next))
                 self.next_ordinal = int(hb.cluster_ordinal[-1]) + 1 if hb.n_clusters else self.next_ordinal
                 res = self.submit_host_batch(hb)
+                texts = None
                 if device_text and not hb.targets and not self.multiple_files:
+                    try:
+                        texts = self.render_device(hb, defer_patterns)
+                    except _lib.PanfeedHipError as e:
+                        # a batch the text kernels cannot lay out (too many passes, an over-long cluster name)
+                        # goes through the host renderers instead
+                        if e.status not in (_lib.ERR_CAPACITY, _lib.ERR_ARG):
+                            raise
+                if texts is not None:
                     out = BatchOutput()
-                    out.kmers_to_hashes, out.hashes_to_patterns = self.render_device(hb)
+                    out.kmers_to_hashes, out.hashes_to_patterns = texts
                     out.kmers_tsv = b""
                     out.stats = {"clusters": int(hb.n_clusters), "instances": int(hb.n_instances),
                                  "device_instances": int(res.n_instances), "unique_kmers": int(res.n_unique),
@@ -197,7 +213,7 @@ class Engine:
                     out.timing = self.timing()
                     yield out
                     continue
-                yield self._render(hb, self.fetch())
+                yield self._render(hb, self.fetch(), defer_patterns)
 
     def pattern_count(self):
         n = C.c_uint64()
@@ -230,7 +246,7 @@ class Engine:
             cells = ["" if isn[i] else cells[i] for i in range(n)]
         return self._md5_b64[pid] + "\t" + "\t".join(cells) + "\n"
 
-    def _render(self, hb, res):
+    def _render(self, hb, res, defer_patterns=False):
         out = BatchOutput()
         C_ = hb.n_clusters
         first_seen = _view(res.pattern_first_seen, int(res.n_patterns), np.uint64)
@@ -261,6 +277,8 @@ class Engine:
                 ci = int(first_seen[pid] >> np.uint64(32)) - ord0
                 hp_by_cluster[ci].append(self._pattern_row(res, pid))
             hp_all = "".join("".join(x) for x in hp_by_cluster)
+        elif defer_patterns:
+            hp_all = ""
         else:
             buf, nb = C.c_void_p(), C.c_uint64()
             _lib.check(self.L.pf_render_hashes_to_patterns(self.ctx, C.byref(buf), C.byref(nb)))
@@ -291,7 +309,7 @@ class Engine:
         out.timing = self.timing()
         return out
 
-    def render_device(self, hb):
+    def render_device(self, hb, defer_patterns=False):
         """(kmers_to_hashes body, hashes_to_patterns body) of the last submit as memoryviews over pinned host memory,
         the text having been written by the GPU (pf_render_device): no pf_fetch, no bytes -> str; valid until the
         render after the next one.  kmers.tsv rows (target strains) still come from `_render` / `_render_targets`."""
@@ -299,10 +317,37 @@ class Engine:
         names = (C.c_char_p * max(C_, 1))(*[s.encode() for s in hb.idx])
         extra = "".join(hb.extra_keys).encode("latin-1") if hb.extra_keys else None
         kh, kn, hp, hn = C.c_void_p(), C.c_uint64(), C.c_void_p(), C.c_uint64()
-        _lib.check(self.L.pf_render_device(self.ctx, names, extra, len(hb.extra_keys), C.byref(kh), C.byref(kn),
-                                           C.byref(hp), C.byref(hn)))
+        _lib.check(self.L.pf_render_device_ex(self.ctx, names, extra, len(hb.extra_keys),
+                                              _lib.RENDER_NO_PATTERN_ROWS if defer_patterns else 0,
+                                              C.byref(kh), C.byref(kn), C.byref(hp), C.byref(hn)))
         mk = (lambda p, n: memoryview((C.c_char * n).from_address(p)).cast("B") if n else memoryview(b""))
         return mk(kh.value, kn.value), mk(hp.value, hn.value)
+
+    # ------------------------------------------------------------------ run-global patterns (multi-GPU)
+    def export_patterns(self):
+        """(md5 uint8 [n,16], first_seen uint64 [n]) of every pattern this engine holds, as numpy arrays"""
+        n = C.c_uint64()
+        p_md5 = C.POINTER(C.c_uint8)()
+        p_fs = C.POINTER(C.c_uint64)()
+        _lib.check(self.L.pf_export_patterns(self.ctx, C.byref(n), C.byref(p_md5), C.byref(p_fs)))
+        n = int(n.value)
+        if n == 0:
+            return np.zeros((0, 16), dtype=np.uint8), np.zeros(0, dtype=np.uint64)
+        md5 = np.ctypeslib.as_array(p_md5, shape=(n * 16,)).reshape(n, 16).copy()
+        return md5, np.ctypeslib.as_array(p_fs, shape=(n,)).copy()
+
+    def render_pattern_rows(self, pids, chunk_bytes=256 << 20):
+        """hashes_to_patterns.tsv rows of the patterns `pids` (any ids of the pool, in this order), written on the
+        device (pf_render_pattern_rows); yields `bytes` blocks of about chunk_bytes."""
+        pids = np.ascontiguousarray(pids, dtype=np.uint32)
+        per_row = 24 + 2 * self.max_strains + 1
+        step = max(1, int(chunk_bytes // per_row))
+        for a in range(0, len(pids), step):
+            part = pids[a:a + step]
+            txt, nb = C.c_void_p(), C.c_uint64()
+            _lib.check(self.L.pf_render_pattern_rows(self.ctx, part.ctypes.data_as(C.c_void_p), len(part),
+                                                     C.byref(txt), C.byref(nb)))
+            yield C.string_at(txt, nb.value)
 
     def _render_targets(self, hb, metas):
         """kmers.tsv rows of `metas` (packing.SeqMeta, in order) through pf_render_kmers_tsv"""
@@ -334,40 +379,3 @@ class Engine:
         self.L.pf_free_text(buf)
         del keep
         return text
-
-    def _positional_rows(self, hb, meta, strand):
-        """one row per instance for a target strain's sequence (panfeed.py:90-107)"""
-        s, k = meta.seq, self.k
-        idx = hb.idx[meta.cluster]
-        seq, comp = s.sequence, s.compsequence
-        # rc-is-canonical flag per pure window, from the device strand bits
-        rc = {}
-        if self.canon and strand is not None:
-            for seg, a, nw in meta.segs:
-                so = int(hb.seg_strand_off[seg])
-                for j in range(nw):
-                    rc[a + j] = (int(strand[so + (j >> 6)]) >> (j & 63)) & 1
-        rows = []
-        for pos in range(meta.num_kmer):
-            if s.strand > 0:                                   # panfeed.py:91-94
-                truestart = s.start + pos
-                trueend = s.start + pos + k
-            else:                                              # panfeed.py:96-99
-                trueend = s.end - pos
-                truestart = s.end - pos - k
-            genestart = pos - s.offset                         # panfeed.py:101-102
-            geneend = pos + k - s.offset
-            head = f"{idx}\t{meta.strain}\t{s.id}\t{s.chromosome}\t{s.strand}\t{truestart}\t{trueend}\t{genestart}\t{geneend}\t"
-            spec = seq[pos:pos + k]
-            if self.canon:
-                if pos in meta.ambig:
-                    canonseq, used = meta.ambig[pos]
-                else:
-                    used = -1 if rc[pos] else 1
-                    canonseq = comp[pos:pos + k][::-1] if rc[pos] else spec
-                rows.append(f"{head}{used}\t{canonseq}\n")      # panfeed.py:104
-            else:
-                rev = comp[pos:pos + k][::-1]
-                rows.append(f"{head}{s.strand}\t{spec}\n")      # panfeed.py:106
-                rows.append(f"{head}{-s.strand}\t{rev}\n")      # panfeed.py:107
-        return "".join(rows)

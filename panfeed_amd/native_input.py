@@ -107,6 +107,19 @@ class Pangenome:
         self.genome_bases = int(sum(lens[i] for i in range(n.value)))
         return self
 
+    def weights(self):
+        """per processed cluster (table rows that pass --genes, table order): its number of gene entries, paralogs
+        counted -- what a sharded run balances its contiguous ranges by (`distributed.shard_range`)"""
+        n = C.c_uint32()
+        _lib.check(self.L.pf_pangenome_weights(self.h, 0, None, C.byref(n)))
+        w = np.zeros(max(n.value, 1), dtype=np.uint32)
+        _lib.check(self.L.pf_pangenome_weights(self.h, n.value, w.ctypes.data_as(C.c_void_p), C.byref(n)))
+        return w[:n.value]
+
+    def set_range(self, first, count):
+        """restrict the reader to processed clusters [first, first + count) and rewind it to `first`"""
+        _lib.check(self.L.pf_pangenome_set_range(self.h, int(first), int(count)))
+
     def close(self):
         if self.h:
             self.L.pf_pangenome_close(self.h)

@@ -30,7 +30,9 @@ def run_files(presence_absence, gffdir, output, fastadir=None, klength=31, canon
     starting empty in each: `panfeed.py:35-43,153-167`) from a panaroo table and a directory (or file of files) of GFFs.  Option names and meaning follow
     the reference's (`__main__.py:86-186`); `patfilt` is what `pattern_hasher` receives (`--no-filter` inverted,
     `__main__.py:283-297`).  Returns a dict of counters."""
-    os.makedirs(output, exist_ok=True)
+    if os.path.isdir(output):                       # the reference refuses an existing directory (input.py:213-216)
+        raise FileExistsError(f"Output directory {output} already exists; remove it or change the output path")
+    os.makedirs(output)
     targets = tuple(targets or ())
     pg = Pangenome(presence_absence, gffdir, fastadir, upstream, downstream, downstream_start_codon, targets=targets,
                    genes=genes)

@@ -8,7 +8,8 @@ per-sequence allele ids for the device-side expansion bench.py uses at full size
 Per cluster c: rng = PCG64(0x9E3779B9 ^ c); gene length ~ lognormal(ln mean_len, 0.5)
 clipped to [min_len, max_len]; 1 + Poisson(7) alleles = ancestral uniform-ACGT sequence
 with allele-specific 1 % substitutions and allele-specific random flanks; allele weights
-~ 2^-i; cluster frequency 0.99 (60 % "core") or U(0.02, 0.9); 1 % of present samples
+~ 2^-i (`allele_decay`^i: 1.0 spreads the samples evenly over the alleles, which is how the bench sweeps the number
+of distinct sequences per cluster); cluster frequency 0.99 (60 % "core") or U(0.02, 0.9); 1 % of present samples
 carry a paralog copy; strand +-1 (affects coordinates only); `n_rate` of the sequences
 get one 'N'.
 """
@@ -95,7 +96,7 @@ def sample_names(n, shuffle_seed=None):
 
 
 def generate_cluster(c, names, flank=0, mean_len=900, min_len=150, max_len=6000, n_rate=0.001,
-                     paralog_rate=0.01, sub_rate=0.01, mean_alleles=7.0, seed=0x9E3779B9):
+                     paralog_rate=0.01, sub_rate=0.01, mean_alleles=7.0, seed=0x9E3779B9, allele_decay=0.5):
     rng = np.random.Generator(np.random.PCG64(seed ^ c))
     S = len(names)
     L = int(np.clip(np.rint(rng.lognormal(np.log(mean_len), 0.5)), min_len, max_len))
@@ -111,7 +112,7 @@ def generate_cluster(c, names, flank=0, mean_len=900, min_len=150, max_len=6000,
             a = np.concatenate([rng.integers(0, 4, size=flank, dtype=np.uint8), a,
                                 rng.integers(0, 4, size=flank, dtype=np.uint8)])
         alleles.append(a)
-    w = 0.5 ** np.arange(H)
+    w = float(allele_decay) ** np.arange(H)     # 0.5: SURVEY 8d's 2^-i; 1.0: every allele equally common
     w /= w.sum()
     p = 0.99 if rng.random() < 0.6 else rng.uniform(0.02, 0.9)
     present = rng.random(S) < p

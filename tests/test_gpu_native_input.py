@@ -184,3 +184,38 @@ def test_run_files_no_cluster_selected(tmp_path):
     assert open(os.path.join(out, "kmers.tsv")).read() == KMERS_TSV_HEADER
     assert open(os.path.join(out, "kmers_to_hashes.tsv")).read() == KMERS_TO_HASHES_HEADER
     assert open(os.path.join(out, "hashes_to_patterns.tsv")).read() == hashes_to_patterns_header(cl[0].names)
+
+
+def test_run_files_refuses_an_existing_output_directory(tmp_path):
+    """input.py:213-216: the reference stops when the output directory exists"""
+    from panfeed_amd import synth
+    from panfeed_amd.pipeline import run_files
+    cl = synth.generate(2, 6, first=1, flank=0, mean_len=100, min_len=40, max_len=200)
+    csvp, gffs, fas = synth.write_pangenome(str(tmp_path / "in"), cl)
+    out = tmp_path / "out"
+    out.mkdir()
+    with pytest.raises(FileExistsError):
+        run_files(csvp, str(tmp_path / "in" / "gffs"), str(out), klength=11)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_run_files_sharded_equals_single_process(tmp_path, world):
+    """files on disk -> files on disk over `world` ranks (each opens the pangenome, takes its weight-balanced range,
+    keeps its genomes resident, writes its parts): the same bytes as the one-process pipeline"""
+    import os
+    from panfeed_amd import synth
+    from panfeed_amd.pipeline import run_files
+    from test_sharded_cpu import FILES, read_out, run_world
+    cl = synth.generate(23, 40, first=500, flank=0, mean_len=300, min_len=50, max_len=900, n_rate=0.03, paralog_rate=0.05)
+    names = cl[0].names
+    src = tmp_path / "in"
+    csvp, gffs, fas = synth.write_pangenome(str(src), cl)
+    single = str(tmp_path / "single")
+    run_files(csvp, str(src / "gffs"), single, klength=23, upstream=30, downstream=10, targets=(names[3], names[20]),
+              batch_clusters=5)
+    out = str(tmp_path / "sharded")
+    stats = run_world("gpu", world, out, f"files:{csvp}:{src / 'gffs'}:23:30:10:{names[3]},{names[20]}")
+    for f in FILES:
+        assert read_out(out, f, False) == read_out(single, f, False), f
+    assert sum(s["clusters"] for s in stats.values()) == 23
+    assert sorted(os.listdir(out)) == sorted(FILES)

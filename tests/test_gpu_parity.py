@@ -378,11 +378,13 @@ def test_run_stream_equals_one_batch():
         eng.close()
 
 
-@pytest.mark.parametrize("S,n,flank,k,head", [(200, 1500, 0, 31, 25), (1000, 600, 100, 31, 3), (1000, 300, 100, 51, 2)],
-                         ids=["cfg1_200s", "cfg2_1000s_flank", "cfg2_k51"])
+@pytest.mark.parametrize("S,n,flank,k,head", [(200, 1500, 0, 31, 25), (1000, 600, 100, 31, 3), (1000, 300, 100, 51, 2),
+                                              (5000, 48, 100, 21, 2), (5000, 32, 100, 51, 2)],
+                         ids=["cfg1_200s", "cfg2_1000s_flank", "cfg2_k51", "cfg4_5000s_k21", "cfg4_5000s_k51"])
 def test_config1_scale_properties(S, n, flank, k, head):
-    """BASELINE configs[1] shape (200 samples, no flanks) and configs[2] shape (1 000 samples, +-100 bp: 32-word rows,
-    both finish classes, key partitions; k = 51: two-word keys) at sizes the oracle cannot cover in seconds:
+    """BASELINE configs[1] shape (200 samples, no flanks), configs[2] shape (1 000 samples, +-100 bp: 32-word rows,
+    both finish classes, key partitions; k = 51: two-word keys) and configs[4] shape (5 000 samples = 157-word rows,
+    k = 21 and 51, paralogs, +-100 bp) at sizes the oracle cannot cover in seconds:
     the whole pipeline with and without the identical-sequence shortcut must agree k-mer for k-mer and digest
     for digest; totals must add up; first_seen must be a strict order; the head of the run equals the oracle."""
     import ctypes as C
@@ -421,26 +423,89 @@ def test_config1_scale_properties(S, n, flank, k, head):
         eng.close()
     for a, b in zip(res[True], res[False]):
         assert np.array_equal(a, b)
-    # the first clusters against the oracle, text for text
-    eng = Engine(klength=k, max_strains=ms)
+    # the first clusters against the oracle, text for text, with target strains (kmers.tsv: the positional rows of
+    # configs[4]'s --targets pass)
+    names = cl[0].names
+    stroi = {names[1], names[S // 2], names[S - 1]}
+    eng = Engine(klength=k, max_strains=ms, stroi=stroi)
     out = eng.run(hb_head)
-    (ek, ekh, ehp), st = _oracle_texts(hb_head, klength=k)
+    (ek, ekh, ehp), st = _oracle_texts(hb_head, stroi=stroi, klength=k)
     assert out.kmers_to_hashes == ekh and out.hashes_to_patterns == ehp
+    assert out.kmers_tsv == ek and len(ek) > 0
+    eng.close()
+
+
+def test_pattern_table_grows_instead_of_failing():
+    """the reference's `patterns` is an unbounded set (panfeed.py:146-150): a table that starts far too small is
+    enlarged and the batch re-run -- in the middle of a run too, with the earlier batches' patterns kept -- and the
+    files are the oracle's"""
+    from panfeed_amd import synth
+    from panfeed_amd.engine import Engine
+    cl = synth.generate(150, 40, first=5, mean_len=200, min_len=60, max_len=500, n_rate=0.0)
+    recs = [c.record() for c in cl]
+    (ek, ekh, ehp), st = _oracle_texts(recs, klength=21)
+    assert st["patterns"] > 2048
+    eng = Engine(klength=21, max_strains=64, pattern_capacity=1024)      # pool of 512 patterns
+    out = eng.run(recs)
+    assert out.kmers_to_hashes == ekh and out.hashes_to_patterns == ehp
+    assert out.stats["patterns"] == st["patterns"]
+    eng.close()
+    # three calls: growth ahead of need, growth after a failed attempt, ids of earlier batches still valid
+    eng = Engine(klength=21, max_strains=64, pattern_capacity=1024)
+    kh, hp = "", ""
+    for part in (recs[:10], recs[10:60], recs[60:]):
+        o = eng.run(part)
+        kh += o.kmers_to_hashes
+        hp += o.hashes_to_patterns
+    assert kh == ekh and hp == ehp
+    # device-written text after growth (base64 table re-made)
+    eng.close()
+    eng = Engine(klength=21, max_strains=64, pattern_capacity=1024)
+    outs = list(eng.run_stream(recs, batch_clusters=40))
+    assert "".join(o.kmers_to_hashes for o in outs) == ekh and "".join(o.hashes_to_patterns for o in outs) == ehp
+    eng.close()
+    got_kh, got_hp = b"", b""
+    eng = Engine(klength=21, max_strains=64, pattern_capacity=1024)
+    from panfeed_amd.packing import build_batch_native
+    ordinal = 0
+    for part in (recs[:10], recs[10:60], recs[60:]):
+        hb = build_batch_native(part, 21, True, eng.W, first_ordinal=ordinal)
+        ordinal += len(part)
+        eng.submit_host_batch(hb)
+        a, b = eng.render_device(hb)
+        got_kh += bytes(a)
+        got_hp += bytes(b)
+    assert got_kh.decode() == ekh and got_hp.decode() == ehp
+    eng.close()
+
+
+def test_multiple_files_resets_the_pool_per_batch():
+    """--multiple-files: the pattern set restarts in every cluster (panfeed.py:165), so the pool must not grow with
+    the number of clusters: many batches through a small table"""
+    from panfeed_amd import synth
+    from panfeed_amd.engine import Engine
+    cl = synth.generate(60, 40, first=77, mean_len=200, min_len=60, max_len=500, n_rate=0.01)
+    recs = [c.record() for c in cl]
+    from oracle import oracle as po
+    eng = Engine(klength=21, max_strains=64, multiple_files=True, pattern_capacity=4096)
+    for a in range(0, 60, 6):
+        out = eng.run(recs[a:a + 6])
+        assert eng.pattern_count() < 2048
+        for (idx, kt, kh, hp), rec in zip(out.per_cluster, recs[a:a + 6]):
+            run = po.OracleRun(klength=21, multiple_files=True)
+            run.feed([rec])
+            ek, ekh, ehp = run.texts()
+            assert (kh, hp) == (ekh, ehp), idx
     eng.close()
 
 
 def test_error_paths():
-    """capacity errors are reported, not silently truncated"""
+    """bad arguments are reported, not silently accepted"""
     from panfeed_amd import synth
     from panfeed_amd._lib import PanfeedHipError
     from panfeed_amd.engine import Engine
-    cl = synth.generate(150, 40, first=5, mean_len=200, min_len=60, max_len=500, n_rate=0.0)
+    cl = synth.generate(20, 40, first=5, mean_len=200, min_len=60, max_len=500, n_rate=0.0)
     recs = [c.record() for c in cl]
-    eng = Engine(klength=21, max_strains=64, pattern_capacity=1024)      # pool of 512 patterns
-    with pytest.raises(PanfeedHipError) as e:
-        eng.run(recs)
-    assert e.value.status == -4 and "pattern" in str(e.value)
-    eng.close()
     with pytest.raises(PanfeedHipError):
         Engine(klength=0, max_strains=64)
     with pytest.raises(PanfeedHipError):

@@ -57,7 +57,7 @@ if not host_only:
     import os, shutil
     from panfeed_amd.pipeline import run_files
     for compress in (False, True):
-        od = tempfile.mkdtemp()
+        od = os.path.join(tempfile.mkdtemp(), "panfeed")      # run_files refuses an existing directory, as the reference does
         t = time.time()
         st = run_files(csvp, os.path.join(d, "gffs"), od, klength=k, upstream=up, downstream=down, compress=compress,
                        batch_clusters=64)
@@ -65,5 +65,5 @@ if not host_only:
         size = sum(os.path.getsize(os.path.join(od, f)) for f in os.listdir(od))
         out["files_to_files_gzip" if compress else "files_to_files"] = dict(
             seconds=round(dt, 3), inst_per_s=st["instances"] / dt, text_bytes=st["bytes"], file_bytes=size)
-        shutil.rmtree(od)
+        shutil.rmtree(os.path.dirname(od))
 print(json.dumps(out))

@@ -1,12 +1,18 @@
+# bench line + rocprofv3 kernel stats + PMC passes (HBM bytes, SQ counters) of the default bench command.
+# usage (on a GPU box): bash tools/profile_round.sh [--prof-only] ; results under gpurun_out/r02/, to be copied into profiles/r02/
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rm -rf gpurun_out/r01b && mkdir -p gpurun_out/r01b
+OUT=gpurun_out/r02
+rm -rf $OUT && mkdir -p $OUT
 if [ "$1" != "--prof-only" ]; then
-timeout -k 10 500 python bench.py --steps 5 --warmup 2 > gpurun_out/r01b/bench.json 2> gpurun_out/r01b/bench.err
+timeout -k 10 500 python bench.py --steps 5 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
 fi
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r01b/stats -o run -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-every-copy-leg > gpurun_out/r01b/stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/r01b/fetch -o run -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-every-copy-leg > gpurun_out/r01b/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/r01b/write -o run -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-every-copy-leg > gpurun_out/r01b/write.log 2>&1
-python tools/pmc_summary.py 4 gpurun_out/r01b/pmc_traffic.json gpurun_out/r01b/fetch gpurun_out/r01b/write
-find gpurun_out/r01b -name "*kernel_trace.csv" -delete
-ls -la gpurun_out/r01b/*
+B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-every-copy-leg"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- $B > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o run -- $B > $OUT/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o run -- $B > $OUT/write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $OUT/sq -o run -- $B > $OUT/sq.log 2>&1
+python tools/pmc_summary.py 4 $OUT/final_pmc_summary.json $OUT/fetch $OUT/write $OUT/sq
+find $OUT -name "*kernel_trace.csv" -delete
+find $OUT -name "*counter_collection.csv" -delete
+ls -la $OUT/*
