@@ -166,9 +166,9 @@ def targets_pass(args, local):
     res = eng.fetch()
     t_fetch = time.time() - t0
     t0 = time.time()
-    text = eng._render_targets(hb, hb.targets)
+    text = eng._render_targets(hb, hb.targets, as_bytes=True)
     t_render = time.time() - t0
-    rows = text.count("\n")
+    rows = text.count(b"\n")
     eng.close()
     return {"clusters": args.targets_clusters, "target_strains": S, "rows": rows, "bytes": len(text),
             "pack_s": t_pack, "submit_s": t_submit, "fetch_s": t_fetch, "render_s": t_render,

@@ -152,6 +152,8 @@ typedef struct {
     float patrows_ms;  /* pattern_rows_kernel (emit_ms excludes it) */
     float md5_ms;      /* md5_kernel (emit_ms excludes it) */
     float finish_ms;   /* finish_kernel (fused rows+emit of single-item deduplicated clusters) */
+    uint32_t n_wide_clusters;  /* clusters that went through the wide dedup class (more than 64 distinct sequences, ...) */
+    uint32_t reserved;
 } pf_timing;
 
 const char* pf_last_error(void);

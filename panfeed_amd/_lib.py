@@ -121,7 +121,8 @@ class Timing(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("scan_ms", C.c_float), ("rows_ms", C.c_float), ("emit_ms", C.c_float),
                 ("scan_launches", C.c_uint32), ("n_items", C.c_uint32), ("n_retried", C.c_uint32),
                 ("n_dedup_clusters", C.c_uint32), ("scan_packed_bytes", C.c_uint64),
-                ("dedup_ms", C.c_float), ("patrows_ms", C.c_float), ("md5_ms", C.c_float), ("finish_ms", C.c_float)]
+                ("dedup_ms", C.c_float), ("patrows_ms", C.c_float), ("md5_ms", C.c_float), ("finish_ms", C.c_float),
+                ("n_wide_clusters", C.c_uint32), ("reserved", C.c_uint32)]
 
 FLAG_NO_DEDUP = 1
 

@@ -106,7 +106,7 @@ struct pf_ctx {
     // scan view built by cluster_dedup_kernel
     DevBuf v_word_off, v_len, v_sample, v_ord, seg_distinct, v_nseg, v_nstr, v_mode, v_dense, extra_off, extra_dense;
     DevBuf bm_occ, bm_keep, pre_occ, pre_keep, mrows, slot_out, it_is_extra, cmask_lo, cmask_hi, it_compact;
-    DevBuf strand_bits, scan_desc, md5_list;
+    DevBuf strand_bits, scan_desc, md5_list, wide_list;
     DevBuf pat_b64, txt_dev, txt_meta;   // device-side rendering: base64 of every digest, the text, its per-row tables
     uint32_t b64_done = 0;               // patterns whose base64 is in pat_b64
     char* txt_pins[2] = {nullptr, nullptr};   // pinned host copies of the rendered text, used alternately so that a
@@ -408,7 +408,7 @@ void pf_destroy(pf_ctx* c) {
     if (c->pin_dedup) (void)hipHostFree(c->pin_dedup);
     if (c->pin_small) (void)hipHostFree(c->pin_small);
     c->scan_desc.release(); c->pat_b64.release(); c->txt_dev.release(); c->txt_meta.release();
-    c->rp_order.release(); c->rp_rlen.release(); c->rp_rowoff.release();
+    c->rp_order.release(); c->rp_rlen.release(); c->rp_rowoff.release(); c->wide_list.release();
     for (int i = 0; i < 2; i++) if (c->txt_pins[i]) (void)hipHostFree(c->txt_pins[i]); c->md5_list.release();
     c->g_store.release(); c->b_literal.release(); c->g_src_off.release(); c->g_src_start.release(); c->g_src_flags.release();
     c->mg_lo.release(); c->mg_hi.release(); c->mg_min.release(); c->mg_cnt.release();
@@ -738,8 +738,8 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
     uint32_t* h_vnstr = h_dense + C8;
     const bool split = C >= 8192;                  // two halves in flight
     const uint32_t half_end[2] = {split ? C / 4 : C, C};   // a quarter first: enough GPU work to hide building the rest
+    pf::DedupParams dp{};
     if (C) {
-        pf::DedupParams dp{};
         dp.packed = d.packed; dp.seg_word_off = d.seg_word_off; dp.seg_len = d.seg_len;
         dp.seg_sample = d.seg_sample; dp.seg_ord_base = d.seg_ord_base;
         dp.cluster_seg_off = d.cluster_seg_off; dp.cluster_nstrains = d.cluster_nstrains;
@@ -757,11 +757,12 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             if (n) {
                 dp.cluster_base = c0;
                 PFCHK(mark_begin(c, 3));
-                hipLaunchKernelGGL(pf::cluster_dedup_kernel, dim3(n), dim3(pf::DEDUP_THREADS), 0, c->stream, dp);
+                hipLaunchKernelGGL(pf::cluster_dedup_kernel<pf::DedupSmall>, dim3(n), dim3(pf::DEDUP_THREADS), 0, c->stream, dp);
                 HIPCHK(hipGetLastError());
                 PFCHK(mark_end(c));
                 hipLaunchKernelGGL(pf::cluster_ninst_kernel, dim3((n + 3) / 4), dim3(256), 0, c->stream, d.cluster_seg_off,
                                    d.seg_len, c->v_len.as<uint32_t>(), c->v_nseg.as<uint32_t>(), c->o.klength, c0, c1,
+                                   (const uint32_t*)nullptr,
                                    c->cl_ninst.as<uint64_t>(), c->cl_vinst.as<uint64_t>(), c->cl_vwords.as<uint64_t>());
                 HIPCHK(hipGetLastError());
                 HIPCHK(hipMemcpyAsync(ninst + c0, c->cl_ninst.as<uint64_t>() + c0, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
@@ -807,12 +808,43 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
     // 31-mers, 40 % of the 51-mers) plus a margin.
     const double share = 1.0 - std::pow(0.99, (double)c->o.klength) + 0.06;
     // what the host does with a half's dedup results once they have arrived (ev_half[h])
+    std::vector<uint32_t> wide_list;
     auto prep_half = [&](int h) -> int {
-        for (uint32_t i = h ? half_end[0] : 0; i < half_end[h]; i++) {
+        const uint32_t c0 = h ? half_end[0] : 0, c1 = half_end[h];
+        // clusters the small dedup class gave up on for lack of room (more than 64 distinct sequences, a sample-set
+        // matrix or an ordinal bitmap that does not fit): the wide class on those alone, then their counts again
+        wide_list.clear();
+        for (uint32_t i = c0; i < c1; i++) if (h_mode[i] & pf::MODE_RETRY_WIDE) wide_list.push_back(i);
+        if (!wide_list.empty()) {
+            const uint32_t nw = (uint32_t)wide_list.size();
+            PFCHK(c->wide_list.ensure((size_t)nw * 4));
+            HIPCHK(hipMemcpyAsync(c->wide_list.p, wide_list.data(), (size_t)nw * 4, hipMemcpyHostToDevice, c->stream));
+            pf::DedupParams dw = dp;
+            dw.cluster_base = 0; dw.cluster_list = c->wide_list.as<uint32_t>();
+            PFCHK(mark_begin(c, 3));
+            hipLaunchKernelGGL(pf::cluster_dedup_kernel<pf::DedupWide>, dim3(nw), dim3(pf::DEDUP_THREADS), 0, c->stream, dw);
+            HIPCHK(hipGetLastError());
+            PFCHK(mark_end(c));
+            hipLaunchKernelGGL(pf::cluster_ninst_kernel, dim3((nw + 3) / 4), dim3(256), 0, c->stream, d.cluster_seg_off,
+                               d.seg_len, c->v_len.as<uint32_t>(), c->v_nseg.as<uint32_t>(), c->o.klength, 0u, nw,
+                               c->wide_list.as<uint32_t>(),
+                               c->cl_ninst.as<uint64_t>(), c->cl_vinst.as<uint64_t>(), c->cl_vwords.as<uint64_t>());
+            HIPCHK(hipGetLastError());
+            const size_t n = c1 - c0;
+            HIPCHK(hipMemcpyAsync(vinst + c0, c->cl_vinst.as<uint64_t>() + c0, n * 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(words + c0, c->cl_vwords.as<uint64_t>() + c0, n * 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(h_mode + c0, c->v_mode.as<uint32_t>() + c0, n * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(h_dense + c0, c->v_dense.as<uint32_t>() + c0, n * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(h_vnstr + c0, c->v_nstr.as<uint32_t>() + c0, n * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            c->timing.n_wide_clusters += nw;
+        }
+        for (uint32_t i = c0; i < c1; i++) {
+            h_mode[i] &= 3u;
             if (ninst[i] * mult >= 0xFFFFFFF0ull) return fail(PF_ERR_ARG, "cluster %u has too many k-mer instances", i);
             total_inst += ninst[i] * mult;
-            c->timing.n_dedup_clusters += h_mode[i];
-            if (h_mode[i] == 1 && h_vnstr[i]) {
+            c->timing.n_dedup_clusters += h_mode[i] ? 1u : 0u;
+            if (h_mode[i] && h_vnstr[i]) {
                 const double D = (double)h_vnstr[i], L = (double)(vinst[i] * mult) / D;
                 const double est = L * (1.0 + share * (D - 1.0));
                 const double room = 0.9 * (double)pf::insert_limit(NS);
@@ -1135,6 +1167,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             pr.item_nslots = em.item_nslots; pr.item_is_extra = c->it_is_extra.as<uint32_t>();
             pr.item_sib0 = em.item_sib0; pr.item_nsib = em.item_nsib; pr.cluster_overflow = em.cluster_overflow;
             pr.v_mode = em.v_mode; pr.v_nstr = c->v_nstr.as<uint32_t>();
+            pr.cluster_seg_off = d.cluster_seg_off; pr.seg_sample = d.seg_sample; pr.seg_distinct = c->seg_distinct.as<uint32_t>();
             pr.cluster_nstrains = d.cluster_nstrains; pr.cluster_npresab = d.cluster_npresab;
             pr.cluster_presab = d.cluster_presab; pr.cluster_kmer_off = em.cluster_kmer_off;
             pr.sorted_pair = em.sorted_pair; pr.kept_prefix = em.kept_prefix;

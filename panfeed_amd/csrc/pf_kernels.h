@@ -598,10 +598,16 @@ __global__ __launch_bounds__(256) void strand_bits_kernel(const uint64_t* packed
 // scan sets "distinct-sequence" bits instead of sample bits, and rows_kernel expands them through
 // M[d] = set of samples that carry distinct sequence d.  Output is identical to scanning every copy.
 // A cluster stays in mode 0 (scan everything) when dedup does not pay or does not fit.
-constexpr uint32_t DEDUP_MAX_SEGS = 16384;    // segments of a cluster (one byte of LDS each)
-constexpr uint32_t DEDUP_MAX_D = 64;          // distinct sequences (two 32-bit presence words)
+constexpr uint32_t DEDUP_MAX_SEGS = 16384;    // segments of a cluster (one table-slot index of LDS each)
+constexpr uint32_t DEDUP_MAX_D = 64;          // distinct sequences of a mode-1 cluster (two 32-bit presence words)
+constexpr uint32_t DEDUP_MAX_D_WIDE = 1024;   // ... of a mode-2 cluster (up to 32 presence words per k-mer)
 constexpr uint32_t DEDUP_MROWS = 4096;        // words of the M matrix: D * ceil4(W) <= this
 constexpr uint32_t DENSE_WORDS = 8192;        // ordinal bitmap words (262144 dense ordinals)
+constexpr uint32_t MODE_RETRY_WIDE = 0x80u;   // v_mode flag: mode 0 only because the small class was too small
+
+// v_mode of a cluster: 0 = scan every segment (sample columns); 1 = scan one representative per distinct sequence,
+// D <= 64, rows through the sample-set matrix M (LDS), ranks from ordinal bitmaps; 2 = the same view with D <= 1024
+// ("wide"): rows gathered through the (distinct index, sample) list of the segments, ranks by sorting.
 
 struct DedupParams {
     const uint64_t* packed; const uint64_t* seg_word_off; const uint32_t* seg_len;
@@ -610,11 +616,12 @@ struct DedupParams {
     const uint32_t* extra_off;        // [C+1] extras per cluster (CSR)
     const uint32_t* extra_ord;        // [n_extra]
     uint64_t* v_word_off; uint32_t* v_len; uint32_t* v_sample; uint32_t* v_ord;   // view, [n_segs]
-    uint32_t* seg_distinct;           // [n_segs] distinct index of every original segment (mode 1)
+    uint32_t* seg_distinct;           // [n_segs] distinct index of every original segment (modes 1, 2)
     uint32_t* v_nseg; uint32_t* v_nstr; uint32_t* v_mode; uint32_t* v_dense;       // [C]
     uint32_t* extra_dense;            // [n_extra] ordinal of the extra row in the cluster's (dense) numbering
     uint32_t k, W, canon, enable;
     uint32_t cluster_base;            // first cluster of this launch (the batch's clusters may be launched in two halves)
+    const uint32_t* cluster_list;     // or: the clusters of this launch (the wide class runs on the flagged ones only)
 };
 
 __device__ __forceinline__ uint64_t mix64(uint64_t x) {
@@ -623,31 +630,38 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
 }
 
 constexpr uint32_t DEDUP_THREADS = 512;
-constexpr uint32_t DEDUP_GTAB = 256;          // hash groups table (mode 1 needs <= DEDUP_MAX_D groups)
-constexpr uint32_t DEDUP_POOL = 2048;         // u64 words of LDS holding one copy of every distinct sequence
 constexpr uint32_t DEDUP_CH = 4;              // 16-byte chunks per lane kept in registers (CH * GL * 64 bases per segment)
 constexpr uint32_t DEDUP_U = 1;               // segments in flight per 16-lane group
 constexpr uint32_t DEDUP_GL = 8;              // lanes that share one segment
 constexpr uint32_t DEDUP_UNSET = 0xFFFFFFFFu;
 constexpr uint32_t DEDUP_INGLOBAL = 0x80000000u;
 
-__global__ __launch_bounds__(DEDUP_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void cluster_dedup_kernel(DedupParams p) {
-    // ~42 KiB in all and 80 VGPRs: three workgroups per CU
-    __shared__ uint64_t t_key[DEDUP_GTAB];     // content hash of the group
-    __shared__ uint64_t t_val[DEDUP_GTAB];     // min over the group's members of (ord_base << 32 | local index)
-    __shared__ uint32_t t_pool[DEDUP_GTAB];    // where the group's sequence sits: pool word offset, or INGLOBAL | index
-    __shared__ uint32_t t_len[DEDUP_GTAB];     // its length in bases
-    __shared__ uint64_t s_pool[DEDUP_POOL];
-    __shared__ uint32_t t_woff[DEDUP_GTAB];    // word offset (relative to the cluster's first segment) of its first member
-    __shared__ uint32_t t_rank[DEDUP_GTAB];    // distinct index of the group (representatives in ordinal order)
-    __shared__ uint8_t s_slot[DEDUP_MAX_SEGS]; // hash group (table slot) of every segment
-    __shared__ uint32_t r_list[DEDUP_MAX_D];   // occupied table slots, unordered
-    __shared__ uint32_t r_rep[DEDUP_MAX_D];    // by distinct index: local index of the representative
-    __shared__ uint32_t r_ord0[DEDUP_MAX_D], r_ninst[DEDUP_MAX_D], r_dense[DEDUP_MAX_D];   // by distinct index
-    __shared__ uint32_t sh_bad, sh_nrep, sh_total, sh_ngroups, sh_pool_used;
+// Two size classes.  Small: every cluster goes through it first -- ~42 KiB of LDS and 80 VGPRs, three workgroups per
+// CU, which is what the HBM-bound pass over the packed bytes needs.  Wide: only the clusters the small class flags
+// (more than 64 distinct sequences, or a sample-set matrix / ordinal bitmap that does not fit): one workgroup per CU.
+struct DedupSmall { static constexpr uint32_t GTAB = 256, MAXD = DEDUP_MAX_D, POOL = 2048, MODE = 1; typedef uint8_t slot_t; };
+struct DedupWide { static constexpr uint32_t GTAB = 2048, MAXD = DEDUP_MAX_D_WIDE, POOL = 1024, MODE = 2; typedef uint16_t slot_t; };
+
+template <class CFG>
+__global__ __launch_bounds__(DEDUP_THREADS) __attribute__((amdgpu_waves_per_eu(CFG::MODE == 1 ? 6 : 2, CFG::MODE == 1 ? 6 : 4)))
+void cluster_dedup_kernel(DedupParams p) {
+    constexpr uint32_t GTAB = CFG::GTAB, MAXD = CFG::MAXD, POOL = CFG::POOL;
+    typedef typename CFG::slot_t slot_t;
+    __shared__ uint64_t t_key[GTAB];           // content hash of the group
+    __shared__ uint64_t t_val[GTAB];           // min over the group's members of (ord_base << 32 | local index)
+    __shared__ uint32_t t_pool[GTAB];          // where the group's sequence sits: pool word offset, or INGLOBAL | index
+    __shared__ uint32_t t_len[GTAB];           // its length in bases
+    __shared__ uint64_t s_pool[POOL];          // u64 words of LDS holding one copy of distinct sequences (while they fit)
+    __shared__ uint32_t t_woff[GTAB];          // word offset (relative to the cluster's first segment) of its first member
+    __shared__ uint32_t t_rank[GTAB];          // distinct index of the group (representatives in ordinal order)
+    __shared__ slot_t s_slot[DEDUP_MAX_SEGS];  // hash group (table slot) of every segment
+    __shared__ uint32_t r_list[MAXD];          // occupied table slots, unordered
+    __shared__ uint32_t r_rep[MAXD];           // by distinct index: local index of the representative
+    __shared__ uint32_t r_ord0[MAXD], r_ninst[MAXD], r_dense[MAXD];   // by distinct index
+    __shared__ uint32_t sh_bad, sh_many, sh_nrep, sh_total, sh_ngroups, sh_pool_used;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint32_t c = blockIdx.x + p.cluster_base;
+    const uint32_t c = p.cluster_list ? p.cluster_list[blockIdx.x] : blockIdx.x + p.cluster_base;
     const uint32_t seg0 = p.cluster_seg_off[c], seg1 = p.cluster_seg_off[c + 1];
     const uint32_t n = seg1 - seg0;
     const uint32_t ex0 = p.extra_off[c], ex1 = p.extra_off[c + 1];
@@ -656,9 +670,10 @@ __global__ __launch_bounds__(DEDUP_THREADS) __attribute__((amdgpu_waves_per_eu(6
     const uint32_t Wp = (p.W + 3) & ~3u;
 
     bool mode1 = p.enable && n >= 4 && n <= DEDUP_MAX_SEGS;
-    if (tid == 0) { sh_bad = 0; sh_nrep = 0; sh_total = 0; sh_ngroups = 0; sh_pool_used = 0; }
+    bool retry_wide = false;                 // small class only: the wide class may still deduplicate this cluster
+    if (tid == 0) { sh_bad = 0; sh_many = 0; sh_nrep = 0; sh_total = 0; sh_ngroups = 0; sh_pool_used = 0; }
     if (mode1) {
-        for (uint32_t i = tid; i < DEDUP_GTAB; i += DEDUP_THREADS) { t_key[i] = EMPTY64; t_val[i] = EMPTY64; t_pool[i] = DEDUP_UNSET; }
+        for (uint32_t i = tid; i < GTAB; i += DEDUP_THREADS) { t_key[i] = EMPTY64; t_val[i] = EMPTY64; t_pool[i] = DEDUP_UNSET; }
     }
     __syncthreads();
     if (mode1) {
@@ -685,6 +700,8 @@ __global__ __launch_bounds__(DEDUP_THREADS) __attribute__((amdgpu_waves_per_eu(6
             nx_woff[u] = sn < n ? (uint32_t)(p.seg_word_off[seg0 + sn] - wbase) : 0;
         }
         for (uint32_t sw = wave_grp0; sw < n; sw += DEDUP_U * ngrp) {
+            // more distinct sequences than this class holds: the rest of the pass would be wasted
+            if (__hip_atomic_load(&sh_many, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
             const uint32_t s = sw + (grp - wave_grp0);
             uint32_t len[DEDUP_U], pc[DEDUP_U], si[DEDUP_U], slot[DEDUP_U];
             bool has[DEDUP_U], registrar[DEDUP_U];
@@ -738,29 +755,33 @@ __global__ __launch_bounds__(DEDUP_THREADS) __attribute__((amdgpu_waves_per_eu(6
                 if (h == EMPTY64) h = EMPTY64 - 1;
                 uint32_t sl = 0, reg = 0;
                 if (gl == 0 && has[u]) {
-                    sl = (uint32_t)h & (DEDUP_GTAB - 1);
+                    sl = (uint32_t)h & (GTAB - 1);
                     for (uint32_t probes = 0;; probes++) {
                         uint64_t cur = __hip_atomic_load(&t_key[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         if (cur == EMPTY64) {
+                            if (__hip_atomic_load(&sh_ngroups, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= MAXD) {
+                                sh_many = 1; sh_bad = 1; sl = GTAB; break;       // too many distinct sequences
+                            }
                             cur = atomicCAS((unsigned long long*)&t_key[sl], (unsigned long long)EMPTY64, (unsigned long long)h);
                             if (cur == EMPTY64) {
                                 reg = 1;
-                                if (atomicAdd(&sh_ngroups, 1u) >= DEDUP_MAX_D) sh_bad = 1;    // too many distinct sequences
+                                if (atomicAdd(&sh_ngroups, 1u) >= MAXD) { sh_many = 1; sh_bad = 1; }
                                 break;
                             }
                         }
                         if (cur == h) break;
-                        sl = (sl + 1) & (DEDUP_GTAB - 1);
-                        if (probes >= DEDUP_GTAB) { sh_bad = 1; sl = DEDUP_GTAB; break; }
+                        sl = (sl + 1) & (GTAB - 1);
+                        if (probes >= GTAB) { sh_many = 1; sh_bad = 1; sl = GTAB; break; }
                     }
-                    if (sl < DEDUP_GTAB)
+                    if (sl < GTAB) {
                         atomicMin((unsigned long long*)&t_val[sl],
                                   (unsigned long long)(((uint64_t)p.seg_ord_base[seg0 + si[u]] << 32) | si[u]));
-                    s_slot[si[u]] = (uint8_t)sl;
+                        s_slot[si[u]] = (slot_t)sl;
+                    }
                 }
                 slot[u] = __shfl(sl, lane & ~(DEDUP_GL - 1));
                 registrar[u] = __shfl(reg, lane & ~(DEDUP_GL - 1)) != 0;
-                if (slot[u] >= DEDUP_GTAB) has[u] = false;      // cluster given up (mode 0)
+                if (slot[u] >= GTAB) has[u] = false;      // cluster given up by this class
             }
             // publish: the first segment of a group leaves its words in the pool
 #pragma unroll
@@ -769,7 +790,7 @@ __global__ __launch_bounds__(DEDUP_THREADS) __attribute__((amdgpu_waves_per_eu(6
                     uint32_t off = 0;
                     if (gl == 0) off = atomicAdd(&sh_pool_used, 2 * pc[u]);
                     off = __shfl(off, lane & ~(DEDUP_GL - 1));
-                    const bool fits = off + 2 * pc[u] <= DEDUP_POOL;
+                    const bool fits = off + 2 * pc[u] <= POOL;
                     if (fits) {
 #pragma unroll
                         for (uint32_t q = 0; q < DEDUP_CH; q++) {
@@ -828,17 +849,25 @@ __global__ __launch_bounds__(DEDUP_THREADS) __attribute__((amdgpu_waves_per_eu(6
         }
         __syncthreads();
         // ---- 4. hash groups -> distinct indices in the ordinal order of their representatives
-        for (uint32_t t = tid; t < DEDUP_GTAB; t += DEDUP_THREADS)
+        for (uint32_t t = tid; t < GTAB; t += DEDUP_THREADS)
             if (t_key[t] != EMPTY64) {
                 const uint32_t at = atomicAdd(&sh_nrep, 1u);
-                if (at < DEDUP_MAX_D) r_list[at] = t;
+                if (at < MAXD) r_list[at] = t;
             }
         __syncthreads();
         const uint32_t D = sh_nrep;
-        mode1 = !sh_bad && D <= DEDUP_MAX_D && D * Wp <= DEDUP_MROWS && 2 * D <= n;
+        const bool worth = 2 * D <= n;                    // at least half of the segments are copies
+        if (CFG::MODE == 1) {
+            // what the wide class can still do for this cluster: more distinct sequences, no sample-set matrix, no
+            // ordinal bitmap; (a hash collision or too few copies stay mode 0)
+            retry_wide = sh_many != 0 || (!sh_bad && worth && D * Wp > DEDUP_MROWS);
+            mode1 = !sh_bad && D <= MAXD && D * Wp <= DEDUP_MROWS && worth;
+        } else {
+            mode1 = !sh_bad && D <= MAXD && worth && ((D + 31) >> 5) <= p.W;
+        }
         if (mode1) {
-            if (tid < D) {
-                const uint32_t slot = r_list[tid];
+            for (uint32_t d = tid; d < D; d += DEDUP_THREADS) {
+                const uint32_t slot = r_list[d];
                 const uint64_t val = t_val[slot];            // (ord_base << 32 | local index) of the representative
                 uint32_t rank = 0;
                 for (uint32_t j = 0; j < D; j++) rank += t_val[r_list[j]] < val ? 1u : 0u;
@@ -849,24 +878,29 @@ __global__ __launch_bounds__(DEDUP_THREADS) __attribute__((amdgpu_waves_per_eu(6
                 r_ninst[rank] = len >= k ? len - k + 1 : 0;
             }
             __syncthreads();
-            if (tid < D) {
+            for (uint32_t d = tid; d < D; d += DEDUP_THREADS) {
                 // dense ordinal of this representative's first window: scanned instances before it plus the
                 // slow-path rows before it (those never fall inside a segment's ordinal range)
                 uint32_t base = 0;
-                for (uint32_t j = 0; j < tid; j++) base += r_ninst[j];
+                for (uint32_t j = 0; j < d; j++) base += r_ninst[j];
                 uint32_t xb = 0;
-                const uint32_t o0 = r_ord0[tid] * mult;
+                const uint32_t o0 = r_ord0[d] * mult;
                 for (uint32_t e = ex0; e < ex1; e++) xb += p.extra_ord[e] < o0 ? 1u : 0u;
-                r_dense[tid] = base + xb;
-                if (tid == D - 1) sh_total = base + r_ninst[tid];
+                r_dense[d] = base + xb;
+                if (d == D - 1) sh_total = base + r_ninst[d];
             }
             __syncthreads();
             const uint64_t dense_bits = ((uint64_t)sh_total + (ex1 - ex0)) * mult;
-            mode1 = dense_bits <= (uint64_t)DENSE_WORDS * 32;
+            if (CFG::MODE == 1) {
+                mode1 = dense_bits <= (uint64_t)DENSE_WORDS * 32;
+                if (!mode1) retry_wide = true;             // ranks by sorting need no bitmap
+            } else {
+                mode1 = dense_bits < 0xFFFFFFF0ull;
+            }
             if (mode1) {
                 for (uint32_t s = tid; s < n; s += DEDUP_THREADS) p.seg_distinct[seg0 + s] = t_rank[s_slot[s]];
-                if (tid < D) {
-                    const uint32_t d = tid, s = r_rep[d];
+                for (uint32_t d = tid; d < D; d += DEDUP_THREADS) {
+                    const uint32_t s = r_rep[d];
                     p.v_word_off[seg0 + d] = p.seg_word_off[seg0 + s];
                     p.v_len[seg0 + d] = p.seg_len[seg0 + s];
                     p.v_sample[seg0 + d] = d;
@@ -886,7 +920,8 @@ __global__ __launch_bounds__(DEDUP_THREADS) __attribute__((amdgpu_waves_per_eu(6
                     p.extra_dense[e] = (below + er) * mult;
                 }
                 if (tid == 0) {
-                    p.v_nseg[c] = D; p.v_nstr[c] = D; p.v_mode[c] = 1; p.v_dense[c] = (uint32_t)dense_bits;
+                    p.v_nseg[c] = D; p.v_nstr[c] = D; p.v_mode[c] = CFG::MODE;
+                    p.v_dense[c] = (uint32_t)min(dense_bits, (uint64_t)0xFFFFFFFFu);
                 }
             }
         }
@@ -900,7 +935,10 @@ __global__ __launch_bounds__(DEDUP_THREADS) __attribute__((amdgpu_waves_per_eu(6
             p.v_ord[seg0 + s] = p.seg_ord_base[seg0 + s];
         }
         for (uint32_t e = ex0 + tid; e < ex1; e += DEDUP_THREADS) p.extra_dense[e] = p.extra_ord[e];
-        if (tid == 0) { p.v_nseg[c] = n; p.v_nstr[c] = p.cluster_nstrains[c]; p.v_mode[c] = 0; p.v_dense[c] = 0; }
+        if (tid == 0) {
+            p.v_nseg[c] = n; p.v_nstr[c] = p.cluster_nstrains[c]; p.v_dense[c] = 0;
+            p.v_mode[c] = retry_wide ? MODE_RETRY_WIDE : 0;
+        }
     }
     (void)lane;
 }
@@ -992,9 +1030,13 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
     __shared__ uint32_t cmask[8];
     __shared__ uint32_t wave_tot[ROWS_THREADS / 64 + 1];
     __shared__ uint32_t sh_cnt, sh_npres, at_count;
-    __shared__ uint64_t at_key[AT_SLOTS];      // mode 1: distinct allele masks of the item
+    __shared__ uint64_t at_key[AT_SLOTS];      // mode 1: distinct allele masks of the item; mode 2: hash50 << 14 | slot
     __shared__ uint4 at_hash[AT_SLOTS];
     __shared__ uint32_t at_keep[AT_SLOTS];
+    // mode 2 ("wide": up to 1024 distinct sequences, a k-mer's allele mask is up to 32 words)
+    __shared__ uint16_t slot_tag[9600];        // per slot: table position of its mask, WIDE_UNTABLED when it has none
+    __shared__ uint32_t mstage[ROWS_THREADS / 32][32];   // the mask being expanded, per half-wave
+    __shared__ uint32_t wstart[MAX_CHUNKS + 1];          // first segment of every 32-sample word
 
     const uint32_t tid = threadIdx.x;
     const uint32_t item = p.work[blockIdx.x];
@@ -1006,8 +1048,10 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         return;
     }
     const uint32_t ns = p.item_nslots[item];
-    const uint32_t mode = p.v_mode[c];
+    const uint32_t mode = p.v_mode[c] & 3u;
     const bool expand = mode == 1 && !p.item_is_extra[item];
+    const bool wide = mode == 2 && !p.item_is_extra[item];
+    const bool bitmaps = mode == 1;                  // ranks from ordinal bitmaps; modes 0 and 2 sort
     const uint32_t nstr = p.cluster_nstrains[c], npres = p.cluster_npresab[c];
     const uint32_t nchunks = (nstr + 31) >> 5;
     const uint32_t Wp = (W + 3) & ~3u;
@@ -1018,7 +1062,9 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
     uint32_t* M = rsh;
     uint32_t* occ = rsh + DEDUP_MROWS;
     uint32_t* keepbm = occ + DENSE_WORDS;
-    const uint32_t dense_words = mode == 1 ? (p.v_dense[c] + 31) >> 5 : 0;
+    const uint32_t dense_words = bitmaps ? (p.v_dense[c] + 31) >> 5 : 0;
+    uint16_t* segd = reinterpret_cast<uint16_t*>(rsh);   // mode 2: (distinct index << 5 | sample & 31) per segment;
+                                                         // lives where `pairs` will be, until the rows are evaluated
 
     if (tid < 8) cmask[tid] = p.chunkmask[slice * 8 + tid];
     if (tid == 0) {
@@ -1027,10 +1073,10 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         for (uint32_t w = 0; w < W; w++) np += __popc(presab[w]);
         sh_npres = np;
     }
-    if (mode == 0) {
-        for (uint32_t i = tid; i < SORT_MAX; i += ROWS_THREADS) pairs[i] = EMPTY64;
-    } else {
+    if (bitmaps) {
         for (uint32_t i = tid; i < DEDUP_MROWS + 2 * DENSE_WORDS; i += ROWS_THREADS) rsh[i] = 0;
+    } else if (!wide) {
+        for (uint32_t i = tid; i < SORT_MAX; i += ROWS_THREADS) pairs[i] = EMPTY64;
     }
     __syncthreads();
     if (expand) {
@@ -1102,6 +1148,114 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         return keep;
     };
 
+    constexpr uint16_t WIDE_UNTABLED = 0xFFFFu;
+    if (wide) {
+        // ---- mode 2.  A k-mer's allele mask (which distinct sequences contain it) is nmw = ceil(D / 32) chunk
+        // words; its presence row is gathered through the segment list: sample s carries the k-mer iff one of its
+        // segments is a copy of a distinct sequence of the mask.  Distinct masks are evaluated once (table keyed by a
+        // 50-bit hash of the words, verified word for word against the slot that opened the entry).
+        const uint32_t s0 = p.cluster_seg_off[c], s1 = p.cluster_seg_off[c + 1], nsegs = s1 - s0;
+        const uint32_t D = p.v_nstr[c], nmw = (D + 31) >> 5;
+        for (uint32_t s = tid; s < nsegs; s += ROWS_THREADS)
+            segd[s] = (uint16_t)((p.seg_distinct[s0 + s] << 5) | (p.seg_sample[s0 + s] & 31u));
+        for (uint32_t w = tid; w <= nchunks; w += ROWS_THREADS)
+            wstart[w] = seg_lower_bound(p.seg_sample, s0, s1, w << 5) - s0;
+        for (uint32_t t = tid; t < AT_SLOTS; t += ROWS_THREADS) at_key[t] = 0;
+        if (tid == 0) at_count = 0;
+        __syncthreads();
+        auto mask_word = [&](uint32_t j, uint32_t i) -> uint32_t {
+            return ((cmask[j >> 5] >> (j & 31)) & 1) ? cb[(size_t)j * NS + i] : 0u;
+        };
+        for (uint32_t i = tid; i < ns; i += ROWS_THREADS) {
+            if (ordp[i] == NO_ORD) continue;
+            uint64_t h = 0x9E3779B97F4A7C15ull;
+            for (uint32_t j = 0; j < nmw; j++) h = mix64(h ^ mask_word(j, i)) + j;
+            uint64_t h50 = h >> 14;
+            if (!h50) h50 = 1;
+            uint16_t tag = WIDE_UNTABLED;
+            uint32_t a = (uint32_t)(h & (AT_SLOTS - 1));
+            for (uint32_t probes = 0; probes < AT_SLOTS; probes++) {
+                uint64_t cur = __hip_atomic_load(&at_key[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (cur == 0) {
+                    if (__hip_atomic_load(&at_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= AT_LIMIT) break;
+                    cur = atomicCAS((unsigned long long*)&at_key[a], 0ull, (unsigned long long)((h50 << 14) | i));
+                    if (cur == 0) { atomicAdd(&at_count, 1u); tag = (uint16_t)a; break; }
+                }
+                if ((cur >> 14) == h50) {
+                    const uint32_t rep = (uint32_t)cur & 0x3FFFu;     // the claim is one word: nothing to wait for
+                    bool same = true;
+                    for (uint32_t j = 0; j < nmw && same; j++) same = mask_word(j, i) == mask_word(j, rep);
+                    if (same) { tag = (uint16_t)a; break; }
+                }
+                a = (a + 1) & (AT_SLOTS - 1);
+            }
+            slot_tag[i] = tag;
+        }
+        __syncthreads();
+        // one half-wave per mask: lane j gathers row word 32 r + j in round r, the 32 words of a round then go through
+        // the row hash in order (eight blocks), every lane running it on the shuffled words
+        const uint32_t hw = tid >> 5, hl = tid & 31u, hbase = (tid & 63u) & 32u;
+        auto eval_slot = [&](uint32_t rep, uint4& hout) -> bool {
+            if (hl < nmw) mstage[hw][hl] = mask_word(hl, rep);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            H128 st;
+            st.h1 = 0x9747b28cu ^ nstr; st.h2 = 0x1b873593u; st.h3 = 0xe6546b64u; st.h4 = 0x85ebca6bu;
+            if (p.multiple_files) { st.h2 ^= (uint32_t)ordinal; st.h3 ^= (uint32_t)(ordinal >> 32); }
+            uint32_t cnt = 0, ne = 0;
+            for (uint32_t w0 = 0; w0 < nchunks; w0 += 32) {
+                const uint32_t w = w0 + hl;
+                uint32_t word = 0;
+                if (w < nchunks) {
+                    for (uint32_t q = wstart[w], qe = wstart[w + 1]; q < qe; q++) {
+                        const uint32_t e = segd[q], d = e >> 5;
+                        word |= ((mstage[hw][d >> 5] >> (d & 31u)) & 1u) << (e & 31u);
+                    }
+                    cnt += __popc(word);
+                    ne |= word != presab[w] ? 1u : 0u;
+                }
+                const uint32_t nb = min(8u, (nchunks - w0 + 3) >> 2);
+                for (uint32_t b = 0; b < nb; b++) {
+                    const uint32_t b0 = __shfl(word, hbase + 4 * b), b1 = __shfl(word, hbase + 4 * b + 1);
+                    const uint32_t b2 = __shfl(word, hbase + 4 * b + 2), b3 = __shfl(word, hbase + 4 * b + 3);
+                    mm3_block(st, b0, b1, b2, b3);
+                }
+            }
+            if (p.consider_missing) {
+                for (uint32_t ch = 0; ch < nchunks; ch += 4) {
+                    uint32_t wv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) wv[j] = (ch + j < nchunks) ? ~presab[ch + j] : 0;
+                    mm3_block(st, wv[0], wv[1], wv[2], wv[3]);
+                }
+            }
+            mm3_final(st, nchunks * 4);
+            for (int dd = 1; dd < 32; dd <<= 1) { cnt += __shfl_xor(cnt, dd); ne |= __shfl_xor(ne, dd); }
+            bool keep = cnt >= lo && cnt <= hi;                 // panfeed.py:197-200
+            if (same_possible && !ne) keep = false;             // panfeed.py:202-204
+            hout = make_uint4(st.h1, st.h2, st.h3, st.h4);
+            __builtin_amdgcn_wave_barrier();                    // mstage[hw] is rewritten by the next call
+            return keep;
+        };
+        for (uint32_t t = hw; t < AT_SLOTS; t += ROWS_THREADS / 32) {
+            const uint64_t key = at_key[t];
+            if (!key) continue;
+            uint4 h;
+            const bool keep = eval_slot((uint32_t)key & 0x3FFFu, h);
+            if (hl == 0) { at_hash[t] = h; at_keep[t] = keep ? 1u : 0u; }
+        }
+        // slots whose mask found no room in the table (rare): one evaluation each, result straight to where the
+        // main loop below would put it
+        for (uint32_t i = hw; i < ns; i += ROWS_THREADS / 32) {
+            if (ordp[i] == NO_ORD || slot_tag[i] != WIDE_UNTABLED) continue;
+            uint4 h;
+            const bool keep = eval_slot(i, h);
+            if (hl == 0) { p.slot_hash[(size_t)slice * NS + i] = h; keepf[i] = keep ? 1 : 0; }
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < SORT_MAX; i += ROWS_THREADS) pairs[i] = EMPTY64;      // segd is no longer needed
+        __syncthreads();
+    }
     if (expand) {
         // Few distinct sequences -> few distinct masks: evaluate each distinct mask once (LDS table), then
         // hand the result to every slot that carries it.
@@ -1152,11 +1306,19 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
             }
             if (found) { h = at_hash[a]; keep = at_keep[a] != 0; }
             else keep = row_eval(true, amask, i, h);          // table was full: evaluate this slot on its own
+        } else if (wide) {
+            const uint32_t tag = slot_tag[i];
+            if (tag == WIDE_UNTABLED) {                         // hash and keep flag are in place already
+                const uint32_t at = atomicAdd(&sh_cnt, 1u);
+                if (at < SORT_MAX) pairs[at] = ((uint64_t)o << 32) | i;
+                continue;
+            }
+            h = at_hash[tag]; keep = at_keep[tag] != 0;
         } else {
             keep = row_eval(false, 0, i, h);
         }
         p.slot_hash[(size_t)slice * NS + i] = h;
-        if (mode == 0) {
+        if (!bitmaps) {
             keepf[i] = keep ? 1 : 0;
             const uint32_t at = atomicAdd(&sh_cnt, 1u);
             if (at < SORT_MAX) pairs[at] = ((uint64_t)o << 32) | i;
@@ -1167,7 +1329,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
     }
     __syncthreads();
 
-    if (mode == 1) {
+    if (bitmaps) {
         // ranks come from the ordinal bitmaps: prefix popcounts per word, stored for emit_kernel
         constexpr uint32_t PW = DENSE_WORDS / ROWS_THREADS;   // 8 words per thread
         uint32_t so = 0, sk = 0;
@@ -1460,7 +1622,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
     const uint32_t sib0 = p.item_sib0[item], nsib = p.item_nsib[item];
     const uint64_t ordinal = p.cluster_ordinal[c];
     const uint64_t obase = p.cluster_kmer_off[c] - p.out_base;
-    const uint32_t mode = p.v_mode[c];
+    const uint32_t mode = p.v_mode[c] & 3u;
 
     if (item == sib0 && tid == 0) {
         // the cluster's own row: md5 of the int64 image of clusterpresab (panfeed.py:175-187)
@@ -1481,7 +1643,8 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
         p.cluster_first[c] = fs;
     }
 
-    if (mode == 0) {
+    if (mode != 1) {
+        // modes 0 and 2: the items' k-mers are sorted by ordinal (rows_kernel); ranks by binary search in the siblings
         const uint64_t* sp = p.sorted_pair + (size_t)slice * NS;
         const uint32_t* kp = p.kept_prefix + (size_t)slice * (NS + 1);
         for (uint32_t r = tid; r < U; r += EMIT_THREADS) {
@@ -2127,6 +2290,7 @@ struct PatRowsParams {
     const uint32_t* item_sib0; const uint32_t* item_nsib;
     const uint32_t* cluster_overflow;
     const uint32_t* v_mode; const uint32_t* v_nstr;
+    const uint32_t* cluster_seg_off; const uint32_t* seg_sample; const uint32_t* seg_distinct;   // caller's segments (mode 2)
     const uint32_t* cluster_nstrains; const uint32_t* cluster_npresab; const uint32_t* cluster_presab;
     const uint64_t* cluster_kmer_off;
     const uint64_t* sorted_pair; const uint32_t* kept_prefix; const uint32_t* chunkbits; const uint32_t* chunkmask;
@@ -2149,6 +2313,11 @@ __global__ __launch_bounds__(256) void pattern_rows_kernel(PatRowsParams p) {
     __shared__ uint32_t l_slot[PR_LIST];
     __shared__ uint32_t l_pid[PR_LIST];
     __shared__ uint32_t l_count;
+    // mode 2: the cluster's (distinct index << 5 | sample & 31) list, the first segment of every 32-sample word, and
+    // the mask a wave is expanding
+    __shared__ uint16_t segd[DEDUP_MAX_SEGS];
+    __shared__ uint32_t wstart[MAX_CHUNKS + 1];
+    __shared__ uint32_t mstage[4][32];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const uint32_t item = p.work[blockIdx.x];
@@ -2164,9 +2333,11 @@ __global__ __launch_bounds__(256) void pattern_rows_kernel(PatRowsParams p) {
     const uint64_t obase = p.cluster_kmer_off[c] - p.out_base;
     const uint32_t* cb = p.chunkbits + (size_t)slice * W * NS;
     const uint32_t* cm = p.chunkmask + slice * 8;
-    const uint32_t mode = p.v_mode[c];
+    const uint32_t mode = p.v_mode[c] & 3u;
     const uint32_t ns = p.item_nslots[item];
     const bool expand = mode == 1 && !p.item_is_extra[item];
+    const bool wide = mode == 2 && !p.item_is_extra[item];
+    const uint32_t nmw = (p.v_nstr[c] + 31) >> 5;
     const uint32_t Wp = (W + 3) & ~3u;
     const uint32_t* M = p.mrows + (size_t)slice * DEDUP_MROWS;
     const uint32_t* sout = p.slot_out + (size_t)slice * NS;
@@ -2193,7 +2364,15 @@ __global__ __launch_bounds__(256) void pattern_rows_kernel(PatRowsParams p) {
         }
         return nn;
     };
-    const uint32_t total = mode == 0 ? U : ns;
+    if (wide) {
+        const uint32_t s0 = p.cluster_seg_off[c], s1 = p.cluster_seg_off[c + 1];
+        for (uint32_t s = tid; s < s1 - s0; s += blockDim.x)
+            segd[s] = (uint16_t)((p.seg_distinct[s0 + s] << 5) | (p.seg_sample[s0 + s] & 31u));
+        for (uint32_t w = tid; w <= nchunks; w += blockDim.x)
+            wstart[w] = seg_lower_bound(p.seg_sample, s0, s1, w << 5) - s0;
+        __syncthreads();
+    }
+    const uint32_t total = mode != 1 ? U : ns;
     const uint32_t stride = blockDim.x;
     const uint32_t rounds_total = (total + stride - 1) / stride;
     uint32_t round = 0;
@@ -2205,7 +2384,7 @@ __global__ __launch_bounds__(256) void pattern_rows_kernel(PatRowsParams p) {
             const uint32_t i = round * stride + tid;
             uint32_t slot = 0xFFFFFFFFu, kept_before = 0;
             if (i < total) {
-                if (mode == 0) {
+                if (mode != 1) {
                     const uint32_t kb = kp[i];
                     if (kp[i + 1] != kb) {
                         const uint64_t pr = sp[i];
@@ -2245,10 +2424,21 @@ __global__ __launch_bounds__(256) void pattern_rows_kernel(PatRowsParams p) {
                 const bool f0 = (cm[0] & 1) != 0, f1 = (cm[0] & 2) != 0;
                 amask = (f0 ? (uint64_t)cb[slot] : 0) | (f1 ? (uint64_t)cb[(size_t)NS + slot] << 32 : 0);
             }
+            if (wide) {
+                __builtin_amdgcn_wave_barrier();
+                if (lane < nmw) mstage[wave][lane] = ((cm[lane >> 5] >> (lane & 31)) & 1) ? cb[(size_t)lane * NS + slot] : 0u;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
             for (uint32_t w = lane; w < W; w += 64) {
                 uint32_t v = 0;
                 if (w < nchunks) {
-                    if (expand) {
+                    if (wide) {
+                        for (uint32_t q = wstart[w], qe = wstart[w + 1]; q < qe; q++) {
+                            const uint32_t e = segd[q], d = e >> 5;
+                            v |= ((mstage[wave][d >> 5] >> (d & 31u)) & 1u) << (e & 31u);
+                        }
+                    } else if (expand) {
                         uint64_t t = amask;
                         while (t) {
                             const uint32_t d = __ffsll((unsigned long long)t) - 1;
@@ -2532,11 +2722,14 @@ __global__ __launch_bounds__(256) void merge_lookup_kernel(MergeParams p) {
 // instances / packed words the scan will actually visit (the view); one wave per cluster
 __global__ __launch_bounds__(256) void cluster_ninst_kernel(const uint32_t* cluster_seg_off, const uint32_t* seg_len,
                                                             const uint32_t* v_len, const uint32_t* v_nseg, uint32_t k,
-                                                            uint32_t c_first, uint32_t c_end, uint64_t* cluster_ninst,
+                                                            uint32_t c_first, uint32_t c_end, const uint32_t* list,
+                                                            uint64_t* cluster_ninst,
                                                             uint64_t* cluster_vinst, uint64_t* cluster_vwords) {
+    // clusters c_first .. c_end - 1, or (list) list[c_first .. c_end - 1]
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t c = c_first + ((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    if (c >= c_end) return;
+    const uint32_t idx = c_first + ((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (idx >= c_end) return;
+    const uint32_t c = list ? list[idx] : idx;
     const uint32_t s0 = cluster_seg_off[c], s1 = cluster_seg_off[c + 1], sv = s0 + v_nseg[c];
     uint64_t n = 0, nv = 0, wv = 0;
     for (uint32_t s = s0 + lane; s < s1; s += 64) {

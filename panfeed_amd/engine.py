@@ -25,6 +25,14 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
 
 
+def _take(ptr, n):
+    """n bytes at `ptr` as `bytes` (ctypes.string_at takes a C int: texts beyond 2 GiB need this)"""
+    p = ptr.value if isinstance(ptr, C.c_void_p) else ptr
+    if not n:
+        return b""
+    return bytes(memoryview((C.c_char * int(n)).from_address(p)))
+
+
 def _view(ptr, n, dtype):
     if n == 0:
         return np.zeros(0, dtype=dtype)
@@ -258,7 +266,7 @@ class Engine:
         buf, nb = C.c_void_p(), C.c_uint64()
         ends = (C.c_uint64 * max(C_, 1))()
         _lib.check(self.L.pf_render_kmers_to_hashes(self.ctx, names, extra, C.byref(buf), C.byref(nb), ends))
-        kh_bytes = C.string_at(buf, nb.value)
+        kh_bytes = _take(buf, nb.value)
         self.L.pf_free_text(buf)
         kh_all = kh_bytes.decode()
         kh_parts = []
@@ -282,7 +290,7 @@ class Engine:
         else:
             buf, nb = C.c_void_p(), C.c_uint64()
             _lib.check(self.L.pf_render_hashes_to_patterns(self.ctx, C.byref(buf), C.byref(nb)))
-            hp_all = C.string_at(buf, nb.value).decode()
+            hp_all = _take(buf, nb.value).decode()
             self.L.pf_free_text(buf)
         # kmers.tsv body (panfeed.py:90-107): one row per window of the target strains' sequences
         kt_by_cluster = [[] for _ in range(C_)]
@@ -347,9 +355,9 @@ class Engine:
             txt, nb = C.c_void_p(), C.c_uint64()
             _lib.check(self.L.pf_render_pattern_rows(self.ctx, part.ctypes.data_as(C.c_void_p), len(part),
                                                      C.byref(txt), C.byref(nb)))
-            yield C.string_at(txt, nb.value)
+            yield _take(txt, nb.value)
 
-    def _render_targets(self, hb, metas):
+    def _render_targets(self, hb, metas, as_bytes=False):
         """kmers.tsv rows of `metas` (packing.SeqMeta, in order) through pf_render_kmers_tsv"""
         n = len(metas)
         arr = (_lib.TargetSeq * n)()
@@ -375,7 +383,7 @@ class Engine:
         buf, nb = C.c_void_p(), C.c_uint64()
         sso = hb.seg_strand_off.ctypes.data_as(C.c_void_p) if hb.n_strand_words else None
         _lib.check(self.L.pf_render_kmers_tsv(self.ctx, arr, n, sso, C.byref(buf), C.byref(nb)))
-        text = C.string_at(buf, nb.value).decode()
+        text = _take(buf, nb.value)
         self.L.pf_free_text(buf)
         del keep
-        return text
+        return text if as_bytes else text.decode()

@@ -38,7 +38,7 @@ class ParallelGzipWriter:
         out, n = C.c_void_p(), C.c_uint64()
         _lib.check(self.L.pf_gzip_members(data, len(data), self.level, self.chunk_bytes, C.byref(out), C.byref(n)))
         try:
-            self.fh.write(C.string_at(out, n.value))
+            self.fh.write(memoryview((C.c_char * n.value).from_address(out.value)) if n.value else b"")
         finally:
             self.L.pf_free_text(out)
         self.wrote = True

@@ -435,6 +435,114 @@ def test_config1_scale_properties(S, n, flank, k, head):
     eng.close()
 
 
+def _allele_cluster(rng, idx, names, D, L, sub=0.02, flank=0, paralogs=0, n_every=0, absent=()):
+    """one cluster whose present samples carry exactly D distinct sequences (allele d = ancestral + its own
+    substitutions + its own flanks), round-robin so that every allele has copies"""
+    from panfeed_amd.classes import Seqinfo
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    anc = rng.integers(0, 4, L)
+    alleles = []
+    seen = set()
+    for d in range(D):
+        while True:
+            a = anc.copy()
+            if d:
+                m = rng.random(L) < sub
+                m[int(rng.integers(0, L))] = True           # at least one substitution
+                a[m] = (a[m] + rng.integers(1, 4, int(m.sum()))) & 3
+            if flank:
+                a = np.concatenate([rng.integers(0, 4, flank), a, rng.integers(0, 4, flank)])
+            b = acgt[a].tobytes()
+            if b not in seen:
+                break
+        seen.add(b)
+        alleles.append(b)
+    assert len(set(alleles)) == D
+    gs, presab = {}, np.zeros(len(names), dtype=np.int64)
+    col = {x: i for i, x in enumerate(sorted(names))}
+    q = 0
+    order = [nm for nm in names if nm not in absent]
+    for i, nm in enumerate(order):
+        seqs = [alleles[i % D]]
+        if paralogs and i % paralogs == 1:
+            seqs.append(alleles[(i * 7 + 3) % D])
+        lst = []
+        for j, sq in enumerate(seqs):
+            if n_every and q % n_every == 5:
+                pos = int(rng.integers(0, len(sq)))
+                sq = sq[:pos] + b"N" + sq[pos + 1:]
+            q += 1
+            lst.append(Seqinfo(sq.decode(), sq.translate(comp).decode(), f"{nm}_{idx}_{j}", f"{nm}_c", 100 + 3 * i,
+                               100 + 3 * i + len(sq) - 1, 1 if i % 3 else -1, flank))
+        gs[nm] = lst
+        presab[col[nm]] = 1
+    for nm in sorted(absent):
+        gs[nm] = []
+    return gs, idx, presab
+
+
+@pytest.mark.parametrize("D,S,L,k,canon,kw", [
+    (64, 200, 260, 31, True, {}),                                   # the last size of the small class
+    (65, 200, 260, 31, True, {}),                                   # one more: the wide class
+    (65, 200, 260, 31, True, {"paralogs": 9, "n_every": 40}),       # + paralogs of other alleles, slow-path rows
+    (200, 600, 300, 31, True, {"paralogs": 11}),
+    (200, 600, 300, 51, False, {"flank": 30}),                      # two-word keys, both strands, key partitions
+    (300, 1000, 150, 21, True, {"absent": 37}),                     # 32-word rows; some samples without the cluster
+    (1024, 2100, 90, 15, True, {}),                                 # the largest wide cluster
+    (1025, 2100, 90, 15, True, {}),                                 # one too many: every copy is scanned
+], ids=["D64", "D65", "D65_paralogs_N", "D200", "D200_k51_noncanon", "D300_1000s", "D1024", "D1025"])
+@pytest.mark.parametrize("missing", [False, True], ids=["", "consider_missing"])
+def test_many_distinct_sequences_vs_oracle(D, S, L, k, canon, kw, missing):
+    """clusters with more distinct sequences than the 64 an allele-mask pair of words holds: representatives are
+    still scanned once each (wide dedup class, rows gathered through the segment list, ranks by sorting) and the
+    files are the oracle's"""
+    from panfeed_amd.engine import Engine
+    if missing and (D not in (65, 300) or kw.get("n_every")):
+        pytest.skip("consider_missing: two shapes are enough")
+    rng = np.random.default_rng(D * 7 + S)
+    names = [f"w{i:04d}" for i in range(S)]
+    kw = dict(kw)
+    nabs = kw.pop("absent", 0)
+    recs = []
+    for ci in range(3):
+        absent = set(names[5::max(2, S // nabs)][:nabs]) if nabs and ci != 1 else ()
+        recs.append(_allele_cluster(rng, f"grp{ci}", names, D if ci < 2 else max(3, D // 9), L, absent=absent, **kw))
+    stroi = {names[2], names[S - 3]}
+    eng = Engine(klength=k, canon=canon, consider_missing=missing, max_strains=(S + 31) // 32 * 32, stroi=stroi)
+    out = eng.run(recs)
+    tm = out.timing
+    third = max(3, D // 9)
+    assert tm["n_wide_clusters"] == sum(1 for x in (D, D, third) if x > 64)     # clusters the wide class was tried on
+    assert tm["n_dedup_clusters"] == (3 if D <= 1024 else 1)
+    (ek, ekh, ehp), st = _oracle_texts(recs, stroi=stroi, klength=k, canon=canon, consider_missing=missing)
+    assert out.kmers_to_hashes == ekh
+    assert out.hashes_to_patterns == ehp
+    assert out.kmers_tsv == ek
+    eng.close()
+    # the same through the no-dedup path
+    eng = Engine(klength=k, canon=canon, consider_missing=missing, max_strains=(S + 31) // 32 * 32, stroi=stroi, dedup=False)
+    out2 = eng.run(recs)
+    assert (out2.kmers_to_hashes, out2.hashes_to_patterns) == (ekh, ehp)
+    eng.close()
+
+
+def test_wide_dedup_with_5000_samples():
+    """configs[4] shape: at 5 000 samples the sample-set matrix only fits 25 distinct sequences: clusters with more
+    go through the wide class instead of scanning all 5 000 copies"""
+    from panfeed_amd.engine import Engine
+    rng = np.random.default_rng(99)
+    S = 5000
+    names = [f"v{i:04d}" for i in range(S)]
+    recs = [_allele_cluster(rng, f"big{ci}", names, D, 400, paralogs=50) for ci, D in enumerate((40, 12, 90))]
+    eng = Engine(klength=21, max_strains=(S + 31) // 32 * 32)
+    out = eng.run(recs)
+    assert out.timing["n_dedup_clusters"] == 3 and out.timing["n_wide_clusters"] == 2
+    (ek, ekh, ehp), st = _oracle_texts(recs, klength=21)
+    assert out.kmers_to_hashes == ekh and out.hashes_to_patterns == ehp
+    eng.close()
+
+
 def test_pattern_table_grows_instead_of_failing():
     """the reference's `patterns` is an unbounded set (panfeed.py:146-150): a table that starts far too small is
     enlarged and the batch re-run -- in the middle of a run too, with the earlier batches' patterns kept -- and the
@@ -444,7 +552,7 @@ def test_pattern_table_grows_instead_of_failing():
     cl = synth.generate(150, 40, first=5, mean_len=200, min_len=60, max_len=500, n_rate=0.0)
     recs = [c.record() for c in cl]
     (ek, ekh, ehp), st = _oracle_texts(recs, klength=21)
-    assert st["patterns"] > 2048
+    assert st["patterns"] > 1024
     eng = Engine(klength=21, max_strains=64, pattern_capacity=1024)      # pool of 512 patterns
     out = eng.run(recs)
     assert out.kmers_to_hashes == ekh and out.hashes_to_patterns == ehp
