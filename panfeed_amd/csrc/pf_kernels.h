@@ -186,8 +186,8 @@ __device__ __forceinline__ void table_update(uint64_t* keys, uint32_t* ord, uint
                                              const Key<KW>& key, uint32_t home, uint32_t myord, uint32_t bit) {
     uint32_t slot = home;
     bool inserted = false;
-    while (active) {
-        if (KW == 1) {
+    if (KW == 1) {
+        while (active) {
             // two-slot buckets: `home` is a bucket index (ns / 2 buckets), both keys come with one 128-bit read,
             // a new key takes the first empty slot of the first bucket that has one.  Half the probe steps of
             // slot-by-slot probing -- the loop runs as long as the slowest of the 64 lanes.
@@ -204,26 +204,32 @@ __device__ __forceinline__ void table_update(uint64_t* keys, uint32_t* ord, uint
                 continue;                                   // the bucket changed under us: look at it again
             }
             slot = slot + 1 == (ns >> 1) ? 0 : slot + 1;
-        } else {
-            // word 0 is claimed by CAS, word 1 published right after; a reader that sees word 0 match but
-            // word 1 still EMPTY re-reads the same slot on its next iteration.
-            uint64_t cur = __hip_atomic_load(&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            bool claimed = false;
-            if (cur == EMPTY64) {
-                cur = atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)EMPTY64,
-                                (unsigned long long)key.w[0]);
+        }
+    } else {
+        // word 0 is claimed by CAS, word 1 published right after.  A lane that sees word 0 match while word 1 is
+        // still EMPTY leaves the probe loop and looks again in the next round of the outer, WAVE-UNIFORM loop: the
+        // claimer -- possibly a lane of this wave -- is never waited for inside divergent code.
+        bool todo = active;
+        for (;;) {
+            while (todo) {
+                uint64_t cur = __hip_atomic_load(&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (cur == EMPTY64) {
-                    __hip_atomic_store(&keys[NS + slot], key.w[KW - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    inserted = true; claimed = true;
+                    cur = atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)EMPTY64,
+                                    (unsigned long long)key.w[0]);
+                    if (cur == EMPTY64) {
+                        __hip_atomic_store(&keys[NS + slot], key.w[KW - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        inserted = true; todo = false;
+                        break;
+                    }
                 }
+                if (cur == key.w[0]) {
+                    const uint64_t c1 = __hip_atomic_load(&keys[NS + slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (c1 == key.w[KW - 1]) { todo = false; break; }
+                    if (c1 == EMPTY64) break;              // not published yet: same slot again next round
+                }
+                slot = slot + 1 == ns ? 0 : slot + 1;
             }
-            if (claimed) break;
-            if (cur == key.w[0]) {
-                uint64_t c1 = __hip_atomic_load(&keys[NS + slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (c1 == key.w[KW - 1]) break;
-                if (c1 == EMPTY64) continue;   // not published yet: look again
-            }
-            slot = slot + 1 == ns ? 0 : slot + 1;
+            if (!__any(todo)) break;
         }
     }
     if (active) {
@@ -1600,12 +1606,12 @@ __device__ __forceinline__ uint32_t pair_lower_bound(const uint64_t* sp, uint32_
 }
 
 constexpr uint32_t EMIT_THREADS = 1024;
-constexpr uint32_t LT_SLOTS = 4096;      // per-cluster pattern table in LDS (mode 1)
+constexpr uint32_t LT_SLOTS = 4096;      // per-item pattern table in LDS
 constexpr uint32_t LT_LIMIT = 3072;
 
 __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
-    // mode 1: the cluster's patterns are first deduplicated in LDS so that the run-global table sees one
-    // insert per distinct pattern of the cluster instead of one per k-mer
+    // The item's patterns are first deduplicated in LDS (identity: the 128-bit row hash) so that the run-global
+    // table sees one insert per distinct pattern of the item instead of one per k-mer.
     __shared__ uint64_t lt_lo[LT_SLOTS];
     __shared__ uint64_t lt_hi[LT_SLOTS];
     __shared__ uint64_t lt_first[LT_SLOTS];
@@ -1623,6 +1629,8 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
     const uint64_t ordinal = p.cluster_ordinal[c];
     const uint64_t obase = p.cluster_kmer_off[c] - p.out_base;
     const uint32_t mode = p.v_mode[c] & 3u;
+    const bool sorted = mode != 1;           // modes 0 and 2: the item's k-mers sorted by ordinal (rows_kernel);
+                                             // mode 1: ordinal bitmaps
 
     if (item == sib0 && tid == 0) {
         // the cluster's own row: md5 of the int64 image of clusterpresab (panfeed.py:175-187)
@@ -1643,71 +1651,82 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
         p.cluster_first[c] = fs;
     }
 
-    if (mode != 1) {
-        // modes 0 and 2: the items' k-mers are sorted by ordinal (rows_kernel); ranks by binary search in the siblings
-        const uint64_t* sp = p.sorted_pair + (size_t)slice * NS;
-        const uint32_t* kp = p.kept_prefix + (size_t)slice * (NS + 1);
-        for (uint32_t r = tid; r < U; r += EMIT_THREADS) {
-            const uint32_t kb = kp[r];
-            const bool keep = kp[r + 1] != kb;
-            const uint64_t pr = sp[r];
-            const uint32_t ord = (uint32_t)(pr >> 32), slot = (uint32_t)pr;
-            uint32_t rank = r, kept_before = kb;
-            for (uint32_t q = 0; q < nsib; q++) {
-                const uint32_t it = sib0 + q;
-                if (it == item) continue;
-                const uint32_t sl = p.item_scratch[it];
-                const uint32_t n = p.item_unique[it];
-                const uint32_t lb = pair_lower_bound(p.sorted_pair + (size_t)sl * NS, n, ord);
-                rank += lb;
-                kept_before += p.kept_prefix[(size_t)sl * (NS + 1) + lb];
-            }
-            if (!keep) continue;
-            const uint64_t fs = (ordinal << 32) | (uint64_t)(rank + 1);
-            const uint4 h = p.slot_hash[(size_t)slice * NS + slot];
-            const uint32_t pid = pattern_insert(p.pt, h, fs);
-            const uint64_t o = obase + kept_before;
-            if (o >= p.out_cap) { p.pt.counters[2] = 1; continue; }   // cannot happen: the arena holds every item's limit
-            p.out_key[o * KW] = p.tab_key[((size_t)slice * KW) * NS + slot];
-            if (KW == 2) p.out_key[o * KW + 1] = p.tab_key[((size_t)slice * KW + 1) * NS + slot];
-            p.out_pid[o] = pid;
-            p.out_first[o] = fs;
-        }
-        return;
-    }
-
-    // ---------------- mode 1: ranks from the ordinal bitmaps of the cluster's items
     const uint32_t ns = p.item_nslots[item];
     const uint32_t dense_words = (p.v_dense[c] + 31) >> 5;
     const uint32_t* ordp = p.tab_ord + (size_t)slice * NS;
     const size_t gb = (size_t)slice * DENSE_WORDS;
-    uint32_t* sout = p.slot_out + (size_t)slice * NS;
+    const uint64_t* sp = p.sorted_pair + (size_t)slice * NS;
+    const uint32_t* kp = p.kept_prefix + (size_t)slice * (NS + 1);
+    uint32_t* sout = p.slot_out + (size_t)slice * NS;    // per entry (slot / sorted position): index of its k-mer in
+                                                         // the cluster's output, NONE when it is not kept
+    const uint32_t n_entries = sorted ? U : ns;
     for (uint32_t i = tid; i < LT_SLOTS; i += EMIT_THREADS) { lt_lo[i] = EMPTY64; lt_hi[i] = EMPTY64; lt_first[i] = EMPTY64; }
     if (tid == 0) lt_count = 0;
     __syncthreads();
-    // pass 1: rank, output index, cluster-local pattern table
-    for (uint32_t i = tid; i < ns; i += EMIT_THREADS) {
-        const uint32_t o = ordp[i];
-        uint32_t res = 0xFFFFFFFFu;
-        if (o != NO_ORD && (o >> 5) < dense_words) {
-            const uint32_t w = o >> 5, below = (1u << (o & 31)) - 1;
-            if ((p.bm_keep[gb + w] >> (o & 31)) & 1) {
-                uint32_t rank = 0, kept_before = 0;
-                for (uint32_t q = 0; q < nsib; q++) {
-                    const size_t g2 = (size_t)p.item_scratch[sib0 + q] * DENSE_WORDS + w;
-                    rank += p.pre_occ[g2] + __popc(p.bm_occ[g2] & below);
-                    kept_before += p.pre_keep[g2] + __popc(p.bm_keep[g2] & below);
+    auto row_id = [&](uint32_t slot, uint64_t& lo, uint64_t& hi) {
+        const uint4 h = p.slot_hash[(size_t)slice * NS + slot];
+        lo = ((uint64_t)h.x << 32) | h.y; hi = ((uint64_t)h.z << 32) | h.w;
+        if (lo == EMPTY64) lo--;
+        if (hi == EMPTY64) hi--;
+    };
+    // pass 1: rank, output index, item-local pattern table
+    for (uint32_t i0 = 0; i0 < n_entries; i0 += EMIT_THREADS) {
+        const uint32_t i = i0 + tid;
+        uint32_t res = 0xFFFFFFFFu, slot = 0;
+        uint64_t fs = 0;
+        if (i < n_entries) {
+            if (sorted) {
+                const uint32_t kb = kp[i];
+                if (kp[i + 1] != kb) {
+                    const uint64_t pr = sp[i];
+                    const uint32_t ord = (uint32_t)(pr >> 32);
+                    slot = (uint32_t)pr;
+                    uint32_t rank = i, kept_before = kb;
+                    for (uint32_t q = 0; q < nsib; q++) {
+                        const uint32_t it = sib0 + q;
+                        if (it == item) continue;
+                        const uint32_t sl = p.item_scratch[it];
+                        const uint32_t lb = pair_lower_bound(p.sorted_pair + (size_t)sl * NS, p.item_unique[it], ord);
+                        rank += lb;
+                        kept_before += p.kept_prefix[(size_t)sl * (NS + 1) + lb];
+                    }
+                    res = kept_before;
+                    fs = (ordinal << 32) | (uint64_t)(rank + 1);
                 }
-                res = kept_before;
-                const uint64_t fs = (ordinal << 32) | (uint64_t)(rank + 1);
-                const uint64_t o_idx = obase + kept_before;
-                if (o_idx < p.out_cap) p.out_first[o_idx] = fs;
-                const uint4 h = p.slot_hash[(size_t)slice * NS + i];
-                uint64_t lo = ((uint64_t)h.x << 32) | h.y, hi = ((uint64_t)h.z << 32) | h.w;
-                if (lo == EMPTY64) lo--;
-                if (hi == EMPTY64) hi--;
-                uint32_t ls = (uint32_t)(lo ^ (hi >> 7)) & (LT_SLOTS - 1);
-                for (uint32_t probes = 0; probes < LT_SLOTS; ) {
+            } else {
+                const uint32_t o = ordp[i];
+                slot = i;
+                if (o != NO_ORD && (o >> 5) < dense_words) {
+                    const uint32_t w = o >> 5, below = (1u << (o & 31)) - 1;
+                    if ((p.bm_keep[gb + w] >> (o & 31)) & 1) {
+                        uint32_t rank = 0, kept_before = 0;
+                        for (uint32_t q = 0; q < nsib; q++) {
+                            const size_t g2 = (size_t)p.item_scratch[sib0 + q] * DENSE_WORDS + w;
+                            rank += p.pre_occ[g2] + __popc(p.bm_occ[g2] & below);
+                            kept_before += p.pre_keep[g2] + __popc(p.bm_keep[g2] & below);
+                        }
+                        res = kept_before;
+                        fs = (ordinal << 32) | (uint64_t)(rank + 1);
+                    }
+                }
+            }
+            sout[i] = res;
+        }
+        // local table: find or claim; an entry whose second word is not published yet is looked at again in the next
+        // round of a WAVE-UNIFORM loop (no lane ever spins inside divergent code)
+        int st = res != 0xFFFFFFFFu ? 2 : 0;
+        uint64_t lo = 0, hi = 0;
+        uint32_t ls = 0;
+        if (st == 2) {
+            const uint64_t o_idx = obase + res;
+            if (o_idx < p.out_cap) p.out_first[o_idx] = fs;
+            row_id(slot, lo, hi);
+            ls = (uint32_t)(lo ^ (hi >> 7)) & (LT_SLOTS - 1);
+        }
+        for (;;) {
+            if (st == 2) {
+                st = 3;                                       // table full: straight to the run-global table in pass 3
+                for (uint32_t probes = 0; probes < LT_SLOTS; probes++) {
                     uint64_t cur = __hip_atomic_load(&lt_lo[ls], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (cur == EMPTY64) {
                         if (__hip_atomic_load(&lt_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= LT_LIMIT) break;
@@ -1715,41 +1734,39 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
                         if (cur == EMPTY64) {
                             __hip_atomic_store(&lt_hi[ls], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             atomicAdd(&lt_count, 1u);
-                            atomicMin((unsigned long long*)&lt_first[ls], (unsigned long long)fs);
+                            st = 1;
                             break;
                         }
                     }
                     if (cur == lo) {
                         const uint64_t h2 = __hip_atomic_load(&lt_hi[ls], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (h2 == EMPTY64) continue;          // claimed, not yet published: look again
-                        if (h2 == hi) { atomicMin((unsigned long long*)&lt_first[ls], (unsigned long long)fs); break; }
+                        if (h2 == EMPTY64) { st = 2; break; }      // claimed, not yet published
+                        if (h2 == hi) { st = 1; break; }
                     }
                     ls = (ls + 1) & (LT_SLOTS - 1);
-                    probes++;
                 }
             }
+            if (!__any(st == 2)) break;
         }
-        sout[i] = res;
+        if (st == 1) atomicMin((unsigned long long*)&lt_first[ls], (unsigned long long)fs);
     }
     __syncthreads();
     // pass 2: one insert into the run-global table per distinct pattern of this item
-    for (uint32_t t = tid; t < LT_SLOTS; t += EMIT_THREADS) {
+    for (uint32_t t0 = 0; t0 < LT_SLOTS; t0 += EMIT_THREADS) {
+        const uint32_t t = t0 + tid;
         const uint64_t lo = lt_lo[t];
-        if (lo == EMPTY64) continue;
-        const uint64_t hi = lt_hi[t];
-        lt_pid[t] = pattern_insert(p.pt, lo, (uint32_t)(hi >> 32), lt_first[t]);
+        if (lo != EMPTY64) lt_pid[t] = pattern_insert(p.pt, lo, (uint32_t)(lt_hi[t] >> 32), lt_first[t]);
     }
     __syncthreads();
     // pass 3: pattern id per kept k-mer, outputs
-    for (uint32_t i = tid; i < ns; i += EMIT_THREADS) {
+    for (uint32_t i = tid; i < n_entries; i += EMIT_THREADS) {
         const uint32_t kb = sout[i];
         if (kb == 0xFFFFFFFFu) continue;
         const uint64_t o_idx = obase + kb;
-        if (o_idx >= p.out_cap) { p.pt.counters[2] = 1; continue; }
-        const uint4 h = p.slot_hash[(size_t)slice * NS + i];
-        uint64_t lo = ((uint64_t)h.x << 32) | h.y, hi = ((uint64_t)h.z << 32) | h.w;
-        if (lo == EMPTY64) lo--;
-        if (hi == EMPTY64) hi--;
+        if (o_idx >= p.out_cap) { p.pt.counters[2] = 1; continue; }   // cannot happen: the arena holds every item's limit
+        const uint32_t slot = sorted ? (uint32_t)sp[i] : i;
+        uint64_t lo, hi;
+        row_id(slot, lo, hi);
         uint32_t ls = (uint32_t)(lo ^ (hi >> 7)) & (LT_SLOTS - 1);
         uint32_t pid = 0xFFFFFFFFu;
         bool found = false;
@@ -1761,8 +1778,8 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
         }
         // not in the local table (it was full): straight to the run-global table
         if (!found) pid = pattern_insert(p.pt, lo, (uint32_t)(hi >> 32), p.out_first[o_idx]);
-        p.out_key[o_idx * KW] = p.tab_key[((size_t)slice * KW) * NS + i];
-        if (KW == 2) p.out_key[o_idx * KW + 1] = p.tab_key[((size_t)slice * KW + 1) * NS + i];
+        p.out_key[o_idx * KW] = p.tab_key[((size_t)slice * KW) * NS + slot];
+        if (KW == 2) p.out_key[o_idx * KW + 1] = p.tab_key[((size_t)slice * KW + 1) * NS + slot];
         p.out_pid[o_idx] = pid;
     }
 }
@@ -2326,7 +2343,7 @@ __global__ __launch_bounds__(256) void pattern_rows_kernel(PatRowsParams p) {
     const uint32_t slice = p.item_scratch[item];
     const uint32_t NS = p.NS, W = p.W;
     const uint32_t U = p.item_unique[item];
-    const uint32_t sib0 = p.item_sib0[item], nsib = p.item_nsib[item];
+    const uint32_t sib0 = p.item_sib0[item];
     const uint32_t nstr = p.cluster_nstrains[c];
     const uint32_t nchunks = (nstr + 31) >> 5;
     const uint32_t* presab = p.cluster_presab + (size_t)c * W;
@@ -2342,7 +2359,6 @@ __global__ __launch_bounds__(256) void pattern_rows_kernel(PatRowsParams p) {
     const uint32_t* M = p.mrows + (size_t)slice * DEDUP_MROWS;
     const uint32_t* sout = p.slot_out + (size_t)slice * NS;
     const uint64_t* sp = p.sorted_pair + (size_t)slice * NS;
-    const uint32_t* kp = p.kept_prefix + (size_t)slice * (NS + 1);
 
     if (item == sib0 && tid == 0) {
         const uint32_t pid = p.cluster_pattern[c];
@@ -2384,25 +2400,9 @@ __global__ __launch_bounds__(256) void pattern_rows_kernel(PatRowsParams p) {
             const uint32_t i = round * stride + tid;
             uint32_t slot = 0xFFFFFFFFu, kept_before = 0;
             if (i < total) {
-                if (mode != 1) {
-                    const uint32_t kb = kp[i];
-                    if (kp[i + 1] != kb) {
-                        const uint64_t pr = sp[i];
-                        const uint32_t ord = (uint32_t)(pr >> 32);
-                        slot = (uint32_t)pr;
-                        kept_before = kb;
-                        for (uint32_t q = 0; q < nsib; q++) {
-                            const uint32_t it = sib0 + q;
-                            if (it == item) continue;
-                            const uint32_t sl = p.item_scratch[it];
-                            const uint32_t lb = pair_lower_bound(p.sorted_pair + (size_t)sl * NS, p.item_unique[it], ord);
-                            kept_before += p.kept_prefix[(size_t)sl * (NS + 1) + lb];
-                        }
-                    }
-                } else {
-                    const uint32_t kb = sout[i];
-                    if (kb != 0xFFFFFFFFu) { slot = i; kept_before = kb; }
-                }
+                // emit_kernel left the output index of every kept entry (sorted position / slot)
+                const uint32_t kb = sout[i];
+                if (kb != 0xFFFFFFFFu) { slot = mode != 1 ? (uint32_t)sp[i] : i; kept_before = kb; }
             }
             if (slot != 0xFFFFFFFFu) {
                 const uint64_t o = obase + kept_before;
@@ -2672,27 +2672,37 @@ __device__ __forceinline__ uint64_t merge_slot(const MergeParams& p, uint64_t lo
     // md5 words are already uniform; keep EMPTY64 out of the key space
     if (lo == EMPTY64) lo = EMPTY64 - 1;
     if (hi == EMPTY64) hi = EMPTY64 - 1;
-    uint64_t slot = (lo ^ (hi >> 17)) & (p.cap - 1);
-    for (uint64_t probes = 0; probes < p.cap; ) {
-        uint64_t cur = __hip_atomic_load(&p.t_lo[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cur == EMPTY64) {
-            if (!insert) return EMPTY64;
-            cur = atomicCAS((unsigned long long*)&p.t_lo[slot], (unsigned long long)EMPTY64, (unsigned long long)lo);
-            if (cur == EMPTY64) {
-                __hip_atomic_store(&p.t_hi[slot], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ++*claimed;
-                return slot;
+    uint64_t slot = (lo ^ (hi >> 17)) & (p.cap - 1), res = EMPTY64;
+    // an entry whose second word is not published yet is looked at again in the next round of the outer, wave-uniform
+    // loop: no lane spins inside divergent code on a value another lane of its wave may have to publish
+    int st = 2;
+    for (;;) {
+        if (st == 2) {
+            st = 0;
+            for (uint64_t probes = 0; probes < p.cap; probes++) {
+                uint64_t cur = __hip_atomic_load(&p.t_lo[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cur == EMPTY64) {
+                    if (!insert) break;
+                    cur = atomicCAS((unsigned long long*)&p.t_lo[slot], (unsigned long long)EMPTY64, (unsigned long long)lo);
+                    if (cur == EMPTY64) {
+                        __hip_atomic_store(&p.t_hi[slot], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ++*claimed;
+                        res = slot;
+                        break;
+                    }
+                }
+                if (cur == lo) {
+                    const uint64_t h = __hip_atomic_load(&p.t_hi[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (h == EMPTY64) { st = 2; break; }            // claimed, not yet published
+                    if (h == hi) { res = slot; break; }
+                }
+                slot = (slot + 1) & (p.cap - 1);
             }
         }
-        if (cur == lo) {
-            const uint64_t h = __hip_atomic_load(&p.t_hi[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (h == EMPTY64) continue;                 // claimed, not yet published: look again
-            if (h == hi) return slot;
-        }
-        slot = (slot + 1) & (p.cap - 1);
-        probes++;
+        if (!__any(st == 2)) break;
+        __builtin_amdgcn_s_sleep(1);
     }
-    return EMPTY64;
+    return res;
 }
 __global__ __launch_bounds__(256) void merge_insert_kernel(MergeParams p) {
     uint32_t claimed = 0;      // distinct digests this thread was first to insert
