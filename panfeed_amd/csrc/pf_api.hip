@@ -136,7 +136,10 @@ struct pf_ctx {
     void* pin_dedup = nullptr;     // pinned host copies of the per-cluster arrays the dedup kernel leaves
     size_t pin_dedup_cap = 0;
     uint64_t* pin_small = nullptr; // pinned scratch: cursor values going up, cursor read-backs of a deferred pass
-    hipEvent_t ev_half[2] = {nullptr, nullptr};
+    static constexpr int MAX_PARTS = 8;
+    hipEvent_t ev_part[MAX_PARTS] = {};    // a part's dedup results have arrived in pinned memory
+    hipEvent_t ev_stage[2] = {nullptr, nullptr};   // a staging slot's upload has left the pinned block
+
     // last batch bookkeeping
     bool have_batch = false;
     uint32_t n_clusters = 0;
@@ -220,6 +223,9 @@ int staged_upload(pf_ctx* c, std::vector<std::pair<DevBuf*, const std::vector<ui
     DevBuf& stage_dev = c->stage_devs[c->stage_slot];
     void*& stage_pin = c->stage_pins[c->stage_slot];
     size_t& stage_pin_cap = c->stage_pin_caps[c->stage_slot];
+    // several passes are queued without a host sync in between: the copy that last used this slot (two passes ago) has
+    // to have left the pinned block before it is written again
+    HIPCHK(hipEventSynchronize(c->ev_stage[c->stage_slot]));
     PFCHK(stage_dev.ensure(total));
     if (total > stage_pin_cap) {
         if (stage_pin) (void)hipHostFree(stage_pin);
@@ -237,6 +243,7 @@ int staged_upload(pf_ctx* c, std::vector<std::pair<DevBuf*, const std::vector<ui
         arrs[i].first->view = true;
     }
     HIPCHK(hipMemcpyAsync(stage_dev.p, stage_pin, total, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipEventRecord(c->ev_stage[c->stage_slot], c->stream));
     return PF_OK;
 }
 
@@ -404,7 +411,9 @@ void pf_destroy(pf_ctx* c) {
     for (Arena* a : c->arenas) { a->key.release(); a->pid.release(); a->first.release(); delete a; }
     for (auto& e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-    for (int i = 0; i < 2; i++) { if (c->stage_pins[i]) (void)hipHostFree(c->stage_pins[i]); c->stage_devs[i].release(); if (c->ev_half[i]) (void)hipEventDestroy(c->ev_half[i]); }
+    for (int i = 0; i < 2; i++) { if (c->stage_pins[i]) (void)hipHostFree(c->stage_pins[i]); c->stage_devs[i].release(); if (c->ev_stage[i]) (void)hipEventDestroy(c->ev_stage[i]); }
+    for (auto e : c->ev_part) if (e) (void)hipEventDestroy(e);
+
     if (c->pin_dedup) (void)hipHostFree(c->pin_dedup);
     if (c->pin_small) (void)hipHostFree(c->pin_small);
     c->scan_desc.release(); c->pat_b64.release(); c->txt_dev.release(); c->txt_meta.release();
@@ -462,8 +471,11 @@ int pf_create(pf_ctx** out, int device, const pf_opts* o) {
     do {
         hipError_t e = hipStreamCreate(&c->stream);
         if (e != hipSuccess) { rc = fail(PF_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); break; }
-        if (hipEventCreate(&c->ev_half[0]) != hipSuccess || hipEventCreate(&c->ev_half[1]) != hipSuccess ||
-            hipHostMalloc((void**)&c->pin_small, 256, hipHostMallocDefault) != hipSuccess ||
+        bool ev_ok = true;
+        for (auto& ev : c->ev_part) ev_ok = ev_ok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+        for (auto& ev : c->ev_stage) ev_ok = ev_ok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+        if (!ev_ok ||
+            hipHostMalloc((void**)&c->pin_small, 512, hipHostMallocDefault) != hipSuccess ||
             hipEventCreate(&c->ev_t0) != hipSuccess || hipEventCreate(&c->ev_t1) != hipSuccess) {
             rc = fail(PF_ERR_HIP, "hipEventCreate failed"); break;
         }
@@ -736,8 +748,13 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
     uint32_t* h_mode = reinterpret_cast<uint32_t*>(words + C8);
     uint32_t* h_dense = h_mode + C8;
     uint32_t* h_vnstr = h_dense + C8;
-    const bool split = C >= 8192;                  // two halves in flight
-    const uint32_t half_end[2] = {split ? C / 4 : C, C};   // a quarter first: enough GPU work to hide building the rest
+    // A large batch goes through in parts, all queued without a host sync in between: the host builds and launches a
+    // part's work items while the GPU is on earlier parts (otherwise it idles for the ~1.2 ms that takes).  Two parts,
+    // a quarter first: enough GPU work to hide building the rest.  (More, equal parts with the MD5 of part i on a second
+    // stream beside part i + 1's finish kernels or part i + 2's dedup were measured and lose: DESIGN.md section 6.)
+    uint32_t P = C >= 8192 ? 2u : 1u;
+    uint32_t part_end[pf_ctx::MAX_PARTS];
+    for (uint32_t q = 0; q < P; q++) part_end[q] = q + 1 == P ? C : (uint32_t)((uint64_t)C * (q + 1) / (2 * P));
     pf::DedupParams dp{};
     if (C) {
         dp.packed = d.packed; dp.seg_word_off = d.seg_word_off; dp.seg_len = d.seg_len;
@@ -752,29 +769,33 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         dp.extra_dense = c->extra_dense.as<uint32_t>();
         dp.k = c->o.klength; dp.W = W; dp.canon = c->o.canon;
         dp.enable = (c->o.flags & PF_FLAG_NO_DEDUP) ? 0u : 1u;
-        for (int h = 0; h < 2; h++) {
-            const uint32_t c0 = h ? half_end[0] : 0, c1 = half_end[h], n = c1 - c0;
-            if (n) {
-                dp.cluster_base = c0;
-                PFCHK(mark_begin(c, 3));
-                hipLaunchKernelGGL(pf::cluster_dedup_kernel<pf::DedupSmall>, dim3(n), dim3(pf::DEDUP_THREADS), 0, c->stream, dp);
-                HIPCHK(hipGetLastError());
-                PFCHK(mark_end(c));
-                hipLaunchKernelGGL(pf::cluster_ninst_kernel, dim3((n + 3) / 4), dim3(256), 0, c->stream, d.cluster_seg_off,
-                                   d.seg_len, c->v_len.as<uint32_t>(), c->v_nseg.as<uint32_t>(), c->o.klength, c0, c1,
-                                   (const uint32_t*)nullptr,
-                                   c->cl_ninst.as<uint64_t>(), c->cl_vinst.as<uint64_t>(), c->cl_vwords.as<uint64_t>());
-                HIPCHK(hipGetLastError());
-                HIPCHK(hipMemcpyAsync(ninst + c0, c->cl_ninst.as<uint64_t>() + c0, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
-                HIPCHK(hipMemcpyAsync(vinst + c0, c->cl_vinst.as<uint64_t>() + c0, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
-                HIPCHK(hipMemcpyAsync(words + c0, c->cl_vwords.as<uint64_t>() + c0, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
-                HIPCHK(hipMemcpyAsync(h_mode + c0, c->v_mode.as<uint32_t>() + c0, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-                HIPCHK(hipMemcpyAsync(h_dense + c0, c->v_dense.as<uint32_t>() + c0, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-                HIPCHK(hipMemcpyAsync(h_vnstr + c0, c->v_nstr.as<uint32_t>() + c0, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-            }
-            HIPCHK(hipEventRecord(c->ev_half[h], c->stream));
-        }
     }
+    // the dedup of part h and its results on their way to pinned memory (ev_part[h]); all parts are queued up front
+    auto launch_dedup_part = [&](uint32_t h) -> int {
+        const uint32_t c0 = h ? part_end[h - 1] : 0, c1 = part_end[h], n = c1 - c0;
+        if (n) {
+            dp.cluster_base = c0;
+            PFCHK(mark_begin(c, 3));
+            hipLaunchKernelGGL(pf::cluster_dedup_kernel<pf::DedupSmall>, dim3(n), dim3(pf::DEDUP_THREADS), 0, c->stream, dp);
+            HIPCHK(hipGetLastError());
+            PFCHK(mark_end(c));
+            hipLaunchKernelGGL(pf::cluster_ninst_kernel, dim3((n + 3) / 4), dim3(256), 0, c->stream, d.cluster_seg_off,
+                               d.seg_len, c->v_len.as<uint32_t>(), c->v_nseg.as<uint32_t>(), c->o.klength, c0, c1,
+                               (const uint32_t*)nullptr,
+                               c->cl_ninst.as<uint64_t>(), c->cl_vinst.as<uint64_t>(), c->cl_vwords.as<uint64_t>());
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(ninst + c0, c->cl_ninst.as<uint64_t>() + c0, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(vinst + c0, c->cl_vinst.as<uint64_t>() + c0, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(words + c0, c->cl_vwords.as<uint64_t>() + c0, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(h_mode + c0, c->v_mode.as<uint32_t>() + c0, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(h_dense + c0, c->v_dense.as<uint32_t>() + c0, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(h_vnstr + c0, c->v_nstr.as<uint32_t>() + c0, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        }
+        HIPCHK(hipEventRecord(c->ev_part[h], c->stream));
+        return PF_OK;
+    };
+    if (C)
+        for (uint32_t h = 0; h < P; h++) PFCHK(launch_dedup_part(h));
     // ---- strand bits of target-strain segments (canonical mode)
     c->n_strand_words = (b->seg_strand_off && c->o.canon) ? b->n_strand_words : 0;
     if (c->n_strand_words && NSEG) {
@@ -797,9 +818,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
     c->cluster_arena.assign(C, 0);
 
     std::vector<uint32_t> nparts(C, 1);
-    std::vector<uint32_t> todo(half_end[0]), todo_second(C - half_end[0]), todo_first;
-    std::iota(todo.begin(), todo.end(), 0u);
-    std::iota(todo_second.begin(), todo_second.end(), half_end[0]);
+    std::vector<uint32_t> todo;
     // a deduplicated cluster whose distinct sequences alone carry far more windows than one table holds will
     // overflow it: start it with two key partitions instead of paying for a failed first scan (a wrong guess
     // only costs time: an overflow still triggers the doubling retry)
@@ -807,10 +826,10 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
     // contributes all of its windows, every further one the share a 1 % divergence touches (1 - 0.99^k: 27 % of the
     // 31-mers, 40 % of the 51-mers) plus a margin.
     const double share = 1.0 - std::pow(0.99, (double)c->o.klength) + 0.06;
-    // what the host does with a half's dedup results once they have arrived (ev_half[h])
+    // what the host does with a part's dedup results once they have arrived (ev_part[h])
     std::vector<uint32_t> wide_list;
     auto prep_half = [&](int h) -> int {
-        const uint32_t c0 = h ? half_end[0] : 0, c1 = half_end[h];
+        const uint32_t c0 = h ? part_end[h - 1] : 0, c1 = part_end[h];
         // clusters the small dedup class gave up on for lack of room (more than 64 distinct sequences, a sample-set
         // matrix or an ordinal bitmap that does not fit): the wide class on those alone, then their counts again
         wide_list.clear();
@@ -856,19 +875,20 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
     uint32_t pass = 0;
     const uint32_t lim_full = pf::insert_limit(NS);
     uint64_t arena_base = 0;
-    Arena* deferred_ar = nullptr;          // the first half's pass, launched and not yet waited for
-    if (C) {
-        HIPCHK(hipEventSynchronize(c->ev_half[0]));
-        lap("first half's dedup results");
-        PFCHK(prep_half(0));
-    }
-
-    while (!todo.empty()) {
+    struct Deferred { Arena* ar; uint32_t pin; };
+    std::vector<Deferred> deferred;        // parts launched and not yet waited for (their cursor read-backs are queued)
+    for (;;) {
         c->stage_slot = (int)(pass & 1);
-        if (split && pass == 1 && deferred_ar) {
-            HIPCHK(hipEventSynchronize(c->ev_half[1]));
-            PFCHK(prep_half(1));
+        if (pass < P) {
+            // this part's dedup results (queued with the others up front) have to be here; its clusters are the pass
+            HIPCHK(hipEventSynchronize(c->ev_part[pass]));
+            if (pass == 0) lap("first part's dedup results");
+            PFCHK(prep_half((int)pass));
+            const uint32_t c0 = pass ? part_end[pass - 1] : 0;
+            todo.resize(part_end[pass] - c0);
+            std::iota(todo.begin(), todo.end(), c0);
         }
+        if (todo.empty()) break;
         // ---- items of this pass
         std::vector<Item>& items = c->hs_items;
         std::vector<uint8_t>& item_fused = c->hs_fused;      // 0 unfused, 1 fused small class, 2 fused large class
@@ -1010,8 +1030,8 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         }
         // the cursor's next free index restarts at this arena's base
         {
-            c->pin_small[pass & 1] = arena_base;
-            HIPCHK(hipMemcpyAsync(c->cursor.p, &c->pin_small[pass & 1], 8, hipMemcpyHostToDevice, c->stream));
+            c->pin_small[pass & 15] = arena_base;
+            HIPCHK(hipMemcpyAsync(c->cursor.p, &c->pin_small[pass & 15], 8, hipMemcpyHostToDevice, c->stream));
         }
 
         lap("upload items");
@@ -1189,13 +1209,12 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         for (uint32_t ci : todo) c->timing.scan_packed_bytes += words[ci] * 8 * nparts[ci];
 
         lap("launch pass");
-        if (split && pass == 0 && !todo_second.empty()) {
-            // no wait: the second half's pass is built now and goes in behind this one
-            HIPCHK(hipMemcpyAsync(&c->pin_small[8], c->cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
-            deferred_ar = ar;
+        if (pass + 1 < P) {
+            // no wait: the next part's pass is built now and goes in behind this one
+            const uint32_t pin = 16 + pass;
+            HIPCHK(hipMemcpyAsync(&c->pin_small[pin], c->cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
+            deferred.push_back(Deferred{ar, pin});
             arena_base += ar->cap;
-            todo_first.swap(todo);
-            todo.swap(todo_second);
             pass++;
             continue;
         }
@@ -1210,14 +1229,16 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         if (ar->used > ar->cap) return fail(PF_ERR_CAPACITY, "output arena overflow (%llu > %llu)",
                                             (unsigned long long)ar->used, (unsigned long long)ar->cap);
         arena_base += ar->cap;
-        if (deferred_ar) {                         // the first half's pass finished before this one started
-            deferred_ar->used = c->pin_small[8] - deferred_ar->base;
-            if (deferred_ar->used > deferred_ar->cap)
-                return fail(PF_ERR_CAPACITY, "output arena overflow (%llu > %llu)", (unsigned long long)deferred_ar->used,
-                            (unsigned long long)deferred_ar->cap);
-            deferred_ar = nullptr;
-            todo.insert(todo.begin(), todo_first.begin(), todo_first.end());
-            todo_first.clear();
+        if (!deferred.empty()) {                   // the earlier parts' passes finished before this one
+            for (const Deferred& df : deferred) {
+                df.ar->used = c->pin_small[df.pin] - df.ar->base;
+                if (df.ar->used > df.ar->cap)
+                    return fail(PF_ERR_CAPACITY, "output arena overflow (%llu > %llu)", (unsigned long long)df.ar->used,
+                                (unsigned long long)df.ar->cap);
+            }
+            deferred.clear();
+            todo.resize(C);                        // every cluster has been through its first pass now
+            std::iota(todo.begin(), todo.end(), 0u);
         }
         std::vector<uint32_t> next;
         for (uint32_t ci : todo)
@@ -1232,6 +1253,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         }
         todo.swap(next);
         pass++;
+        if (todo.empty()) break;
     }
     for (size_t a = pass; a < c->arenas.size(); a++) c->arenas[a]->used = 0;   // arenas of an earlier, longer batch
     c->n_passes = pass;
@@ -1248,7 +1270,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         mp.pat_bits = c->pat_bits.as<uint32_t>();
         mp.pat_nan = c->o.consider_missing ? c->pat_nan.as<uint32_t>() : nullptr;
         mp.pat_n = c->pat_n.as<uint32_t>(); mp.pat_md5 = c->pat_md5.as<uint8_t>();
-        mp.pid0 = c->pid0; mp.pid1 = pid1; mp.W = W;
+        mp.pid0 = c->pid0; mp.pid1 = pid1; mp.W = W; mp.range = nullptr;
         // int64 rows (the clusters' own rows) are listed by the float pass and hashed by a second, small one
         PFCHK(c->md5_list.ensure(((size_t)C + 2) * 4));
         HIPCHK(hipMemsetAsync(c->md5_list.p, 0, 4, c->stream));
@@ -1258,8 +1280,8 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         hipLaunchKernelGGL(pf::md5_kernel<true>, dim3((pid1 - c->pid0 + pf::MD5_THREADS - 1) / pf::MD5_THREADS), dim3(pf::MD5_THREADS),
                            md5_lds, c->stream, mp);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(pf::md5_kernel<false>, dim3((C + pf::MD5_THREADS - 1) / pf::MD5_THREADS), dim3(pf::MD5_THREADS),
-                           md5_lds, c->stream, mp);
+        hipLaunchKernelGGL(pf::md5_kernel<false>, dim3(std::min<uint32_t>((C + pf::MD5_THREADS - 1) / pf::MD5_THREADS, 1024u)),
+                           dim3(pf::MD5_THREADS), md5_lds, c->stream, mp);
         HIPCHK(hipGetLastError());
         PFCHK(mark_end(c));
     }

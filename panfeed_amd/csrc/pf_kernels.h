@@ -635,6 +635,33 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     return x;
 }
 
+#ifndef PF_DEDUP_HASH
+#define PF_DEDUP_HASH 1
+#endif
+#ifndef PF_DEDUP_NT
+#define PF_DEDUP_NT 0
+#endif
+// Contribution of 64-bit word `x` at word index idx of a segment to the segment's content hash.  Summed over the
+// words (any order: eight lanes hold different words), then finalised once per segment with mix64.  A multiply of the
+// two salted halves ("mum" folding): one v_mad_u64_u32 instead of the two 64-bit multiplies of a mix64 -- the pass is
+// HBM-bound only as long as the hashing stays well inside the vector-issue budget (a 64-bit multiply is four
+// quarter-rate 32-bit ones).  The hash only has to separate distinct sequences well: equal hashes are compared word for word.
+__device__ __forceinline__ uint64_t dedup_word_hash(uint64_t x, uint32_t salt_lo, uint32_t salt_hi) {
+    return (uint64_t)((uint32_t)x ^ salt_lo) * (uint64_t)((uint32_t)(x >> 32) ^ salt_hi);
+}
+__device__ __forceinline__ uint32_t dedup_salt_lo(uint32_t idx) { return 0x9E3779B1u * (2u * idx + 1u); }
+__device__ __forceinline__ uint32_t dedup_salt_hi(uint32_t idx) { return 0x85EBCA77u * (2u * idx + 1u) + 0x165667B1u; }
+typedef uint32_t pf_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ ulonglong2 dedup_load16(const ulonglong2* p) {
+#if PF_DEDUP_NT
+    // read once, never again by this kernel: non-temporal
+    const pf_u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const pf_u32x4*>(p));
+    return make_ulonglong2(((uint64_t)t.y << 32) | t.x, ((uint64_t)t.w << 32) | t.z);
+#else
+    return *p;
+#endif
+}
+
 constexpr uint32_t DEDUP_THREADS = 512;
 constexpr uint32_t DEDUP_CH = 4;              // 16-byte chunks per lane kept in registers (CH * GL * 64 bases per segment)
 constexpr uint32_t DEDUP_U = 1;               // segments in flight per 16-lane group
@@ -698,6 +725,8 @@ void cluster_dedup_kernel(DedupParams p) {
         const uint32_t wave_grp0 = (tid >> 6) * (64 / DEDUP_GL);
         // segment metadata is read from global memory one trip ahead (no LDS copy: clusters of thousands of samples
         // have thousands of segments)
+        const uint32_t salt_lo0 = dedup_salt_lo(2 * gl), salt_hi0 = dedup_salt_hi(2 * gl);   // word 2 * gl (q = 0, first word)
+        (void)salt_lo0; (void)salt_hi0;
         uint32_t nx_len[DEDUP_U], nx_woff[DEDUP_U];
 #pragma unroll
         for (int u = 0; u < (int)DEDUP_U; u++) {
@@ -730,7 +759,7 @@ void cluster_dedup_kernel(DedupParams p) {
 #pragma unroll
                 for (uint32_t q = 0; q < DEDUP_CH; q++) {
                     const uint32_t j = gl + DEDUP_GL * q;
-                    v[u][q] = j < pc[u] ? w[u][j] : make_ulonglong2(0, 0);
+                    v[u][q] = j < pc[u] ? dedup_load16(&w[u][j]) : make_ulonglong2(0, 0);
                 }
 #pragma unroll
             for (int u = 0; u < (int)DEDUP_U; u++) {          // the next trip's metadata, behind this trip's data
@@ -743,13 +772,26 @@ void cluster_dedup_kernel(DedupParams p) {
 #pragma unroll
                 for (uint32_t q = 0; q < DEDUP_CH; q++) {
                     const uint32_t j = gl + DEDUP_GL * q;
-                    if (j < pc[u])
+                    if (j < pc[u]) {
+#if PF_DEDUP_HASH
+                        // salts of words 2j and 2j + 1: lane part + a compile-time step per q
+                        acc[u] += dedup_word_hash(v[u][q].x, salt_lo0 + q * (4u * DEDUP_GL * 0x9E3779B1u), salt_hi0 + q * (4u * DEDUP_GL * 0x85EBCA77u)) +
+                                  dedup_word_hash(v[u][q].y, salt_lo0 + q * (4u * DEDUP_GL * 0x9E3779B1u) + 2u * 0x9E3779B1u,
+                                                  salt_hi0 + q * (4u * DEDUP_GL * 0x85EBCA77u) + 2u * 0x85EBCA77u);
+#else
                         acc[u] += mix64(v[u][q].x + 0x9E3779B97F4A7C15ull * (2 * j + 1)) ^
                                   mix64(v[u][q].y + 0xC2B2AE3D27D4EB4Full * (2 * j + 2));
+#endif
+                    }
                 }
                 for (uint32_t j = gl + DEDUP_GL * DEDUP_CH; j < pc[u]; j += DEDUP_GL) {      // longer than the registers hold
                     const ulonglong2 x = w[u][j];
+#if PF_DEDUP_HASH
+                    acc[u] += dedup_word_hash(x.x, dedup_salt_lo(2 * j), dedup_salt_hi(2 * j)) +
+                              dedup_word_hash(x.y, dedup_salt_lo(2 * j + 1), dedup_salt_hi(2 * j + 1));
+#else
                     acc[u] += mix64(x.x + 0x9E3779B97F4A7C15ull * (2 * j + 1)) ^ mix64(x.y + 0xC2B2AE3D27D4EB4Full * (2 * j + 2));
+#endif
                 }
             }
             // claim: lane 0 of the group finds or opens the hash group
@@ -1173,7 +1215,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
             return ((cmask[j >> 5] >> (j & 31)) & 1) ? cb[(size_t)j * NS + i] : 0u;
         };
         for (uint32_t i = tid; i < ns; i += ROWS_THREADS) {
-            if (ordp[i] == NO_ORD) continue;
+            if (ordp[i] == NO_ORD) { slot_tag[i] = 0; continue; }
             uint64_t h = 0x9E3779B97F4A7C15ull;
             for (uint32_t j = 0; j < nmw; j++) h = mix64(h ^ mask_word(j, i)) + j;
             uint64_t h50 = h >> 14;
@@ -1253,7 +1295,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         // slots whose mask found no room in the table (rare): one evaluation each, result straight to where the
         // main loop below would put it
         for (uint32_t i = hw; i < ns; i += ROWS_THREADS / 32) {
-            if (ordp[i] == NO_ORD || slot_tag[i] != WIDE_UNTABLED) continue;
+            if (slot_tag[i] != WIDE_UNTABLED) continue;
             uint4 h;
             const bool keep = eval_slot(i, h);
             if (hl == 0) { p.slot_hash[(size_t)slice * NS + i] = h; keepf[i] = keep ? 1 : 0; }
@@ -2536,7 +2578,8 @@ struct Md5Params {
     const uint32_t* pat_bits; const uint32_t* pat_nan; const uint32_t* pat_n;
     uint8_t* pat_md5;
     uint32_t* int_list;      // [0] = count, [1..] = pattern ids of int64 rows (cluster rows) met by the float pass
-    uint32_t pid0, pid1, W;
+    const uint32_t* range;   // device: {first id, one past the last id} of this launch, or null:
+    uint32_t pid0, pid1, W;  // ... the range given here
 };
 constexpr uint32_t MD5_THREADS = 256;
 constexpr uint32_t MD5_TILE = 16;     // row words staged per round (512 vector elements = 64 MD5 blocks)
@@ -2544,29 +2587,13 @@ constexpr uint32_t MD5_TILE = 16;     // row words staged per round (512 vector 
 // FLOAT_ROWS: the pass over all new patterns, specialised for the float64 image of k-mer rows (98 % of the patterns):
 // the low word of every element is zero, which the inlined md5_block folds away (32 of its 64 message additions);
 // the few int64 rows (one per cluster at most) are only listed.  !FLOAT_ROWS: the listed int64 rows.
+// One tile = the 256 patterns of a workgroup: rows loaded coalesced into LDS, 16 words per row and round (odd row
+// stride: conflict-free), every lane then walks its own row.
 template <bool FLOAT_ROWS>
-__global__ __launch_bounds__(MD5_THREADS) void md5_kernel(Md5Params p) {
-    // The rows of a block's 256 patterns are loaded coalesced into LDS, 16 words per row and round (odd row stride:
-    // conflict-free), and every lane then walks its own row.
-    extern __shared__ uint32_t md5_lds[];            // 17 KiB (+17 KiB with a NaN mask): 8 waves per SIMD stay resident
-    __shared__ uint32_t row_pid[MD5_THREADS];
-    uint32_t* t_bits = md5_lds;
-    uint32_t* t_nan = md5_lds + MD5_THREADS * (MD5_TILE + 1);
+__device__ __forceinline__ void md5_tile(const Md5Params& p, uint32_t pid, bool live, uint32_t rows, uint32_t* row_pid,
+                                         uint32_t* t_bits, uint32_t* t_nan) {
     const uint32_t tid = threadIdx.x;
-    uint32_t pid, rows;
-    bool live;
-    if (FLOAT_ROWS) {
-        const uint32_t pbase = p.pid0 + blockIdx.x * MD5_THREADS;
-        pid = pbase + tid;
-        live = pid < p.pid1;
-        rows = min(MD5_THREADS, p.pid1 - pbase);
-    } else {
-        const uint32_t cnt = p.int_list[0], i0 = blockIdx.x * MD5_THREADS;
-        if (i0 >= cnt) return;
-        rows = min(MD5_THREADS, cnt - i0);
-        live = tid < rows;
-        pid = live ? p.int_list[1 + i0 + tid] : 0;
-    }
+    __syncthreads();                                          // the previous tile's row_pid / staging are done with
     row_pid[tid] = pid;
     const uint32_t nk = live ? p.pat_n[pid] : 0;
     const bool is_int = (nk >> 31) != 0;
@@ -2646,9 +2673,31 @@ __global__ __launch_bounds__(MD5_THREADS) void md5_kernel(Md5Params p) {
     m[15] = (uint32_t)((nbytes << 3) >> 32);
     md5_block(st, m);
     uint8_t* out = p.pat_md5 + (size_t)pid * 16;
-    uint32_t o4[4];
-    for (int i = 0; i < 4; i++) o4[i] = st[i];
-    *reinterpret_cast<uint4*>(out) = make_uint4(o4[0], o4[1], o4[2], o4[3]);   // little-endian words = MD5 byte order
+    *reinterpret_cast<uint4*>(out) = make_uint4(st[0], st[1], st[2], st[3]);   // little-endian words = MD5 byte order
+}
+
+template <bool FLOAT_ROWS>
+__global__ __launch_bounds__(MD5_THREADS) void md5_kernel(Md5Params p) {
+    extern __shared__ uint32_t md5_lds[];            // 17 KiB (+17 KiB with a NaN mask): 8 waves per SIMD stay resident
+    __shared__ uint32_t row_pid[MD5_THREADS];
+    uint32_t* t_bits = md5_lds;
+    uint32_t* t_nan = md5_lds + MD5_THREADS * (MD5_TILE + 1);
+    const uint32_t tid = threadIdx.x;
+    if (FLOAT_ROWS) {
+        // tiles blockIdx.x, blockIdx.x + gridDim.x, ... of the id range (the grid is sized before the range is known)
+        const uint32_t r0 = p.range ? p.range[0] : p.pid0, r1 = p.range ? p.range[1] : p.pid1;
+        for (uint64_t pbase = (uint64_t)r0 + (uint64_t)blockIdx.x * MD5_THREADS; pbase < r1; pbase += (uint64_t)gridDim.x * MD5_THREADS) {
+            const uint32_t pid = (uint32_t)pbase + tid;
+            md5_tile<true>(p, pid, pid < r1, min(MD5_THREADS, r1 - (uint32_t)pbase), row_pid, t_bits, t_nan);
+        }
+    } else {
+        const uint32_t cnt = p.int_list[0];
+        for (uint32_t i0 = blockIdx.x * MD5_THREADS; i0 < cnt; i0 += gridDim.x * MD5_THREADS) {
+            const uint32_t rows = min(MD5_THREADS, cnt - i0);
+            const bool live = tid < rows;
+            md5_tile<false>(p, live ? p.int_list[1 + i0 + tid] : 0, live, rows, row_pid, t_bits, t_nan);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -134,6 +134,9 @@ def from_synth(engine, clusters, k, canon=True, first_ordinal=0):
     b.seg_word_off = db._put("seg_word_off", seg_word_off)
     b.seg_len = db._put("seg_len", seg_len)
     b.packed = db._alloc("packed", n_words * 8)
+    # the two words of tail padding are not covered by the expansion kernel: zero them (fresh device memory is not)
+    zeros = np.zeros(2, dtype=np.uint64)
+    _lib.check(db.L.pf_dev_upload(engine.ctx, C.c_void_p(b.packed + (n_words - 2) * 8), zeros.ctypes.data_as(C.c_void_p), 16))
     _lib.check(db.L.pf_synth_expand(engine.ctx, p_aw, p_ao, p_sa, b.seg_word_off, b.seg_len, len(seg_len), b.packed))
     b.seg_sample = db._put("seg_sample", seg_sample)
     b.seg_ord_base = db._put("seg_ord_base", seg_ord)
