@@ -410,6 +410,25 @@ int pf_render_pattern_rows(pf_ctx* ctx, const uint32_t* pids, uint64_t n, const 
  * concatenated, to be appended to the .gz file.  Decompresses to exactly `data`. */
 int pf_gzip_members(const char* data, uint64_t n, int level, uint64_t chunk_bytes, char** out, uint64_t* out_n);
 
+/*
+ * Row filter of the downstream tools on the device: the rows of kmers_to_hashes.tsv whose
+ * hashed_pattern is one of a set of hashes (/root/reference/panfeed/get_clusters.py:89-94, get_kmers.py:103-106:
+ * `x[x['hashed_pattern'].isin(passing_hashes)]` over 100 000-row pandas chunks) and the rows of kmers.tsv whose cluster
+ * is one of a set of clusters (get_kmers.py:131-134).  first_field = 1: the key is the first tab-separated field of a
+ * line (cluster); 0: the last one (hashed_pattern).  pf_rowfilter_scan takes a block of the file that starts at a line
+ * start, tests every complete line of it on the GPU (64-bit hashes of the key field against a device hash set, every
+ * candidate then checked against the exact keys on the host) and returns the matching lines, in file order, as
+ * [begin, end) byte ranges of `text` (end includes the newline; valid until the next call); *consumed = bytes of complete
+ * lines: the caller puts text[consumed:] in front of its next block.  The file's header line is the caller's business.
+ */
+typedef struct pf_rowfilter pf_rowfilter;
+int pf_rowfilter_create(int device, int first_field, const char* const* keys, const uint32_t* key_len, uint64_t n_keys,
+                        pf_rowfilter** out);
+int pf_rowfilter_scan(pf_rowfilter* f, const char* text, uint64_t nbytes, const uint64_t** line_begin,
+                      const uint64_t** line_end, uint64_t* n_lines, uint64_t* consumed);
+int pf_rowfilter_stats(pf_rowfilter* f, uint64_t* bytes_scanned, float* device_ms);
+void pf_rowfilter_destroy(pf_rowfilter* f);
+
 #ifdef __cplusplus
 }
 #endif

@@ -137,7 +137,8 @@ EXPORTS = ["pf_last_error", "pf_version", "pf_device_count", "pf_create", "pf_de
            "pf_pangenome_open", "pf_pangenome_close", "pf_pangenome_info", "pf_pangenome_strain",
            "pf_pangenome_take_log", "pf_pangenome_next", "pf_records_free", "pf_pangenome_contigs",
            "pf_pangenome_set_store", "pf_genomes_upload", "pf_genomes_clear", "pf_submit_gather", "pf_gzip_members", "pf_render_device",
-           "pf_render_device_ex", "pf_render_pattern_rows", "pf_pangenome_weights", "pf_pangenome_set_range"]
+           "pf_render_device_ex", "pf_render_pattern_rows", "pf_pangenome_weights", "pf_pangenome_set_range",
+           "pf_rowfilter_create", "pf_rowfilter_scan", "pf_rowfilter_stats", "pf_rowfilter_destroy"]
 
 RENDER_NO_PATTERN_ROWS = 1
 ERR_ARG, ERR_OOM, ERR_HIP, ERR_CAPACITY, ERR_STATE = -1, -2, -3, -4, -5
@@ -222,6 +223,12 @@ def load():
     L.pf_render_pattern_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.pf_pangenome_weights.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]
     L.pf_pangenome_set_range.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    L.pf_rowfilter_create.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_char_p), C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
+    L.pf_rowfilter_scan.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.POINTER(C.POINTER(C.c_uint64)),
+                                    C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.pf_rowfilter_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
+    L.pf_rowfilter_destroy.argtypes = [C.c_void_p]
+    L.pf_rowfilter_destroy.restype = None
     L.pf_gzip_members.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.pf_submit_gather.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(Gather), C.POINTER(Result)]
     L.pf_records_free.argtypes = [C.c_void_p]
