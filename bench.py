@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--mean-alleles", type=float, default=7.0)
     ap.add_argument("--allele-decay", type=float, default=0.5, help="allele weights decay^i (1.0: uniform)")
+    ap.add_argument("--n-rate", type=float, default=0.0, help="share of the sequences that carry one 'N' (SURVEY 8d: 0.001)")
     ap.add_argument("--max-items", type=int, default=65536)
     ap.add_argument("--cpu-clusters", type=int, default=0, help="clusters in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -77,7 +78,7 @@ def cpu_baseline(args, threads):
     from panfeed_amd import synth
     per_cluster = max(1, args.samples // 1000)
     n = args.cpu_clusters or max(8, min(args.clusters, 80 * threads // per_cluster))   # ~15-25 s at ~5e6 instances/s/thread
-    cl = synth.generate(n, args.samples, first=0, flank=args.flank, n_rate=0.0, mean_alleles=args.mean_alleles,
+    cl = synth.generate(n, args.samples, first=0, flank=args.flank, n_rate=args.n_rate, mean_alleles=args.mean_alleles,
                         allele_decay=args.allele_decay)
     recs = [c.record() for c in cl]
     ninst = sum(c.n_instances(args.k) for c in cl)
@@ -252,7 +253,7 @@ def main():
     slab = max(1, 50000 * 1000 // max(S, 1))
     dbs = []
     for s0 in range(0, n_mine, slab):
-        cl = synth.generate(min(slab, n_mine - s0), S, first=first + s0, flank=args.flank, n_rate=0.0,
+        cl = synth.generate(min(slab, n_mine - s0), S, first=first + s0, flank=args.flank, n_rate=args.n_rate,
                             mean_alleles=args.mean_alleles, allele_decay=args.allele_decay)
         dbs.append(devbatch.from_synth(eng, cl, k, first_ordinal=first + s0))
         del cl
@@ -324,7 +325,7 @@ def main():
             pk["algorithmic_GBps"] = packed_bytes / (pk["ms"] / 1e3) / 1e9     # it has to read the packed input once
             pk["frac_of_hbm_peak"] = pk["algorithmic_GBps"] / HBM_PEAK_GBS
         default_cmd = (args.clusters, S, k, args.flank, world, args.no_dedup, strong, args.mean_alleles,
-                       args.allele_decay) == (50000, 1000, 31, 100, 1, False, False, 7.0, 0.5)
+                       args.allele_decay, args.n_rate) == (50000, 1000, 31, 100, 1, False, False, 7.0, 0.5, 0.0)
         pmc, pmc_rel = load_pmc() if default_cmd else (None, None)
         if pmc:
             tot = 0.0
@@ -350,8 +351,12 @@ def main():
         workload = (f"synthetic {n_mine} clusters x {S} samples on this GPU"
                     + (f" ({args.total_clusters} over {world} GPUs)" if strong else " per GPU")
                     + f", k={k}, +-{args.flank} bp flanks, canonical, maf 0.01")
+        if args.n_rate:
+            workload += f", {args.n_rate:g} of the sequences with one 'N'"
         if default_cmd:
             workload += " (BASELINE.json configs[2], pure-ACGT)"
+        elif (args.clusters, S, k, args.flank, world, strong, args.n_rate) == (50000, 1000, 31, 100, 1, False, 0.001):
+            workload += " (BASELINE.json configs[2] with SURVEY 8d's share of 'N's)"
         elif strong and (args.total_clusters, S, k, args.flank) == (50000, 1000, 31, 100):
             workload += " (BASELINE.json configs[3]: configs[2] sharded)"
         elif S == 5000:

@@ -903,7 +903,18 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         for (uint32_t ci : todo) {
             const uint32_t np = nparts[ci];
             const uint32_t nex = ex_first[ci + 1] - ex_first[ci];
-            const uint32_t nex_items = (nex + lim_full - 1) / lim_full;
+            // a deduplicated cluster that is one work item (or a few key partitions) is finished by one fused kernel
+            // (rows + emit in LDS); its slow-path rows (a few k-mers around an 'N') are folded in by that kernel
+            const uint32_t mwords = h_vnstr[ci] * ((W + 3) & ~3u);
+            uint8_t fused = 0;   // 1/2: single item, small/large class; 3: first of several partitions; 4: the others
+            if (h_mode[ci] == 1 && nex <= pf::FUSED_MAX_EXTRA && NS <= 9600) {
+                const bool fits_large = h_dense[ci] < pf::FinLarge::DW * 32 - 1 && mwords <= pf::FinLarge::MR;
+                if (np == 1) {
+                    if (h_dense[ci] < pf::FinSmall::DW * 32 - 1 && mwords <= pf::FinSmall::MR) fused = 1;
+                    else if (fits_large) fused = 2;
+                } else if (fits_large) fused = 3;
+            }
+            const uint32_t nex_items = fused ? 0 : (nex + lim_full - 1) / lim_full;
             const uint32_t nit = np + nex_items;
             if (nit > c->max_items)
                 return fail(PF_ERR_CAPACITY, "cluster %u needs %u work items; raise max_items (%u)", ci, nit, c->max_items);
@@ -917,16 +928,6 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             const uint64_t inst = vinst[ci] * mult;
             if (np == 1 && NS > 4096 + pf::INSERT_SLACK && inst <= pf::insert_limit(4096)) ns = 4096;
             else if (np == 1 && NS > 6144 + pf::INSERT_SLACK && inst <= pf::insert_limit(6144)) ns = 6144;
-            // a deduplicated cluster that is one work item is finished by one fused kernel (rows + emit in LDS)
-            const uint32_t mwords = h_vnstr[ci] * ((W + 3) & ~3u);
-            uint8_t fused = 0;   // 1/2: single item, small/large class; 3: first of several partitions; 4: the others
-            if (h_mode[ci] == 1 && nex == 0 && NS <= 9600) {
-                const bool fits_large = h_dense[ci] < pf::FinLarge::DW * 32 - 1 && mwords <= pf::FinLarge::MR;
-                if (np == 1) {
-                    if (h_dense[ci] < pf::FinSmall::DW * 32 - 1 && mwords <= pf::FinSmall::MR) fused = 1;
-                    else if (fits_large) fused = 2;
-                } else if (fits_large) fused = 3;
-            }
             for (uint32_t q = 0; q < np; q++) {
                 items.push_back(Item{ci, q, np, ns, cur.nitems + q, sib0, nit, 0, 0});
                 item_fused.push_back(fused == 3 && q > 0 ? 4 : fused);
@@ -1090,6 +1091,8 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
                 fp.tab_key = c->tab_key.as<uint64_t>(); fp.tab_ord = c->tab_ord.as<uint32_t>();
                 fp.cmask_lo = c->cmask_lo.as<uint32_t>(); fp.cmask_hi = c->cmask_hi.as<uint32_t>();
                 fp.item_count = c->it_count.as<uint32_t>();
+                fp.extra_off = c->extra_off.as<uint32_t>(); fp.extra_dense = c->extra_dense.as<uint32_t>();
+                fp.extra_bits = d.extra_bits;
                 fp.out_key = ar->key.as<uint64_t>(); fp.out_pid = ar->pid.as<uint32_t>();
                 fp.cluster_kmer_off = c->cl_kmer_off.as<uint64_t>(); fp.cluster_kmer_cnt = c->cl_kmer_cnt.as<uint32_t>();
                 fp.cluster_unique = c->cl_unique.as<uint32_t>(); fp.cluster_pattern = c->cl_pattern.as<uint32_t>();

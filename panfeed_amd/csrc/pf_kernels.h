@@ -1840,6 +1840,7 @@ struct FinSmall { static constexpr uint32_t THREADS = 512, DW = 1024, MR = 1024,
 struct FinLarge { static constexpr uint32_t THREADS = 1024, DW = 2048, MR = 2048, AT = 512, ATL = 384; typedef uint16_t tag_t; };
 constexpr uint32_t FUSED_DENSE_WORDS = FinLarge::DW;   // < 65536 dense ordinals (prefix counts are 16-bit)
 constexpr uint32_t FUSED_MROWS = FinLarge::MR;         // D * ceil4(W) words of M
+constexpr uint32_t FUSED_MAX_EXTRA = 1024;             // slow-path rows of a cluster the fused kernel takes along
 static_assert(nslots_max(1) <= 9600, "slot_at too small");
 
 struct FinishParams {
@@ -1854,6 +1855,9 @@ struct FinishParams {
     const uint32_t* maf_lo; const uint32_t* maf_hi;
     const uint32_t* item_count;      // entries of the item's compact table
     const uint64_t* tab_key; const uint32_t* tab_ord; const uint32_t* cmask_lo; const uint32_t* cmask_hi;
+    // slow-path rows of the cluster (k-mers with a non-ACGT base, grouped by the caller): CSR per cluster, their
+    // ordinals in the cluster's dense numbering (cluster_dedup_kernel), their presence rows
+    const uint32_t* extra_off; const uint32_t* extra_dense; const uint32_t* extra_bits;
     uint64_t* out_key; uint32_t* out_pid;
     uint64_t* cluster_kmer_off; uint32_t* cluster_kmer_cnt; uint32_t* cluster_unique; uint32_t* cluster_pattern;
     uint64_t* cursor;                // [0] next free output index [1] unique total [2] kept total
@@ -2018,6 +2022,37 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
         hout = make_uint4(s.h1, s.h2, s.h3, s.h4);
         return keep;
     };
+    // the same for a row given word by word (the cluster's slow-path rows)
+    auto row_eval_words = [&](const uint32_t* words, uint4& hout) -> bool {
+        H128 s;
+        s.h1 = 0x9747b28cu ^ nstr; s.h2 = 0x1b873593u; s.h3 = 0xe6546b64u; s.h4 = 0x85ebca6bu;
+        if (p.multiple_files) { s.h2 ^= (uint32_t)ordinal; s.h3 ^= (uint32_t)(ordinal >> 32); }
+        uint32_t cnt = 0;
+        bool eq = true;
+        for (uint32_t ch = 0; ch < nchunks; ch += 4) {
+            uint32_t wv[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                wv[j] = ch + j < nchunks ? words[ch + j] : 0;
+                if (ch + j < nchunks) { cnt += __popc(wv[j]); if (same_possible) eq = eq && (wv[j] == presab[ch + j]); }
+            }
+            mm3_block(s, wv[0], wv[1], wv[2], wv[3]);
+        }
+        if (p.consider_missing) {
+            for (uint32_t ch = 0; ch < nchunks; ch += 4) {
+                uint32_t wv[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) wv[j] = (ch + j < nchunks) ? ~presab[ch + j] : 0;
+                mm3_block(s, wv[0], wv[1], wv[2], wv[3]);
+            }
+        }
+        mm3_final(s, nchunks * 4);
+        bool keep = cnt >= lo && cnt <= hi;                 // panfeed.py:197-200
+        if (same_possible && eq) keep = false;              // panfeed.py:202-204
+        hout = make_uint4(s.h1, s.h2, s.h3, s.h4);
+        return keep;
+    };
+    const uint32_t ex0 = p.extra_off ? p.extra_off[c] : 0, ex1 = p.extra_off ? p.extra_off[c + 1] : 0;
     auto write_row = [&](uint32_t pid, uint64_t amask) {
         for (uint32_t w = 0; w < W; w += 4) {
             uint32_t wv[4] = {0, 0, 0, 0};
@@ -2152,6 +2187,15 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
                 if (row_eval(amask, h)) atomicOr(&keepbm[o >> 5], 1u << (o & 31));
             }
         }
+    }
+    // the cluster's slow-path rows: one ordinal each, kept or not by their own row
+#pragma unroll 1
+    for (uint32_t e = ex0 + tid; e < ex1; e += T) {
+        const uint32_t o = p.extra_dense[e];
+        if ((o >> 5) >= dense_words) continue;
+        atomicOr(&occ[o >> 5], 1u << (o & 31));
+        uint4 h;
+        if (row_eval_words(p.extra_bits + (size_t)e * W, h)) atomicOr(&keepbm[o >> 5], 1u << (o & 31));
     }
     __syncthreads();
     PF_PROF_STAMP(3);
@@ -2332,6 +2376,38 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
                 p.out_pid[oi] = pid;
             }
         }
+    }
+    // slow-path rows that are kept: their own insert into the run-global table, their row if they are its first
+#pragma unroll 1
+    for (uint32_t e = ex0 + tid; e < ex1; e += T) {
+        const uint32_t o = p.extra_dense[e];
+        if ((o >> 5) >= dense_words || !((keepbm[o >> 5] >> (o & 31)) & 1)) continue;
+        const uint32_t* words = p.extra_bits + (size_t)e * W;
+        uint4 h;
+        row_eval_words(words, h);
+        bool lw;
+        const uint32_t pid = pattern_insert_lower(p.pt, ((uint64_t)h.x << 32) | h.y, h.z,
+                                                  (ordinal << 32) | (uint64_t)(rank_of(o) + 1), &lw);
+        if (lw && pid < p.pt.pool) {
+            for (uint32_t w = 0; w < W; w++) {
+                p.pat_bits[(size_t)pid * W + w] = w < nchunks ? words[w] : 0;
+                if (p.pat_nan) {
+                    uint32_t nn = 0;
+                    if (p.consider_missing && w < nchunks) {
+                        nn = ~presab[w];
+                        const uint32_t rem = nstr - (w << 5);
+                        if (rem < 32) nn &= (1u << rem) - 1;
+                    }
+                    p.pat_nan[(size_t)pid * W + w] = nn;
+                }
+            }
+            p.pat_n[pid] = nstr;
+        }
+        const uint64_t oi = obase + kept_before(o);
+        if (oi >= p.out_cap) { p.pt.counters[2] = 1; continue; }
+        p.out_key[oi * KW] = KEY_EXTRA_FLAG | (uint64_t)e;
+        if (KW == 2) p.out_key[oi * KW + 1] = 0;
+        p.out_pid[oi] = pid;
     }
     __syncthreads();
     PF_PROF_STAMP(7);

@@ -80,9 +80,15 @@ def from_host_batch(engine, hb):
     return db
 
 
+_N_COMP = bytes.maketrans(b"ACGTN", b"TGCAN")
+_ASCII = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
 def from_synth(engine, clusters, k, canon=True, first_ordinal=0):
-    """clusters: list of synth.SynthCluster with no 'N' (n_rate=0) and sample names in sorted
-    order (iteration order == column order)."""
+    """clusters: list of synth.SynthCluster with sample names in sorted order (iteration order == column order).
+    Sequences with an 'N' (synth's n_rate; canonical mode only) are split at it into their A/C/G/T runs, packed on the
+    host as literals, and the windows that contain the 'N' become slow-path rows with the reference's string
+    semantics (panfeed.py:65-79) -- what `packing` does for records, without ever making the other sequences' strings."""
     W = engine.W
     allele_words, allele_off, allele_len = [], [], []
     woff = 0
@@ -90,28 +96,75 @@ def from_synth(engine, clusters, k, canon=True, first_ordinal=0):
     cl_seg_off = np.zeros(len(clusters) + 1, dtype=np.int64)
     cl_nstr = np.zeros(len(clusters), dtype=np.uint32)
     cl_presab = np.zeros((len(clusters), W), dtype=np.uint32)
+    ex_cluster, ex_ord, ex_bits = [], [], []
     n_inst = 0
+
+    def add_allele(codes):
+        nonlocal woff
+        w = pack_codes(codes)
+        allele_words.append(w)
+        allele_off.append(woff)
+        allele_len.append(len(codes))
+        woff += len(w)
+        return len(allele_off) - 1
+
     for ci, cl in enumerate(clusters):
-        if (cl.seq_npos >= 0).any():
-            raise ValueError("from_synth needs pure-ACGT clusters (n_rate=0)")
+        has_n = cl.seq_npos >= 0
+        if has_n.any() and not canon:
+            raise ValueError("from_synth: sequences with 'N' are supported in canonical mode only")
         if cl.names != sorted(cl.names):
             raise ValueError("from_synth needs sample names in sorted order")
         a0 = len(allele_off)
         for a in cl.alleles:
-            w = pack_codes(a)
-            allele_words.append(w)
-            allele_off.append(woff)
-            allele_len.append(len(a))
-            woff += len(w)
+            add_allele(a)
         lens = np.array([len(a) for a in cl.alleles], dtype=np.int64)[cl.seq_allele]
         ninst = np.maximum(lens - k + 1, 0)
         ob = np.concatenate(([0], np.cumsum(ninst)[:-1])) if len(ninst) else np.zeros(0, np.int64)
-        keep = lens >= k
-        seg_allele.append((a0 + cl.seq_allele[keep]).astype(np.uint32))
-        seg_len.append(lens[keep].astype(np.uint32))
-        seg_sample.append(cl.seq_sample[keep].astype(np.uint32))
-        seg_ord.append(ob[keep].astype(np.uint32))
-        cl_seg_off[ci + 1] = cl_seg_off[ci] + int(keep.sum())
+        keep = (lens >= k) & ~has_n
+        s_allele = (a0 + cl.seq_allele).astype(np.int64)
+        s_len, s_smp, s_ord, s_seq = lens.copy(), cl.seq_sample.astype(np.int64), ob.copy(), np.arange(len(lens))
+        rows = [(s_allele[keep], s_len[keep], s_smp[keep], s_ord[keep], s_seq[keep] * 2)]
+        if has_n.any():
+            amb = {}
+            for q in np.flatnonzero(has_n):
+                q = int(q)
+                codes = cl.alleles[int(cl.seq_allele[q])]
+                L, p, col = len(codes), int(cl.seq_npos[q]), int(cl.seq_sample[q])
+                for part, (a, b) in enumerate(((0, p), (p + 1, L))):     # the A/C/G/T runs on both sides of the N
+                    if b - a >= k:
+                        lit = add_allele(codes[a:b])
+                        rows.append((np.array([lit]), np.array([b - a]), np.array([col]), np.array([ob[q] + a]),
+                                     np.array([q * 2 + part])))
+                if L >= k:
+                    seq = bytearray(_ASCII[codes].tobytes())
+                    seq[p] = ord("N")
+                    seq = bytes(seq)
+                    comp = seq.translate(_N_COMP)
+                    for pos in range(max(0, p - k + 1), min(L - k, p) + 1):
+                        spec = seq[pos:pos + k]                           # panfeed.py:65
+                        rev = comp[pos:pos + k][::-1]                     # panfeed.py:67
+                        key = spec if spec <= rev else rev                # panfeed.py:70-75
+                        ent = amb.setdefault(key, [int(ob[q]) + pos, set()])
+                        ent[0] = min(ent[0], int(ob[q]) + pos)
+                        ent[1].add(col)
+            for key, (o, cols) in amb.items():
+                row = np.zeros(W, dtype=np.uint32)
+                for c in cols:
+                    row[c >> 5] |= np.uint32(1 << (c & 31))
+                ex_cluster.append(ci)
+                ex_ord.append(o)
+                ex_bits.append(row)
+        al = np.concatenate([r[0] for r in rows])
+        ln = np.concatenate([r[1] for r in rows])
+        sm = np.concatenate([r[2] for r in rows])
+        od = np.concatenate([r[3] for r in rows])
+        sq = np.concatenate([r[4] for r in rows])
+        order = np.lexsort((sq, sm))                  # by sample column, then the reference's iteration order
+        seg_allele.append(al[order].astype(np.uint32))
+        seg_len.append(ln[order].astype(np.uint32))
+        seg_sample.append(sm[order].astype(np.uint32))
+        seg_ord.append(od[order].astype(np.uint32))
+        cl_seg_off[ci + 1] = cl_seg_off[ci] + len(order)
         cl_nstr[ci] = len(cl.names)
         pres = np.flatnonzero(cl.present)
         np.bitwise_or.at(cl_presab[ci], pres >> 5, (np.uint32(1) << (pres & 31).astype(np.uint32)))
@@ -145,9 +198,15 @@ def from_synth(engine, clusters, k, canon=True, first_ordinal=0):
     b.cluster_npresab = db._put("cluster_npresab", cl_nstr)
     b.cluster_presab = db._put("cluster_presab", cl_presab)
     b.cluster_ordinal = db._put("cluster_ordinal", (first_ordinal + np.arange(len(clusters))).astype(np.uint64))
+    b.n_extra = len(ex_ord)
+    if b.n_extra:
+        b.extra_cluster = db._put("extra_cluster", np.asarray(ex_cluster, dtype=np.uint32))
+        b.extra_ord = db._put("extra_ord", np.asarray(ex_ord, dtype=np.uint32))
+        b.extra_bits = db._put("extra_bits", np.stack(ex_bits).astype(np.uint32))
     for name in ("allele_words", "allele_off", "seg_allele"):
         db.L.pf_dev_free(engine.ctx, db.ptrs.pop(name))
     db.n_instances = n_inst * (1 if canon else 2)
+    db.n_extra = int(b.n_extra)
     db.packed_bytes = int(((seg_len.astype(np.int64) + 3) // 4).sum())
     db.n_clusters, db.n_segs = len(clusters), len(seg_len)
     return db

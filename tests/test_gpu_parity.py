@@ -286,6 +286,35 @@ def test_device_resident_batch_matches_host_batch():
     eng2.close()
 
 
+@pytest.mark.parametrize("S,flank,n_rate,missing", [(64, 15, 0.05, False), (300, 40, 0.01, False), (300, 40, 0.01, True),
+                                                    (1000, 100, 0.002, False)])
+def test_device_resident_batch_with_N(S, flank, n_rate, missing):
+    """synthetic batches built on the device from allele pools, some sequences with an 'N' (split into their A/C/G/T
+    runs, the windows around the 'N' as slow-path rows): the texts are the oracle's.  The fused finish kernel takes
+    the slow-path rows of its clusters along."""
+    from panfeed_amd import devbatch, synth
+    from panfeed_amd.engine import Engine
+    from panfeed_amd.packing import build_batch
+    cl = synth.generate(14, S, first=77, flank=flank, mean_len=350, min_len=60, max_len=900, n_rate=n_rate, paralog_rate=0.02)
+    assert sum(int((c.seq_npos >= 0).sum()) for c in cl) > 3
+    recs = [c.record() for c in cl]
+    eng = Engine(klength=31, max_strains=(S + 31) // 32 * 32, consider_missing=missing)
+    db = devbatch.from_synth(eng, cl, 31)
+    assert db.n_extra > 0
+    res = db.submit()
+    tm = eng.timing()
+    assert tm["finish_ms"] > 0                       # clusters with slow-path rows stay on the fused path
+    hb = build_batch(recs, 31, True, eng.W)
+    assert int(res.n_instances) + 0 <= hb.n_instances
+    got = eng._render(hb, eng.fetch())
+    (ek, ekh, ehp), st = _oracle_texts(recs, klength=31, consider_missing=missing)
+    assert got.kmers_to_hashes == ekh
+    assert got.hashes_to_patterns == ehp
+    assert got.stats["unique_kmers"] == st["unique_kmers"]
+    db.free()
+    eng.close()
+
+
 @pytest.mark.parametrize("flags", [dict(), dict(consider_missing=True), dict(patfilt=False, maf=0.0), dict(canon=False)])
 def test_dedup_big_alleles_repartition(flags):
     """few distinct but long alleles x many samples: mode 1 with a table overflow (key partitions) and,
