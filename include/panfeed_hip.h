@@ -34,7 +34,7 @@ enum pf_status {
     PF_ERR_STATE = -5     /* call order violated */
 };
 
-#define PF_MAX_K 63 /* 2 bits/base in at most two 63-bit key words */
+#define PF_MAX_K 126 /* 2 bits/base in at most four 63-bit key words */
 
 /* Options of one run = the arguments functools.partial freezes at __main__.py:277-297. */
 typedef struct {
@@ -70,7 +70,8 @@ typedef struct {
  * sequence; the windows that contain one are the caller's slow path and come back in as
  * `extra_*` rows).  Packing: 2 bits per base (A=0 C=1 G=2 T=3), 32 bases per uint64 word, the first
  * base in bits 63:62; every segment starts on a 16-byte boundary; the buffer carries 16 bytes
- * of padding after the last segment.
+ * of padding after the last segment (32 bytes when klength > 63: a lane reads up to four words past its window's
+ * first one).
  *
  * Padding bits inside a segment's last 16 bytes are zero.  cluster_seg_off[0] == 0.
  * Inside a cluster the segments are sorted by seg_sample (stable).  A window starting at base
@@ -115,15 +116,16 @@ typedef struct {
     uint64_t n_kept;           /* rows of kmers_to_hashes.tsv minus the per-cluster rows */
     uint64_t n_new_patterns;   /* rows this batch adds to hashes_to_patterns.tsv */
     uint32_t W;                /* uint32 words per presence row */
-    uint32_t key_words;        /* 1 (k <= 31) or 2 */
+    uint32_t key_words;        /* KW = ceil(2k / 63): 1 (k <= 31), 2 (<= 63), 3 (<= 94), 4 (<= 126) */
     /* per cluster (batch order) */
     const uint64_t* cluster_kmer_off;  /* [n_clusters] first kept k-mer in kmer_* */
     const uint32_t* cluster_kmer_cnt;  /* [n_clusters] */
     const uint32_t* cluster_pattern;   /* [n_clusters] pattern id of the cluster row (panfeed.py:175-187) */
     const uint32_t* cluster_unique;    /* [n_clusters] len(cluster_dict) */
     /* per kept k-mer, in dict insertion order inside each cluster (panfeed.py:189) */
-    const uint64_t* kmer_key;          /* [n_kept_total * key_words]; bit 63 of word 0 set: slow-path row,
-                                          low 32 bits = index into the batch's extra_* arrays */
+    const uint64_t* kmer_key;          /* [n_kept_total * key_words]: the k-mer's 2k-bit value (first base most
+                                          significant), most significant word first, 63 bits per word; bit 63 of
+                                          word 0 set: slow-path row, low 32 bits = index into the batch's extra_* arrays */
     const uint32_t* kmer_pattern;      /* [n_kept_total] pattern id */
     /* patterns first seen in this batch, sorted by first_seen = the order of hashes_to_patterns.tsv */
     const uint32_t* new_pattern_id;    /* [n_new_patterns] */

@@ -328,8 +328,12 @@ int scan_attr_t(pf_ctx* c) {
     return PF_OK;
 }
 int scan_attr(pf_ctx* c) {
-    if (c->KW == 1) return c->o.canon ? scan_attr_t<1, true>(c) : scan_attr_t<1, false>(c);
-    return c->o.canon ? scan_attr_t<2, true>(c) : scan_attr_t<2, false>(c);
+    switch (c->KW) {
+        case 1: return c->o.canon ? scan_attr_t<1, true>(c) : scan_attr_t<1, false>(c);
+        case 2: return c->o.canon ? scan_attr_t<2, true>(c) : scan_attr_t<2, false>(c);
+        case 3: return c->o.canon ? scan_attr_t<3, true>(c) : scan_attr_t<3, false>(c);
+        default: return c->o.canon ? scan_attr_t<4, true>(c) : scan_attr_t<4, false>(c);
+    }
 }
 
 template <int KW, bool CANON>
@@ -349,8 +353,12 @@ int launch_scan_t(pf_ctx* c, const pf::ScanParams& sp, uint32_t n) {
     return PF_OK;
 }
 int launch_scan(pf_ctx* c, const pf::ScanParams& sp, uint32_t n) {
-    if (c->KW == 1) return c->o.canon ? launch_scan_t<1, true>(c, sp, n) : launch_scan_t<1, false>(c, sp, n);
-    return c->o.canon ? launch_scan_t<2, true>(c, sp, n) : launch_scan_t<2, false>(c, sp, n);
+    switch (c->KW) {
+        case 1: return c->o.canon ? launch_scan_t<1, true>(c, sp, n) : launch_scan_t<1, false>(c, sp, n);
+        case 2: return c->o.canon ? launch_scan_t<2, true>(c, sp, n) : launch_scan_t<2, false>(c, sp, n);
+        case 3: return c->o.canon ? launch_scan_t<3, true>(c, sp, n) : launch_scan_t<3, false>(c, sp, n);
+        default: return c->o.canon ? launch_scan_t<4, true>(c, sp, n) : launch_scan_t<4, false>(c, sp, n);
+    }
 }
 
 }  // namespace
@@ -448,7 +456,7 @@ int pf_create(pf_ctx** out, int device, const pf_opts* o) {
     c->device = device;
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->o = *o;
-    c->KW = o->klength <= 31 ? 1 : 2;
+    c->KW = (int)((2 * o->klength + 62) / 63);       // 63 key bits per word: k <= 31 one word ... k <= 126 four
     c->NS = pf::nslots_max(c->KW);
     c->W = (o->max_strains + 31) / 32;
     c->max_items = o->max_items ? o->max_items : 2048;
@@ -628,10 +636,11 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
                             "(%u != %u)", i, b->cluster_npresab[i], b->cluster_nstrains[i]);
         }
         if (C && b->cluster_seg_off[0] != 0) return fail(PF_ERR_ARG, "cluster_seg_off[0] must be 0");
+        const uint32_t pad_words = KW <= 2 ? 2u : 4u;     // a lane reads KW + 1 words from its window's first word
         for (uint32_t s = 0; s < NSEG; s++) {
             const uint64_t nw = 2ull * ((b->seg_len[s] + 63) / 64);
-            if ((b->seg_word_off[s] & 1) || b->seg_word_off[s] + nw + 2 > total_words)
-                return fail(PF_ERR_ARG, "segment %u: misaligned or outside packed[] (needs 2 words of tail padding)", s);
+            if ((b->seg_word_off[s] & 1) || b->seg_word_off[s] + nw + pad_words > total_words)
+                return fail(PF_ERR_ARG, "segment %u: misaligned or outside packed[] (needs %u words of tail padding)", s, pad_words);
         }
         for (uint32_t i = 0; i < C; i++)
             for (uint32_t s = b->cluster_seg_off[i]; s < b->cluster_seg_off[i + 1]; s++) {
@@ -658,15 +667,15 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
                     return fail(PF_ERR_ARG, "segment %u: source range outside the resident genomes", s);
                 }
             }
-            PFCHK(c->b_packed.ensure((size_t)std::max<uint64_t>(total_words, 2) * 8));
+            PFCHK(c->b_packed.ensure((size_t)std::max<uint64_t>(total_words, 4) * 8));
             d.packed = c->b_packed.as<uint64_t>();
             const uint64_t* lit; const uint64_t* so; const uint32_t* ss; const uint32_t* sf;
             PFCHK(upload(c, c->b_literal, b->packed, (size_t)b->n_words, &lit));
             PFCHK(upload(c, c->g_src_off, gth->src_off, NSEG, &so));
             PFCHK(upload(c, c->g_src_start, gth->src_start, NSEG, &ss));
             PFCHK(upload(c, c->g_src_flags, gth->src_flags, NSEG, &sf));
-            if (total_words >= 2)
-                HIPCHK(hipMemsetAsync(c->b_packed.as<uint64_t>() + (total_words - 2), 0, 16, c->stream));
+            if (total_words >= 4)
+                HIPCHK(hipMemsetAsync(c->b_packed.as<uint64_t>() + (total_words - 4), 0, 32, c->stream));
             if (NSEG) {
                 pf::GatherParams gp{};
                 gp.store = c->g_store.as<uint64_t>(); gp.literal = lit; gp.src_off = so; gp.src_start = ss; gp.src_flags = sf;
@@ -802,12 +811,16 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         PFCHK(c->strand_bits.ensure((size_t)c->n_strand_words * 8));
         HIPCHK(hipMemsetAsync(c->strand_bits.p, 0, (size_t)c->n_strand_words * 8, c->stream));
         const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)NSEG + 3) / 4, 4096);
-        if (KW == 1)
-            hipLaunchKernelGGL(pf::strand_bits_kernel<1>, dim3(blocks), dim3(256), 0, c->stream, d.packed, d.seg_word_off,
-                               d.seg_len, d.seg_strand_off, NSEG, c->o.klength, c->strand_bits.as<uint64_t>());
-        else
-            hipLaunchKernelGGL(pf::strand_bits_kernel<2>, dim3(blocks), dim3(256), 0, c->stream, d.packed, d.seg_word_off,
-                               d.seg_len, d.seg_strand_off, NSEG, c->o.klength, c->strand_bits.as<uint64_t>());
+        auto strand = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, c->stream, d.packed, d.seg_word_off, d.seg_len,
+                               d.seg_strand_off, NSEG, c->o.klength, c->strand_bits.as<uint64_t>());
+        };
+        switch (KW) {
+            case 1: strand(pf::strand_bits_kernel<1>); break;
+            case 2: strand(pf::strand_bits_kernel<2>); break;
+            case 3: strand(pf::strand_bits_kernel<3>); break;
+            default: strand(pf::strand_bits_kernel<4>); break;
+        }
         HIPCHK(hipGetLastError());
     }
     lap("upload+dedup launch");
@@ -1484,12 +1497,12 @@ int pf_render_kmers_to_hashes(pf_ctx* c, const char* const* names, const char* c
                     if (!extra_keys) { bad = true; memset(w, '?', k); }
                     else memcpy(w, extra_keys[(uint32_t)key[0]], k);
                 } else {
-                    // 2k-bit value, first base most significant; two words = two 63-bit halves
-                    uint64_t hi = 0, lo = key[0];
-                    if (KW == 2) { hi = key[0] >> 1; lo = ((key[0] & 1) << 63) | key[1]; }
+                    // 2k-bit value, first base most significant, in KW words of 63 bits: bit b lives in word
+                    // KW - 1 - b / 63 at bit b % 63
                     for (uint32_t q = 0; q < k; q++) {
-                        const uint32_t bit = 2 * (k - 1 - q);
-                        const uint32_t code = bit >= 64 ? (uint32_t)(hi >> (bit - 64)) & 3 : (uint32_t)(lo >> bit) & 3;
+                        const uint32_t b0 = 2 * (k - 1 - q), b1 = b0 + 1;
+                        const uint32_t code = (uint32_t)((key[KW - 1 - b0 / 63] >> (b0 % 63)) & 1) |
+                                              ((uint32_t)((key[KW - 1 - b1 / 63] >> (b1 % 63)) & 1) << 1);
                         w[q] = "ACGT"[code];
                     }
                 }
@@ -1753,7 +1766,7 @@ int pf_genomes_upload(pf_ctx* c, uint32_t n, const char* const* ascii, const uin
     for (uint32_t i = 0; i < n; i++) {
         if (len[i] >= 0xFFFFFF00ull) return fail(PF_ERR_ARG, "contig %u is too long for 32-bit coordinates", i);
         word_off[i] = total;
-        total += 2 * ((len[i] + 63) / 64) + 2;
+        total += 2 * ((len[i] + 63) / 64) + 4;
     }
     c->g_store.release();
     PFCHK(c->g_store.ensure((size_t)std::max<uint64_t>(total, 2) * 8));
@@ -1794,7 +1807,7 @@ int pf_genomes_upload(pf_ctx* c, uint32_t n, const char* const* ascii, const uin
                 memset(pin + fill + take, 'A', padded - take);
                 pf::PackPiece pc{};
                 pc.ascii_off = fill; pc.dst_word = word_off[i] + done / 32; pc.nbases = (uint32_t)take;
-                const uint64_t contig_words = 2 * ((L + 63) / 64) + 2;
+                const uint64_t contig_words = 2 * ((L + 63) / 64) + 4;
                 pc.nwords = (uint32_t)(last ? contig_words - done / 32 : take / 32);
                 pc.block0 = blocks;
                 blocks += (pc.nwords + 255) / 256;

@@ -72,7 +72,8 @@ __device__ __forceinline__ uint32_t key_hash(const Key<KW>& k) {
     // two 32-bit multiplies (quarter-rate on CDNA): fold the halves with a rotate, then xor-shift / multiply.
     // The slot takes the high bits (umulhi), the key partition the low 16.
     uint32_t x = (uint32_t)k.w[0] ^ rotl32((uint32_t)(k.w[0] >> 32), 15);
-    if (KW == 2) x ^= rotl32((uint32_t)k.w[1], 7) ^ rotl32((uint32_t)(k.w[1] >> 32), 23);
+#pragma unroll
+    for (int j = 1; j < KW; j++) x = rotl32(x, 11) ^ rotl32((uint32_t)k.w[j], 7) ^ rotl32((uint32_t)(k.w[j] >> 32), 23);
     x *= 0x9E3779B1u;
     x ^= x >> 15;
     x *= 0x85EBCA77u;
@@ -217,15 +218,23 @@ __device__ __forceinline__ void table_update(uint64_t* keys, uint32_t* ord, uint
                     cur = atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)EMPTY64,
                                     (unsigned long long)key.w[0]);
                     if (cur == EMPTY64) {
-                        __hip_atomic_store(&keys[NS + slot], key.w[KW - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        // the middle words first, the last word publishes (a lane's LDS stores complete in order)
+#pragma unroll
+                        for (int j = 1; j < KW - 1; j++)
+                            __hip_atomic_store(&keys[(size_t)j * NS + slot], key.w[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(&keys[(size_t)(KW - 1) * NS + slot], key.w[KW - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         inserted = true; todo = false;
                         break;
                     }
                 }
                 if (cur == key.w[0]) {
-                    const uint64_t c1 = __hip_atomic_load(&keys[NS + slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (c1 == key.w[KW - 1]) { todo = false; break; }
+                    const uint64_t c1 = __hip_atomic_load(&keys[(size_t)(KW - 1) * NS + slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (c1 == EMPTY64) break;              // not published yet: same slot again next round
+                    bool same = c1 == key.w[KW - 1];
+#pragma unroll
+                    for (int j = 1; j < KW - 1; j++)
+                        same = same && __hip_atomic_load(&keys[(size_t)j * NS + slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == key.w[j];
+                    if (same) { todo = false; break; }
                 }
                 slot = slot + 1 == ns ? 0 : slot + 1;
             }
@@ -242,32 +251,66 @@ __device__ __forceinline__ void table_update(uint64_t* keys, uint32_t* ord, uint
     }
 }
 
-// forward and reverse-complement key of this lane's window; w0..w2 = packed words at index 2u + (lane>>5)
+// forward and reverse-complement key of this lane's window; w[0..KW] = packed words at index 2u + (lane>>5) ...
+// A key is the 2k-bit value of the k-mer (first base most significant, so integer order = the reference's string
+// order on A/C/G/T) cut into KW words of 63 bits, most significant first -- 63 so that no word of a real key equals
+// the EMPTY64 sentinel: k <= 31 one word, <= 63 two, <= 94 three, <= 126 four.
 template <int KW>
-__device__ __forceinline__ bool window_keys(uint32_t k, uint32_t lane, uint64_t w0, uint64_t w1, uint64_t w2,
-                                            Key<KW>& fwd, Key<KW>& rc) {
+__device__ __forceinline__ bool window_keys(uint32_t k, uint32_t lane, const uint64_t (&w)[KW + 1], Key<KW>& fwd, Key<KW>& rc) {
     const uint32_t sh = (lane & 31) << 1;
     if (KW == 1) {
-        const uint64_t x = (w0 << sh) | ((w1 >> 1) >> (63 - sh));
+        const uint64_t x = (w[0] << sh) | ((w[1] >> 1) >> (63 - sh));
         fwd.w[0] = x >> (64 - 2 * k);
         rc.w[0] = rev_groups(~x) & ((1ull << (2 * k)) - 1);   // low 2k bits of the reversed complement
         return rc.w[0] < fwd.w[0];
     } else {
-        const uint64_t x0 = (w0 << sh) | ((w1 >> 1) >> (63 - sh));
-        const uint64_t x1 = (w1 << sh) | ((w2 >> 1) >> (63 - sh));
-        // V = top 2k bits of (x0:x1), right aligned in 128 bits, 32 <= k <= 63
-        const uint32_t r = 128 - 2 * k;                       // 2..64
-        uint64_t vhi, vlo;
-        if (r == 64) { vhi = 0; vlo = x0; }
-        else { vhi = x0 >> r; vlo = (x0 << (64 - r)) | (x1 >> r); }
-        // reversed complement of the 128-bit window: its low 2k bits are the k-mer's reverse complement
-        uint64_t chi = rev_groups(~x1), clo = rev_groups(~x0);
-        const uint32_t kb = 2 * k;                             // 64..126
-        chi = kb == 64 ? 0 : (chi & ((1ull << (kb - 64)) - 1));
-        // split the 2k-bit values into two 63-bit words
-        fwd.w[0] = (vhi << 1) | (vlo >> 63); fwd.w[KW - 1] = vlo & 0x7FFFFFFFFFFFFFFFull;
-        rc.w[0] = (chi << 1) | (clo >> 63);  rc.w[KW - 1] = clo & 0x7FFFFFFFFFFFFFFFull;
-        return rc.w[0] < fwd.w[0] || (rc.w[0] == fwd.w[0] && rc.w[KW - 1] < fwd.w[KW - 1]);
+        // x = the 64 KW bits that start at this lane's base, most significant word first
+        uint64_t x[KW], f[KW], c[KW];
+#pragma unroll
+        for (int j = 0; j < KW; j++) x[j] = (w[j] << sh) | ((w[j + 1] >> 1) >> (63 - sh));
+        // forward: the top 2k bits of x, right-aligned (shift right by r = 64 KW - 2k, 2 <= r < 64 (KW - 1) + 64)
+        const uint32_t r = 64 * KW - 2 * k, rw = r >> 6, rb = r & 63;
+#pragma unroll
+        for (int j = 0; j < KW; j++) {
+            const int a = j - (int)rw;                          // source word of the low part
+            uint64_t v = 0;
+#pragma unroll
+            for (int t = 0; t < KW; t++) {
+                if (t == a) v |= x[t] >> rb;
+                if (t == a - 1 && rb) v |= x[t] << (64 - rb);
+            }
+            f[j] = v;
+        }
+        // reversed complement of the whole window: its low 2k bits are the k-mer's reverse complement
+#pragma unroll
+        for (int j = 0; j < KW; j++) c[j] = rev_groups(~x[KW - 1 - j]);
+#pragma unroll
+        for (int j = 0; j < KW; j++) {
+            // keep bits below 2k: word j covers bits [64 (KW-1-j), 64 (KW-j))
+            const int lo = 64 * (KW - 1 - j);
+            const int keep = (int)(2 * k) - lo;                 // bits of this word that belong to the value
+            if (keep <= 0) c[j] = 0;
+            else if (keep < 64) c[j] &= (1ull << keep) - 1;
+        }
+        // 64-bit words -> 63-bit words (word KW-1 = bits 0..62, word KW-2 = bits 63..125, ...)
+        auto split = [](const uint64_t (&v)[KW], Key<KW>& out) {
+#pragma unroll
+            for (int j = 0; j < KW; j++) {
+                const int bit = 63 * (KW - 1 - j);              // lowest bit of 63-bit word j
+                const int wi = KW - 1 - (bit >> 6), sb = bit & 63;      // 64-bit word holding it, offset inside
+                uint64_t t = v[wi] >> sb;
+                if (sb > 0 && wi > 0) t |= v[wi - 1] << (64 - sb);
+                out.w[j] = t & 0x7FFFFFFFFFFFFFFFull;
+            }
+        };
+        split(f, fwd);
+        split(c, rc);
+        bool less = false, decided = false;
+#pragma unroll
+        for (int j = 0; j < KW; j++) {
+            if (!decided && rc.w[j] != fwd.w[j]) { less = rc.w[j] < fwd.w[j]; decided = true; }
+        }
+        return less;
     }
 }
 
@@ -275,12 +318,12 @@ __device__ __forceinline__ bool window_keys(uint32_t k, uint32_t lane, uint64_t 
 template <int KW, bool CANON>
 __device__ __forceinline__ void scan_unit(uint64_t* keys, uint32_t* ord, uint32_t* bits, uint32_t* misc,
                                           uint32_t NS, uint32_t ns, uint32_t limit, uint32_t k, uint32_t lane,
-                                          uint32_t part, uint32_t nparts, uint64_t w0, uint64_t w1, uint64_t w2,
+                                          uint32_t part, uint32_t nparts, const uint64_t (&cw)[KW + 1],
                                           uint32_t u, uint32_t ninst, uint32_t ordb, uint32_t bit) {
     const uint32_t pos = (u << 6) + lane;
     const bool valid = pos < ninst;
     Key<KW> fwd, rc;
-    const bool rc_smaller = window_keys<KW>(k, lane, w0, w1, w2, fwd, rc);
+    const bool rc_smaller = window_keys<KW>(k, lane, cw, fwd, rc);
     if (CANON) {
         Key<KW> key = rc_smaller ? rc : fwd;          // specseq <= revspecseq -> forward (panfeed.py:70)
         const uint32_t h = key_hash<KW>(key);
@@ -363,8 +406,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
     if (wn < p.n_work && tid < 16) nd_word = reinterpret_cast<const uint32_t*>(p.desc + wn)[tid];
 
     for (uint32_t i = tid; i < ns; i += SCAN_THREADS) {
-        keys[i] = EMPTY64;
-        if (KW == 2) keys[NS + i] = EMPTY64;
+#pragma unroll
+        for (int j = 0; j < KW; j++) keys[(size_t)j * NS + i] = EMPTY64;
         ord[i] = NO_ORD;
         bits[i] = 0;
     }
@@ -477,7 +520,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
                 uint32_t ninst = misc[M_NINST + s], ordb = misc[M_ORDB + s], bit = 1u << (misc[M_SAMPLE + s] & 31);
                 const uint64_t* q = p.packed + (((uint64_t)misc[M_WOFF + 2 * s + 1] << 32) | misc[M_WOFF + 2 * s]) +
                                     2 * (size_t)u + (lane >> 5);
-                uint64_t c0 = q[0], c1 = q[1], c2 = KW == 2 ? q[2] : 0;
+                uint64_t cw[KW + 1];
+#pragma unroll
+                for (int j = 0; j <= KW; j++) cw[j] = q[j];
                 while (g < gend) {
                     // unconditional prefetch (re-reads the current address past the end) so that the compiler
                     // keeps exactly one load in flight across the table work: s_waitcnt vmcnt(1), not 0
@@ -497,12 +542,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
                                  2 * (size_t)un + (lane >> 5);
                         }
                     }
-                    const uint64_t n0 = qn[0], n1 = qn[1], n2 = KW == 2 ? qn[2] : 0;
+                    uint64_t nw[KW + 1];
+#pragma unroll
+                    for (int j = 0; j <= KW; j++) nw[j] = qn[j];
                     // table past its limit: stop inserting (the cluster is re-run with more key partitions)
                     if (__hip_atomic_load(&misc[M_OVERFLOW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-                    scan_unit<KW, CANON>(keys, ord, bits, misc, NS, ns, limit, k, lane, part, nparts, c0, c1, c2,
+                    scan_unit<KW, CANON>(keys, ord, bits, misc, NS, ns, limit, k, lane, part, nparts, cw,
                                          u, ninst, ordb, bit);
-                    c0 = n0; c1 = n1; c2 = n2;
+#pragma unroll
+                    for (int j = 0; j <= KW; j++) cw[j] = nw[j];
                     q = qn; s = sn; send = sendn; u = un; ninst = ninstn; ordb = ordbn; bit = bitn;
                     g = gn;
                 }
@@ -541,8 +589,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
             else if (have_c0) lo = g0[i];
             if (last_live && ch == 1) hi = bits[i];
             const uint32_t e = atomicAdd(&misc[M_COUNT], 1u);
-            p.tab_key[((size_t)slice * KW) * NS + e] = keys[i];
-            if (KW == 2) p.tab_key[((size_t)slice * KW + 1) * NS + e] = keys[NS + i];
+#pragma unroll
+            for (int j = 0; j < KW; j++) p.tab_key[((size_t)slice * KW + j) * NS + e] = keys[(size_t)j * NS + i];
             p.tab_ord[(size_t)slice * NS + e] = o;
             p.cmask_lo[(size_t)slice * NS + e] = lo;
             p.cmask_hi[(size_t)slice * NS + e] = hi;
@@ -551,8 +599,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
         if (tid == 0) p.item_count[item] = misc[M_COUNT];
     } else {
         for (uint32_t i = tid; i < ns; i += SCAN_THREADS) {
-            p.tab_key[((size_t)slice * KW) * NS + i] = keys[i];
-            if (KW == 2) p.tab_key[((size_t)slice * KW + 1) * NS + i] = keys[NS + i];
+#pragma unroll
+            for (int j = 0; j < KW; j++) p.tab_key[((size_t)slice * KW + j) * NS + i] = keys[(size_t)j * NS + i];
             p.tab_ord[(size_t)slice * NS + i] = ord[i];
         }
         if (tid < 8) p.chunkmask[slice * 8 + tid] = mask_word;
@@ -588,7 +636,10 @@ __global__ __launch_bounds__(256) void strand_bits_kernel(const uint64_t* packed
         for (uint32_t u = 0; u < (ninst + 63) >> 6; u++) {
             const uint64_t* q = wp + 2 * (size_t)u + (lane >> 5);
             Key<KW> fwd, rc;
-            const bool rc_smaller = window_keys<KW>(k, lane, q[0], q[1], KW == 2 ? q[2] : 0, fwd, rc);
+            uint64_t cw[KW + 1];
+#pragma unroll
+            for (int j = 0; j <= KW; j++) cw[j] = q[j];
+            const bool rc_smaller = window_keys<KW>(k, lane, cw, fwd, rc);
             const uint64_t bal = __ballot(((u << 6) + lane) < ninst && rc_smaller);
             if (lane == 0) strand_bits[(size_t)soff + u] = bal;
         }
@@ -664,7 +715,13 @@ __device__ __forceinline__ ulonglong2 dedup_load16(const ulonglong2* p) {
 
 constexpr uint32_t DEDUP_THREADS = 512;
 constexpr uint32_t DEDUP_CH = 4;              // 16-byte chunks per lane kept in registers (CH * GL * 64 bases per segment)
-constexpr uint32_t DEDUP_U = 1;               // segments in flight per 16-lane group
+#ifndef PF_DEDUP_U
+#define PF_DEDUP_U 1
+#endif
+#ifndef PF_DEDUP_WAVES
+#define PF_DEDUP_WAVES 6
+#endif
+constexpr uint32_t DEDUP_U = PF_DEDUP_U;       // segments in flight per 8-lane group
 constexpr uint32_t DEDUP_GL = 8;              // lanes that share one segment
 constexpr uint32_t DEDUP_UNSET = 0xFFFFFFFFu;
 constexpr uint32_t DEDUP_INGLOBAL = 0x80000000u;
@@ -676,7 +733,7 @@ struct DedupSmall { static constexpr uint32_t GTAB = 256, MAXD = DEDUP_MAX_D, PO
 struct DedupWide { static constexpr uint32_t GTAB = 2048, MAXD = DEDUP_MAX_D_WIDE, POOL = 1024, MODE = 2; typedef uint16_t slot_t; };
 
 template <class CFG>
-__global__ __launch_bounds__(DEDUP_THREADS) __attribute__((amdgpu_waves_per_eu(CFG::MODE == 1 ? 6 : 2, CFG::MODE == 1 ? 6 : 4)))
+__global__ __launch_bounds__(DEDUP_THREADS) __attribute__((amdgpu_waves_per_eu(CFG::MODE == 1 ? PF_DEDUP_WAVES : 2, CFG::MODE == 1 ? PF_DEDUP_WAVES : 4)))
 void cluster_dedup_kernel(DedupParams p) {
     constexpr uint32_t GTAB = CFG::GTAB, MAXD = CFG::MAXD, POOL = CFG::POOL;
     typedef typename CFG::slot_t slot_t;
@@ -1009,7 +1066,7 @@ __global__ void extra_fill_kernel(ExtraParams p) {
     const uint32_t first = p.item_first[item], n = p.item_nslots[item], slice = p.item_scratch[item];
     for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
         p.tab_key[((size_t)slice * p.KW) * p.NS + e] = KEY_EXTRA_FLAG | (uint64_t)(first + e);
-        if (p.KW == 2) p.tab_key[((size_t)slice * p.KW + 1) * p.NS + e] = 0;
+        for (uint32_t j = 1; j < p.KW; j++) p.tab_key[((size_t)slice * p.KW + j) * p.NS + e] = 0;
         p.tab_ord[(size_t)slice * p.NS + e] = p.extra_ord[first + e];
         for (uint32_t w = 0; w < p.W; w++)
             p.chunkbits[((size_t)slice * p.W + w) * p.NS + e] = p.extra_bits[(size_t)(first + e) * p.W + w];
@@ -1821,7 +1878,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
         // not in the local table (it was full): straight to the run-global table
         if (!found) pid = pattern_insert(p.pt, lo, (uint32_t)(hi >> 32), p.out_first[o_idx]);
         p.out_key[o_idx * KW] = p.tab_key[((size_t)slice * KW) * NS + slot];
-        if (KW == 2) p.out_key[o_idx * KW + 1] = p.tab_key[((size_t)slice * KW + 1) * NS + slot];
+        for (uint32_t j = 1; j < KW; j++) p.out_key[o_idx * KW + j] = p.tab_key[((size_t)slice * KW + j) * NS + slot];
         p.out_pid[o_idx] = pid;
     }
 }
@@ -2348,7 +2405,7 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
         const uint64_t oi = obase + kept_before(o);
         if (oi >= p.out_cap) { p.pt.counters[2] = 1; continue; }
         p.out_key[oi * KW] = k0_[u];
-        if (KW == 2) p.out_key[oi * KW + 1] = p.tab_key[((size_t)slice * KW + 1) * NS + i];
+        for (uint32_t j = 1; j < KW; j++) p.out_key[oi * KW + j] = p.tab_key[((size_t)slice * KW + j) * NS + i];
         p.out_pid[oi] = at_pid[tag];
       }
     }
@@ -2372,7 +2429,7 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
                 const uint64_t oi = obase + kept_before(o);
                 if (oi >= p.out_cap) { p.pt.counters[2] = 1; continue; }
                 p.out_key[oi * KW] = p.tab_key[((size_t)slice * KW) * NS + i];
-                if (KW == 2) p.out_key[oi * KW + 1] = p.tab_key[((size_t)slice * KW + 1) * NS + i];
+                for (uint32_t j = 1; j < KW; j++) p.out_key[oi * KW + j] = p.tab_key[((size_t)slice * KW + j) * NS + i];
                 p.out_pid[oi] = pid;
             }
         }
@@ -2406,7 +2463,7 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
         const uint64_t oi = obase + kept_before(o);
         if (oi >= p.out_cap) { p.pt.counters[2] = 1; continue; }
         p.out_key[oi * KW] = KEY_EXTRA_FLAG | (uint64_t)e;
-        if (KW == 2) p.out_key[oi * KW + 1] = 0;
+        for (uint32_t j = 1; j < KW; j++) p.out_key[oi * KW + j] = 0;
         p.out_pid[oi] = pid;
     }
     __syncthreads();
@@ -2955,11 +3012,11 @@ __global__ __launch_bounds__(256) void kh_text_kernel(KhTextParams p) {
                 const char* e = p.extra_keys + (size_t)(uint32_t)k0 * k;
                 for (uint32_t q = 0; q < k; q++) w[q] = e[q];
             } else {
-                uint64_t hi = 0, lo = k0;
-                if (p.KW == 2) { const uint64_t k1 = keys[j * 2 + 1]; hi = k0 >> 1; lo = ((k0 & 1) << 63) | k1; }
+                // bit b of the 2k-bit value lives in 63-bit word KW - 1 - b / 63, at bit b % 63
                 for (uint32_t q = 0; q < k; q++) {
-                    const uint32_t bit = 2 * (k - 1 - q);
-                    const uint32_t code = bit >= 64 ? (uint32_t)(hi >> (bit - 64)) & 3 : (uint32_t)(lo >> bit) & 3;
+                    const uint32_t b0 = 2 * (k - 1 - q), b1 = b0 + 1;
+                    const uint64_t w0 = keys[j * p.KW + (p.KW - 1 - b0 / 63)], w1 = keys[j * p.KW + (p.KW - 1 - b1 / 63)];
+                    const uint32_t code = (uint32_t)((w0 >> (b0 % 63)) & 1) | ((uint32_t)((w1 >> (b1 % 63)) & 1) << 1);
                     w[q] = (char)(0x54474341u >> (8 * code));               // "ACGT"
                 }
             }

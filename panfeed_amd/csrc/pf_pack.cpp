@@ -279,9 +279,9 @@ int pf_pack_records(const pf_pack_in* in, pf_packed** out) {
     }
     p->t_seg_off.push_back((uint32_t)p->t_seg_index.size());
     p->t_amb_off.push_back((uint32_t)p->t_amb_pos.size());
-    p->packed.push_back(0);
-    p->packed.push_back(0);                       // 16 bytes of tail padding
-    p->n_words_dev = p->gather ? woff + 2 : 0;
+    for (int i = 0; i < 4; i++) p->packed.push_back(0);   // 32 bytes of tail padding (a window of k <= 126 bases
+                                                          // reaches up to four words past its own)
+    p->n_words_dev = p->gather ? woff + 4 : 0;
     p->n_strand_words = strand_words;
     *out = p;
     return PF_OK;

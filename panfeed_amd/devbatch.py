@@ -175,21 +175,21 @@ def from_synth(engine, clusters, k, canon=True, first_ordinal=0):
     seg_ord = np.concatenate(seg_ord) if seg_ord else np.zeros(0, np.uint32)
     seg_words = 2 * ((seg_len.astype(np.int64) + 63) // 64)
     seg_word_off = np.concatenate(([0], np.cumsum(seg_words)[:-1])).astype(np.uint64) if len(seg_len) else np.zeros(0, np.uint64)
-    n_words = int(seg_words.sum()) + 2
+    n_words = int(seg_words.sum()) + 4
 
     db = DeviceBatch(engine)
     b = db.batch
     b.n_clusters, b.n_segs, b.n_words, b.on_device = len(clusters), len(seg_len), n_words, 1
-    aw = np.concatenate(allele_words + [np.zeros(2, np.uint64)])
+    aw = np.concatenate(allele_words + [np.zeros(4, np.uint64)])
     p_aw = db._put("allele_words", aw)
     p_ao = db._put("allele_off", np.asarray(allele_off, dtype=np.uint64))
     p_sa = db._put("seg_allele", seg_allele)
     b.seg_word_off = db._put("seg_word_off", seg_word_off)
     b.seg_len = db._put("seg_len", seg_len)
     b.packed = db._alloc("packed", n_words * 8)
-    # the two words of tail padding are not covered by the expansion kernel: zero them (fresh device memory is not)
-    zeros = np.zeros(2, dtype=np.uint64)
-    _lib.check(db.L.pf_dev_upload(engine.ctx, C.c_void_p(b.packed + (n_words - 2) * 8), zeros.ctypes.data_as(C.c_void_p), 16))
+    # the four words of tail padding are not covered by the expansion kernel: zero them (fresh device memory is not)
+    zeros = np.zeros(4, dtype=np.uint64)
+    _lib.check(db.L.pf_dev_upload(engine.ctx, C.c_void_p(b.packed + (n_words - 4) * 8), zeros.ctypes.data_as(C.c_void_p), 32))
     _lib.check(db.L.pf_synth_expand(engine.ctx, p_aw, p_ao, p_sa, b.seg_word_off, b.seg_len, len(seg_len), b.packed))
     b.seg_sample = db._put("seg_sample", seg_sample)
     b.seg_ord_base = db._put("seg_ord_base", seg_ord)

@@ -227,7 +227,7 @@ def build_batch(records, klength, canon, W, stroi=(), first_ordinal=0, want_stra
             ex_bits.append(row)
             hb.extra_keys.append(key)
 
-    words.append(np.zeros(2, dtype=np.uint64))   # 16 bytes of tail padding
+    words.append(np.zeros(4, dtype=np.uint64))   # 32 bytes of tail padding
     hb.packed = np.ascontiguousarray(np.concatenate(words))
     hb.seg_word_off = np.asarray(seg_word_off, dtype=np.uint64)
     hb.seg_len = np.asarray(seg_len, dtype=np.uint32)
@@ -247,28 +247,21 @@ def build_batch(records, klength, canon, W, stroi=(), first_ordinal=0, want_stra
 
 
 def decode_keys(keys, k, key_words):
-    """device k-mer keys -> list of str.  One word: the k bases in the low 2k bits, first base on
-    top.  Two words: a 2k-bit value split into two 63-bit words (word 0 = high part)."""
+    """device k-mer keys -> list of str.  A key is the k-mer's 2k-bit value (first base most significant) in
+    `key_words` words of 63 bits, most significant word first: bit b lives in word key_words - 1 - b // 63, bit b % 63."""
     keys = np.asarray(keys, dtype=np.uint64).reshape(-1, key_words)
     n = len(keys)
     if n == 0:
         return []
-    if key_words == 1:
-        hi = np.zeros(n, dtype=np.uint64)
-        lo = keys[:, 0]
-    else:
-        hi = keys[:, 0] >> np.uint64(1)
-        lo = ((keys[:, 0] & np.uint64(1)) << np.uint64(63)) | keys[:, 1]
     out = np.empty((n, k), dtype=np.uint8)
+
+    def bit(b):
+        return (keys[:, key_words - 1 - b // 63] >> np.uint64(b % 63)) & np.uint64(1)
     for i in range(k):
-        bit = 2 * (k - 1 - i)
-        if bit >= 64:
-            code = (hi >> np.uint64(bit - 64)) & np.uint64(3)
-        else:
-            code = (lo >> np.uint64(bit)) & np.uint64(3)
+        b0 = 2 * (k - 1 - i)
+        code = bit(b0) | (bit(b0 + 1) << np.uint64(1))
         out[:, i] = _ASCII[code.astype(np.intp)]
     return [row.tobytes().decode() for row in out]
-
 
 
 def _fill_from_packed(L, hb, handle, n_clusters, seq_ref):

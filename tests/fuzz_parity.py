@@ -14,7 +14,7 @@ fails = 0
 t0 = time.time()
 for case in range(n_cases):
     rng = np.random.default_rng(seed0 * 100003 + case)
-    k = int(rng.choice([3, 7, 15, 21, 31, 32, 33, 47, 63]))
+    k = int(rng.choice([3, 7, 15, 21, 31, 32, 33, 47, 63, 64, 80, 95, 126]))
     S = int(rng.choice([300, 640, 1000, 1100])) if big else int(rng.choice([5, 17, 33, 64, 90, 130, 260]))
     ncl = int(rng.integers(1, 5 if big else 9))
     kw = dict(klength=k, canon=bool(rng.random() < 0.7), consider_missing=bool(rng.random() < 0.3),

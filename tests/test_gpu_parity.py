@@ -34,10 +34,7 @@ def test_golden_engine(case, dedup):
     from panfeed_amd._lib import PanfeedHipError
     o = case["opts"]
     ms = max(32, (len(case["all_strains"]) + 31) // 32 * 32)
-    if o["klength"] > 63:
-        with pytest.raises(PanfeedHipError):
-            _engine(o, ms)
-        return
+    assert o["klength"] <= 126              # rand12_k64 runs with three key words
     eng = _engine(o, ms, dedup=dedup)
     out = eng.run(case_records(case))
     hk, hkh, hhp = _headers(case)
@@ -55,7 +52,7 @@ def test_golden_engine(case, dedup):
     eng.close()
 
 
-@pytest.mark.parametrize("case", [c for c in CASES if not c["opts"]["multiple_files"] and c["opts"]["klength"] <= 63][::3],
+@pytest.mark.parametrize("case", [c for c in CASES if not c["opts"]["multiple_files"]][::3],
                          ids=lambda c: c["name"])
 def test_golden_mirror_one_cluster_per_call(case):
     """The reference's own driver loop (__main__.py:350-356) over the mirror API, one cluster per call."""
@@ -88,9 +85,12 @@ def _oracle_texts(records, stroi=(), **kw):
 
 
 @pytest.mark.parametrize("dedup", [True, False], ids=["dedup", "nodedup"])
-@pytest.mark.parametrize("k,canon,S,flank", [(31, True, 200, 0), (31, False, 96, 10), (51, True, 130, 0), (21, True, 333, 25)])
+@pytest.mark.parametrize("k,canon,S,flank", [(31, True, 200, 0), (31, False, 96, 10), (51, True, 130, 0), (21, True, 333, 25),
+                                             (64, True, 70, 0), (77, False, 70, 20), (94, True, 90, 10), (95, True, 90, 10),
+                                             (126, False, 70, 40)])
 def test_seeded_vs_oracle(k, canon, S, flank, dedup):
-    """mid-size seeded clusters (multi-word rows, several sample chunks, paralogs, Ns)"""
+    """mid-size seeded clusters (multi-word rows, several sample chunks, paralogs, Ns); k up to 126 = one to four
+    63-bit key words (the reference slices any length, panfeed.py:65-67)"""
     from panfeed_amd import synth
     from panfeed_amd.engine import Engine
     cl = synth.generate(10, S, first=1234, flank=flank, mean_len=400, min_len=80, max_len=1500, n_rate=0.01,
@@ -645,6 +645,8 @@ def test_error_paths():
     recs = [c.record() for c in cl]
     with pytest.raises(PanfeedHipError):
         Engine(klength=0, max_strains=64)
+    with pytest.raises(PanfeedHipError):
+        Engine(klength=127, max_strains=64)                              # more than four 63-bit key words
     with pytest.raises(PanfeedHipError):
         Engine(klength=31, max_strains=9000)
     eng = Engine(klength=21, max_strains=32)

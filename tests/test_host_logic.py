@@ -79,16 +79,14 @@ def test_pack_and_decode_roundtrip():
         assert lib.pf_pack_acgt(s, n, out.ctypes.data) == len(w)
         assert np.array_equal(out, w)
     assert L[ord("N")] == 255
-    # key decode, one and two words
-    for k, kw in ((5, 1), (31, 1), (32, 2), (51, 2), (63, 2)):
+    # key decode, one to four 63-bit words
+    for k, kw in ((5, 1), (31, 1), (32, 2), (51, 2), (63, 2), (64, 3), (94, 3), (95, 4), (126, 4)):
+        assert kw == (2 * k + 62) // 63
         codes = rng.integers(0, 4, k)
         val = 0
         for c in codes:
             val = (val << 2) | int(c)
-        if kw == 1:
-            keys = np.array([val], dtype=np.uint64)
-        else:
-            keys = np.array([val >> 63, val & ((1 << 63) - 1)], dtype=np.uint64)
+        keys = np.array([(val >> (63 * (kw - 1 - j))) & ((1 << 63) - 1) for j in range(kw)], dtype=np.uint64)
         assert packing.decode_keys(keys, k, kw) == ["".join("ACGT"[c] for c in codes)]
 
 
@@ -133,8 +131,6 @@ def test_native_packer_equals_numpy_packer():
     from panfeed_amd import synth
     for case in all_cases():
         o = case["opts"]
-        if o["klength"] > 63:
-            continue
         recs = case_records(case)
         W = max(1, (len(case["all_strains"]) + 31) // 32)
         kw = dict(stroi=set(o["stroi"] or ()), first_ordinal=17)
