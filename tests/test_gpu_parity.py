@@ -262,7 +262,7 @@ def test_device_resident_batch_matches_host_batch():
     """pf_submit on device pointers (the bench path) == on host pointers; synth expansion == host packing"""
     from panfeed_amd import devbatch, synth
     from panfeed_amd.engine import Engine
-    from panfeed_amd.packing import build_batch
+    from numpy_packer import build_batch
     cl = synth.generate(9, 64, first=42, flank=15, mean_len=300, min_len=50, max_len=800, n_rate=0.0)
     recs = [c.record() for c in cl]
     eng = Engine(klength=31, max_strains=64)
@@ -294,7 +294,7 @@ def test_device_resident_batch_with_N(S, flank, n_rate, missing):
     the slow-path rows of its clusters along."""
     from panfeed_amd import devbatch, synth
     from panfeed_amd.engine import Engine
-    from panfeed_amd.packing import build_batch
+    from numpy_packer import build_batch
     cl = synth.generate(14, S, first=77, flank=flank, mean_len=350, min_len=60, max_len=900, n_rate=n_rate, paralog_rate=0.02)
     assert sum(int((c.seq_npos >= 0).sum()) for c in cl) > 3
     recs = [c.record() for c in cl]

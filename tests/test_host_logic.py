@@ -6,6 +6,8 @@ import re
 import numpy as np
 import pytest
 
+from numpy_packer import build_batch
+
 from conftest import REPO, all_cases, case_records
 from panfeed_amd import packing
 
@@ -95,7 +97,7 @@ def test_build_batch_invariants():
         o = case["opts"]
         recs = case_records(case)
         W = max(1, (len(case["all_strains"]) + 31) // 32)
-        hb = packing.build_batch(recs, o["klength"], o["canon"], W, stroi=set(o["stroi"] or ()))
+        hb = build_batch(recs, o["klength"], o["canon"], W, stroi=set(o["stroi"] or ()))
         assert hb.n_clusters == len(recs)
         assert len(hb.packed) >= 2 and hb.packed[-1] == 0 and hb.packed[-2] == 0
         assert (hb.seg_word_off % 2 == 0).all()
@@ -134,14 +136,14 @@ def test_native_packer_equals_numpy_packer():
         recs = case_records(case)
         W = max(1, (len(case["all_strains"]) + 31) // 32)
         kw = dict(stroi=set(o["stroi"] or ()), first_ordinal=17)
-        _same_batch(packing.build_batch(recs, o["klength"], o["canon"], W, **kw),
+        _same_batch(build_batch(recs, o["klength"], o["canon"], W, **kw),
                     packing.build_batch_native(recs, o["klength"], o["canon"], W, **kw))
     for canon in (True, False):
         cl = synth.generate(12, 90, first=31, flank=20, mean_len=250, min_len=40, max_len=700, n_rate=0.05,
                             paralog_rate=0.05, shuffle_columns=3)
         recs = [c.record() for c in cl]
         st = {cl[0].names[0], cl[0].names[50]}
-        _same_batch(packing.build_batch(recs, 31, canon, 3, stroi=st), packing.build_batch_native(recs, 31, canon, 3, stroi=st))
+        _same_batch(build_batch(recs, 31, canon, 3, stroi=st), packing.build_batch_native(recs, 31, canon, 3, stroi=st))
 
 
 def test_native_packer_rejects_bad_complement():
@@ -151,7 +153,7 @@ def test_native_packer_rejects_bad_complement():
     with pytest.raises(PanfeedHipError):
         packing.build_batch_native([rec], 5, True, 1)
     with pytest.raises(ValueError):
-        packing.build_batch([rec], 5, True, 1)
+        build_batch([rec], 5, True, 1)
 
 
 def test_device_md5_block_source_on_host(tmp_path):

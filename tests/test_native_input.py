@@ -6,6 +6,8 @@ import os
 import numpy as np
 import pytest
 
+from numpy_packer import build_batch
+
 from oracle import input_restatement as ir
 from panfeed_amd import native_input as ni
 from panfeed_amd import packing, synth
@@ -77,7 +79,7 @@ def test_batches_equal_packer_over_restated_records(pangenome, k, canon, ntg):
     pos = 0
     for hb in hbs:
         n = len(hb.idx)
-        ref = packing.build_batch(exp[pos:pos + n], k, canon, W, stroi=tg, first_ordinal=5 + pos)
+        ref = build_batch(exp[pos:pos + n], k, canon, W, stroi=tg, first_ordinal=5 + pos)
         for f in ("packed", "seg_word_off", "seg_len", "seg_sample", "seg_ord_base", "seg_strand_off",
                   "cluster_seg_off", "extra_cluster", "extra_ord", "extra_bits", "cluster_nstrains",
                   "cluster_npresab", "cluster_presab", "cluster_ordinal"):
