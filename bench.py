@@ -104,8 +104,10 @@ def load_pmc():
     return None, None
 
 
-# which roof bounds which kernel, and why
-KERNEL_BOUND = {"cluster_dedup_kernel": "hbm", "kmer_scan_kernel": "valu", "md5_kernel": "valu",
+# which roof bounds which kernel, and why (DESIGN.md sections 4 and 6): the dedup pass streams the packed input (HBM);
+# MD5 is a chain of dependent integer ops (vector issue); the scan waits on LDS round trips at the four waves per SIMD
+# its whole-LDS table leaves it, the finish kernels on dependent global loads / atomics (latency)
+KERNEL_BOUND = {"cluster_dedup_kernel": "hbm", "kmer_scan_kernel": "lds-latency", "md5_kernel": "valu",
                 "finish_kernel": "latency", "rows_kernel": "latency", "emit_kernel": "latency",
                 "pattern_rows_kernel": "latency"}
 
@@ -392,9 +394,11 @@ def main():
                                  "design -- a k-mer carries a pattern id -- so must_move_* prices only the bytes the path "
                                  "has to move (packed input, key + pattern id per kept k-mer, one row per new pattern). "
                                  "Only cluster_dedup_kernel is HBM-bound; per_kernel gives each kernel its own roof: hbm = "
-                                 "bytes it must read / time vs 8 TB/s, valu = SQ_INSTS_VALU / time vs the chip's vector "
-                                 "issue rate (256 CU x 4 SIMD x 1 wave-instruction / 2 cycles x 2.4 GHz), latency = share "
-                                 "of wave cycles spent waiting (SQ_WAIT_ANY / SQ_WAVE_CYCLES).  traffic = HBM bytes of "
+                                 "bytes it must read / time vs 8 TB/s (algorithmic_GBps, frac_of_hbm_peak), valu = "
+                                 "SQ_INSTS_VALU / time vs the chip's vector issue rate, 256 CU x 4 SIMD x 1 "
+                                 "wave-instruction / 2 cycles x 2.4 GHz (valu_frac_of_issue_peak), latency / lds-latency "
+                                 "= share of wave cycles spent waiting, SQ_WAIT_ANY / SQ_WAVE_CYCLES "
+                                 "(wave_cycles_waiting_frac).  traffic = HBM bytes of "
                                  "every pf:: kernel of a step (FETCH_SIZE x 2 + WRITE_SIZE, fill and count kernels "
                                  "included) from the committed PMC passes of this same command."},
             "device_ms_per_step": dict(kern_ms, submit_total=last["total_ms"]),

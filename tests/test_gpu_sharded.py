@@ -70,3 +70,22 @@ def test_sharded_gzip_and_multiple_files(tmp_path):
     for d in exp:
         for f in exp[d]:
             assert read_out(os.path.join(out, d), f, False) == exp[d][f], (d, f)
+
+
+def test_single_rank_with_device_tensors(tmp_path):
+    """world 1 through the sharded driver with the digests kept on the GPU (the tensors an RCCL run exchanges; the marks
+    come from the library's hash-table kernels, pf_merge_patterns): the files are the reference's"""
+    import torch
+
+    from conftest import case_records
+    from panfeed_amd import sharded
+    case = CASES["rand70_shuffled"]
+    out = str(tmp_path / "one")
+    os.mkdir(out)
+    o = case["opts"]
+    stats = sharded.run_records_sharded(case_records(case), out, case["all_strains"], 0, 1, None, torch.device("cuda", 0),
+                                        klength=o["klength"], canon=o["canon"], consider_missing=o["consider_missing"],
+                                        patfilt=o["patfilt"], maf=o["maf"], targets=o["stroi"] or (), batch_clusters=2)
+    for f in FILES:
+        assert read_out(out, f, False) == case["expect"][f], f
+    assert stats["patterns"] == case["expect"]["n_patterns"] == stats["pattern_rows"]
