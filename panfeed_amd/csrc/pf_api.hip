@@ -1292,12 +1292,17 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         HIPCHK(hipMemsetAsync(c->md5_list.p, 0, 4, c->stream));
         mp.int_list = c->md5_list.as<uint32_t>();
         PFCHK(mark_begin(c, 5));
-        const uint32_t md5_lds = pf::MD5_THREADS * (pf::MD5_TILE + 1) * 4 * (c->o.consider_missing ? 2 : 1);
-        hipLaunchKernelGGL(pf::md5_kernel<true>, dim3((pid1 - c->pid0 + pf::MD5_THREADS - 1) / pf::MD5_THREADS), dim3(pf::MD5_THREADS),
-                           md5_lds, c->stream, mp);
-        HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(pf::md5_kernel<false>, dim3(std::min<uint32_t>((C + pf::MD5_THREADS - 1) / pf::MD5_THREADS, 1024u)),
-                           dim3(pf::MD5_THREADS), md5_lds, c->stream, mp);
+        const dim3 g_float((pid1 - c->pid0 + pf::MD5_THREADS - 1) / pf::MD5_THREADS);
+        const dim3 g_int(std::min<uint32_t>((C + pf::MD5_THREADS - 1) / pf::MD5_THREADS, 1024u));
+        if (mp.pat_nan) {
+            hipLaunchKernelGGL((pf::md5_kernel<true, true>), g_float, dim3(pf::MD5_THREADS), 0, c->stream, mp);
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL((pf::md5_kernel<false, true>), g_int, dim3(pf::MD5_THREADS), 0, c->stream, mp);
+        } else {
+            hipLaunchKernelGGL((pf::md5_kernel<true, false>), g_float, dim3(pf::MD5_THREADS), 0, c->stream, mp);
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL((pf::md5_kernel<false, false>), g_int, dim3(pf::MD5_THREADS), 0, c->stream, mp);
+        }
         HIPCHK(hipGetLastError());
         PFCHK(mark_end(c));
     }

@@ -27,9 +27,21 @@ __device__ unsigned long long pf_prof[64];
 #define PF_PROF_BEGIN() uint64_t prof_t_ = __builtin_readcyclecounter()
 #define PF_PROF_STAMP(k) do { if (threadIdx.x == 0) { const uint64_t n_ = __builtin_readcyclecounter(); \
     atomicAdd(&pf_prof[k], (unsigned long long)(n_ - prof_t_)); prof_t_ = n_; } } while (0)
+// per wave: cycles since the last stamp of this wave added to counter k by lane 0 (s_memtime is a scalar read)
+// (accumulated in registers, slot j of 4; PF_WPROF_FLUSH adds them to counters k0 .. k0+3: one atomic per slot and flush --
+// an atomic per stamp on one address serialises the whole chip and measures itself)
+#define PF_WPROF_BEGIN() uint64_t wprof_t_ = __builtin_readcyclecounter(), wprof_a_[4] = {0, 0, 0, 0}
+#define PF_WPROF_STAMP(j) do { const uint64_t n_ = __builtin_readcyclecounter(); wprof_a_[j] += n_ - wprof_t_; wprof_t_ = n_; } while (0)
+#define PF_WPROF_COUNT(j, n) do { wprof_a_[j] += (n); } while (0)
+#define PF_WPROF_FLUSH(k0) do { if ((threadIdx.x & 63) == 0) { for (int j_ = 0; j_ < 4; j_++) \
+    if (wprof_a_[j_]) atomicAdd(&pf_prof[(k0) + j_], (unsigned long long)wprof_a_[j_]); } } while (0)
 #else
 #define PF_PROF_BEGIN() do { } while (0)
 #define PF_PROF_STAMP(k) do { } while (0)
+#define PF_WPROF_BEGIN() do { } while (0)
+#define PF_WPROF_STAMP(j) do { } while (0)
+#define PF_WPROF_COUNT(j, n) do { } while (0)
+#define PF_WPROF_FLUSH(k0) do { } while (0)
 #endif
 
 constexpr uint32_t SCAN_THREADS = 1024;
@@ -38,8 +50,9 @@ constexpr uint32_t LDS_BYTES = 163840;           // 160 KiB, whole CU
 constexpr uint32_t MISC_WORDS = 2560;            // counters, chunk offsets, staged segment metadata (10 KiB)
 constexpr uint32_t MAX_CHUNKS = 256;             // 32 samples each -> max_strains <= 8192
 constexpr uint32_t INSERT_SLACK = 2176;          // > 2*SCAN_THREADS: inserts that can land after the limit trips
-                                                 // (every wave re-checks the flag before each 64-window unit; a
-                                                 // unit inserts at most 2 keys per lane in non-canonical mode)
+                                                 // (a wave stops after the 64-window unit in which one of its own
+                                                 // inserts sees the count past the limit; a unit inserts at most
+                                                 // 2 keys per lane in non-canonical mode)
 constexpr uint64_t EMPTY64 = ~0ull;
 constexpr uint32_t NO_ORD = 0xFFFFFFFFu;
 constexpr uint64_t KEY_EXTRA_FLAG = 1ull << 63;  // tab_key of a slow-path row
@@ -53,6 +66,10 @@ __host__ __device__ inline uint32_t insert_limit(uint32_t ns) {
     return a < b ? a : b;
 }
 
+#ifndef PF_SCAN_EXP
+#define PF_SCAN_EXP 0          // 1..3: destructive timing experiments on the scan's window loop (never shipped)
+#endif
+constexpr uint32_t M_TMP_EXP = 2300;
 template <int KW>
 struct Key {
     uint64_t w[KW];
@@ -180,32 +197,45 @@ __device__ __forceinline__ uint32_t seg_lower_bound(const uint32_t* seg_sample, 
     return a;
 }
 
-// insert-or-find `key` in the LDS table, then fold (ordinal, sample bit) into the slot
+// insert-or-find `key` in the LDS table, then fold (ordinal, sample bit) into the slot.  Returns true for the lanes
+// whose insert found the table past `limit` (the caller stops its wave; the cluster is re-run with more partitions).
 template <int KW>
-__device__ __forceinline__ void table_update(uint64_t* keys, uint32_t* ord, uint32_t* bits, uint32_t* misc,
+__device__ __forceinline__ bool table_update(uint64_t* keys, uint32_t* ord, uint32_t* bits, uint32_t* misc,
                                              uint32_t NS, uint32_t ns, uint32_t limit, bool active,
                                              const Key<KW>& key, uint32_t home, uint32_t myord, uint32_t bit) {
     uint32_t slot = home;
     bool inserted = false;
     if (KW == 1) {
-        while (active) {
-            // two-slot buckets: `home` is a bucket index (ns / 2 buckets), both keys come with one 128-bit read,
-            // a new key takes the first empty slot of the first bucket that has one.  Half the probe steps of
-            // slot-by-slot probing -- the loop runs as long as the slowest of the 64 lanes.
-            const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(&keys[2 * slot]);
-            const bool hit0 = kk.x == key.w[0], hit1 = kk.y == key.w[0];
-            if (hit0 || hit1) { slot = 2 * slot + (hit0 ? 0u : 1u); break; }
-            const bool e0 = kk.x == EMPTY64, e1 = kk.y == EMPTY64;
-            if (e0 || e1) {
-                const uint32_t s2 = 2 * slot + (e0 ? 0u : 1u);
-                const uint64_t cur = atomicCAS((unsigned long long*)&keys[s2], (unsigned long long)EMPTY64,
+        // four-slot buckets: `home` is a bucket index (ns / 4 buckets), the four keys come with two 128-bit reads
+        // issued together, a new key takes the first empty slot of the first bucket that has one.  The loop runs as long
+        // as the slowest of the 64 lanes, so what counts is how often ANY lane has to go past its home bucket: with
+        // two-slot buckets (round 1) a unit took ~3.5 trips at the usual fill and the trips after the first were 38 % of
+        // the kernel's time (PF_SCAN_EXP=4 against 0).  ONE loop for the wave, its condition uniform (`__any`), the
+        // lanes predicated inside it.
+        bool pending = active;
+        uint32_t bucket = home;
+        const uint32_t nb = ns >> 2;
+        do {
+            const ulonglong2 ka = *reinterpret_cast<const ulonglong2*>(&keys[4 * bucket]);
+            const ulonglong2 kb = *reinterpret_cast<const ulonglong2*>(&keys[4 * bucket + 2]);
+            const bool h0 = ka.x == key.w[0], h1 = ka.y == key.w[0], h2 = kb.x == key.w[0], h3 = kb.y == key.w[0];
+            const bool e0 = ka.x == EMPTY64, e1 = ka.y == EMPTY64, e2 = kb.x == EMPTY64, e3 = kb.y == EMPTY64;
+            const bool hit = h0 || h1 || h2 || h3, emp = e0 || e1 || e2 || e3;
+            const uint32_t ih = h0 ? 0u : h1 ? 1u : h2 ? 2u : 3u, ie = e0 ? 0u : e1 ? 1u : e2 ? 2u : 3u;
+            const uint32_t cand = 4 * bucket + (hit ? ih : ie);
+            bool got = pending && hit;
+            if (pending && !hit && emp) {
+                const uint64_t cur = atomicCAS((unsigned long long*)&keys[cand], (unsigned long long)EMPTY64,
                                                (unsigned long long)key.w[0]);
-                if (cur == EMPTY64) { inserted = true; slot = s2; break; }
-                if (cur == key.w[0]) { slot = s2; break; }
-                continue;                                   // the bucket changed under us: look at it again
+                inserted = cur == EMPTY64;
+                got = inserted || cur == key.w[0];          // else the bucket changed under us: look at it again
             }
-            slot = slot + 1 == (ns >> 1) ? 0 : slot + 1;
-        }
+            if (got) { slot = cand; pending = false; }
+            if (pending && !emp) bucket = bucket + 1 == nb ? 0 : bucket + 1;    // full of other keys: next bucket
+#if PF_SCAN_EXP == 4
+            if (pending) { active = false; pending = false; }                  // one trip only (timing experiment)
+#endif
+        } while (__any(pending));
     } else {
         // word 0 is claimed by CAS, word 1 published right after.  A lane that sees word 0 match while word 1 is
         // still EMPTY leaves the probe loop and looks again in the next round of the outer, WAVE-UNIFORM loop: the
@@ -241,14 +271,20 @@ __device__ __forceinline__ void table_update(uint64_t* keys, uint32_t* ord, uint
             if (!__any(todo)) break;
         }
     }
+    bool over = false;
+#if PF_SCAN_EXP == 1
+    if (active && slot == 0xFFFFFFF0u) misc[M_TMP_EXP] = 1;
+    active = false;
+#endif
     if (active) {
         atomicMin(&ord[slot], myord);
         atomicOr(&bits[slot], bit);
         if (inserted) {
             uint32_t c = atomicAdd(&misc[0], 1u);
-            if (c + 1 > limit) misc[1] = 1;   // overflow: the cluster is re-run with more partitions
+            if (c + 1 > limit) { misc[1] = 1; over = true; }   // overflow: the cluster is re-run with more partitions
         }
     }
+    return over;
 }
 
 // forward and reverse-complement key of this lane's window; w[0..KW] = packed words at index 2u + (lane>>5) ...
@@ -314,9 +350,10 @@ __device__ __forceinline__ bool window_keys(uint32_t k, uint32_t lane, const uin
     }
 }
 
-// One 64-window unit of one segment: fold this lane's window into the table.
+// One 64-window unit of one segment: fold this lane's window into the table.  True (wave-uniform) when an insert of
+// this wave found the table past its limit.
 template <int KW, bool CANON>
-__device__ __forceinline__ void scan_unit(uint64_t* keys, uint32_t* ord, uint32_t* bits, uint32_t* misc,
+__device__ __forceinline__ bool scan_unit(uint64_t* keys, uint32_t* ord, uint32_t* bits, uint32_t* misc,
                                           uint32_t NS, uint32_t ns, uint32_t limit, uint32_t k, uint32_t lane,
                                           uint32_t part, uint32_t nparts, const uint64_t (&cw)[KW + 1],
                                           uint32_t u, uint32_t ninst, uint32_t ordb, uint32_t bit) {
@@ -324,22 +361,34 @@ __device__ __forceinline__ void scan_unit(uint64_t* keys, uint32_t* ord, uint32_
     const bool valid = pos < ninst;
     Key<KW> fwd, rc;
     const bool rc_smaller = window_keys<KW>(k, lane, cw, fwd, rc);
+    const uint32_t nhome = KW == 1 ? ns >> 2 : ns;
+    bool over;
+#if PF_SCAN_EXP == 2
+    {   // keys and hash only
+        Key<KW> key = rc_smaller ? rc : fwd;
+        const uint32_t h = key_hash<KW>(key);
+        if (valid && __umulhi(h, nhome) == 0xFFFFFFF0u) misc[M_TMP_EXP] = 1;
+        return false;
+    }
+#elif PF_SCAN_EXP == 3
+    if (valid && cw[0] == 0x123456789ull && cw[1] == 77) misc[M_TMP_EXP] = 1;
+    return false;
+#endif
     if (CANON) {
         Key<KW> key = rc_smaller ? rc : fwd;          // specseq <= revspecseq -> forward (panfeed.py:70)
         const uint32_t h = key_hash<KW>(key);
         const bool mine = nparts == 1 || (((h & 0xFFFFu) * nparts) >> 16) == part;
-        table_update<KW>(keys, ord, bits, misc, NS, ns, limit, valid && mine, key, __umulhi(h, KW == 1 ? ns >> 1 : ns), ordb + pos, bit);
+        over = table_update<KW>(keys, ord, bits, misc, NS, ns, limit, valid && mine, key, __umulhi(h, nhome), ordb + pos, bit);
     } else {
         // forward then reverse complement, both inserted (panfeed.py:82-88)
         uint32_t h = key_hash<KW>(fwd);
         bool mine = nparts == 1 || (((h & 0xFFFFu) * nparts) >> 16) == part;
-        table_update<KW>(keys, ord, bits, misc, NS, ns, limit, valid && mine, fwd, __umulhi(h, KW == 1 ? ns >> 1 : ns),
-                         2 * (ordb + pos), bit);
+        over = table_update<KW>(keys, ord, bits, misc, NS, ns, limit, valid && mine, fwd, __umulhi(h, nhome), 2 * (ordb + pos), bit);
         h = key_hash<KW>(rc);
         mine = nparts == 1 || (((h & 0xFFFFu) * nparts) >> 16) == part;
-        table_update<KW>(keys, ord, bits, misc, NS, ns, limit, valid && mine, rc, __umulhi(h, KW == 1 ? ns >> 1 : ns),
-                         2 * (ordb + pos) + 1, bit);
+        over |= table_update<KW>(keys, ord, bits, misc, NS, ns, limit, valid && mine, rc, __umulhi(h, nhome), 2 * (ordb + pos) + 1, bit);
     }
+    return __any(over);
 }
 
 // chunkmask word 0 is accumulated by thread 0
@@ -348,6 +397,7 @@ __device__ __forceinline__ uint32_t mask_word_any(uint32_t mask_word, uint32_t t
 // misc[] layout (uint32 words)
 constexpr uint32_t M_COUNT = 0, M_OVERFLOW = 1, M_CHUNK = 2;            // chunk offsets: MAX_CHUNKS + 2 words
 constexpr uint32_t SEG_TILE = 256;                                       // segments staged per tile
+constexpr uint32_t SCAN_TOUCH = 6;                                       // lines (128 B = 512 bases) of a segment touched ahead
 constexpr uint32_t M_WOFF = 272;                                         // [2*SEG_TILE] word offset (lo, hi)
 constexpr uint32_t M_NINST = M_WOFF + 2 * SEG_TILE;
 constexpr uint32_t M_ORDB = M_NINST + SEG_TILE;
@@ -377,6 +427,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
     // first-tile metadata of the item about to start, one segment per thread (tid < SEG_TILE)
     uint32_t pm_len = 0, pm_ordb = 0, pm_sample = 0;
     uint64_t pm_wo = 0;
+    // "Touch": one dword of each of the first SCAN_TOUCH 128-byte lines of a segment, requested as soon as the segment's
+    // word offset is known and never looked at (the registers are consumed after the last item, behind a condition that
+    // never holds).  The window loop asks for a unit's packed words only one unit ahead -- ~2 000 cycles of table work
+    // against ~4 500 cycles of HBM latency under load, so before this every unit waited ~2 500 cycles for its words;
+    // now they come from L2.
+    uint32_t tch[SCAN_TOUCH] = {};
+    auto touch = [&](uint64_t wo, uint32_t len) {
+        const uint32_t nwords = (len + 31) >> 5;
+#pragma unroll
+        for (uint32_t j = 0; j < SCAN_TOUCH; j++)
+            if (j * 16 < nwords) tch[j] = reinterpret_cast<const uint32_t*>(p.packed + wo + 16 * j)[0];
+    };
     auto fetch_tile0 = [&](uint32_t seg0, uint32_t nseg) {
         if (tid < min(nseg, SEG_TILE)) {
             const uint32_t s = seg0 + tid;
@@ -387,6 +449,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
         if (tid < 16) misc[M_DESC + tid] = reinterpret_cast<const uint32_t*>(p.desc + blockIdx.x)[tid];
         __syncthreads();
         fetch_tile0(misc[M_DESC + 6], misc[M_DESC + 7]);
+        if (tid < min(misc[M_DESC + 7], SEG_TILE)) touch(pm_wo, pm_len);
     }
 
     PF_PROF_BEGIN();
@@ -467,6 +530,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
             misc[M_NINST + tid] = len >= k ? len - k + 1 : 0;
             misc[M_ORDB + tid] = p.seg_ord_base[s];
             misc[M_SAMPLE + tid] = p.seg_sample[s];
+            touch(wo, len);
         }
         __syncthreads();
         if (wave == 0) {
@@ -507,11 +571,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
             const uint32_t cend = misc[M_CHUNK + ch + 1];
             const uint32_t hi = min(nseg, cend - t0);
             const uint32_t ubase = misc[M_UPREF + lo], utot = misc[M_UPREF + hi] - ubase;
-            // ---- this wave's units: a contiguous share of [ubase, ubase+utot), so that consecutive units
-            // mostly stay inside one segment; the next unit's words are requested before this one is processed
-            const uint32_t q16 = utot / SCAN_WAVES, r16 = utot % SCAN_WAVES;
-            uint32_t g = ubase + wave * q16 + min(wave, r16);
-            const uint32_t gend = g + q16 + (wave < r16 ? 1u : 0u);
+            // ---- this wave's units: ubase + wave, + 16, ... -- dealt round robin, NOT in contiguous shares: the units
+            // of the chunk's first sequence insert 64 new keys each (CAS + counter round trips) and cost about twice
+            // a unit of a later, nearly identical sequence; with contiguous shares the one or two waves that got the
+            // first sequence kept the other fourteen waiting at the barrier for half of the chunk's time.  The next
+            // unit's words are requested before this one is processed.
+            uint32_t g = ubase + wave;
+            const uint32_t gend = ubase + utot;
+            PF_WPROF_BEGIN();
             if (g < gend) {
                 uint32_t s = lo;
                 while (g >= misc[M_UPREF + s + 1]) s++;
@@ -526,11 +593,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
                 while (g < gend) {
                     // unconditional prefetch (re-reads the current address past the end) so that the compiler
                     // keeps exactly one load in flight across the table work: s_waitcnt vmcnt(1), not 0
-                    const uint32_t gn = g + 1;
+                    const uint32_t gn = g + SCAN_WAVES;
                     const uint64_t* qn = q;
                     uint32_t sn = s, sendn = send, un = u, ninstn = ninst, ordbn = ordb, bitn = bit;
                     if (gn < gend) {
-                        if (gn < send) { qn = q + 2; un = u + 1; }
+                        if (gn < send) { qn = q + 2 * SCAN_WAVES; un = u + SCAN_WAVES; }
                         else {
                             sn = s + 1;
                             while (gn >= misc[M_UPREF + sn + 1]) sn++;
@@ -545,10 +612,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
                     uint64_t nw[KW + 1];
 #pragma unroll
                     for (int j = 0; j <= KW; j++) nw[j] = qn[j];
-                    // table past its limit: stop inserting (the cluster is re-run with more key partitions)
-                    if (__hip_atomic_load(&misc[M_OVERFLOW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-                    scan_unit<KW, CANON>(keys, ord, bits, misc, NS, ns, limit, k, lane, part, nparts, cw,
-                                         u, ninst, ordb, bit);
+                    // table past its limit: this wave stops inserting (the cluster is re-run with more key
+                    // partitions).  A wave learns it from its own inserts -- no look at the flag per unit, that is an
+                    // LDS round trip in front of every unit -- so after the limit trips every wave finishes at most the
+                    // unit it is in: 16 waves x 64 lanes x 2 keys < INSERT_SLACK.
+                    PF_WPROF_STAMP(0);                      // bookkeeping + prefetch issue of the next unit
+                    if (scan_unit<KW, CANON>(keys, ord, bits, misc, NS, ns, limit, k, lane, part, nparts, cw,
+                                             u, ninst, ordb, bit)) break;
+                    PF_WPROF_STAMP(1);                      // the unit itself
+                    PF_WPROF_COUNT(3, 1);
 #pragma unroll
                     for (int j = 0; j <= KW; j++) cw[j] = nw[j];
                     q = qn; s = sn; send = sendn; u = un; ninst = ninstn; ordb = ordbn; bit = bitn;
@@ -557,7 +629,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
             }
             chunk_dirty = true;
             lo = hi;
+            PF_WPROF_STAMP(0);                     // (entry, first loads)
             __syncthreads();                       // the chunk part is complete in LDS
+            PF_WPROF_STAMP(2);                     // waiting for the other waves
+            PF_WPROF_FLUSH(32);
             PF_PROF_STAMP(18);
             if (misc[M_OVERFLOW]) { overflow = true; break; }
         }
@@ -606,6 +681,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
         if (tid < 8) p.chunkmask[slice * 8 + tid] = mask_word;
         if (tid == 0) p.item_count[item] = misc[M_COUNT];
     }
+    // the next item's first tile: its metadata (requested before the dump) is here by now; get its sequence lines moving
+    if (wn < p.n_work && tid < min(misc[M_NDESC + 7], SEG_TILE)) touch(pm_wo, pm_len);
     __syncthreads();                               // the table and misc[] are free again
     PF_PROF_STAMP(20);
     if (tid < 16) misc[M_DESC + tid] = misc[M_NDESC + tid];
@@ -614,6 +691,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
 #ifdef PF_PROF
     if (tid == 0) atomicAdd(&pf_prof[24], 1ull);
 #endif
+    }
+    if (p.n_work == 0xFFFFFFFFu) {                   // never: keeps the touched dwords' registers allocated until here
+        uint32_t x = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < SCAN_TOUCH; j++) x ^= tch[j];
+        p.item_count[0] = x;
     }
 }
 
@@ -721,6 +804,9 @@ constexpr uint32_t DEDUP_CH = 4;              // 16-byte chunks per lane kept in
 #ifndef PF_DEDUP_WAVES
 #define PF_DEDUP_WAVES 6
 #endif
+#ifndef PF_DEDUP_TD
+#define PF_DEDUP_TD 0           // trips the L2 touches run ahead of the data (0: none)
+#endif
 constexpr uint32_t DEDUP_U = PF_DEDUP_U;       // segments in flight per 8-lane group
 constexpr uint32_t DEDUP_GL = 8;              // lanes that share one segment
 constexpr uint32_t DEDUP_UNSET = 0xFFFFFFFFu;
@@ -791,6 +877,19 @@ void cluster_dedup_kernel(DedupParams p) {
             nx_len[u] = sn < n ? p.seg_len[seg0 + sn] : 0;
             nx_woff[u] = sn < n ? (uint32_t)(p.seg_word_off[seg0 + sn] - wbase) : 0;
         }
+#if PF_DEDUP_TD
+        // Touch-ahead: metadata runs PF_DEDUP_TD trips further ahead than the data, and every trip one dword of each
+        // 128-byte line of the segments PF_DEDUP_TD trips ahead is requested and never looked at: the line is on its way
+        // from HBM to L2 while the trips in between are worked on, and the 16-byte loads of its own trip find it there.
+        uint32_t fa_len[PF_DEDUP_TD], fa_woff[PF_DEDUP_TD];        // metadata of trips t + 1 .. t + TD
+#pragma unroll
+        for (int d = 0; d < PF_DEDUP_TD; d++) {
+            const uint32_t sn = grp + (d + 1) * DEDUP_U * ngrp;
+            fa_len[d] = sn < n ? p.seg_len[seg0 + sn] : 0;
+            fa_woff[d] = sn < n ? (uint32_t)(p.seg_word_off[seg0 + sn] - wbase) : 0;
+        }
+        uint32_t tch = 0, tch_sink = 0;
+#endif
         for (uint32_t sw = wave_grp0; sw < n; sw += DEDUP_U * ngrp) {
             // more distinct sequences than this class holds: the rest of the pass would be wasted
             if (__hip_atomic_load(&sh_many, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
@@ -818,12 +917,29 @@ void cluster_dedup_kernel(DedupParams p) {
                     const uint32_t j = gl + DEDUP_GL * q;
                     v[u][q] = j < pc[u] ? dedup_load16(&w[u][j]) : make_ulonglong2(0, 0);
                 }
+#if PF_DEDUP_TD
+            static_assert(DEDUP_U == 1, "touch-ahead is written for one segment per lane group");
+            const uint32_t tch_prev = tch;
+            {
+                // metadata of trip t + TD + 1 behind this trip's data, then the touches for trip t + TD
+                const uint32_t sn = si[0] + (PF_DEDUP_TD + 1) * ngrp;
+                const uint32_t l2 = sn < n ? p.seg_len[seg0 + sn] : 0;
+                const uint32_t w2 = sn < n ? (uint32_t)(p.seg_word_off[seg0 + sn] - wbase) : 0;
+                const uint32_t tpc = (fa_len[PF_DEDUP_TD - 1] + 63) >> 6;          // 16-byte chunks of that segment
+                tch = 8 * gl < tpc ? reinterpret_cast<const uint32_t*>(cbase + (fa_woff[PF_DEDUP_TD - 1] >> 1) + 8 * gl)[0] : 0;
+                nx_len[0] = fa_len[0]; nx_woff[0] = fa_woff[0];
+#pragma unroll
+                for (int d = 0; d + 1 < PF_DEDUP_TD; d++) { fa_len[d] = fa_len[d + 1]; fa_woff[d] = fa_woff[d + 1]; }
+                fa_len[PF_DEDUP_TD - 1] = l2; fa_woff[PF_DEDUP_TD - 1] = w2;
+            }
+#else
 #pragma unroll
             for (int u = 0; u < (int)DEDUP_U; u++) {          // the next trip's metadata, behind this trip's data
                 const uint32_t sn = si[u] + DEDUP_U * ngrp;
                 nx_len[u] = sn < n ? p.seg_len[seg0 + sn] : 0;
                 nx_woff[u] = sn < n ? (uint32_t)(p.seg_word_off[seg0 + sn] - wbase) : 0;
             }
+#endif
 #pragma unroll
             for (int u = 0; u < (int)DEDUP_U; u++) {
 #pragma unroll
@@ -851,6 +967,9 @@ void cluster_dedup_kernel(DedupParams p) {
 #endif
                 }
             }
+#if PF_DEDUP_TD
+            tch_sink += tch_prev;            // requested a trip ago, older than the data just hashed: no wait here
+#endif
             // claim: lane 0 of the group finds or opens the hash group
 #pragma unroll
             for (int u = 0; u < (int)DEDUP_U; u++) {
@@ -952,6 +1071,9 @@ void cluster_dedup_kernel(DedupParams p) {
                 }
             }
         }
+#if PF_DEDUP_TD
+        if (tch_sink + tch == 0x9E3779B9u && p.k == 0xFFFFFFFFu) sh_bad = 1;    // never: the touched dwords end here
+#endif
         __syncthreads();
         // ---- 4. hash groups -> distinct indices in the ordinal order of their representatives
         for (uint32_t t = tid; t < GTAB; t += DEDUP_THREADS)
@@ -2636,74 +2758,82 @@ __global__ __launch_bounds__(256) void pattern_rows_kernel(PatRowsParams p) {
 // ---------------------------------------------------------------------------------------------
 // md5_kernel: one lane per pattern, MD5 (RFC 1321) of the 8*n-byte image generated from the bits
 // ---------------------------------------------------------------------------------------------
-// MD5 (RFC 1321), fully unrolled with literal constants: F1/F2 in their 3-operation forms, K and the rotation
-// amounts as immediates
+// MD5 (RFC 1321), fully unrolled: the four round functions are ONE v_bitop3_b32 each (truth tables over
+// src0 = 0xF0, src1 = 0xCC, src2 = 0xAA) -- left to itself the compiler builds H from two v_xor and uses 1.5 vector
+// instructions per logic function; K and the rotation amounts are immediates.  Issue costs on gfx950
+// (profiles/r02/valu_issue_costs_gfx950.txt): v_bitop3 / v_add_u32 2.3 cycles per wave and SIMD, v_add3_u32 /
+// v_alignbit_b32 4.15: a step is 13 cycles of issue, 15.4 with a message word.
+#define MD5_F(x, y, z) __builtin_amdgcn_bitop3_b32((x), (y), (z), 0xCA)     // (x & y) | (~x & z)
+#define MD5_G(x, y, z) __builtin_amdgcn_bitop3_b32((x), (y), (z), 0xE4)     // (x & z) | (y & ~z)
+#define MD5_H(x, y, z) __builtin_amdgcn_bitop3_b32((x), (y), (z), 0x96)     // x ^ y ^ z
+#define MD5_I(x, y, z) __builtin_amdgcn_bitop3_b32((x), (y), (z), 0x39)     // y ^ (x | ~z)
+#define MD5_STEP(f, a, b, c, d, k, s, mw) a += f(b, c, d) + (k) + (mw); a = b + __builtin_rotateleft32(a, s);
 __device__ __forceinline__ void md5_block(uint32_t st[4], const uint32_t m[16]) {
     uint32_t a = st[0], b = st[1], c = st[2], d = st[3];
-    a += (d ^ (b & (c ^ d))) + 0xd76aa478u + m[0]; a = b + ((a << 7) | (a >> 25));
-    d += (c ^ (a & (b ^ c))) + 0xe8c7b756u + m[1]; d = a + ((d << 12) | (d >> 20));
-    c += (b ^ (d & (a ^ b))) + 0x242070dbu + m[2]; c = d + ((c << 17) | (c >> 15));
-    b += (a ^ (c & (d ^ a))) + 0xc1bdceeeu + m[3]; b = c + ((b << 22) | (b >> 10));
-    a += (d ^ (b & (c ^ d))) + 0xf57c0fafu + m[4]; a = b + ((a << 7) | (a >> 25));
-    d += (c ^ (a & (b ^ c))) + 0x4787c62au + m[5]; d = a + ((d << 12) | (d >> 20));
-    c += (b ^ (d & (a ^ b))) + 0xa8304613u + m[6]; c = d + ((c << 17) | (c >> 15));
-    b += (a ^ (c & (d ^ a))) + 0xfd469501u + m[7]; b = c + ((b << 22) | (b >> 10));
-    a += (d ^ (b & (c ^ d))) + 0x698098d8u + m[8]; a = b + ((a << 7) | (a >> 25));
-    d += (c ^ (a & (b ^ c))) + 0x8b44f7afu + m[9]; d = a + ((d << 12) | (d >> 20));
-    c += (b ^ (d & (a ^ b))) + 0xffff5bb1u + m[10]; c = d + ((c << 17) | (c >> 15));
-    b += (a ^ (c & (d ^ a))) + 0x895cd7beu + m[11]; b = c + ((b << 22) | (b >> 10));
-    a += (d ^ (b & (c ^ d))) + 0x6b901122u + m[12]; a = b + ((a << 7) | (a >> 25));
-    d += (c ^ (a & (b ^ c))) + 0xfd987193u + m[13]; d = a + ((d << 12) | (d >> 20));
-    c += (b ^ (d & (a ^ b))) + 0xa679438eu + m[14]; c = d + ((c << 17) | (c >> 15));
-    b += (a ^ (c & (d ^ a))) + 0x49b40821u + m[15]; b = c + ((b << 22) | (b >> 10));
-    a += (c ^ (d & (b ^ c))) + 0xf61e2562u + m[1]; a = b + ((a << 5) | (a >> 27));
-    d += (b ^ (c & (a ^ b))) + 0xc040b340u + m[6]; d = a + ((d << 9) | (d >> 23));
-    c += (a ^ (b & (d ^ a))) + 0x265e5a51u + m[11]; c = d + ((c << 14) | (c >> 18));
-    b += (d ^ (a & (c ^ d))) + 0xe9b6c7aau + m[0]; b = c + ((b << 20) | (b >> 12));
-    a += (c ^ (d & (b ^ c))) + 0xd62f105du + m[5]; a = b + ((a << 5) | (a >> 27));
-    d += (b ^ (c & (a ^ b))) + 0x02441453u + m[10]; d = a + ((d << 9) | (d >> 23));
-    c += (a ^ (b & (d ^ a))) + 0xd8a1e681u + m[15]; c = d + ((c << 14) | (c >> 18));
-    b += (d ^ (a & (c ^ d))) + 0xe7d3fbc8u + m[4]; b = c + ((b << 20) | (b >> 12));
-    a += (c ^ (d & (b ^ c))) + 0x21e1cde6u + m[9]; a = b + ((a << 5) | (a >> 27));
-    d += (b ^ (c & (a ^ b))) + 0xc33707d6u + m[14]; d = a + ((d << 9) | (d >> 23));
-    c += (a ^ (b & (d ^ a))) + 0xf4d50d87u + m[3]; c = d + ((c << 14) | (c >> 18));
-    b += (d ^ (a & (c ^ d))) + 0x455a14edu + m[8]; b = c + ((b << 20) | (b >> 12));
-    a += (c ^ (d & (b ^ c))) + 0xa9e3e905u + m[13]; a = b + ((a << 5) | (a >> 27));
-    d += (b ^ (c & (a ^ b))) + 0xfcefa3f8u + m[2]; d = a + ((d << 9) | (d >> 23));
-    c += (a ^ (b & (d ^ a))) + 0x676f02d9u + m[7]; c = d + ((c << 14) | (c >> 18));
-    b += (d ^ (a & (c ^ d))) + 0x8d2a4c8au + m[12]; b = c + ((b << 20) | (b >> 12));
-    a += (b ^ c ^ d) + 0xfffa3942u + m[5]; a = b + ((a << 4) | (a >> 28));
-    d += (a ^ b ^ c) + 0x8771f681u + m[8]; d = a + ((d << 11) | (d >> 21));
-    c += (d ^ a ^ b) + 0x6d9d6122u + m[11]; c = d + ((c << 16) | (c >> 16));
-    b += (c ^ d ^ a) + 0xfde5380cu + m[14]; b = c + ((b << 23) | (b >> 9));
-    a += (b ^ c ^ d) + 0xa4beea44u + m[1]; a = b + ((a << 4) | (a >> 28));
-    d += (a ^ b ^ c) + 0x4bdecfa9u + m[4]; d = a + ((d << 11) | (d >> 21));
-    c += (d ^ a ^ b) + 0xf6bb4b60u + m[7]; c = d + ((c << 16) | (c >> 16));
-    b += (c ^ d ^ a) + 0xbebfbc70u + m[10]; b = c + ((b << 23) | (b >> 9));
-    a += (b ^ c ^ d) + 0x289b7ec6u + m[13]; a = b + ((a << 4) | (a >> 28));
-    d += (a ^ b ^ c) + 0xeaa127fau + m[0]; d = a + ((d << 11) | (d >> 21));
-    c += (d ^ a ^ b) + 0xd4ef3085u + m[3]; c = d + ((c << 16) | (c >> 16));
-    b += (c ^ d ^ a) + 0x04881d05u + m[6]; b = c + ((b << 23) | (b >> 9));
-    a += (b ^ c ^ d) + 0xd9d4d039u + m[9]; a = b + ((a << 4) | (a >> 28));
-    d += (a ^ b ^ c) + 0xe6db99e5u + m[12]; d = a + ((d << 11) | (d >> 21));
-    c += (d ^ a ^ b) + 0x1fa27cf8u + m[15]; c = d + ((c << 16) | (c >> 16));
-    b += (c ^ d ^ a) + 0xc4ac5665u + m[2]; b = c + ((b << 23) | (b >> 9));
-    a += (c ^ (b | ~d)) + 0xf4292244u + m[0]; a = b + ((a << 6) | (a >> 26));
-    d += (b ^ (a | ~c)) + 0x432aff97u + m[7]; d = a + ((d << 10) | (d >> 22));
-    c += (a ^ (d | ~b)) + 0xab9423a7u + m[14]; c = d + ((c << 15) | (c >> 17));
-    b += (d ^ (c | ~a)) + 0xfc93a039u + m[5]; b = c + ((b << 21) | (b >> 11));
-    a += (c ^ (b | ~d)) + 0x655b59c3u + m[12]; a = b + ((a << 6) | (a >> 26));
-    d += (b ^ (a | ~c)) + 0x8f0ccc92u + m[3]; d = a + ((d << 10) | (d >> 22));
-    c += (a ^ (d | ~b)) + 0xffeff47du + m[10]; c = d + ((c << 15) | (c >> 17));
-    b += (d ^ (c | ~a)) + 0x85845dd1u + m[1]; b = c + ((b << 21) | (b >> 11));
-    a += (c ^ (b | ~d)) + 0x6fa87e4fu + m[8]; a = b + ((a << 6) | (a >> 26));
-    d += (b ^ (a | ~c)) + 0xfe2ce6e0u + m[15]; d = a + ((d << 10) | (d >> 22));
-    c += (a ^ (d | ~b)) + 0xa3014314u + m[6]; c = d + ((c << 15) | (c >> 17));
-    b += (d ^ (c | ~a)) + 0x4e0811a1u + m[13]; b = c + ((b << 21) | (b >> 11));
-    a += (c ^ (b | ~d)) + 0xf7537e82u + m[4]; a = b + ((a << 6) | (a >> 26));
-    d += (b ^ (a | ~c)) + 0xbd3af235u + m[11]; d = a + ((d << 10) | (d >> 22));
-    c += (a ^ (d | ~b)) + 0x2ad7d2bbu + m[2]; c = d + ((c << 15) | (c >> 17));
-    b += (d ^ (c | ~a)) + 0xeb86d391u + m[9]; b = c + ((b << 21) | (b >> 11));
+    MD5_STEP(MD5_F, a, b, c, d, 0xd76aa478u, 7, m[0])
+    MD5_STEP(MD5_F, d, a, b, c, 0xe8c7b756u, 12, m[1])
+    MD5_STEP(MD5_F, c, d, a, b, 0x242070dbu, 17, m[2])
+    MD5_STEP(MD5_F, b, c, d, a, 0xc1bdceeeu, 22, m[3])
+    MD5_STEP(MD5_F, a, b, c, d, 0xf57c0fafu, 7, m[4])
+    MD5_STEP(MD5_F, d, a, b, c, 0x4787c62au, 12, m[5])
+    MD5_STEP(MD5_F, c, d, a, b, 0xa8304613u, 17, m[6])
+    MD5_STEP(MD5_F, b, c, d, a, 0xfd469501u, 22, m[7])
+    MD5_STEP(MD5_F, a, b, c, d, 0x698098d8u, 7, m[8])
+    MD5_STEP(MD5_F, d, a, b, c, 0x8b44f7afu, 12, m[9])
+    MD5_STEP(MD5_F, c, d, a, b, 0xffff5bb1u, 17, m[10])
+    MD5_STEP(MD5_F, b, c, d, a, 0x895cd7beu, 22, m[11])
+    MD5_STEP(MD5_F, a, b, c, d, 0x6b901122u, 7, m[12])
+    MD5_STEP(MD5_F, d, a, b, c, 0xfd987193u, 12, m[13])
+    MD5_STEP(MD5_F, c, d, a, b, 0xa679438eu, 17, m[14])
+    MD5_STEP(MD5_F, b, c, d, a, 0x49b40821u, 22, m[15])
+    MD5_STEP(MD5_G, a, b, c, d, 0xf61e2562u, 5, m[1])
+    MD5_STEP(MD5_G, d, a, b, c, 0xc040b340u, 9, m[6])
+    MD5_STEP(MD5_G, c, d, a, b, 0x265e5a51u, 14, m[11])
+    MD5_STEP(MD5_G, b, c, d, a, 0xe9b6c7aau, 20, m[0])
+    MD5_STEP(MD5_G, a, b, c, d, 0xd62f105du, 5, m[5])
+    MD5_STEP(MD5_G, d, a, b, c, 0x02441453u, 9, m[10])
+    MD5_STEP(MD5_G, c, d, a, b, 0xd8a1e681u, 14, m[15])
+    MD5_STEP(MD5_G, b, c, d, a, 0xe7d3fbc8u, 20, m[4])
+    MD5_STEP(MD5_G, a, b, c, d, 0x21e1cde6u, 5, m[9])
+    MD5_STEP(MD5_G, d, a, b, c, 0xc33707d6u, 9, m[14])
+    MD5_STEP(MD5_G, c, d, a, b, 0xf4d50d87u, 14, m[3])
+    MD5_STEP(MD5_G, b, c, d, a, 0x455a14edu, 20, m[8])
+    MD5_STEP(MD5_G, a, b, c, d, 0xa9e3e905u, 5, m[13])
+    MD5_STEP(MD5_G, d, a, b, c, 0xfcefa3f8u, 9, m[2])
+    MD5_STEP(MD5_G, c, d, a, b, 0x676f02d9u, 14, m[7])
+    MD5_STEP(MD5_G, b, c, d, a, 0x8d2a4c8au, 20, m[12])
+    MD5_STEP(MD5_H, a, b, c, d, 0xfffa3942u, 4, m[5])
+    MD5_STEP(MD5_H, d, a, b, c, 0x8771f681u, 11, m[8])
+    MD5_STEP(MD5_H, c, d, a, b, 0x6d9d6122u, 16, m[11])
+    MD5_STEP(MD5_H, b, c, d, a, 0xfde5380cu, 23, m[14])
+    MD5_STEP(MD5_H, a, b, c, d, 0xa4beea44u, 4, m[1])
+    MD5_STEP(MD5_H, d, a, b, c, 0x4bdecfa9u, 11, m[4])
+    MD5_STEP(MD5_H, c, d, a, b, 0xf6bb4b60u, 16, m[7])
+    MD5_STEP(MD5_H, b, c, d, a, 0xbebfbc70u, 23, m[10])
+    MD5_STEP(MD5_H, a, b, c, d, 0x289b7ec6u, 4, m[13])
+    MD5_STEP(MD5_H, d, a, b, c, 0xeaa127fau, 11, m[0])
+    MD5_STEP(MD5_H, c, d, a, b, 0xd4ef3085u, 16, m[3])
+    MD5_STEP(MD5_H, b, c, d, a, 0x04881d05u, 23, m[6])
+    MD5_STEP(MD5_H, a, b, c, d, 0xd9d4d039u, 4, m[9])
+    MD5_STEP(MD5_H, d, a, b, c, 0xe6db99e5u, 11, m[12])
+    MD5_STEP(MD5_H, c, d, a, b, 0x1fa27cf8u, 16, m[15])
+    MD5_STEP(MD5_H, b, c, d, a, 0xc4ac5665u, 23, m[2])
+    MD5_STEP(MD5_I, a, b, c, d, 0xf4292244u, 6, m[0])
+    MD5_STEP(MD5_I, d, a, b, c, 0x432aff97u, 10, m[7])
+    MD5_STEP(MD5_I, c, d, a, b, 0xab9423a7u, 15, m[14])
+    MD5_STEP(MD5_I, b, c, d, a, 0xfc93a039u, 21, m[5])
+    MD5_STEP(MD5_I, a, b, c, d, 0x655b59c3u, 6, m[12])
+    MD5_STEP(MD5_I, d, a, b, c, 0x8f0ccc92u, 10, m[3])
+    MD5_STEP(MD5_I, c, d, a, b, 0xffeff47du, 15, m[10])
+    MD5_STEP(MD5_I, b, c, d, a, 0x85845dd1u, 21, m[1])
+    MD5_STEP(MD5_I, a, b, c, d, 0x6fa87e4fu, 6, m[8])
+    MD5_STEP(MD5_I, d, a, b, c, 0xfe2ce6e0u, 10, m[15])
+    MD5_STEP(MD5_I, c, d, a, b, 0xa3014314u, 15, m[6])
+    MD5_STEP(MD5_I, b, c, d, a, 0x4e0811a1u, 21, m[13])
+    MD5_STEP(MD5_I, a, b, c, d, 0xf7537e82u, 6, m[4])
+    MD5_STEP(MD5_I, d, a, b, c, 0xbd3af235u, 10, m[11])
+    MD5_STEP(MD5_I, c, d, a, b, 0x2ad7d2bbu, 15, m[2])
+    MD5_STEP(MD5_I, b, c, d, a, 0xeb86d391u, 21, m[9])
     st[0] += a; st[1] += b; st[2] += c; st[3] += d;
 }
 
@@ -2715,121 +2845,99 @@ struct Md5Params {
     uint32_t pid0, pid1, W;  // ... the range given here
 };
 constexpr uint32_t MD5_THREADS = 256;
-constexpr uint32_t MD5_TILE = 16;     // row words staged per round (512 vector elements = 64 MD5 blocks)
 
+// One lane per pattern, no LDS and no barriers: every lane reads its own row, four words (16 MD5 blocks) ahead of the
+// words it is hashing, so a wave never waits for another and only registers limit the waves per SIMD (52: eight).
 // FLOAT_ROWS: the pass over all new patterns, specialised for the float64 image of k-mer rows (98 % of the patterns):
-// the low word of every element is zero, which the inlined md5_block folds away (32 of its 64 message additions);
-// the few int64 rows (one per cluster at most) are only listed.  !FLOAT_ROWS: the listed int64 rows.
-// One tile = the 256 patterns of a workgroup: rows loaded coalesced into LDS, 16 words per row and round (odd row
-// stride: conflict-free), every lane then walks its own row.
-template <bool FLOAT_ROWS>
-__device__ __forceinline__ void md5_tile(const Md5Params& p, uint32_t pid, bool live, uint32_t rows, uint32_t* row_pid,
-                                         uint32_t* t_bits, uint32_t* t_nan) {
-    const uint32_t tid = threadIdx.x;
-    __syncthreads();                                          // the previous tile's row_pid / staging are done with
-    row_pid[tid] = pid;
-    const uint32_t nk = live ? p.pat_n[pid] : 0;
-    const bool is_int = (nk >> 31) != 0;
-    if (FLOAT_ROWS && live && is_int) {                       // left to the second pass
-        p.int_list[1 + atomicAdd(&p.int_list[0], 1u)] = pid;
-        live = false;
-    }
-    const uint32_t n = nk & 0x7FFFFFFFu;
-    const bool has_nan = p.pat_nan != nullptr;
-    uint32_t st[4] = {0x67452301u, 0xefcdab89u, 0x98badcfeu, 0x10325476u};
-    const uint64_t nbytes = (uint64_t)n * 8;
-    const uint32_t full = n >> 3;             // whole 64-byte blocks = 8 elements each
-    const uint32_t rem = n & 7;
-    uint32_t m[16];
-    uint32_t tail_bw = 0, tail_nw = 0;
+// the low word of every element is zero, which the inlined md5_block folds away (32 of its 64 message additions); the
+// few int64 rows (the clusters' own, one per cluster at most) are only listed.  !FLOAT_ROWS: the listed int64 rows.
+// HAS_NAN: a NaN mask exists (--consider-missing-cluster); compiled apart, the common case pays nothing for it.
+// Vector-issue bound: 310 instructions per block at the ~4 cycles per wave-instruction this mix of 2- and 4-cycle
+// operations sustains on a SIMD (tools/micro/valu_chain.hip: 4.05 with one to eight waves, one to four chains per wave).
+template <bool FLOAT_ROWS, bool HAS_NAN>
+__global__ __launch_bounds__(MD5_THREADS) void md5_kernel(Md5Params p) {
+    // rows blockIdx.x * 256 + tid, + gridDim.x * 256, ... of the id range (the grid is sized before the range is known)
+    const uint32_t r0 = FLOAT_ROWS ? (p.range ? p.range[0] : p.pid0) : 0;
+    const uint32_t r1 = FLOAT_ROWS ? (p.range ? p.range[1] : p.pid1) : p.int_list[0];
     const uint32_t W = p.W;
-    for (uint32_t w0 = 0; w0 < W; w0 += MD5_TILE) {
-        const uint32_t tw = min(MD5_TILE, W - w0);
-        __syncthreads();
-        for (uint32_t i = tid; i < rows * tw; i += MD5_THREADS) {
-            const uint32_t r = i / tw, w = i - r * tw;
-            t_bits[r * (MD5_TILE + 1) + w] = p.pat_bits[(size_t)row_pid[r] * W + w0 + w];
-            if (has_nan) t_nan[r * (MD5_TILE + 1) + w] = p.pat_nan[(size_t)row_pid[r] * W + w0 + w];
+    for (uint64_t base = (uint64_t)r0 + (uint64_t)blockIdx.x * MD5_THREADS; base < r1; base += (uint64_t)gridDim.x * MD5_THREADS) {
+        const uint32_t idx = (uint32_t)base + threadIdx.x;
+        if (idx >= r1) continue;
+        const uint32_t pid = FLOAT_ROWS ? idx : p.int_list[1 + idx];
+        const uint32_t nk = p.pat_n[pid];
+        if (FLOAT_ROWS && (nk >> 31)) {                       // an int64 row: left to the second pass
+            p.int_list[1 + atomicAdd(&p.int_list[0], 1u)] = pid;
+            continue;
         }
-        __syncthreads();
-        if (!live) continue;
-        const uint32_t* rb = t_bits + tid * (MD5_TILE + 1);
-        const uint32_t* rn = t_nan + tid * (MD5_TILE + 1);
-        // blocks whose 8 elements lie in this tile: block b covers elements 8b..8b+7 -> word b/4
-        const uint32_t b0 = w0 * 4, b1 = min(full, (w0 + tw) * 4);
-        for (uint32_t blk = b0; blk < b1; blk++) {
-            const uint32_t e0 = (blk << 3) - (w0 << 5);
-            const uint32_t bw = (rb[e0 >> 5] >> (e0 & 31)) & 0xFF;
-            const uint32_t nw = has_nan ? (rn[e0 >> 5] >> (e0 & 31)) & 0xFF : 0;
+        const uint32_t n = nk & 0x7FFFFFFFu;
+        const uint32_t* rb = p.pat_bits + (size_t)pid * W;
+        const uint32_t* rn = HAS_NAN ? p.pat_nan + (size_t)pid * W : nullptr;
+        uint32_t st[4] = {0x67452301u, 0xefcdab89u, 0x98badcfeu, 0x10325476u};
+        const uint64_t nbytes = (uint64_t)n * 8;
+        const uint32_t full = n >> 3, rem = n & 7;            // whole 64-byte blocks = 8 elements each, and the rest
+        uint32_t m[16];
+        uint32_t qb[4], qn[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                // int64 LE: 01 00.. ; float64 LE: 1.0 = 0x3FF00000:00000000, NaN = 0x7FF80000:00000000 (np.nan);
-                // branch-free: masks of the element's bit / NaN flag ANDed with constants
-                const uint32_t bm = 0u - ((bw >> j) & 1), nm = 0u - ((nw >> j) & 1);
-                if (FLOAT_ROWS) {
-                    m[2 * j] = 0;
-                    m[2 * j + 1] = (bm & 0x3FF00000u) | (nm & 0x7FF80000u);
-                } else {
-                    m[2 * j] = bm & 1u;
-                    m[2 * j + 1] = 0;
+        for (int j = 0; j < 4; j++) {
+            qb[j] = rb[min((uint32_t)j, W - 1)];
+            if (HAS_NAN) qn[j] = rn[min((uint32_t)j, W - 1)];
+        }
+        uint32_t tail_bw = 0, tail_nw = 0;
+        for (uint32_t w0 = 0; w0 < W; w0 += 4) {
+            uint32_t nb[4], nn[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {                     // the next four words, in flight while these are hashed
+                nb[j] = rb[min(w0 + 4 + j, W - 1)];
+                if (HAS_NAN) nn[j] = rn[min(w0 + 4 + j, W - 1)];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t blk0 = (w0 + j) * 4;           // a row word = 32 elements = 4 blocks
+                const uint32_t nblk = full > blk0 ? min(4u, full - blk0) : 0;
+                for (uint32_t q = 0; q < nblk; q++) {
+                    const uint32_t bw = (qb[j] >> (q * 8)) & 0xFF;
+                    const uint32_t nw = HAS_NAN ? (qn[j] >> (q * 8)) & 0xFF : 0;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        // int64 LE: 01 00.. ; float64 LE: 1.0 = 0x3FF00000:00000000, NaN = 0x7FF80000:00000000 (np.nan);
+                        // branch-free: masks of the element's bit / NaN flag ANDed with constants
+                        const uint32_t bm = 0u - ((bw >> e) & 1), nm = 0u - ((nw >> e) & 1);
+                        m[2 * e] = FLOAT_ROWS ? 0 : bm & 1u;
+                        m[2 * e + 1] = FLOAT_ROWS ? (bm & 0x3FF00000u) | (nm & 0x7FF80000u) : 0;
+                    }
+                    md5_block(st, m);
+                }
+                if (rem && (full >> 2) == w0 + j) {           // the (at most 7) elements after the last whole block
+                    tail_bw = (qb[j] >> ((full & 3) * 8)) & 0xFF;
+                    tail_nw = HAS_NAN ? (qn[j] >> ((full & 3) * 8)) & 0xFF : 0;
                 }
             }
-            md5_block(st, m);
-        }
-        // the (at most 7) elements after the last whole block, if they live in this tile
-        if (rem && (full >> 2) >= w0 && (full >> 2) < w0 + tw) {
-            const uint32_t e0 = (full << 3) - (w0 << 5);
-            tail_bw = (rb[e0 >> 5] >> (e0 & 31)) & 0xFF;
-            tail_nw = has_nan ? (rn[e0 >> 5] >> (e0 & 31)) & 0xFF : 0;
-        }
-    }
-    if (!live) return;
-    // tail: remaining elements, 0x80, zero pad, 64-bit length
 #pragma unroll
-    for (int j = 0; j < 16; j++) m[j] = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const uint32_t bit = (tail_bw >> j) & 1, isn = (tail_nw >> j) & 1;
-        if ((uint32_t)j < rem) {
-            m[2 * j] = FLOAT_ROWS ? 0 : bit;
-            m[2 * j + 1] = FLOAT_ROWS ? (bit ? 0x3FF00000u : (isn ? 0x7FF80000u : 0)) : 0;
-        } else if ((uint32_t)j == rem) {
-            m[2 * j] = 0x80;              // first pad byte right after the data
+            for (int j = 0; j < 4; j++) { qb[j] = nb[j]; qn[j] = nn[j]; }
         }
-    }
-    if (rem == 7) {                           // 56 data bytes + 0x80 leaves no room for the length
-        md5_block(st, m);
+        // tail: remaining elements, 0x80, zero pad, 64-bit length
 #pragma unroll
         for (int j = 0; j < 16; j++) m[j] = 0;
-    }
-    m[14] = (uint32_t)(nbytes << 3);
-    m[15] = (uint32_t)((nbytes << 3) >> 32);
-    md5_block(st, m);
-    uint8_t* out = p.pat_md5 + (size_t)pid * 16;
-    *reinterpret_cast<uint4*>(out) = make_uint4(st[0], st[1], st[2], st[3]);   // little-endian words = MD5 byte order
-}
-
-template <bool FLOAT_ROWS>
-__global__ __launch_bounds__(MD5_THREADS) void md5_kernel(Md5Params p) {
-    extern __shared__ uint32_t md5_lds[];            // 17 KiB (+17 KiB with a NaN mask): 8 waves per SIMD stay resident
-    __shared__ uint32_t row_pid[MD5_THREADS];
-    uint32_t* t_bits = md5_lds;
-    uint32_t* t_nan = md5_lds + MD5_THREADS * (MD5_TILE + 1);
-    const uint32_t tid = threadIdx.x;
-    if (FLOAT_ROWS) {
-        // tiles blockIdx.x, blockIdx.x + gridDim.x, ... of the id range (the grid is sized before the range is known)
-        const uint32_t r0 = p.range ? p.range[0] : p.pid0, r1 = p.range ? p.range[1] : p.pid1;
-        for (uint64_t pbase = (uint64_t)r0 + (uint64_t)blockIdx.x * MD5_THREADS; pbase < r1; pbase += (uint64_t)gridDim.x * MD5_THREADS) {
-            const uint32_t pid = (uint32_t)pbase + tid;
-            md5_tile<true>(p, pid, pid < r1, min(MD5_THREADS, r1 - (uint32_t)pbase), row_pid, t_bits, t_nan);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t bit = (tail_bw >> j) & 1, isn = (tail_nw >> j) & 1;
+            if ((uint32_t)j < rem) {
+                m[2 * j] = FLOAT_ROWS ? 0 : bit;
+                m[2 * j + 1] = FLOAT_ROWS ? (bit ? 0x3FF00000u : (isn ? 0x7FF80000u : 0)) : 0;
+            } else if ((uint32_t)j == rem) {
+                m[2 * j] = 0x80;                              // first pad byte right after the data
+            }
         }
-    } else {
-        const uint32_t cnt = p.int_list[0];
-        for (uint32_t i0 = blockIdx.x * MD5_THREADS; i0 < cnt; i0 += gridDim.x * MD5_THREADS) {
-            const uint32_t rows = min(MD5_THREADS, cnt - i0);
-            const bool live = tid < rows;
-            md5_tile<false>(p, live ? p.int_list[1 + i0 + tid] : 0, live, rows, row_pid, t_bits, t_nan);
+        if (rem == 7) {                                       // 56 data bytes + 0x80 leaves no room for the length
+            md5_block(st, m);
+#pragma unroll
+            for (int j = 0; j < 16; j++) m[j] = 0;
         }
+        m[14] = (uint32_t)(nbytes << 3);
+        m[15] = (uint32_t)((nbytes << 3) >> 32);
+        md5_block(st, m);
+        // little-endian words = MD5 byte order
+        *reinterpret_cast<uint4*>(p.pat_md5 + (size_t)pid * 16) = make_uint4(st[0], st[1], st[2], st[3]);
     }
 }
 
