@@ -117,8 +117,9 @@ def make_step(eng, dbs, world, dist, dev, method):
     from panfeed_amd import _lib
     from panfeed_amd.distributed import merge_patterns
 
-    def step(eng=eng):
+    def step(eng=eng, checksum=False):
         _lib.check(eng.L.pf_reset_patterns(eng.ctx))
+        sums = []
         tot = {"kept": 0, "new": 0, "scan_ms": 0.0, "rows_ms": 0.0, "emit_ms": 0.0, "total_ms": 0.0, "dedup_ms": 0.0,
                "patrows_ms": 0.0, "md5_ms": 0.0, "finish_ms": 0.0, "merge_ms": 0.0,
                "launches": 0, "items": 0, "retried": 0, "unique": 0, "dedup_clusters": 0, "scan_bytes": 0}
@@ -135,6 +136,9 @@ def make_step(eng, dbs, world, dist, dev, method):
             tot["launches"] += tm["scan_launches"]
             tot["items"] += tm["n_items"]
             tot["retried"] += tm["n_retried"]
+            if checksum:                 # untimed legs only: what the files of this batch would hold, row for row
+                sums.append(eng.result_checksum())
+        tot["checksums"] = sums
         n_global = tot["new"]
         if world > 1:
             t0 = time.time()
@@ -298,9 +302,15 @@ def main():
         torch.cuda.synchronize()
         dt1 = time.time() - t1
         assert (e["kept"], e["new"], e["unique"]) == (last["kept"], last["new"], last["unique"]), "dedup changed the result"
+        # full-size parity property: both paths must write the same rows in the same places -- a device-side checksum over
+        # every (cluster, position, k-mer key, pattern digest) and every cluster row (pf_result_checksum), batch by batch
+        sum_on, sum_off = step(eng, checksum=True)["checksums"], step(eng2, checksum=True)["checksums"]
+        assert sum_on == sum_off and sum(c[2] for c in sum_on) == last["kept"], "dedup changed the rows"
         every = {"value": n_inst / dt1, "unit": "kmer_instances/s", "ms_per_step": dt1 * 1e3, "scan_ms": e["scan_ms"],
                  "rows_ms": e["rows_ms"], "emit_ms": e["emit_ms"], "clusters_repartitioned": e["retried"],
-                 "note": "PF_FLAG_NO_DEDUP: every copy of every sequence scanned; same outputs"}
+                 "rows_checksum": [f"{x:016x}" for x in (sum(c[0] for c in sum_on) & (2 ** 64 - 1), sum(c[1] for c in sum_on) & (2 ** 64 - 1))],
+                 "note": "PF_FLAG_NO_DEDUP: every copy of every sequence scanned; same outputs (counts and the device-side "
+                         "checksum over every k-mer row and cluster row, pf_result_checksum, equal to the timed path's)"}
         eng2.close()
 
     if rank == 0:

@@ -215,6 +215,14 @@ int pf_merge_patterns(pf_ctx* ctx, const void* d_gathered, uint64_t n_total, uin
 int pf_merge_patterns_padded(pf_ctx* ctx, const void* d_gathered, uint64_t world, uint64_t slot_rows,
                              const void* d_slot_counts, uint64_t rank, uint64_t my_count, void* d_keep,
                              uint64_t* n_global);
+/* A checksum of checksums of the last pf_submit's results, computed on the device (no pf_fetch): out[0] = wrapping sum
+ * over every kept k-mer of h(cluster index in the batch, its position in the cluster's output order, key words, MD5
+ * digest of its pattern) -- i.e. of what its kmers_to_hashes.tsv row holds and where it stands (panfeed.py:208);
+ * out[1] = the same per cluster over (kept, unique, digest of the cluster's own row, :177); out[2] = kept k-mers.
+ * Independent of arena placement and pattern ids: two runs that would write the same files give the same three
+ * numbers.  For parity checks at sizes no CPU checker covers (bench.py: identical-sequence shortcut on vs off at
+ * BASELINE's full size; tests). */
+int pf_result_checksum(pf_ctx* ctx, uint64_t out[3]);
 /* Number of patterns in the run-global set after the last pf_submit. */
 int pf_pattern_count(pf_ctx* ctx, uint64_t* n);
 

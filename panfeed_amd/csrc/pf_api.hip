@@ -1740,6 +1740,43 @@ int pf_merge_patterns_padded(pf_ctx* c, const void* d_gathered, uint64_t world, 
     return merge_impl(c, d_gathered, world * slot_rows, rank * slot_rows, my_count, d_slot_counts, slot_rows, d_keep, n_global);
 }
 
+int pf_result_checksum(pf_ctx* c, uint64_t out[3]) {
+    if (!c || !out) return fail(PF_ERR_ARG, "null argument");
+    if (!c->have_batch) return fail(PF_ERR_STATE, "pf_result_checksum without a successful pf_submit");
+    HIPCHK(hipSetDevice(c->device));
+    const uint32_t C = c->n_clusters, KW = (uint32_t)c->KW;
+    out[0] = out[1] = out[2] = 0;
+    if (!C) return PF_OK;
+    // where each cluster's k-mers stand: arena of the cluster + offset inside it
+    std::vector<uint64_t> off(C);
+    HIPCHK(hipMemcpy(off.data(), c->cl_kmer_off.p, (size_t)C * 8, hipMemcpyDeviceToHost));
+    std::vector<const uint64_t*> kp(C);
+    std::vector<const uint32_t*> pp(C);
+    for (uint32_t i = 0; i < C; i++) {
+        const Arena* ar = c->arenas[c->cluster_arena[i]];
+        const uint64_t local = off[i] >= ar->base ? off[i] - ar->base : 0;      // clusters without k-mers: never read
+        kp[i] = ar->key.as<uint64_t>() + local * KW;
+        pp[i] = ar->pid.as<uint32_t>() + local;
+    }
+    DevBuf d_kp, d_pp, d_acc;
+    PFCHK(d_kp.ensure((size_t)C * 8)); PFCHK(d_pp.ensure((size_t)C * 8)); PFCHK(d_acc.ensure(24));
+    int rc = PF_OK;
+    if (hipMemcpy(d_kp.p, kp.data(), (size_t)C * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_pp.p, pp.data(), (size_t)C * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemsetAsync(d_acc.p, 0, 24, c->stream) != hipSuccess) rc = fail(PF_ERR_HIP, "pf_result_checksum: copy failed");
+    if (rc == PF_OK) {
+        hipLaunchKernelGGL(pf::result_checksum_kernel, dim3(C), dim3(256), 0, c->stream,
+                           (const uint64_t* const*)d_kp.p, (const uint32_t* const*)d_pp.p, c->cl_kmer_cnt.as<uint32_t>(),
+                           c->cl_unique.as<uint32_t>(), c->cl_pattern.as<uint32_t>(), c->pat_md5.as<uint8_t>(), KW,
+                           (unsigned long long*)d_acc.p);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess ||
+            hipMemcpy(out, d_acc.p, 24, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(PF_ERR_HIP, "pf_result_checksum: kernel failed");
+    }
+    d_kp.release(); d_pp.release(); d_acc.release();
+    return rc;
+}
+
 int pf_pattern_count(pf_ctx* c, uint64_t* n) {
     if (!c || !n) return fail(PF_ERR_ARG, "null argument");
     *n = c->n_patterns;

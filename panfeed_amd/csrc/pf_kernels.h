@@ -70,6 +70,10 @@ __host__ __device__ inline uint32_t insert_limit(uint32_t ns) {
 #define PF_SCAN_EXP 0          // 1..3: destructive timing experiments on the scan's window loop (never shipped)
 #endif
 constexpr uint32_t M_TMP_EXP = 2300;
+#ifndef PF_SCAN_BUCKET
+#define PF_SCAN_BUCKET 4
+#endif
+constexpr uint32_t SCAN_BUCKET = PF_SCAN_BUCKET;   // slots per bucket of the one-word-key table (ns is a multiple of 64)
 template <int KW>
 struct Key {
     uint64_t w[KW];
@@ -214,15 +218,21 @@ __device__ __forceinline__ bool table_update(uint64_t* keys, uint32_t* ord, uint
         // lanes predicated inside it.
         bool pending = active;
         uint32_t bucket = home;
-        const uint32_t nb = ns >> 2;
+        const uint32_t nb = ns / SCAN_BUCKET;
         do {
-            const ulonglong2 ka = *reinterpret_cast<const ulonglong2*>(&keys[4 * bucket]);
-            const ulonglong2 kb = *reinterpret_cast<const ulonglong2*>(&keys[4 * bucket + 2]);
-            const bool h0 = ka.x == key.w[0], h1 = ka.y == key.w[0], h2 = kb.x == key.w[0], h3 = kb.y == key.w[0];
-            const bool e0 = ka.x == EMPTY64, e1 = ka.y == EMPTY64, e2 = kb.x == EMPTY64, e3 = kb.y == EMPTY64;
-            const bool hit = h0 || h1 || h2 || h3, emp = e0 || e1 || e2 || e3;
-            const uint32_t ih = h0 ? 0u : h1 ? 1u : h2 ? 2u : 3u, ie = e0 ? 0u : e1 ? 1u : e2 ? 2u : 3u;
-            const uint32_t cand = 4 * bucket + (hit ? ih : ie);
+            ulonglong2 kk[SCAN_BUCKET / 2];
+#pragma unroll
+            for (uint32_t j = 0; j < SCAN_BUCKET / 2; j++) kk[j] = *reinterpret_cast<const ulonglong2*>(&keys[SCAN_BUCKET * bucket + 2 * j]);
+            bool hit = false, emp = false;
+            uint32_t ih = 0, ie = 0;
+#pragma unroll
+            for (int j = SCAN_BUCKET / 2 - 1; j >= 0; j--) {             // downwards: the lowest index wins
+                if (kk[j].y == key.w[0]) { hit = true; ih = 2 * j + 1; }
+                if (kk[j].x == key.w[0]) { hit = true; ih = 2 * j; }
+                if (kk[j].y == EMPTY64) { emp = true; ie = 2 * j + 1; }
+                if (kk[j].x == EMPTY64) { emp = true; ie = 2 * j; }
+            }
+            const uint32_t cand = SCAN_BUCKET * bucket + (hit ? ih : ie);
             bool got = pending && hit;
             if (pending && !hit && emp) {
                 const uint64_t cur = atomicCAS((unsigned long long*)&keys[cand], (unsigned long long)EMPTY64,
@@ -361,7 +371,7 @@ __device__ __forceinline__ bool scan_unit(uint64_t* keys, uint32_t* ord, uint32_
     const bool valid = pos < ninst;
     Key<KW> fwd, rc;
     const bool rc_smaller = window_keys<KW>(k, lane, cw, fwd, rc);
-    const uint32_t nhome = KW == 1 ? ns >> 2 : ns;
+    const uint32_t nhome = KW == 1 ? ns / SCAN_BUCKET : ns;
     bool over;
 #if PF_SCAN_EXP == 2
     {   // keys and hash only
@@ -397,7 +407,6 @@ __device__ __forceinline__ uint32_t mask_word_any(uint32_t mask_word, uint32_t t
 // misc[] layout (uint32 words)
 constexpr uint32_t M_COUNT = 0, M_OVERFLOW = 1, M_CHUNK = 2;            // chunk offsets: MAX_CHUNKS + 2 words
 constexpr uint32_t SEG_TILE = 256;                                       // segments staged per tile
-constexpr uint32_t SCAN_TOUCH = 6;                                       // lines (128 B = 512 bases) of a segment touched ahead
 constexpr uint32_t M_WOFF = 272;                                         // [2*SEG_TILE] word offset (lo, hi)
 constexpr uint32_t M_NINST = M_WOFF + 2 * SEG_TILE;
 constexpr uint32_t M_ORDB = M_NINST + SEG_TILE;
@@ -427,18 +436,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
     // first-tile metadata of the item about to start, one segment per thread (tid < SEG_TILE)
     uint32_t pm_len = 0, pm_ordb = 0, pm_sample = 0;
     uint64_t pm_wo = 0;
-    // "Touch": one dword of each of the first SCAN_TOUCH 128-byte lines of a segment, requested as soon as the segment's
-    // word offset is known and never looked at (the registers are consumed after the last item, behind a condition that
-    // never holds).  The window loop asks for a unit's packed words only one unit ahead -- ~2 000 cycles of table work
-    // against ~4 500 cycles of HBM latency under load, so before this every unit waited ~2 500 cycles for its words;
-    // now they come from L2.
-    uint32_t tch[SCAN_TOUCH] = {};
-    auto touch = [&](uint64_t wo, uint32_t len) {
-        const uint32_t nwords = (len + 31) >> 5;
-#pragma unroll
-        for (uint32_t j = 0; j < SCAN_TOUCH; j++)
-            if (j * 16 < nwords) tch[j] = reinterpret_cast<const uint32_t*>(p.packed + wo + 16 * j)[0];
-    };
     auto fetch_tile0 = [&](uint32_t seg0, uint32_t nseg) {
         if (tid < min(nseg, SEG_TILE)) {
             const uint32_t s = seg0 + tid;
@@ -449,7 +446,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
         if (tid < 16) misc[M_DESC + tid] = reinterpret_cast<const uint32_t*>(p.desc + blockIdx.x)[tid];
         __syncthreads();
         fetch_tile0(misc[M_DESC + 6], misc[M_DESC + 7]);
-        if (tid < min(misc[M_DESC + 7], SEG_TILE)) touch(pm_wo, pm_len);
     }
 
     PF_PROF_BEGIN();
@@ -530,7 +526,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
             misc[M_NINST + tid] = len >= k ? len - k + 1 : 0;
             misc[M_ORDB + tid] = p.seg_ord_base[s];
             misc[M_SAMPLE + tid] = p.seg_sample[s];
-            touch(wo, len);
         }
         __syncthreads();
         if (wave == 0) {
@@ -681,8 +676,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
         if (tid < 8) p.chunkmask[slice * 8 + tid] = mask_word;
         if (tid == 0) p.item_count[item] = misc[M_COUNT];
     }
-    // the next item's first tile: its metadata (requested before the dump) is here by now; get its sequence lines moving
-    if (wn < p.n_work && tid < min(misc[M_NDESC + 7], SEG_TILE)) touch(pm_wo, pm_len);
     __syncthreads();                               // the table and misc[] are free again
     PF_PROF_STAMP(20);
     if (tid < 16) misc[M_DESC + tid] = misc[M_NDESC + tid];
@@ -691,12 +684,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
 #ifdef PF_PROF
     if (tid == 0) atomicAdd(&pf_prof[24], 1ull);
 #endif
-    }
-    if (p.n_work == 0xFFFFFFFFu) {                   // never: keeps the touched dwords' registers allocated until here
-        uint32_t x = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < SCAN_TOUCH; j++) x ^= tch[j];
-        p.item_count[0] = x;
     }
 }
 
@@ -804,12 +791,10 @@ constexpr uint32_t DEDUP_CH = 4;              // 16-byte chunks per lane kept in
 #ifndef PF_DEDUP_WAVES
 #define PF_DEDUP_WAVES 6
 #endif
-#ifndef PF_DEDUP_TD
-#define PF_DEDUP_TD 0           // trips the L2 touches run ahead of the data (0: none)
-#endif
 constexpr uint32_t DEDUP_U = PF_DEDUP_U;       // segments in flight per 8-lane group
 constexpr uint32_t DEDUP_GL = 8;              // lanes that share one segment
 constexpr uint32_t DEDUP_UNSET = 0xFFFFFFFFu;
+constexpr uint32_t DEDUP_EX_LDS = 1024;       // slow-path rows of a cluster whose ordinals are staged in LDS
 constexpr uint32_t DEDUP_INGLOBAL = 0x80000000u;
 
 // Two size classes.  Small: every cluster goes through it first -- ~42 KiB of LDS and 80 VGPRs, three workgroups per
@@ -835,6 +820,7 @@ void cluster_dedup_kernel(DedupParams p) {
     __shared__ uint32_t r_rep[MAXD];           // by distinct index: local index of the representative
     __shared__ uint32_t r_ord0[MAXD], r_ninst[MAXD], r_dense[MAXD];   // by distinct index
     __shared__ uint32_t sh_bad, sh_many, sh_nrep, sh_total, sh_ngroups, sh_pool_used;
+    __shared__ uint32_t s_ex[DEDUP_EX_LDS];    // the cluster's slow-path ordinals (read E times per row further down)
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t c = p.cluster_list ? p.cluster_list[blockIdx.x] : blockIdx.x + p.cluster_base;
@@ -847,6 +833,10 @@ void cluster_dedup_kernel(DedupParams p) {
 
     bool mode1 = p.enable && n >= 4 && n <= DEDUP_MAX_SEGS;
     bool retry_wide = false;                 // small class only: the wide class may still deduplicate this cluster
+    const bool ex_lds = ex1 - ex0 <= DEDUP_EX_LDS;
+    if (mode1 && ex_lds)
+        for (uint32_t e = tid; e < ex1 - ex0; e += DEDUP_THREADS) s_ex[e] = p.extra_ord[ex0 + e];
+    auto ex_ord = [&](uint32_t e) { return ex_lds ? s_ex[e - ex0] : p.extra_ord[e]; };
     if (tid == 0) { sh_bad = 0; sh_many = 0; sh_nrep = 0; sh_total = 0; sh_ngroups = 0; sh_pool_used = 0; }
     if (mode1) {
         for (uint32_t i = tid; i < GTAB; i += DEDUP_THREADS) { t_key[i] = EMPTY64; t_val[i] = EMPTY64; t_pool[i] = DEDUP_UNSET; }
@@ -877,19 +867,6 @@ void cluster_dedup_kernel(DedupParams p) {
             nx_len[u] = sn < n ? p.seg_len[seg0 + sn] : 0;
             nx_woff[u] = sn < n ? (uint32_t)(p.seg_word_off[seg0 + sn] - wbase) : 0;
         }
-#if PF_DEDUP_TD
-        // Touch-ahead: metadata runs PF_DEDUP_TD trips further ahead than the data, and every trip one dword of each
-        // 128-byte line of the segments PF_DEDUP_TD trips ahead is requested and never looked at: the line is on its way
-        // from HBM to L2 while the trips in between are worked on, and the 16-byte loads of its own trip find it there.
-        uint32_t fa_len[PF_DEDUP_TD], fa_woff[PF_DEDUP_TD];        // metadata of trips t + 1 .. t + TD
-#pragma unroll
-        for (int d = 0; d < PF_DEDUP_TD; d++) {
-            const uint32_t sn = grp + (d + 1) * DEDUP_U * ngrp;
-            fa_len[d] = sn < n ? p.seg_len[seg0 + sn] : 0;
-            fa_woff[d] = sn < n ? (uint32_t)(p.seg_word_off[seg0 + sn] - wbase) : 0;
-        }
-        uint32_t tch = 0, tch_sink = 0;
-#endif
         for (uint32_t sw = wave_grp0; sw < n; sw += DEDUP_U * ngrp) {
             // more distinct sequences than this class holds: the rest of the pass would be wasted
             if (__hip_atomic_load(&sh_many, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
@@ -917,29 +894,12 @@ void cluster_dedup_kernel(DedupParams p) {
                     const uint32_t j = gl + DEDUP_GL * q;
                     v[u][q] = j < pc[u] ? dedup_load16(&w[u][j]) : make_ulonglong2(0, 0);
                 }
-#if PF_DEDUP_TD
-            static_assert(DEDUP_U == 1, "touch-ahead is written for one segment per lane group");
-            const uint32_t tch_prev = tch;
-            {
-                // metadata of trip t + TD + 1 behind this trip's data, then the touches for trip t + TD
-                const uint32_t sn = si[0] + (PF_DEDUP_TD + 1) * ngrp;
-                const uint32_t l2 = sn < n ? p.seg_len[seg0 + sn] : 0;
-                const uint32_t w2 = sn < n ? (uint32_t)(p.seg_word_off[seg0 + sn] - wbase) : 0;
-                const uint32_t tpc = (fa_len[PF_DEDUP_TD - 1] + 63) >> 6;          // 16-byte chunks of that segment
-                tch = 8 * gl < tpc ? reinterpret_cast<const uint32_t*>(cbase + (fa_woff[PF_DEDUP_TD - 1] >> 1) + 8 * gl)[0] : 0;
-                nx_len[0] = fa_len[0]; nx_woff[0] = fa_woff[0];
-#pragma unroll
-                for (int d = 0; d + 1 < PF_DEDUP_TD; d++) { fa_len[d] = fa_len[d + 1]; fa_woff[d] = fa_woff[d + 1]; }
-                fa_len[PF_DEDUP_TD - 1] = l2; fa_woff[PF_DEDUP_TD - 1] = w2;
-            }
-#else
 #pragma unroll
             for (int u = 0; u < (int)DEDUP_U; u++) {          // the next trip's metadata, behind this trip's data
                 const uint32_t sn = si[u] + DEDUP_U * ngrp;
                 nx_len[u] = sn < n ? p.seg_len[seg0 + sn] : 0;
                 nx_woff[u] = sn < n ? (uint32_t)(p.seg_word_off[seg0 + sn] - wbase) : 0;
             }
-#endif
 #pragma unroll
             for (int u = 0; u < (int)DEDUP_U; u++) {
 #pragma unroll
@@ -967,9 +927,6 @@ void cluster_dedup_kernel(DedupParams p) {
 #endif
                 }
             }
-#if PF_DEDUP_TD
-            tch_sink += tch_prev;            // requested a trip ago, older than the data just hashed: no wait here
-#endif
             // claim: lane 0 of the group finds or opens the hash group
 #pragma unroll
             for (int u = 0; u < (int)DEDUP_U; u++) {
@@ -1071,9 +1028,6 @@ void cluster_dedup_kernel(DedupParams p) {
                 }
             }
         }
-#if PF_DEDUP_TD
-        if (tch_sink + tch == 0x9E3779B9u && p.k == 0xFFFFFFFFu) sh_bad = 1;    // never: the touched dwords end here
-#endif
         __syncthreads();
         // ---- 4. hash groups -> distinct indices in the ordinal order of their representatives
         for (uint32_t t = tid; t < GTAB; t += DEDUP_THREADS)
@@ -1112,7 +1066,7 @@ void cluster_dedup_kernel(DedupParams p) {
                 for (uint32_t j = 0; j < d; j++) base += r_ninst[j];
                 uint32_t xb = 0;
                 const uint32_t o0 = r_ord0[d] * mult;
-                for (uint32_t e = ex0; e < ex1; e++) xb += p.extra_ord[e] < o0 ? 1u : 0u;
+                for (uint32_t e = ex0; e < ex1; e++) xb += ex_ord(e) < o0 ? 1u : 0u;
                 r_dense[d] = base + xb;
                 if (d == D - 1) sh_total = base + r_ninst[d];
             }
@@ -1135,7 +1089,7 @@ void cluster_dedup_kernel(DedupParams p) {
                 }
                 for (uint32_t e = ex0 + tid; e < ex1; e += DEDUP_THREADS) {
                     // F(o) = scanned instances below o + slow-path rows below o  (monotone in the reference order)
-                    const uint32_t o = p.extra_ord[e];
+                    const uint32_t o = ex_ord(e);
                     const uint32_t oi = o / mult;
                     uint32_t below = 0;
                     for (uint32_t d = 0; d < D; d++) {
@@ -1143,7 +1097,7 @@ void cluster_dedup_kernel(DedupParams p) {
                         below += oi <= a ? 0u : min(oi - a, r_ninst[d]);
                     }
                     uint32_t er = 0;
-                    for (uint32_t f = ex0; f < ex1; f++) er += p.extra_ord[f] < o ? 1u : 0u;
+                    for (uint32_t f = ex0; f < ex1; f++) er += ex_ord(f) < o ? 1u : 0u;
                     p.extra_dense[e] = (below + er) * mult;
                 }
                 if (tid == 0) {
@@ -2938,6 +2892,40 @@ __global__ __launch_bounds__(MD5_THREADS) void md5_kernel(Md5Params p) {
         md5_block(st, m);
         // little-endian words = MD5 byte order
         *reinterpret_cast<uint4*>(p.pat_md5 + (size_t)pid * 16) = make_uint4(st[0], st[1], st[2], st[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// result_checksum_kernel: a checksum of checksums of a batch's results, for full-size parity checks
+// ---------------------------------------------------------------------------------------------
+// One workgroup per cluster.  acc[0] += sum over the cluster's kept k-mers of h(cluster index, position in the cluster's
+// output order, key words, MD5 digest of the k-mer's pattern); acc[1] += h(cluster index, kept, unique, digest of the
+// cluster's own pattern); acc[2] += kept.  Sums wrap; every term depends on WHERE in the file a row would stand and
+// on the bytes it would hold, nothing on arena placement or pattern ids.
+__global__ __launch_bounds__(256) void result_checksum_kernel(const uint64_t* const* key_ptr, const uint32_t* const* pid_ptr,
+                                                              const uint32_t* cnt, const uint32_t* uniq, const uint32_t* cpat,
+                                                              const uint8_t* pat_md5, uint32_t KW, unsigned long long* acc) {
+    const uint32_t c = blockIdx.x;
+    const uint32_t n = cnt[c];
+    const uint64_t* keys = key_ptr[c];
+    const uint32_t* pids = pid_ptr[c];
+    uint64_t sum = 0;
+    for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
+        uint64_t h = mix64(((uint64_t)c << 32) ^ j ^ 0x9E3779B97F4A7C15ull);
+        for (uint32_t w = 0; w < KW; w++) h = mix64(h ^ keys[(size_t)j * KW + w]);
+        const uint64_t* d = reinterpret_cast<const uint64_t*>(pat_md5 + (size_t)pids[j] * 16);
+        sum += mix64(mix64(h ^ d[0]) + d[1]);
+    }
+    for (int d = 1; d < 64; d <<= 1) sum += __shfl_xor(sum, d);
+    if ((threadIdx.x & 63) == 0 && sum) atomicAdd(&acc[0], (unsigned long long)sum);
+    if (threadIdx.x == 0) {
+        uint64_t h = mix64(((uint64_t)c << 32) ^ n) ^ mix64(((uint64_t)uniq[c] << 32) | 0x5bd1e995u);
+        if (cpat[c] != 0xFFFFFFFFu) {
+            const uint64_t* d = reinterpret_cast<const uint64_t*>(pat_md5 + (size_t)cpat[c] * 16);
+            h = mix64(mix64(h ^ d[0]) + d[1]);
+        }
+        atomicAdd(&acc[1], (unsigned long long)mix64(h));
+        atomicAdd(&acc[2], (unsigned long long)n);
     }
 }
 

@@ -223,6 +223,12 @@ class Engine:
                     continue
                 yield self._render(hb, self.fetch(), defer_patterns)
 
+    def result_checksum(self):
+        """(k-mer rows, cluster rows, kept) checksums of the last submit, computed on the device (pf_result_checksum)"""
+        out = (C.c_uint64 * 3)()
+        _lib.check(self.L.pf_result_checksum(self.ctx, out))
+        return tuple(int(x) for x in out)
+
     def pattern_count(self):
         n = C.c_uint64()
         _lib.check(self.L.pf_pattern_count(self.ctx, C.byref(n)))

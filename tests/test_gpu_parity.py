@@ -242,6 +242,62 @@ def test_table_overflow_repartitions(k, canon):
     eng.close()
 
 
+def _mix64(x):
+    x = x.astype(np.uint64)
+    x ^= x >> np.uint64(30); x *= np.uint64(0xbf58476d1ce4e5b9); x ^= x >> np.uint64(27)
+    x *= np.uint64(0x94d049bb133111eb); x ^= x >> np.uint64(31)
+    return x
+
+
+@pytest.mark.parametrize("k", [31, 51])
+def test_result_checksum_is_the_checksum_of_the_fetched_rows(k):
+    """pf_result_checksum (the full-size parity property of bench.py) recomputed in numpy from pf_fetch: every
+    (cluster, position, key words, digest) and every cluster row enters it; the identical-sequence shortcut does not
+    change it"""
+    import ctypes as C
+    from panfeed_amd import synth
+    from panfeed_amd.engine import Engine
+    cl = synth.generate(40, 130, first=5, flank=30, mean_len=300, min_len=60, max_len=900, n_rate=0.02, paralog_rate=0.05)
+    recs = [c.record() for c in cl]
+    sums = {}
+    for dedup in (True, False):
+        eng = Engine(klength=k, max_strains=160, dedup=dedup)
+        eng.run(recs)
+        got = eng.result_checksum()
+        f = eng.fetch()
+        n = len(recs)
+        KW = 1 if k <= 31 else 2
+        off = np.ctypeslib.as_array(f.cluster_kmer_off, shape=(n,)).astype(np.int64)
+        cnt = np.ctypeslib.as_array(f.cluster_kmer_cnt, shape=(n,)).astype(np.int64)
+        uniq = np.ctypeslib.as_array(f.cluster_unique, shape=(n,)).astype(np.uint64)
+        cpat = np.ctypeslib.as_array(f.cluster_pattern, shape=(n,)).copy()
+        tot = int(cnt.sum())
+        keys = np.ctypeslib.as_array(f.kmer_key, shape=(tot * KW,)).reshape(tot, KW)
+        pids = np.ctypeslib.as_array(f.kmer_pattern, shape=(tot,))
+        P = int(f.n_patterns)
+        md5 = np.ctypeslib.as_array(f.pattern_md5, shape=(P * 16,)).copy().view(np.uint64).reshape(P, 2)
+        with np.errstate(over="ignore"):
+            a0 = np.uint64(0)
+            a1 = np.uint64(0)
+            for c in range(n):
+                j = np.arange(cnt[c], dtype=np.uint64)
+                h = _mix64((np.uint64(c) << np.uint64(32)) ^ j ^ np.uint64(0x9E3779B97F4A7C15))
+                rows = slice(int(off[c]), int(off[c] + cnt[c]))
+                for w in range(KW):
+                    h = _mix64(h ^ keys[rows, w])
+                d = md5[pids[rows]]
+                a0 += _mix64(_mix64(h ^ d[:, 0]) + d[:, 1]).sum(dtype=np.uint64)
+                hc = _mix64(np.array([(np.uint64(c) << np.uint64(32)) ^ np.uint64(cnt[c])], np.uint64)) ^ \
+                    _mix64(np.array([(uniq[c] << np.uint64(32)) | np.uint64(0x5bd1e995)], np.uint64))
+                if cpat[c] != 0xFFFFFFFF:
+                    hc = _mix64(_mix64(hc ^ md5[cpat[c], 0]) + md5[cpat[c], 1])
+                a1 += _mix64(hc)[0]
+        assert got == (int(a0), int(a1), tot)
+        sums[dedup] = got
+        eng.close()
+    assert sums[True] == sums[False] and sums[True][2] > 0
+
+
 def test_sub_batches_and_pattern_carry_over():
     """max_items=3 forces many internal sub-batches; two run() calls share the run-global patterns"""
     from panfeed_amd import synth
@@ -444,7 +500,7 @@ def test_config1_scale_properties(S, n, flank, k, head):
         assert len(np.unique(md5.view([("a", "u8"), ("b", "u8")]))) == P      # one pool entry per digest
         # per cluster: keys in order + digest per k-mer, independent of arena placement
         order = np.concatenate([np.arange(int(o), int(o) + int(c), dtype=np.int64) for o, c in zip(off, cnt)]) if tot else np.zeros(0, np.int64)
-        res[dedup] = (cnt, uniq, keys[order], md5[pids[order]], md5[cpat], np.sort(fs))
+        res[dedup] = (cnt, uniq, keys[order], md5[pids[order]], md5[cpat], np.sort(fs), np.array(eng.result_checksum(), np.uint64))
         if dedup:
             assert eng.timing()["n_dedup_clusters"] > n * 0.9
             hb_head = [c.record() for c in cl[:head]]
