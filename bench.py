@@ -35,8 +35,13 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s HBM3E peak (6.3 TB/s measured achievable)
-# vector issue: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles per SIMD, 2.4 GHz
+# vector issue: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles per SIMD, 2.4 GHz (the guide's figure; on
+# this chip only the plain two-operand integer operations and v_bitop3 issue at that rate)
 VALU_PEAK_WAVE_INSTS = 256 * 4 * 0.5 * 2.4e9
+# what a SIMD sustains on the integer mix these kernels are made of (v_add3 / v_alignbit / v_lshl_add / v_cmp / v_mad / 64-bit
+# shifts: 4 cycles; MD5's bitop3-add3-alignbit-add chain: 4.05 cycles per instruction with one to eight waves and one to
+# four chains per wave) -- measured, tools/micro/valu_chain.hip + valu_ops.hip, profiles/r02/valu_*.txt
+INT_MIX_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 4.05
 
 
 def parse():
@@ -354,6 +359,7 @@ def main():
                 if valu:
                     pk["valu_wave_insts"] = valu
                     pk["valu_frac_of_issue_peak"] = valu / (pk["ms"] / 1e3) / VALU_PEAK_WAVE_INSTS
+                    pk["valu_frac_of_measured_integer_issue_rate"] = valu / (pk["ms"] / 1e3) / INT_MIX_PEAK_WAVE_INSTS
                 wc = sum(v.get("SQ_WAVE_CYCLES_per_step", 0.0) for v in sel)
                 if wc:
                     pk["wave_cycles_waiting_frac"] = sum(v.get("SQ_WAIT_ANY_per_step", 0.0) for v in sel) / wc

@@ -161,11 +161,18 @@ def test_device_md5_block_source_on_host(tmp_path):
     import hashlib
     import subprocess
     src = open(os.path.join(REPO, "panfeed_amd", "csrc", "pf_kernels.h")).read()
-    a = src.index("__device__ __forceinline__ void md5_block(uint32_t st[4], const uint32_t m[16]) {")
+    a = src.index("#define MD5_F(x, y, z)")
     b = src.index("struct Md5Params {")
     fn = src[a:b].replace("__device__ __forceinline__", "static")
+    # the two builtins of the device code, restated for the host: v_bitop3_b32 is a 3-input lookup table per bit
+    # (index = src0 bit << 2 | src1 bit << 1 | src2 bit), so the truth tables MD5_F..MD5_I carry are checked here too
+    shim = ("static uint32_t host_bitop3(uint32_t a, uint32_t b, uint32_t c, uint32_t t) { uint32_t r = 0;\n"
+            "  for (int i = 0; i < 32; i++) { int idx = (((a >> i) & 1) << 2) | (((b >> i) & 1) << 1) | ((c >> i) & 1);\n"
+            "    r |= ((t >> idx) & 1u) << i; } return r; }\n"
+            "static uint32_t host_rotl(uint32_t x, int s) { return (x << s) | (x >> (32 - s)); }\n"
+            "#define __builtin_amdgcn_bitop3_b32 host_bitop3\n#define __builtin_rotateleft32 host_rotl\n")
     msgs = [b"", b"abc", b"message digest", b"a" * 55, b"1234567890" * 8]
-    prog = ["#include <stdint.h>\n#include <stdio.h>\n#include <string.h>\n", fn, "int main(){\n"]
+    prog = ["#include <stdint.h>\n#include <stdio.h>\n#include <string.h>\n", shim, fn, "int main(){\n"]
     for msg in msgs:
         pad = msg + b"\x80" + b"\x00" * ((55 - len(msg)) % 64) + (8 * len(msg)).to_bytes(8, "little")
         words = np.frombuffer(pad, dtype="<u4")
