@@ -788,6 +788,9 @@ constexpr uint32_t DEDUP_CH = 4;              // 16-byte chunks per lane kept in
 #ifndef PF_DEDUP_U
 #define PF_DEDUP_U 1
 #endif
+#ifndef PF_DEDUP_EXP
+#define PF_DEDUP_EXP 0          // 1..3: destructive timing experiments on the pass over the bytes (never shipped)
+#endif
 #ifndef PF_DEDUP_WAVES
 #define PF_DEDUP_WAVES 6
 #endif
@@ -812,7 +815,7 @@ void cluster_dedup_kernel(DedupParams p) {
     __shared__ uint64_t t_val[GTAB];           // min over the group's members of (ord_base << 32 | local index)
     __shared__ uint32_t t_pool[GTAB];          // where the group's sequence sits: pool word offset, or INGLOBAL | index
     __shared__ uint32_t t_len[GTAB];           // its length in bases
-    __shared__ uint64_t s_pool[POOL];          // u64 words of LDS holding one copy of distinct sequences (while they fit)
+    __shared__ __align__(16) uint64_t s_pool[POOL];   // u64 words of LDS holding one copy of distinct sequences (while they fit)
     __shared__ uint32_t t_woff[GTAB];          // word offset (relative to the cluster's first segment) of its first member
     __shared__ uint32_t t_rank[GTAB];          // distinct index of the group (representatives in ordinal order)
     __shared__ slot_t s_slot[DEDUP_MAX_SEGS];  // hash group (table slot) of every segment
@@ -860,12 +863,13 @@ void cluster_dedup_kernel(DedupParams p) {
         // have thousands of segments)
         const uint32_t salt_lo0 = dedup_salt_lo(2 * gl), salt_hi0 = dedup_salt_hi(2 * gl);   // word 2 * gl (q = 0, first word)
         (void)salt_lo0; (void)salt_hi0;
-        uint32_t nx_len[DEDUP_U], nx_woff[DEDUP_U];
+        uint32_t nx_len[DEDUP_U], nx_woff[DEDUP_U], nx_ord[DEDUP_U];
 #pragma unroll
         for (int u = 0; u < (int)DEDUP_U; u++) {
             const uint32_t sn = grp + u * ngrp;
             nx_len[u] = sn < n ? p.seg_len[seg0 + sn] : 0;
             nx_woff[u] = sn < n ? (uint32_t)(p.seg_word_off[seg0 + sn] - wbase) : 0;
+            nx_ord[u] = sn < n ? p.seg_ord_base[seg0 + sn] : 0;
         }
         for (uint32_t sw = wave_grp0; sw < n; sw += DEDUP_U * ngrp) {
             // more distinct sequences than this class holds: the rest of the pass would be wasted
@@ -876,6 +880,7 @@ void cluster_dedup_kernel(DedupParams p) {
             const ulonglong2* w[DEDUP_U];
             ulonglong2 v[DEDUP_U][DEDUP_CH];
             uint64_t acc[DEDUP_U] = {};
+            uint32_t my_woff[DEDUP_U], my_ord[DEDUP_U];
 #pragma unroll
             for (int u = 0; u < (int)DEDUP_U; u++) {
                 si[u] = s + u * ngrp;
@@ -884,9 +889,8 @@ void cluster_dedup_kernel(DedupParams p) {
                 pc[u] = (len[u] + 63) >> 6;
                 w[u] = cbase + (nx_woff[u] >> 1);
             }
-            uint32_t my_woff[DEDUP_U];
 #pragma unroll
-            for (int u = 0; u < (int)DEDUP_U; u++) my_woff[u] = nx_woff[u];
+            for (int u = 0; u < (int)DEDUP_U; u++) { my_woff[u] = nx_woff[u]; my_ord[u] = nx_ord[u]; }
 #pragma unroll
             for (int u = 0; u < (int)DEDUP_U; u++)
 #pragma unroll
@@ -899,6 +903,7 @@ void cluster_dedup_kernel(DedupParams p) {
                 const uint32_t sn = si[u] + DEDUP_U * ngrp;
                 nx_len[u] = sn < n ? p.seg_len[seg0 + sn] : 0;
                 nx_woff[u] = sn < n ? (uint32_t)(p.seg_word_off[seg0 + sn] - wbase) : 0;
+                nx_ord[u] = sn < n ? p.seg_ord_base[seg0 + sn] : 0;     // (read at claim time it was a global round trip per trip)
             }
 #pragma unroll
             for (int u = 0; u < (int)DEDUP_U; u++) {
@@ -927,6 +932,11 @@ void cluster_dedup_kernel(DedupParams p) {
 #endif
                 }
             }
+#if PF_DEDUP_EXP == 1 || PF_DEDUP_EXP == 4
+            if (acc[0] == 0x123456789abcdefull) sh_total = 1;   // timing experiment: loads and hash only
+            sh_bad = 1;
+            continue;
+#endif
             // claim: lane 0 of the group finds or opens the hash group
 #pragma unroll
             for (int u = 0; u < (int)DEDUP_U; u++) {
@@ -956,7 +966,7 @@ void cluster_dedup_kernel(DedupParams p) {
                     }
                     if (sl < GTAB) {
                         atomicMin((unsigned long long*)&t_val[sl],
-                                  (unsigned long long)(((uint64_t)p.seg_ord_base[seg0 + si[u]] << 32) | si[u]));
+                                  (unsigned long long)(((uint64_t)my_ord[u] << 32) | si[u]));
                         s_slot[si[u]] = (slot_t)sl;
                     }
                 }
@@ -964,6 +974,10 @@ void cluster_dedup_kernel(DedupParams p) {
                 registrar[u] = __shfl(reg, lane & ~(DEDUP_GL - 1)) != 0;
                 if (slot[u] >= GTAB) has[u] = false;      // cluster given up by this class
             }
+#if PF_DEDUP_EXP == 2
+            sh_bad = 1;                                          // timing experiment: no publish, no compare
+            continue;
+#endif
             // publish: the first segment of a group leaves its words in the pool
 #pragma unroll
             for (int u = 0; u < (int)DEDUP_U; u++) {
@@ -976,7 +990,7 @@ void cluster_dedup_kernel(DedupParams p) {
 #pragma unroll
                         for (uint32_t q = 0; q < DEDUP_CH; q++) {
                             const uint32_t j = gl + DEDUP_GL * q;
-                            if (j < pc[u]) { s_pool[off + 2 * j] = v[u][q].x; s_pool[off + 2 * j + 1] = v[u][q].y; }
+                            if (j < pc[u]) *reinterpret_cast<ulonglong2*>(&s_pool[off + 2 * j]) = v[u][q];     // off is even: 16-byte stores
                         }
                         for (uint32_t j = gl + DEDUP_GL * DEDUP_CH; j < pc[u]; j += DEDUP_GL) {
                             const ulonglong2 x = w[u][j];
@@ -991,6 +1005,10 @@ void cluster_dedup_kernel(DedupParams p) {
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
+#if PF_DEDUP_EXP == 3
+            sh_bad = 1;                                          // timing experiment: no compare
+            continue;
+#endif
             // compare: every other segment of the group against the pool (or against the first one's global words)
 #pragma unroll
             for (int u = 0; u < (int)DEDUP_U; u++) {
@@ -1017,7 +1035,10 @@ void cluster_dedup_kernel(DedupParams p) {
 #pragma unroll
                         for (uint32_t q = 0; q < DEDUP_CH; q++) {
                             const uint32_t j = gl + DEDUP_GL * q;
-                            if (j < pc[u]) diff = diff || s_pool[pp + 2 * j] != v[u][q].x || s_pool[pp + 2 * j + 1] != v[u][q].y;
+                            if (j < pc[u]) {
+                                const ulonglong2 y = *reinterpret_cast<const ulonglong2*>(&s_pool[pp + 2 * j]);   // one 16-byte read
+                                diff = diff || y.x != v[u][q].x || y.y != v[u][q].y;
+                            }
                         }
                         for (uint32_t j = gl + DEDUP_GL * DEDUP_CH; j < pc[u]; j += DEDUP_GL) {
                             const ulonglong2 x = w[u][j];
@@ -1028,6 +1049,11 @@ void cluster_dedup_kernel(DedupParams p) {
                 }
             }
         }
+#if PF_DEDUP_EXP >= 4
+        // timing experiment: the pass over the bytes alone -- an empty view, no epilogue
+        if (tid == 0) { p.v_nseg[c] = 0; p.v_nstr[c] = p.cluster_nstrains[c]; p.v_dense[c] = 0; p.v_mode[c] = 0; }
+        return;
+#endif
         __syncthreads();
         // ---- 4. hash groups -> distinct indices in the ordinal order of their representatives
         for (uint32_t t = tid; t < GTAB; t += DEDUP_THREADS)
