@@ -27,21 +27,9 @@ __device__ unsigned long long pf_prof[64];
 #define PF_PROF_BEGIN() uint64_t prof_t_ = __builtin_readcyclecounter()
 #define PF_PROF_STAMP(k) do { if (threadIdx.x == 0) { const uint64_t n_ = __builtin_readcyclecounter(); \
     atomicAdd(&pf_prof[k], (unsigned long long)(n_ - prof_t_)); prof_t_ = n_; } } while (0)
-// per wave: cycles since the last stamp of this wave added to counter k by lane 0 (s_memtime is a scalar read)
-// (accumulated in registers, slot j of 4; PF_WPROF_FLUSH adds them to counters k0 .. k0+3: one atomic per slot and flush --
-// an atomic per stamp on one address serialises the whole chip and measures itself)
-#define PF_WPROF_BEGIN() uint64_t wprof_t_ = __builtin_readcyclecounter(), wprof_a_[4] = {0, 0, 0, 0}
-#define PF_WPROF_STAMP(j) do { const uint64_t n_ = __builtin_readcyclecounter(); wprof_a_[j] += n_ - wprof_t_; wprof_t_ = n_; } while (0)
-#define PF_WPROF_COUNT(j, n) do { wprof_a_[j] += (n); } while (0)
-#define PF_WPROF_FLUSH(k0) do { if ((threadIdx.x & 63) == 0) { for (int j_ = 0; j_ < 4; j_++) \
-    if (wprof_a_[j_]) atomicAdd(&pf_prof[(k0) + j_], (unsigned long long)wprof_a_[j_]); } } while (0)
 #else
 #define PF_PROF_BEGIN() do { } while (0)
 #define PF_PROF_STAMP(k) do { } while (0)
-#define PF_WPROF_BEGIN() do { } while (0)
-#define PF_WPROF_STAMP(j) do { } while (0)
-#define PF_WPROF_COUNT(j, n) do { } while (0)
-#define PF_WPROF_FLUSH(k0) do { } while (0)
 #endif
 
 constexpr uint32_t SCAN_THREADS = 1024;
@@ -573,7 +561,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
             // unit's words are requested before this one is processed.
             uint32_t g = ubase + wave;
             const uint32_t gend = ubase + utot;
-            PF_WPROF_BEGIN();
             if (g < gend) {
                 uint32_t s = lo;
                 while (g >= misc[M_UPREF + s + 1]) s++;
@@ -611,11 +598,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
                     // partitions).  A wave learns it from its own inserts -- no look at the flag per unit, that is an
                     // LDS round trip in front of every unit -- so after the limit trips every wave finishes at most the
                     // unit it is in: 16 waves x 64 lanes x 2 keys < INSERT_SLACK.
-                    PF_WPROF_STAMP(0);                      // bookkeeping + prefetch issue of the next unit
                     if (scan_unit<KW, CANON>(keys, ord, bits, misc, NS, ns, limit, k, lane, part, nparts, cw,
                                              u, ninst, ordb, bit)) break;
-                    PF_WPROF_STAMP(1);                      // the unit itself
-                    PF_WPROF_COUNT(3, 1);
 #pragma unroll
                     for (int j = 0; j <= KW; j++) cw[j] = nw[j];
                     q = qn; s = sn; send = sendn; u = un; ninst = ninstn; ordb = ordbn; bit = bitn;
@@ -624,10 +608,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
             }
             chunk_dirty = true;
             lo = hi;
-            PF_WPROF_STAMP(0);                     // (entry, first loads)
             __syncthreads();                       // the chunk part is complete in LDS
-            PF_WPROF_STAMP(2);                     // waiting for the other waves
-            PF_WPROF_FLUSH(32);
             PF_PROF_STAMP(18);
             if (misc[M_OVERFLOW]) { overflow = true; break; }
         }
@@ -651,14 +632,36 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
         __syncthreads();
         const bool have_c0 = misc[M_TMP] != 0;
         const uint32_t* g0 = p.chunkbits + ((size_t)slice * p.W) * NS;
-        for (uint32_t i = tid; i < ns; i += SCAN_THREADS) {
-            const uint32_t o = ord[i];
+        // occupied slots -> consecutive entries.  All of a thread's slots are looked at first (their LDS reads in flight
+        // together), positions inside the wave's block come from ballots, and ONE LDS atomic per wave reserves the block:
+        // an atomic per trip was ten dependent LDS round trips per wave with nothing to hide them.
+        constexpr uint32_t DUMP_U = (nslots_max(KW) + SCAN_THREADS - 1) / SCAN_THREADS;
+        uint32_t o_[DUMP_U], at_[DUMP_U];
+        uint32_t tot = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < DUMP_U; u++) {
+            const uint32_t i = tid + u * SCAN_THREADS;
+            o_[u] = i < ns ? ord[i] : NO_ORD;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < DUMP_U; u++) {
+            const uint64_t m = __ballot(o_[u] != NO_ORD);
+            at_[u] = tot + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            tot += (uint32_t)__popcll(m);
+        }
+        uint32_t blk = 0;
+        if (lane == 0 && tot) blk = atomicAdd(&misc[M_COUNT], tot);
+        blk = __builtin_amdgcn_readfirstlane(blk);
+#pragma unroll
+        for (uint32_t u = 0; u < DUMP_U; u++) {
+            const uint32_t i = tid + u * SCAN_THREADS;
+            const uint32_t o = o_[u];
             if (o == NO_ORD) continue;
             uint32_t lo = 0, hi = 0;
             if (last_live && ch == 0) lo = bits[i];
             else if (have_c0) lo = g0[i];
             if (last_live && ch == 1) hi = bits[i];
-            const uint32_t e = atomicAdd(&misc[M_COUNT], 1u);
+            const uint32_t e = blk + at_[u];
 #pragma unroll
             for (int j = 0; j < KW; j++) p.tab_key[((size_t)slice * KW + j) * NS + e] = keys[(size_t)j * NS + i];
             p.tab_ord[(size_t)slice * NS + e] = o;

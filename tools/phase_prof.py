@@ -30,10 +30,4 @@ for lo, hi, cnt in ((0, 8, 8), (16, 24, 24)):
         if v[i]:
             print(f"{i:2d} {names.get(i, ''):24s} {v[i]:14d} {100.0 * v[i] / tot if i < hi else 0:6.1f}%"
                   + (f"  {v[i] / v[cnt]:9.0f} cyc/item" if i < hi and v[cnt] else ""))
-if v[35]:
-    tot = v[32] + v[33] + v[34]
-    print("scan, per wave (sum over waves of s_memtime deltas):")
-    for i, nm in ((32, "next-unit bookkeeping + prefetch, entry"), (33, "unit: keys, hash, table"), (34, "barrier wait at the end of a chunk part")):
-        print(f"{i:2d} {nm:40s} {v[i]:14d} {100.0 * v[i] / tot:6.1f}%  {v[i] / v[35]:8.0f} cyc per unit")
-    print(f"   units {v[35]}")
 print(eng.timing())
