@@ -1202,7 +1202,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             pr.item_cluster = em.item_cluster; pr.item_scratch = em.item_scratch; pr.item_unique = em.item_unique;
             pr.item_nslots = em.item_nslots; pr.item_is_extra = c->it_is_extra.as<uint32_t>();
             pr.item_sib0 = em.item_sib0; pr.item_nsib = em.item_nsib; pr.cluster_overflow = em.cluster_overflow;
-            pr.v_mode = em.v_mode; pr.v_nstr = c->v_nstr.as<uint32_t>();
+            pr.v_mode = em.v_mode; pr.v_nstr = c->v_nstr.as<uint32_t>(); pr.v_dense = em.v_dense;
             pr.cluster_seg_off = d.cluster_seg_off; pr.seg_sample = d.seg_sample; pr.seg_distinct = c->seg_distinct.as<uint32_t>();
             pr.cluster_nstrains = d.cluster_nstrains; pr.cluster_npresab = d.cluster_npresab;
             pr.cluster_presab = d.cluster_presab; pr.cluster_kmer_off = em.cluster_kmer_off;

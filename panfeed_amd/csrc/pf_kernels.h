@@ -596,8 +596,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
                     for (int j = 0; j <= KW; j++) nw[j] = qn[j];
                     // table past its limit: this wave stops inserting (the cluster is re-run with more key
                     // partitions).  A wave learns it from its own inserts -- no look at the flag per unit, that is an
-                    // LDS round trip in front of every unit -- so after the limit trips every wave finishes at most the
-                    // unit it is in: 16 waves x 64 lanes x 2 keys < INSERT_SLACK.
+                    // LDS round trip in front of every unit (looking every fourth unit was measured too: slower, 4.36 ->
+                    // 4.55 ms) -- so after the limit trips every wave finishes at most the unit it is in:
+                    // 16 waves x 64 lanes x 2 keys < INSERT_SLACK.
                     if (scan_unit<KW, CANON>(keys, ord, bits, misc, NS, ns, limit, k, lane, part, nparts, cw,
                                              u, ninst, ordb, bit)) break;
 #pragma unroll
@@ -734,6 +735,13 @@ constexpr uint32_t DEDUP_MAX_D_WIDE = 1024;   // ... of a mode-2 cluster (up to 
 constexpr uint32_t DEDUP_MROWS = 4096;        // words of the M matrix: D * ceil4(W) <= this
 constexpr uint32_t DENSE_WORDS = 8192;        // ordinal bitmap words (262144 dense ordinals)
 constexpr uint32_t MODE_RETRY_WIDE = 0x80u;   // v_mode flag: mode 0 only because the small class was too small
+// How a cluster's k-mers get their rank (position in dict insertion order): from bitmaps over the cluster's dense ordinal
+// space -- prefix popcounts, summed over the cluster's key partitions -- whenever that space fits (every mode-1 cluster, and
+// a mode-2 cluster of up to DENSE_WORDS * 32 windows over its distinct sequences); otherwise every partition sorts its
+// (ordinal, slot) pairs and a k-mer's rank is a binary search in each sibling partition.
+__host__ __device__ inline bool ranks_by_bitmap(uint32_t mode, uint32_t v_dense) {
+    return mode == 1 || (mode == 2 && v_dense <= DENSE_WORDS * 32);
+}
 
 // v_mode of a cluster: 0 = scan every segment (sample columns); 1 = scan one representative per distinct sequence,
 // D <= 64, rows through the sample-set matrix M (LDS), ranks from ordinal bitmaps; 2 = the same view with D <= 1024
@@ -1261,7 +1269,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
     const uint32_t mode = p.v_mode[c] & 3u;
     const bool expand = mode == 1 && !p.item_is_extra[item];
     const bool wide = mode == 2 && !p.item_is_extra[item];
-    const bool bitmaps = mode == 1;                  // ranks from ordinal bitmaps; modes 0 and 2 sort
+    const bool bitmaps = ranks_by_bitmap(mode, p.v_dense[c]);     // ranks from ordinal bitmaps; else sorted pairs
     const uint32_t nstr = p.cluster_nstrains[c], npres = p.cluster_npresab[c];
     const uint32_t nchunks = (nstr + 31) >> 5;
     const uint32_t Wp = (W + 3) & ~3u;
@@ -1283,7 +1291,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         for (uint32_t w = 0; w < W; w++) np += __popc(presab[w]);
         sh_npres = np;
     }
-    if (bitmaps) {
+    if (bitmaps && !wide) {
         for (uint32_t i = tid; i < DEDUP_MROWS + 2 * DENSE_WORDS; i += ROWS_THREADS) rsh[i] = 0;
     } else if (!wide) {
         for (uint32_t i = tid; i < SORT_MAX; i += ROWS_THREADS) pairs[i] = EMPTY64;
@@ -1358,7 +1366,9 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         return keep;
     };
 
-    constexpr uint16_t WIDE_UNTABLED = 0xFFFFu;
+    // slot_tag of a slot whose mask found no room in the table: it is evaluated on its own, its hash goes straight to
+    // slot_hash and its keep flag into the tag
+    constexpr uint16_t WIDE_UNTABLED = 0xFFFFu, WIDE_UNTABLED_KEEP = 0xFFFEu, WIDE_UNTABLED_DROP = 0xFFFDu;
     if (wide) {
         // ---- mode 2.  A k-mer's allele mask (which distinct sequences contain it) is nmw = ceil(D / 32) chunk
         // words; its presence row is gathered through the segment list: sample s carries the k-mer iff one of its
@@ -1460,10 +1470,12 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
             if (slot_tag[i] != WIDE_UNTABLED) continue;
             uint4 h;
             const bool keep = eval_slot(i, h);
-            if (hl == 0) { p.slot_hash[(size_t)slice * NS + i] = h; keepf[i] = keep ? 1 : 0; }
+            if (hl == 0) { p.slot_hash[(size_t)slice * NS + i] = h; slot_tag[i] = keep ? WIDE_UNTABLED_KEEP : WIDE_UNTABLED_DROP; }
         }
         __syncthreads();
-        for (uint32_t i = tid; i < SORT_MAX; i += ROWS_THREADS) pairs[i] = EMPTY64;      // segd is no longer needed
+        // segd is no longer needed: its place is the bitmaps' or the pairs'
+        if (bitmaps) { for (uint32_t i = tid; i < 2 * DENSE_WORDS; i += ROWS_THREADS) occ[i] = 0; }
+        else { for (uint32_t i = tid; i < SORT_MAX; i += ROWS_THREADS) pairs[i] = EMPTY64; }
         __syncthreads();
     }
     if (expand) {
@@ -1503,7 +1515,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         const uint32_t o = ordp[i];
         if (o == NO_ORD) continue;
         uint4 h;
-        bool keep;
+        bool keep, have_hash = false;                          // have_hash: slot_hash[i] is written already
         if (expand) {
             const uint64_t amask = (f0 ? (uint64_t)cb[i] : 0) | (f1 ? (uint64_t)cb[(size_t)NS + i] << 32 : 0);
             bool found = false;
@@ -1518,16 +1530,12 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
             else keep = row_eval(true, amask, i, h);          // table was full: evaluate this slot on its own
         } else if (wide) {
             const uint32_t tag = slot_tag[i];
-            if (tag == WIDE_UNTABLED) {                         // hash and keep flag are in place already
-                const uint32_t at = atomicAdd(&sh_cnt, 1u);
-                if (at < SORT_MAX) pairs[at] = ((uint64_t)o << 32) | i;
-                continue;
-            }
-            h = at_hash[tag]; keep = at_keep[tag] != 0;
+            if (tag >= WIDE_UNTABLED_DROP) { keep = tag == WIDE_UNTABLED_KEEP; have_hash = true; }
+            else { h = at_hash[tag]; keep = at_keep[tag] != 0; }
         } else {
             keep = row_eval(false, 0, i, h);
         }
-        p.slot_hash[(size_t)slice * NS + i] = h;
+        if (!have_hash) p.slot_hash[(size_t)slice * NS + i] = h;
         if (!bitmaps) {
             keepf[i] = keep ? 1 : 0;
             const uint32_t at = atomicAdd(&sh_cnt, 1u);
@@ -1833,8 +1841,8 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
     const uint64_t ordinal = p.cluster_ordinal[c];
     const uint64_t obase = p.cluster_kmer_off[c] - p.out_base;
     const uint32_t mode = p.v_mode[c] & 3u;
-    const bool sorted = mode != 1;           // modes 0 and 2: the item's k-mers sorted by ordinal (rows_kernel);
-                                             // mode 1: ordinal bitmaps
+    const bool sorted = !ranks_by_bitmap(mode, p.v_dense[c]);    // the item's k-mers sorted by ordinal (rows_kernel), or
+                                                                 // ordinal bitmaps
 
     if (item == sib0 && tid == 0) {
         // the cluster's own row: md5 of the int64 image of clusterpresab (panfeed.py:175-187)
@@ -2586,7 +2594,7 @@ struct PatRowsParams {
     const uint32_t* item_nslots; const uint32_t* item_is_extra;
     const uint32_t* item_sib0; const uint32_t* item_nsib;
     const uint32_t* cluster_overflow;
-    const uint32_t* v_mode; const uint32_t* v_nstr;
+    const uint32_t* v_mode; const uint32_t* v_nstr; const uint32_t* v_dense;
     const uint32_t* cluster_seg_off; const uint32_t* seg_sample; const uint32_t* seg_distinct;   // caller's segments (mode 2)
     const uint32_t* cluster_nstrains; const uint32_t* cluster_npresab; const uint32_t* cluster_presab;
     const uint64_t* cluster_kmer_off;
@@ -2668,7 +2676,8 @@ __global__ __launch_bounds__(256) void pattern_rows_kernel(PatRowsParams p) {
             wstart[w] = seg_lower_bound(p.seg_sample, s0, s1, w << 5) - s0;
         __syncthreads();
     }
-    const uint32_t total = mode != 1 ? U : ns;
+    const bool sorted = !ranks_by_bitmap(mode, p.v_dense[c]);      // entries = sorted positions, or slots (emit_kernel)
+    const uint32_t total = sorted ? U : ns;
     const uint32_t stride = blockDim.x;
     const uint32_t rounds_total = (total + stride - 1) / stride;
     uint32_t round = 0;
@@ -2682,7 +2691,7 @@ __global__ __launch_bounds__(256) void pattern_rows_kernel(PatRowsParams p) {
             if (i < total) {
                 // emit_kernel left the output index of every kept entry (sorted position / slot)
                 const uint32_t kb = sout[i];
-                if (kb != 0xFFFFFFFFu) { slot = mode != 1 ? (uint32_t)sp[i] : i; kept_before = kb; }
+                if (kb != 0xFFFFFFFFu) { slot = sorted ? (uint32_t)sp[i] : i; kept_before = kb; }
             }
             if (slot != 0xFFFFFFFFu) {
                 const uint64_t o = obase + kept_before;
