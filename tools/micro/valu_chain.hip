@@ -29,6 +29,27 @@ __global__ __launch_bounds__(256) void md5ish(uint32_t* out, uint32_t iters, uin
     out[blockIdx.x * 256 + threadIdx.x] = r;
 }
 
+// the same steps with the three-operand add split into two two-operand adds (kept apart by empty asm statements): does
+// a stream of mostly 2-cycle instructions around the one 4-cycle rotate issue faster than bitop3 / add3 / alignbit / add?
+template <int C>
+__global__ __launch_bounds__(256) void md5ish_split(uint32_t* out, uint32_t iters, uint32_t mval) {
+    uint32_t a[C], b[C], c[C], d[C];
+#pragma unroll
+    for (int i = 0; i < C; i++) { a[i] = threadIdx.x + i; b[i] = blockIdx.x * 7 + i; c[i] = 0x98badcfeu + i; d[i] = 0x10325476u ^ i; }
+    for (uint32_t it = 0; it < iters; it++) {
+#define STEP2(A, B, Cc, D, K, S, M) _Pragma("unroll") for (int i = 0; i < C; i++) { uint32_t f = __builtin_amdgcn_bitop3_b32(B[i], Cc[i], D[i], 0xCA); \
+            uint32_t t = A[i] + (K + M); asm volatile("" : "+v"(t)); t += f; asm volatile("" : "+v"(t)); A[i] = B[i] + rotl(t, S); }
+        STEP2(a, b, c, d, 0xd76aa478u, 7, 0) STEP2(d, a, b, c, 0xe8c7b756u, 12, mval) STEP2(c, d, a, b, 0x242070dbu, 17, 0) STEP2(b, c, d, a, 0xc1bdceeeu, 22, mval)
+        STEP2(a, b, c, d, 0xf57c0fafu, 7, 0) STEP2(d, a, b, c, 0x4787c62au, 12, mval) STEP2(c, d, a, b, 0xa8304613u, 17, 0) STEP2(b, c, d, a, 0xfd469501u, 22, mval)
+        STEP2(a, b, c, d, 0x698098d8u, 7, 0) STEP2(d, a, b, c, 0x8b44f7afu, 12, mval) STEP2(c, d, a, b, 0xffff5bb1u, 17, 0) STEP2(b, c, d, a, 0x895cd7beu, 22, mval)
+        STEP2(a, b, c, d, 0x6b901122u, 7, 0) STEP2(d, a, b, c, 0xfd987193u, 12, mval) STEP2(c, d, a, b, 0xa679438eu, 17, 0) STEP2(b, c, d, a, 0x49b40821u, 22, mval)
+    }
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 0; i < C; i++) r ^= a[i] ^ b[i] ^ c[i] ^ d[i];
+    out[blockIdx.x * 256 + threadIdx.x] = r;
+}
+
 // plain dependent v_add_u32 chain (VOP2, 4-byte encodings) on C independent accumulators
 template <int C>
 __global__ __launch_bounds__(256) void addchain(uint32_t* out, uint32_t iters, uint32_t inc) {
@@ -118,6 +139,8 @@ int main() {
         report("md5ish", 1, time_ms([&] { md5ish<1><<<grid, 256>>>(out, iters, 0x3FF00000u); }), 64);
         report("md5ish", 2, time_ms([&] { md5ish<2><<<grid, 256>>>(out, iters, 0x3FF00000u); }), 64);
         report("md5ish", 4, time_ms([&] { md5ish<4><<<grid, 256>>>(out, iters, 0x3FF00000u); }), 64);
+        report("md5split", 1, time_ms([&] { md5ish_split<1><<<grid, 256>>>(out, iters, 0x3FF00000u); }), 80);
+        report("md5split", 2, time_ms([&] { md5ish_split<2><<<grid, 256>>>(out, iters, 0x3FF00000u); }), 80);
         report("addchain", 1, time_ms([&] { addchain<1><<<grid, 256>>>(out, iters, 0x9E3779B9u); }), 128);
         report("addchain", 2, time_ms([&] { addchain<2><<<grid, 256>>>(out, iters, 0x9E3779B9u); }), 128);
         report("addchain", 4, time_ms([&] { addchain<4><<<grid, 256>>>(out, iters, 0x9E3779B9u); }), 128);
