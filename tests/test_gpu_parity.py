@@ -576,12 +576,15 @@ def _allele_cluster(rng, idx, names, D, L, sub=0.02, flank=0, paralogs=0, n_ever
     (300, 1000, 150, 21, True, {"absent": 37}),                     # 32-word rows; some samples without the cluster
     (1024, 2100, 90, 15, True, {}),                                 # the largest wide cluster
     (1025, 2100, 90, 15, True, {}),                                 # one too many: every copy is scanned
-], ids=["D64", "D65", "D65_paralogs_N", "D200", "D200_k51_noncanon", "D300_1000s", "D1024", "D1025"])
+    (300, 700, 1000, 31, True, {}),                                 # 291 000 windows over the distinct sequences: more than
+                                                                    # the ordinal bitmaps hold -> ranks by sorting (the
+                                                                    # shorter wide cases above rank from bitmaps)
+], ids=["D64", "D65", "D65_paralogs_N", "D200", "D200_k51_noncanon", "D300_1000s", "D1024", "D1025", "D300_long_sorted"])
 @pytest.mark.parametrize("missing", [False, True], ids=["", "consider_missing"])
 def test_many_distinct_sequences_vs_oracle(D, S, L, k, canon, kw, missing):
     """clusters with more distinct sequences than the 64 an allele-mask pair of words holds: representatives are
-    still scanned once each (wide dedup class, rows gathered through the segment list, ranks by sorting) and the
-    files are the oracle's"""
+    still scanned once each (wide dedup class, rows gathered through the segment list, ranks from ordinal bitmaps or,
+    for the largest, by sorting) and the files are the oracle's"""
     from panfeed_amd.engine import Engine
     if missing and (D not in (65, 300) or kw.get("n_every")):
         pytest.skip("consider_missing: two shapes are enough")
