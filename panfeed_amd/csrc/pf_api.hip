@@ -18,6 +18,7 @@
 #include <numeric>
 #include <thread>
 #include <string>
+#include <atomic>
 #include <vector>
 
 namespace {
@@ -1587,57 +1588,75 @@ int pf_render_kmers_tsv(pf_ctx* c, const pf_target_seq* seqs, uint32_t n, const 
     if (!c->have_batch) return fail(PF_ERR_STATE, "pf_render_* needs pf_fetch first");
     const uint32_t k = c->o.klength;
     const bool canon = c->o.canon != 0;
-    // pass 1: exact size per sequence
-    std::vector<uint64_t> off((size_t)n + 1, 0);
+    // pass 1 (parallel): which strand every window of a target sequence uses (from the device's strand bits), and with
+    // that the exact size of the sequence's rows -- no worst-case sizing, no compaction afterwards
+    std::vector<uint64_t> off((size_t)n + 1, 0), fl_off((size_t)n + 1, 0);
     for (uint32_t i = 0; i < n; i++) {
-        const pf_target_seq& s = seqs[i];
-        const long long nk = (long long)s.len - k + 1;
-        uint64_t b = 0;
-        if (nk > 0) {
+        const long long nk = (long long)seqs[i].len - k + 1;
+        fl_off[i + 1] = fl_off[i] + (canon && nk > 0 ? (uint64_t)nk : 0);
+    }
+    std::vector<uint8_t> rcflags(fl_off[n], 2);     // 2 = unknown, 0 forward, 1 reverse complement is canonical
+    std::vector<uint64_t> size(n, 0);
+    std::atomic<bool> bad{false};
+    parallel_for(n, [&](uint64_t a, uint64_t b) {
+        for (uint64_t i = a; i < b; i++) {
+            const pf_target_seq& s = seqs[i];
+            const long long nk = (long long)s.len - k + 1;
+            if (nk <= 0) continue;
+            uint8_t* rcflag = canon ? rcflags.data() + fl_off[i] : nullptr;
+            if (canon) {
+                for (uint32_t j = 0; j < s.n_segs; j++) {
+                    if (!seg_strand_off || c->h_strand.empty()) { bad = true; break; }
+                    const uint32_t so = seg_strand_off[s.seg_index[j]];
+                    for (uint32_t q = 0; q < s.seg_nwin[j]; q++) {
+                        const size_t word = (size_t)so + (q >> 6);
+                        if (so == 0xFFFFFFFFu || word >= c->h_strand.size() || s.seg_start[j] + q >= (uint64_t)nk) { bad = true; break; }
+                        rcflag[s.seg_start[j] + q] = (uint8_t)((c->h_strand[word] >> (q & 63)) & 1);
+                    }
+                }
+            }
             const size_t head = strlen(s.cluster) + strlen(s.strain) + strlen(s.id) + strlen(s.chromosome) + 4 +
                                 len_i64(s.strand) + 1;
+            uint64_t bytes = 0;
+            uint32_t ai = 0;
             for (long long pos = 0; pos < nk; pos++) {
                 long long ts, te;
                 if (s.strand > 0) { ts = s.start + pos; te = s.start + pos + k; }
                 else { te = s.end - pos; ts = s.end - pos - k; }
                 const size_t mid = len_i64(ts) + len_i64(te) + len_i64(pos - s.offset) + len_i64(pos + k - s.offset) + 4;
-                // strand column: +-1 (canonical: used_strand) / feature strand then its negation
-                if (canon) b += head + mid + 2 /* worst case "-1" */ + 1 + k + 1;
-                else b += 2 * (head + mid + k + 2) + len_i64(s.strand) + len_i64(-(long long)s.strand);
+                if (canon) {
+                    // strand column: the window's own (+-1), or what the caller worked out for a non-ACGT window
+                    size_t us;
+                    while (ai < s.n_ambig && s.ambig_pos[ai] < (uint64_t)pos) ai++;
+                    if (ai < s.n_ambig && s.ambig_pos[ai] == (uint64_t)pos) us = len_i64(s.ambig_used[ai]);
+                    else { if (rcflag[pos] > 1) bad = true; us = rcflag[pos] == 1 ? 2 : 1; }
+                    bytes += head + mid + us + 1 + k + 1;
+                } else {
+                    bytes += 2 * (head + mid + k + 2) + len_i64(s.strand) + len_i64(-(long long)s.strand);
+                }
             }
+            size[i] = bytes;
         }
-        off[i + 1] = off[i] + b;
-    }
+    });
+    if (bad) return fail(PF_ERR_STATE, "pf_render_kmers_tsv: strand bits missing for a target window");
+    for (uint32_t i = 0; i < n; i++) off[i + 1] = off[i] + size[i];
     char* buf = (char*)malloc(off[n] + 1);
     if (!buf) return fail(PF_ERR_OOM, "malloc(%llu) failed", (unsigned long long)off[n]);
-    std::vector<uint64_t> used(n, 0);
-    bool bad = false;
+    std::atomic<bool> bad2{false};
+    // pass 2 (parallel): the rows, each sequence at its exact place
     parallel_for(n, [&](uint64_t a, uint64_t b) {
-        std::vector<uint8_t> rcflag;
         for (uint64_t i = a; i < b; i++) {
             const pf_target_seq& s = seqs[i];
             const long long nk = (long long)s.len - k + 1;
             char* w = buf + off[i];
             if (nk > 0) {
-                rcflag.assign((size_t)nk, 2);       // 2 = unknown, 0 forward, 1 reverse complement is canonical
-                if (canon) {
-                    for (uint32_t j = 0; j < s.n_segs; j++) {
-                        if (!seg_strand_off || c->h_strand.empty()) { bad = true; break; }
-                        const uint32_t so = seg_strand_off[s.seg_index[j]];
-                        for (uint32_t q = 0; q < s.seg_nwin[j]; q++) {
-                            const size_t word = (size_t)so + (q >> 6);
-                            if (so == 0xFFFFFFFFu || word >= c->h_strand.size() || s.seg_start[j] + q >= (uint64_t)nk) { bad = true; break; }
-                            rcflag[s.seg_start[j] + q] = (uint8_t)((c->h_strand[word] >> (q & 63)) & 1);
-                        }
-                    }
-                }
+                const uint8_t* rcflag = canon ? rcflags.data() + fl_off[i] : nullptr;
                 uint32_t ai = 0;
                 for (long long pos = 0; pos < nk; pos++) {
                     long long ts, te;
                     if (s.strand > 0) { ts = s.start + pos; te = s.start + pos + k; }       // panfeed.py:91-94
                     else { te = s.end - pos; ts = s.end - pos - k; }                         // panfeed.py:96-99
                     for (int rep = 0; rep < (canon ? 1 : 2); rep++) {
-                        char* row = w;
                         size_t l;
                         l = strlen(s.cluster); memcpy(w, s.cluster, l); w += l; *w++ = '\t';
                         l = strlen(s.strain); memcpy(w, s.strain, l); w += l; *w++ = '\t';
@@ -1655,7 +1674,6 @@ int pf_render_kmers_tsv(pf_ctx* c, const pf_target_seq* seqs, uint32_t n, const 
                                 memcpy(w, s.ambig_key[ai], k); w += k;
                             } else {
                                 const uint8_t rc = rcflag[(size_t)pos];
-                                if (rc > 1) { bad = true; }
                                 w = put_i64(w, rc == 1 ? -1 : 1); *w++ = '\t';
                                 if (rc == 1) for (uint32_t q = 0; q < k; q++) w[q] = s.compsequence[pos + k - 1 - q];
                                 else memcpy(w, s.sequence + pos, k);
@@ -1668,23 +1686,16 @@ int pf_render_kmers_tsv(pf_ctx* c, const pf_target_seq* seqs, uint32_t n, const 
                             w += k;
                         }
                         *w++ = '\n';
-                        (void)row;
                     }
                 }
             }
-            used[i] = (uint64_t)(w - (buf + off[i]));
+            if ((uint64_t)(w - (buf + off[i])) != size[i]) bad2 = true;
         }
     });
-    if (bad) { free(buf); return fail(PF_ERR_STATE, "pf_render_kmers_tsv: strand bits missing for a target window"); }
-    // canonical rows were sized for "-1": close the gaps
-    uint64_t total = 0;
-    for (uint32_t i = 0; i < n; i++) {
-        if (total != off[i]) memmove(buf + total, buf + off[i], used[i]);
-        total += used[i];
-    }
-    buf[total] = 0;
+    if (bad2) { free(buf); return fail(PF_ERR_STATE, "pf_render_kmers_tsv: row sizes of the two passes differ"); }
+    buf[off[n]] = 0;
     *out = buf;
-    *nbytes = total;
+    *nbytes = off[n];
     return PF_OK;
 }
 
