@@ -388,7 +388,9 @@ typedef struct {
 
 /* Rows of kmers.tsv for `n` target sequences, in the given order: one row per window ("cluster, strain,
  * feature_id, contig, feature_strand, contig_start, contig_end, gene_start, gene_end, strand, k-mer"), two per
- * window in non-canonical mode (panfeed.py:104-107).  seg_strand_off: the batch's array. */
+ * window in non-canonical mode (panfeed.py:104-107).  seg_strand_off: the batch's array.  Needs the last pf_submit
+ * only (the windows' used_strand bits are copied from the device by the call itself; no pf_fetch).  Sizes and rows are
+ * both produced by all host threads; *out is malloc'd (pf_free_text). */
 int pf_render_kmers_tsv(pf_ctx* ctx, const pf_target_seq* seqs, uint32_t n, const uint32_t* seg_strand_off,
                         char** out, uint64_t* nbytes);
 void pf_free_text(char* p);

@@ -143,6 +143,7 @@ struct pf_ctx {
 
     // last batch bookkeeping
     bool have_batch = false;
+    bool h_strand_fresh = false;        // h_strand holds the strand bits of the last submit
     uint32_t n_clusters = 0;
     uint64_t n_strand_words = 0;
     std::vector<uint32_t> cluster_arena;   // arena index per cluster
@@ -1338,6 +1339,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
     c->counters.W = W;
     c->counters.key_words = KW;
     c->have_batch = true;
+    c->h_strand_fresh = false;
     if (counters) *counters = c->counters;
     return PF_OK;
 }
@@ -1369,6 +1371,18 @@ int pf_get_timing(pf_ctx* c, pf_timing* t) {
     *t = c->timing;
     return PF_OK;
 }
+
+namespace {
+// used_strand bits of the last submit's target windows (strand_bits_kernel) to the host, once per batch
+int fetch_strand_bits(pf_ctx* c) {
+    if (c->h_strand_fresh) return PF_OK;
+    c->h_strand.resize((size_t)c->n_strand_words);
+    if (c->n_strand_words)
+        HIPCHK(hipMemcpy(c->h_strand.data(), c->strand_bits.p, (size_t)c->n_strand_words * 8, hipMemcpyDeviceToHost));
+    c->h_strand_fresh = true;
+    return PF_OK;
+}
+}  // namespace
 
 int pf_fetch(pf_ctx* c, pf_result* res) {
     if (!c || !res) return fail(PF_ERR_ARG, "null argument");
@@ -1417,9 +1431,7 @@ int pf_fetch(pf_ctx* c, pf_result* res) {
     std::iota(c->h_new_pid.begin(), c->h_new_pid.end(), p0);
     std::sort(c->h_new_pid.begin(), c->h_new_pid.end(),
               [&](uint32_t x, uint32_t y) { return c->h_first_seen[x] < c->h_first_seen[y]; });
-    c->h_strand.resize((size_t)c->n_strand_words);
-    if (c->n_strand_words)
-        HIPCHK(hipMemcpy(c->h_strand.data(), c->strand_bits.p, (size_t)c->n_strand_words * 8, hipMemcpyDeviceToHost));
+    PFCHK(fetch_strand_bits(c));
 
     *res = c->counters;
     res->cluster_kmer_off = c->h_kmer_off.data();
@@ -1585,7 +1597,9 @@ inline size_t len_i64(long long v) { char t[24]; return (size_t)(put_i64(t, v) -
 int pf_render_kmers_tsv(pf_ctx* c, const pf_target_seq* seqs, uint32_t n, const uint32_t* seg_strand_off, char** out,
                         uint64_t* nbytes) {
     if (!c || !out || !nbytes || (n && !seqs)) return fail(PF_ERR_ARG, "null argument");
-    if (!c->have_batch) return fail(PF_ERR_STATE, "pf_render_* needs pf_fetch first");
+    if (!c->have_batch) return fail(PF_ERR_STATE, "pf_render_kmers_tsv without a successful pf_submit");
+    HIPCHK(hipSetDevice(c->device));
+    PFCHK(fetch_strand_bits(c));          // all this renderer needs from the device (pf_fetch is not required)
     const uint32_t k = c->o.klength;
     const bool canon = c->o.canon != 0;
     // pass 1 (parallel): which strand every window of a target sequence uses (from the device's strand bits), and with

@@ -33,6 +33,33 @@ def _take(ptr, n):
     return bytes(memoryview((C.c_char * int(n)).from_address(p)))
 
 
+class OwnedText:
+    """a block of text the library malloc'd (pf_free_text), handed on without a copy: `view` for the writer, `release()`
+    (or garbage collection) to give it back"""
+
+    def __init__(self, L, ptr, n):
+        self._L, self._p, self._n = L, (ptr.value if isinstance(ptr, C.c_void_p) else ptr), int(n)
+        self.view = memoryview((C.c_char * self._n).from_address(self._p)).cast("B") if self._n else memoryview(b"")
+
+    def __len__(self):
+        return self._n
+
+    def __bytes__(self):
+        return bytes(self.view)
+
+    def release(self):
+        if self._p:
+            self.view = memoryview(b"")
+            self._L.pf_free_text(C.c_void_p(self._p))
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:   # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
 def _view(ptr, n, dtype):
     if n == 0:
         return np.zeros(0, dtype=dtype)
@@ -202,7 +229,7 @@ class Engine:
                 self.next_ordinal = int(hb.cluster_ordinal[-1]) + 1 if hb.n_clusters else self.next_ordinal
                 res = self.submit_host_batch(hb)
                 texts = None
-                if device_text and not hb.targets and not self.multiple_files:
+                if device_text and not self.multiple_files:
                     try:
                         texts = self.render_device(hb, defer_patterns)
                     except _lib.PanfeedHipError as e:
@@ -213,7 +240,8 @@ class Engine:
                 if texts is not None:
                     out = BatchOutput()
                     out.kmers_to_hashes, out.hashes_to_patterns = texts
-                    out.kmers_tsv = b""
+                    # target strains: their rows by the library's host renderer (only the strand bits leave the device)
+                    out.kmers_tsv = self._render_targets(hb, hb.targets, owned=True) if hb.targets else b""
                     out.stats = {"clusters": int(hb.n_clusters), "instances": int(hb.n_instances),
                                  "device_instances": int(res.n_instances), "unique_kmers": int(res.n_unique),
                                  "kept_kmers": int(res.n_kept), "new_patterns": int(res.n_new_patterns),
@@ -363,8 +391,11 @@ class Engine:
                                                      C.byref(txt), C.byref(nb)))
             yield _take(txt, nb.value)
 
-    def _render_targets(self, hb, metas, as_bytes=False):
-        """kmers.tsv rows of `metas` (packing.SeqMeta, in order) through pf_render_kmers_tsv"""
+    def _render_targets(self, hb, metas, as_bytes=False, owned=False):
+        """kmers.tsv rows of `metas` (packing.SeqMeta, in order) through pf_render_kmers_tsv: str, `bytes` (as_bytes) or
+        the library's own block without a copy (owned: an OwnedText)"""
+        import time as _time
+        t0 = _time.time()
         n = len(metas)
         arr = (_lib.TargetSeq * n)()
         keep = []
@@ -388,8 +419,15 @@ class Engine:
                 au.ctypes.data_as(C.POINTER(C.c_int8)), ak)
         buf, nb = C.c_void_p(), C.c_uint64()
         sso = hb.seg_strand_off.ctypes.data_as(C.c_void_p) if hb.n_strand_words else None
+        t1 = _time.time()
         _lib.check(self.L.pf_render_kmers_tsv(self.ctx, arr, n, sso, C.byref(buf), C.byref(nb)))
+        t2 = _time.time()
+        del keep
+        if owned:
+            self.render_targets_timing = {"marshal_s": t1 - t0, "render_s": t2 - t1, "copy_s": 0.0}
+            return OwnedText(self.L, buf, nb.value)
         text = _take(buf, nb.value)
         self.L.pf_free_text(buf)
-        del keep
+        # where the time of the last call went: Python marshalling of the records, the library's renderer, the copy out
+        self.render_targets_timing = {"marshal_s": t1 - t0, "render_s": t2 - t1, "copy_s": _time.time() - t2}
         return text if as_bytes else text.decode()

@@ -9,7 +9,7 @@ import os
 import queue
 import threading
 
-from .engine import Engine
+from .engine import Engine, OwnedText
 from .native_input import Pangenome
 from .output import create_hash_files, create_kmer_stroi, write_headers
 
@@ -62,6 +62,11 @@ def run_files(presence_absence, gffdir, output, fastadir=None, klength=31, canon
             # text the GPU wrote arrives as bytes: straight into the file's binary layer (or the gzip writer)
             if isinstance(data, str):
                 fh.write(data)
+            elif isinstance(data, OwnedText):        # engine.OwnedText: the library's block, written where it lies
+                try:
+                    put(fh, data.view)
+                finally:
+                    data.release()
             elif len(data):
                 raw = getattr(fh, "buffer", None)
                 if raw is not None:

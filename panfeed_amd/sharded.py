@@ -25,7 +25,7 @@ import shutil
 
 import numpy as np
 
-from .engine import KMERS_TO_HASHES_HEADER, KMERS_TSV_HEADER, hashes_to_patterns_header
+from .engine import KMERS_TO_HASHES_HEADER, KMERS_TSV_HEADER, OwnedText, hashes_to_patterns_header
 
 FILES = ("kmers.tsv", "kmers_to_hashes.tsv", "hashes_to_patterns.tsv")
 
@@ -67,9 +67,17 @@ class ShardWriter:
         self.bytes = 0
 
     def write_batch(self, kmers_tsv, kmers_to_hashes):
-        self.handles["kmers.tsv"].write(kmers_tsv)
+        if isinstance(kmers_tsv, OwnedText):     # engine.OwnedText: the library's block, written where it lies
+            try:
+                self.handles["kmers.tsv"].write(kmers_tsv.view)
+            finally:
+                n_kt = len(kmers_tsv)
+                kmers_tsv.release()
+        else:
+            self.handles["kmers.tsv"].write(kmers_tsv)
+            n_kt = len(kmers_tsv)
         self.handles["kmers_to_hashes.tsv"].write(kmers_to_hashes)
-        self.bytes += len(kmers_tsv) + len(kmers_to_hashes)
+        self.bytes += n_kt + len(kmers_to_hashes)
 
     def write_patterns(self, blocks):
         for b in blocks:
