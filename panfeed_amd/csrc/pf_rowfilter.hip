@@ -21,6 +21,7 @@
 #include <cstring>
 #include <string>
 #include <unordered_set>
+#include <thread>
 #include <vector>
 
 extern "C" void pf_set_error_(const char* msg);
@@ -220,34 +221,54 @@ int pf_rowfilter_scan(pf_rowfilter* f, const char* text, uint64_t nbytes, const 
         RFCHK(hipHostMalloc((void**)&f->pin, want, hipHostMallocDefault));
         f->text_cap = want;
     }
-    // every line could match: one candidate per line at most
-    const size_t max_lines = (size_t)std::count(text, text + n, '\n') + 1;
-    if (max_lines > f->out_cap) {
+    // room for the candidates: the filter keeps few rows, so the room is a guess (a position per 64 bytes of text, a
+    // million at least) and the kernel is run again with what it asked for should the guess be too small -- counting
+    // the lines of the block on the host to size it for the worst case cost more than the kernel itself
+    const size_t guess = std::max<size_t>((size_t)1 << 20, (size_t)(n / 64));
+    if (guess > f->out_cap) {
         if (f->d_out) (void)hipFree(f->d_out);
         f->d_out = nullptr; f->out_cap = 0;
-        RFCHK(hipMalloc((void**)&f->d_out, (max_lines + max_lines / 8) * 8));
-        f->out_cap = max_lines + max_lines / 8;
+        RFCHK(hipMalloc((void**)&f->d_out, guess * 8));
+        f->out_cap = guess;
     }
-    memcpy(f->pin, text, n);
+    {   // the block into pinned memory on a few threads (one memcpy of 256 MB is slower than the rest of the call)
+        const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(8, n >> 22));
+        std::vector<std::thread> th;
+        const uint64_t step = (n + nt - 1) / nt;
+        for (unsigned t = 1; t < nt; t++) {
+            const uint64_t a = t * step, b = std::min<uint64_t>(n, a + step);
+            if (a < b) th.emplace_back([=] { memcpy(f->pin + a, text + a, (size_t)(b - a)); });
+        }
+        memcpy(f->pin, text, (size_t)std::min<uint64_t>(n, step));
+        for (auto& t : th) t.join();
+    }
     memset(f->pin + n, 0, padded - n);
     RFCHK(hipMemcpyAsync(f->d_text, f->pin, padded, hipMemcpyHostToDevice, f->stream));
-    RFCHK(hipMemsetAsync(f->d_count, 0, 8, f->stream));
-    RfParams p{};
-    p.text = f->d_text; p.n = n; p.set = f->d_set; p.cap = f->cap; p.first_field = f->first_field;
-    p.out = f->d_out; p.count = f->d_count; p.out_cap = f->out_cap;
-    const uint64_t nvec = (n + 15) / 16;
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>((nvec + 255) / 256, 256 * 16);
-    RFCHK(hipEventRecord(f->e0, f->stream));
-    hipLaunchKernelGGL(rowfilter_kernel, dim3(blocks), dim3(256), 0, f->stream, p);
-    RFCHK(hipGetLastError());
-    RFCHK(hipEventRecord(f->e1, f->stream));
     unsigned long long cnt = 0;
-    RFCHK(hipMemcpyAsync(&cnt, f->d_count, 8, hipMemcpyDeviceToHost, f->stream));
-    RFCHK(hipStreamSynchronize(f->stream));
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, f->e0, f->e1) == hipSuccess) f->device_ms += ms;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        RFCHK(hipMemsetAsync(f->d_count, 0, 8, f->stream));
+        RfParams p{};
+        p.text = f->d_text; p.n = n; p.set = f->d_set; p.cap = f->cap; p.first_field = f->first_field;
+        p.out = f->d_out; p.count = f->d_count; p.out_cap = f->out_cap;
+        const uint64_t nvec = (n + 15) / 16;
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((nvec + 255) / 256, 256 * 16);
+        RFCHK(hipEventRecord(f->e0, f->stream));
+        hipLaunchKernelGGL(rowfilter_kernel, dim3(blocks), dim3(256), 0, f->stream, p);
+        RFCHK(hipGetLastError());
+        RFCHK(hipEventRecord(f->e1, f->stream));
+        RFCHK(hipMemcpyAsync(&cnt, f->d_count, 8, hipMemcpyDeviceToHost, f->stream));
+        RFCHK(hipStreamSynchronize(f->stream));
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, f->e0, f->e1) == hipSuccess) f->device_ms += ms;
+        if (cnt <= f->out_cap) break;
+        // more candidates than room (the kernel counted them all and kept what fitted): again, with room for all
+        (void)hipFree(f->d_out);
+        f->d_out = nullptr; f->out_cap = 0;
+        RFCHK(hipMalloc((void**)&f->d_out, ((size_t)cnt + (size_t)cnt / 8) * 8));
+        f->out_cap = (size_t)cnt + (size_t)cnt / 8;
+    }
     f->bytes_scanned += n;
-    if (cnt > f->out_cap) return rf_fail(PF_ERR_STATE, "pf_rowfilter_scan: more candidates than lines");
+    if (cnt > f->out_cap) return rf_fail(PF_ERR_STATE, "pf_rowfilter_scan: more candidates than room, twice");
     std::vector<uint64_t> pos((size_t)cnt);
     if (cnt) RFCHK(hipMemcpy(pos.data(), f->d_out, (size_t)cnt * 8, hipMemcpyDeviceToHost));
     std::sort(pos.begin(), pos.end());

@@ -53,32 +53,46 @@ class RowFilter:
         _lib.check(self.L.pf_rowfilter_stats(self.h, C.byref(n), C.byref(ms)))
         return {"bytes_scanned": int(n.value), "device_ms": float(ms.value)}
 
-    def scan_block(self, data):
-        """(matching lines of the complete lines of `data`, joined; number of bytes consumed)"""
+    def scan_block(self, data, n=None):
+        """(matching lines of the complete lines of `data` (bytes, or the first n bytes of a bytearray), joined; number of
+        bytes consumed)"""
         b, e = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)()
-        n, used = C.c_uint64(), C.c_uint64()
-        _lib.check(self.L.pf_rowfilter_scan(self.h, data, len(data), C.byref(b), C.byref(e), C.byref(n), C.byref(used)))
+        cnt, used = C.c_uint64(), C.c_uint64()
+        if isinstance(data, bytearray):
+            n = len(data) if n is None else n
+            ptr = (C.c_char * len(data)).from_buffer(data)          # no copy
+        else:
+            n, ptr = len(data), data
+        _lib.check(self.L.pf_rowfilter_scan(self.h, ptr, n, C.byref(b), C.byref(e), C.byref(cnt), C.byref(used)))
         view = memoryview(data)
-        return b"".join(view[b[i]:e[i]] for i in range(n.value)), int(used.value)
+        got = b"".join(view[b[i]:e[i]] for i in range(cnt.value))
+        del ptr, view
+        return got, int(used.value)
 
     def filter_file(self, path, block_bytes=None):
-        """(header line, matching data lines) of a TSV file (.gz read through gzip, as pandas does by the name)"""
+        """(header line, matching data lines) of a TSV file (.gz read through gzip, as pandas does by the name).  The file
+        is read block by block straight into one buffer; what follows a block's last complete line is moved to the front
+        for the next block."""
         block_bytes = block_bytes or BLOCK_BYTES
         opener = gzip.open if str(path).endswith(".gz") else open
         out = []
         with opener(path, "rb") as fh:
             header = fh.readline()
-            rest = b""
+            buf = bytearray(block_bytes + (1 << 16))
+            have = 0                                         # bytes carried over, at the front of buf
             while True:
-                chunk = fh.read(block_bytes)
-                if not chunk:
+                if have + block_bytes > len(buf):            # a line longer than the slack
+                    buf.extend(bytes(have + block_bytes - len(buf)))
+                got_n = fh.readinto(memoryview(buf)[have:have + block_bytes])
+                if not got_n:
                     break
-                data = rest + chunk
-                got, used = self.scan_block(data)
+                total = have + got_n
+                got, used = self.scan_block(buf, total)
                 out.append(got)
-                rest = data[used:]
-            if rest:                                     # a last line without its newline
-                got, _ = self.scan_block(rest + b"\n")
+                have = total - used
+                buf[:have] = buf[used:total]
+            if have:                                         # a last line without its newline
+                got, _ = self.scan_block(bytes(buf[:have]) + b"\n")
                 out.append(got)
         return header, b"".join(out)
 
