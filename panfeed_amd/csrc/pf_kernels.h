@@ -58,6 +58,9 @@ __host__ __device__ inline uint32_t insert_limit(uint32_t ns) {
 #define PF_SCAN_EXP 0          // 1..3: destructive timing experiments on the scan's window loop (never shipped)
 #endif
 constexpr uint32_t M_TMP_EXP = 2300;
+#ifndef PF_SCAN_LAZY_CLEAR
+#define PF_SCAN_LAZY_CLEAR (PF_SCAN_EXP == 0)     // the timing experiments leave slots behind that no dump visits
+#endif
 #ifndef PF_SCAN_BUCKET
 #define PF_SCAN_BUCKET 4
 #endif
@@ -436,6 +439,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
         fetch_tile0(misc[M_DESC + 6], misc[M_DESC + 7]);
     }
 
+#if PF_SCAN_LAZY_CLEAR
+    // The table is emptied ONCE here; after that every item leaves it empty behind itself -- the dump looks at every slot
+    // anyway and resets the occupied ones (a third of them) as it goes, where a clearing pass over all slots at the start
+    // of every item was 8 % of the kernel.
+    for (uint32_t i = tid; i < NS; i += SCAN_THREADS) {
+#pragma unroll
+        for (int j = 0; j < KW; j++) keys[(size_t)j * NS + i] = EMPTY64;
+        ord[i] = NO_ORD;
+        bits[i] = 0;
+    }
+#endif
     PF_PROF_BEGIN();
     for (uint32_t wi = blockIdx.x; wi < p.n_work; wi += gridDim.x) {
     // ---- the current item (M_DESC was written before the barrier that ended the previous trip)
@@ -452,12 +466,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
     uint32_t nd_word = 0;
     if (wn < p.n_work && tid < 16) nd_word = reinterpret_cast<const uint32_t*>(p.desc + wn)[tid];
 
+#if !PF_SCAN_LAZY_CLEAR
     for (uint32_t i = tid; i < ns; i += SCAN_THREADS) {
 #pragma unroll
         for (int j = 0; j < KW; j++) keys[(size_t)j * NS + i] = EMPTY64;
         ord[i] = NO_ORD;
         bits[i] = 0;
     }
+#endif
     if (tid < 2) misc[tid] = 0;
     const bool one_tile = seg1 - seg0 <= SEG_TILE;
     if (!one_tile) {
@@ -625,6 +641,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
 
     if (overflow) {
         if (tid == 0) { atomicOr(&p.cluster_overflow[c], 1u); p.item_count[item] = 0; }
+#if PF_SCAN_LAZY_CLEAR
+        for (uint32_t i = tid; i < ns; i += SCAN_THREADS) {      // nothing is dumped: the table is emptied as a whole
+#pragma unroll
+            for (int j = 0; j < KW; j++) keys[(size_t)j * NS + i] = EMPTY64;
+            ord[i] = NO_ORD;
+            bits[i] = 0;
+        }
+#endif
     } else if (compact) {
         // chunk 0 words were flushed to global memory iff a chunk 1 followed; the last chunk is still in bits[]
         const bool last_live = chunk_dirty;
@@ -668,6 +692,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
             p.tab_ord[(size_t)slice * NS + e] = o;
             p.cmask_lo[(size_t)slice * NS + e] = lo;
             p.cmask_hi[(size_t)slice * NS + e] = hi;
+#if PF_SCAN_LAZY_CLEAR
+#pragma unroll
+            for (int j = 0; j < KW; j++) keys[(size_t)j * NS + i] = EMPTY64;
+            ord[i] = NO_ORD;
+            bits[i] = 0;
+#endif
         }
         __syncthreads();
         if (tid == 0) p.item_count[item] = misc[M_COUNT];
@@ -676,6 +706,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
 #pragma unroll
             for (int j = 0; j < KW; j++) p.tab_key[((size_t)slice * KW + j) * NS + i] = keys[(size_t)j * NS + i];
             p.tab_ord[(size_t)slice * NS + i] = ord[i];
+#if PF_SCAN_LAZY_CLEAR
+#pragma unroll
+            for (int j = 0; j < KW; j++) keys[(size_t)j * NS + i] = EMPTY64;
+            ord[i] = NO_ORD;                                    // (bits[] went out, and to zero, with the last chunk)
+#endif
         }
         if (tid < 8) p.chunkmask[slice * 8 + tid] = mask_word;
         if (tid == 0) p.item_count[item] = misc[M_COUNT];
