@@ -451,14 +451,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
     }
 #endif
     PF_PROF_BEGIN();
+    uint32_t dcur = M_DESC, dnxt = M_NDESC;      // the two descriptor slots take turns: nothing is copied between items
     for (uint32_t wi = blockIdx.x; wi < p.n_work; wi += gridDim.x) {
-    // ---- the current item (M_DESC was written before the barrier that ended the previous trip)
-    const uint32_t item = misc[M_DESC + 0], c = misc[M_DESC + 1];
-    const uint32_t part = misc[M_DESC + 2], nparts = misc[M_DESC + 3];
-    const uint32_t ns = misc[M_DESC + 4], slice = misc[M_DESC + 5];
-    const uint32_t seg0 = misc[M_DESC + 6], seg1 = seg0 + misc[M_DESC + 7];
-    const uint32_t nstr = misc[M_DESC + 8];
-    const bool compact = misc[M_DESC + 9] != 0;  // view has <= 64 columns: at most chunks 0 and 1
+    // ---- the current item (its descriptor was written before the barrier in front of the previous item's dump)
+    const uint32_t item = misc[dcur + 0], c = misc[dcur + 1];
+    const uint32_t part = misc[dcur + 2], nparts = misc[dcur + 3];
+    const uint32_t ns = misc[dcur + 4], slice = misc[dcur + 5];
+    const uint32_t seg0 = misc[dcur + 6], seg1 = seg0 + misc[dcur + 7];
+    const uint32_t nstr = misc[dcur + 8];
+    const bool compact = misc[dcur + 9] != 0;  // view has <= 64 columns: at most chunks 0 and 1
     const uint32_t nchunks = (nstr + 31) >> 5;
     const uint32_t limit = insert_limit(ns);
     // request the next item's descriptor now; it is looked at after the scan loop
@@ -634,9 +635,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
     if (!overflow && chunk_dirty && !compact) { flush_chunk(); }
     // ---- the next item: descriptor to LDS, first tile of its segment metadata into registers (in flight
     // while this item's table is written out)
-    if (tid < 16) misc[M_NDESC + tid] = nd_word;
+    if (tid < 16) misc[dnxt + tid] = nd_word;
     __syncthreads();
-    if (wn < p.n_work) fetch_tile0(misc[M_NDESC + 6], misc[M_NDESC + 7]);
+    if (wn < p.n_work) fetch_tile0(misc[dnxt + 6], misc[dnxt + 7]);
     PF_PROF_STAMP(19);
 
     if (overflow) {
@@ -717,8 +718,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
     }
     __syncthreads();                               // the table and misc[] are free again
     PF_PROF_STAMP(20);
-    if (tid < 16) misc[M_DESC + tid] = misc[M_NDESC + tid];
-    __syncthreads();
+    { const uint32_t t = dcur; dcur = dnxt; dnxt = t; }
     PF_PROF_STAMP(21);
 #ifdef PF_PROF
     if (tid == 0) atomicAdd(&pf_prof[24], 1ull);
