@@ -71,6 +71,23 @@ def test_sharded_gzip_parts_concatenate(tmp_path):
         assert subprocess.run(["gzip", "-t", os.path.join(out, f + ".gz")]).returncode == 0
 
 
+def test_world_8_as_on_a_full_node(tmp_path):
+    """eight ranks (the node the multi-GPU runs are for), 12 clusters: ranges of one or two clusters each, every rank but
+    the first dropping the patterns an earlier one saw; gzip parts of eight ranks concatenate"""
+    out = str(tmp_path / "w8")
+    os.mkdir(out)
+    stats = run_world("oracle", 8, out, "rand12_basic", timeout=900)
+    exp = CASES["rand12_basic"]["expect"]
+    for f in FILES:
+        assert read_out(out, f, False) == exp[f], f
+    assert sum(s["pattern_rows"] for s in stats.values()) == exp["n_patterns"]
+    out = str(tmp_path / "w8gz")
+    os.mkdir(out)
+    run_world("oracle", 8, out, "rand12_missing", compress=True, timeout=900)
+    for f in FILES:
+        assert read_out(out, f, True) == CASES["rand12_missing"]["expect"][f], f
+
+
 def test_more_ranks_than_clusters(tmp_path):
     """edge_k5 has 4 clusters: with world 3 the ranges are 2/1/1, with a 1-cluster case some ranks are empty"""
     out = str(tmp_path / "a")
