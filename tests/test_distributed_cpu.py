@@ -37,7 +37,7 @@ def _worker(rank, world, port, q, method="owner"):
 
 
 @pytest.mark.parametrize("method", ["owner", "allgather"])
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_merge_patterns_gloo(world, method):
     """both forms of the exchange (all-to-all to the digest's owner and back / all-gather) mark the same rows"""
     ctx = mp.get_context("spawn")
