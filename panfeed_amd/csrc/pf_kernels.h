@@ -846,7 +846,7 @@ constexpr uint32_t DEDUP_UNSET = 0xFFFFFFFFu;
 constexpr uint32_t DEDUP_EX_LDS = 1024;       // slow-path rows of a cluster whose ordinals are staged in LDS
 constexpr uint32_t DEDUP_INGLOBAL = 0x80000000u;
 
-// Two size classes.  Small: every cluster goes through it first -- ~42 KiB of LDS and 80 VGPRs, three workgroups per
+// Two size classes.  Small: every cluster goes through it first -- ~46 KiB of LDS and 80 VGPRs, three workgroups per
 // CU, which is what the HBM-bound pass over the packed bytes needs.  Wide: only the clusters the small class flags
 // (more than 64 distinct sequences, or a sample-set matrix / ordinal bitmap that does not fit): one workgroup per CU.
 struct DedupSmall { static constexpr uint32_t GTAB = 256, MAXD = DEDUP_MAX_D, POOL = 2048, MODE = 1; typedef uint8_t slot_t; };
