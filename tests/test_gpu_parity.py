@@ -711,6 +711,8 @@ def test_error_paths():
     eng = Engine(klength=21, max_strains=32)
     with pytest.raises(ValueError):
         eng.run(recs)                                                    # 40 strains > max_strains 32
+    with pytest.raises(PanfeedHipError):
+        eng.result_checksum()                                            # nothing has been submitted yet
     eng.close()
 
 
