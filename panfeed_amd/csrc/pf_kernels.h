@@ -58,6 +58,9 @@ __host__ __device__ inline uint32_t insert_limit(uint32_t ns) {
 #define PF_SCAN_EXP 0          // 1..3: destructive timing experiments on the scan's window loop (never shipped)
 #endif
 constexpr uint32_t M_TMP_EXP = 2300;
+#ifndef PF_FIN_EXP
+#define PF_FIN_EXP 0            // 1..7: finish_kernel cut off after its phase n - 1 (timing experiments, never shipped)
+#endif
 #ifndef PF_SCAN_LAZY_CLEAR
 #define PF_SCAN_LAZY_CLEAR (PF_SCAN_EXP == 0)     // the timing experiments leave slots behind that no dump visits
 #endif
@@ -2148,6 +2151,9 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
         }
     }
     PF_PROF_STAMP(0);
+#if PF_FIN_EXP == 1
+    return;                                   // timing experiment: the kernel up to here
+#endif
     // phase A: distinct allele masks
     for (uint32_t q = 0; q < nparts; q++) {
     set_part(q);
@@ -2184,6 +2190,9 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
     }
     __syncthreads();
     PF_PROF_STAMP(1);
+#if PF_FIN_EXP == 2
+    return;                                   // timing experiment: the kernel up to here
+#endif
     const uint32_t npresent = sh_npres;
     const uint32_t n_eff = p.consider_missing ? npresent : nstr;               // panfeed.py:191 / :196
     const uint32_t lo = p.maf_lo[n_eff], hi = p.maf_hi[n_eff];
@@ -2351,6 +2360,9 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
     }
     __syncthreads();
     PF_PROF_STAMP(2);
+#if PF_FIN_EXP == 3
+    return;                                   // timing experiment: the kernel up to here
+#endif
     // phase C: ordinal bitmaps, lowest ordinal per mask.  Slots whose mask did not fit the table (rare) are left to
     // a second, plain loop so that the batched one stays small.
     bool saw_untabled = false;
@@ -2404,6 +2416,9 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
     }
     __syncthreads();
     PF_PROF_STAMP(3);
+#if PF_FIN_EXP == 4
+    return;                                   // timing experiment: the kernel up to here
+#endif
     // prefix popcounts over the bitmap words
     uint32_t tot_o, tot_k;
     {
@@ -2423,6 +2438,9 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
     if (tid == 0) at_count = 0;      // from here on: number of pattern-table slots this workgroup claims
     __syncthreads();
     PF_PROF_STAMP(4);
+#if PF_FIN_EXP == 5
+    return;                                   // timing experiment: the kernel up to here
+#endif
     auto rank_of = [&](uint32_t o) -> uint32_t { return pocc[o >> 5] + __popc(occ[o >> 5] & ((1u << (o & 31)) - 1)); };
     auto kept_before = [&](uint32_t o) -> uint32_t { return pkeep[o >> 5] + __popc(keepbm[o >> 5] & ((1u << (o & 31)) - 1)); };
     // ---- run-global pattern table, bulk protocol.  Entry AT-1 of the mask table (never a hash position) stands
@@ -2478,6 +2496,9 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
     }
     __syncthreads();
     PF_PROF_STAMP(5);
+#if PF_FIN_EXP == 6
+    return;                                   // timing experiment: the kernel up to here
+#endif
     if (tid == 0) {
         const uint32_t nnew = at_count;
         uint32_t base = 0;
@@ -2517,6 +2538,9 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
     }
     __syncthreads();
     PF_PROF_STAMP(6);
+#if PF_FIN_EXP == 7
+    return;                                   // timing experiment: the kernel up to here
+#endif
     const uint64_t obase = sh_base - p.out_base;
     // rows of the patterns whose first_seen this workgroup lowered (at_minord is free by now: the list of their
     // mask-table positions)
