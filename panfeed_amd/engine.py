@@ -397,26 +397,78 @@ class Engine:
         import time as _time
         t0 = _time.time()
         n = len(metas)
-        arr = (_lib.TargetSeq * n)()
-        keep = []
-        for i, m in enumerate(metas):
-            s = m.seq
-            seq, comp = s.sequence.encode(), s.compsequence.encode()
-            segs = np.asarray(m.segs, dtype=np.uint32).reshape(-1, 3)
-            si = np.ascontiguousarray(segs[:, 0])
-            ss = np.ascontiguousarray(segs[:, 1])
-            sn = np.ascontiguousarray(segs[:, 2])
-            apos = sorted(m.ambig)
-            ap = np.asarray(apos, dtype=np.uint32)
-            au = np.asarray([m.ambig[q][1] for q in apos], dtype=np.int8)
-            ak = (C.c_char_p * max(1, len(apos)))(*[m.ambig[q][0].encode() for q in apos])
-            keep += [seq, comp, si, ss, sn, ap, au, ak]
-            arr[i] = _lib.TargetSeq(
-                hb.idx[m.cluster].encode(), str(m.strain).encode(), str(s.id).encode(), str(s.chromosome).encode(),
-                seq, comp, len(seq), int(s.strand), int(s.start), int(s.end), int(s.offset), len(si), len(apos),
-                si.ctypes.data_as(C.POINTER(C.c_uint32)), ss.ctypes.data_as(C.POINTER(C.c_uint32)),
-                sn.ctypes.data_as(C.POINTER(C.c_uint32)), ap.ctypes.data_as(C.POINTER(C.c_uint32)),
-                au.ctypes.data_as(C.POINTER(C.c_int8)), ak)
+        # The C structs are filled column by column (numpy) instead of sequence by sequence (ctypes): every kind of
+        # string goes into ONE NUL-separated block whose pieces are addressed by offset, the few per-sequence lists
+        # (ACGT runs, non-ACGT windows) into flat arrays.  23 -> ~4 us per target sequence.
+        TS = np.dtype([("cluster", "u8"), ("strain", "u8"), ("id", "u8"), ("chromosome", "u8"), ("sequence", "u8"),
+                       ("compsequence", "u8"), ("len", "u4"), ("strand", "i4"), ("start", "i8"), ("end", "i8"),
+                       ("offset", "i8"), ("n_segs", "u4"), ("n_ambig", "u4"), ("seg_index", "u8"), ("seg_start", "u8"),
+                       ("seg_nwin", "u8"), ("ambig_pos", "u8"), ("ambig_used", "u8"), ("ambig_key", "u8")])
+        assert TS.itemsize == C.sizeof(_lib.TargetSeq)
+        rec = np.zeros(max(n, 1), dtype=TS)
+        keep = [rec]
+
+        def block(strings):
+            """addresses of `strings` laid out NUL-terminated in one bytes object"""
+            blob = ("\0".join(strings) + "\0").encode()
+            ends = np.flatnonzero(np.frombuffer(blob, dtype=np.uint8) == 0)
+            if len(ends) != len(strings):
+                raise ValueError("a NUL byte inside a name or sequence")
+            starts = np.concatenate(([0], ends[:-1] + 1)).astype(np.uint64)
+            keep.append(blob)
+            base = C.cast(C.c_char_p(blob), C.c_void_p).value
+            return starts + np.uint64(base), (ends - starts.astype(np.int64)).astype(np.uint32)
+
+        if n:
+            seqs = [m.seq for m in metas]
+            # names repeat (a cluster, a strain, a contig): one copy each
+            for field, values in (("cluster", [hb.idx[m.cluster] for m in metas]), ("strain", [str(m.strain) for m in metas]),
+                                  ("id", [str(s.id) for s in seqs]), ("chromosome", [str(s.chromosome) for s in seqs])):
+                uniq = {}
+                idx = np.fromiter((uniq.setdefault(v, len(uniq)) for v in values), dtype=np.int64, count=n)
+                addr, _ = block(list(uniq))
+                rec[field][:n] = addr[idx]
+            addr, lens = block([s.sequence for s in seqs])
+            rec["sequence"][:n], rec["len"][:n] = addr, lens
+            addr, lens2 = block([s.compsequence for s in seqs])
+            rec["compsequence"][:n] = addr
+            if not np.array_equal(lens, lens2):
+                raise ValueError("sequence and compsequence of different lengths")
+            rec["strand"][:n] = np.fromiter((int(s.strand) for s in seqs), dtype=np.int32, count=n)
+            rec["start"][:n] = np.fromiter((int(s.start) for s in seqs), dtype=np.int64, count=n)
+            rec["end"][:n] = np.fromiter((int(s.end) for s in seqs), dtype=np.int64, count=n)
+            rec["offset"][:n] = np.fromiter((int(s.offset) for s in seqs), dtype=np.int64, count=n)
+            # ACGT runs: (segment index, first window, windows) per run, flat
+            nseg = np.fromiter((len(m.segs) for m in metas), dtype=np.int64, count=n)
+            flat = np.array([x for m in metas for t in m.segs for x in t], dtype=np.uint32).reshape(-1, 3)
+            cols = [np.ascontiguousarray(flat[:, j]) for j in range(3)] if len(flat) else [np.zeros(1, np.uint32)] * 3
+            keep += cols
+            soff = (np.concatenate(([0], np.cumsum(nseg)[:-1])) * 4).astype(np.uint64)
+            rec["n_segs"][:n] = nseg
+            for field, col in zip(("seg_index", "seg_start", "seg_nwin"), cols):
+                rec[field][:n] = np.uint64(col.ctypes.data) + soff
+            # windows with a non-ACGT letter (rare): position, strand used and text, as the packer worked them out
+            namb = np.fromiter((len(m.ambig) for m in metas), dtype=np.int64, count=n)
+            rec["n_ambig"][:n] = namb
+            tot = int(namb.sum())
+            ap = np.zeros(max(tot, 1), dtype=np.uint32)
+            au = np.zeros(max(tot, 1), dtype=np.int8)
+            akeys = []
+            at = 0
+            for i in np.flatnonzero(namb):
+                m = metas[int(i)]
+                for q in sorted(m.ambig):
+                    ap[at], au[at] = q, m.ambig[q][1]
+                    akeys.append(m.ambig[q][0])
+                    at += 1
+            kaddr = block(akeys)[0] if akeys else np.zeros(1, dtype=np.uint64)
+            kaddr = np.ascontiguousarray(kaddr)
+            keep += [ap, au, kaddr]
+            aoff = np.concatenate(([0], np.cumsum(namb)[:-1])).astype(np.uint64)
+            rec["ambig_pos"][:n] = np.uint64(ap.ctypes.data) + aoff * np.uint64(4)
+            rec["ambig_used"][:n] = np.uint64(au.ctypes.data) + aoff
+            rec["ambig_key"][:n] = np.uint64(kaddr.ctypes.data) + aoff * np.uint64(8)
+        arr = C.cast(rec.ctypes.data, C.POINTER(_lib.TargetSeq))
         buf, nb = C.c_void_p(), C.c_uint64()
         sso = hb.seg_strand_off.ctypes.data_as(C.c_void_p) if hb.n_strand_words else None
         t1 = _time.time()
