@@ -181,7 +181,12 @@ def build_batch_native(records, klength, canon, W, stroi=(), first_ordinal=0, wa
     L = _lib.load()
     k = int(klength)
     hb = HostBatch(k=k, canon=bool(canon), W=W)
-    seqs, comps, lens, cols, tgts, seq_ref = [], [], [], [], [], []
+    # The sequences are handed over as ONE block per kind (all `sequence`s NUL-joined, all `compsequence`s) with their
+    # addresses worked out by numpy, not as one bytes object and one pointer per Seqinfo: the per-sequence Python work
+    # (two encodes, five appends) was what bounded the host-strings path.
+    flat_s = []                                   # Seqinfo per sequence, iteration order (panfeed.py:54-55)
+    col_parts, tgt_parts, strain_parts = [], [], []
+    cl_names = []
     cl_off = [0]
     cl_nstr, cl_npres, cl_presab, cl_ord = [], [], [], []
     any_target = False
@@ -207,31 +212,51 @@ def build_batch_native(records, klength, canon, W, stroi=(), first_ordinal=0, wa
         cl_npres.append(len(presab))
         cl_presab.append(pb)
         cl_ord.append(first_ordinal + ci)
-        for strain in names:                                      # panfeed.py:54
-            c = col[strain]
-            t = 1 if (bool(stroi) and strain in stroi) else 0     # panfeed.py:90
-            any_target = any_target or bool(t)
-            for s in gs[strain]:                                  # panfeed.py:55
-                sq, cp = s.sequence.encode("latin-1"), s.compsequence.encode("latin-1")
-                if len(sq) != len(cp):
-                    raise ValueError(f"{idx}/{strain}: sequence and compsequence differ in length")
-                seqs.append(sq); comps.append(cp); lens.append(len(sq)); cols.append(c); tgts.append(t)
-                seq_ref.append((ci, strain, s))
-        cl_off.append(len(seqs))
-    nseq = len(seqs)
-    a_seq = (C.c_char_p * max(nseq, 1))(*seqs)
-    a_comp = (C.c_char_p * max(nseq, 1))(*comps)
-    a_len = np.asarray(lens, dtype=np.uint32)
-    a_col = np.asarray(cols, dtype=np.uint32)
-    a_tgt = np.asarray(tgts, dtype=np.uint8)
+        counts = np.fromiter((len(gs[x]) for x in names), dtype=np.int64, count=n)
+        flat_s += [s for x in names for s in gs[x]]               # panfeed.py:54-55
+        col_parts.append(np.repeat(np.fromiter((col[x] for x in names), dtype=np.uint32, count=n), counts))
+        tg = np.fromiter(((1 if (stroi and x in stroi) else 0) for x in names), dtype=np.uint8, count=n)   # panfeed.py:90
+        any_target = any_target or bool(tg.any())
+        tgt_parts.append(np.repeat(tg, counts))
+        strain_parts.append(np.repeat(np.arange(n, dtype=np.uint32), counts))
+        cl_names.append(names)
+        cl_off.append(len(flat_s))
+    nseq = len(flat_s)
+    seq_strs = [s.sequence for s in flat_s]
+    comp_strs = [s.compsequence for s in flat_s]
+    a_len = np.fromiter(map(len, seq_strs), dtype=np.int64, count=nseq)
+    if not np.array_equal(a_len, np.fromiter(map(len, comp_strs), dtype=np.int64, count=nseq)):
+        q = int(np.flatnonzero(a_len != np.fromiter(map(len, comp_strs), dtype=np.int64, count=nseq))[0])
+        ci = int(np.searchsorted(np.asarray(cl_off), q, side="right") - 1)
+        raise ValueError(f"{hb.idx[ci]}: sequence and compsequence differ in length")
+    seq_blob = "\0".join(seq_strs).encode("latin-1")
+    comp_blob = "\0".join(comp_strs).encode("latin-1")
+    if len(seq_blob) != int(a_len.sum()) + max(nseq - 1, 0) or len(comp_blob) != len(seq_blob):
+        raise ValueError("a sequence with characters outside latin-1")
+    starts = np.zeros(max(nseq, 1), dtype=np.uint64)
+    if nseq > 1:
+        starts[1:nseq] = np.cumsum(a_len[:-1] + 1).astype(np.uint64)
+    a_seq = np.ascontiguousarray(starts + np.uint64(C.cast(C.c_char_p(seq_blob), C.c_void_p).value or 0))
+    a_comp = np.ascontiguousarray(starts + np.uint64(C.cast(C.c_char_p(comp_blob), C.c_void_p).value or 0))
+    a_len = a_len.astype(np.uint32)
+    a_col = np.concatenate(col_parts).astype(np.uint32) if col_parts else np.zeros(0, dtype=np.uint32)
+    a_tgt = np.concatenate(tgt_parts).astype(np.uint8) if tgt_parts else np.zeros(0, dtype=np.uint8)
+    a_strain = np.concatenate(strain_parts) if strain_parts else np.zeros(0, dtype=np.uint32)
     a_off = np.asarray(cl_off, dtype=np.uint32)
-    pin = _lib.PackIn(len(cl_nstr), nseq, a_seq, a_comp, a_len.ctypes.data, a_col.ctypes.data,
+    seq_cluster = np.repeat(np.arange(len(cl_nstr)), np.diff(a_off.astype(np.int64)))
+
+    def seq_ref(q):
+        ci = int(seq_cluster[q])
+        return ci, cl_names[ci][int(a_strain[q])], flat_s[q]
+
+    pin = _lib.PackIn(len(cl_nstr), nseq, C.cast(a_seq.ctypes.data, C.POINTER(C.c_char_p)),
+                      C.cast(a_comp.ctypes.data, C.POINTER(C.c_char_p)), a_len.ctypes.data, a_col.ctypes.data,
                       a_tgt.ctypes.data if any_target else None, a_off.ctypes.data, k, int(bool(canon)), W,
                       int(bool(want_strand)))
     handle = C.c_void_p()
     _lib.check(L.pf_pack_records(C.byref(pin), C.byref(handle)))
     try:
-        _fill_from_packed(L, hb, handle, len(cl_nstr), seq_ref.__getitem__)
+        _fill_from_packed(L, hb, handle, len(cl_nstr), seq_ref)
     finally:
         L.pf_packed_free(handle)
     hb.cluster_nstrains = np.asarray(cl_nstr, dtype=np.uint32)
