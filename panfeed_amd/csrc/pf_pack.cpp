@@ -50,7 +50,15 @@ struct ClusterOut {
 
 struct CodeLut {
     int8_t t[256];
-    CodeLut() { for (int i = 0; i < 256; i++) t[i] = -1; t['A'] = 0; t['C'] = 1; t['G'] = 2; t['T'] = 3; }
+    // for the branch-free check of a whole sequence: u[seq byte] ^ v[comp byte] is 0 exactly when the first is A/C/G/T
+    // and the second its complement
+    uint8_t u[256], v[256];
+    CodeLut() {
+        for (int i = 0; i < 256; i++) { t[i] = -1; u[i] = 4; v[i] = 8; }
+        t['A'] = 0; t['C'] = 1; t['G'] = 2; t['T'] = 3;
+        u['A'] = 0; u['C'] = 1; u['G'] = 2; u['T'] = 3;
+        v['T'] = 0; v['G'] = 1; v['C'] = 2; v['A'] = 3;
+    }
 };
 const CodeLut g_lut;
 inline int code_of(unsigned char ch) { return g_lut.t[ch]; }   // table lookup: no data-dependent branches
@@ -63,8 +71,19 @@ void pack_cluster(const pf_pack_in* in, uint32_t ci, ClusterOut& o) {
     std::unordered_map<std::string, uint32_t> amb_index;      // key -> index in o.extras (insertion order kept)
     uint64_t ord_base = 0;
     uint32_t order = 0;
-    std::vector<int8_t> codes;
     std::string rev(k, 'A');
+    {   // room for the common case (every sequence one segment) in one go: growing the word vector by doubling is a dozen
+        // mmap / page-fault / munmap rounds per cluster, and those take a process-wide lock -- the packer's threads then
+        // run one after the other
+        uint64_t nw = 0;
+        for (uint32_t q = s0; q < s1; q++) nw += 2 * (((uint64_t)in->seq_len[q] + 63) / 64);
+        o.words.reserve((size_t)nw + 16);
+        const size_t ns = (size_t)(s1 - s0) + 16;
+        segs.reserve(ns);
+        o.seg_woff.reserve(ns); o.seg_len.reserve(ns); o.seg_sample.reserve(ns); o.seg_ord.reserve(ns);
+        o.seg_wants_strand.reserve(ns); o.seg_strand_nw.reserve(ns); o.seg_lit.reserve(ns);
+        o.seg_src_off.reserve(ns); o.seg_src_start.reserve(ns); o.seg_src_flags.reserve(ns);
+    }
     for (uint32_t q = s0; q < s1; q++) {
         const char* seq = in->seq[q];
         const char* comp = in->comp[q];
@@ -75,14 +94,21 @@ void pack_cluster(const pf_pack_in* in, uint32_t ci, ClusterOut& o) {
         const bool byref = in->seq_flags && (in->seq_flags[q] & 1u);
         if (byref && target) { o.error = "a target strain's sequence cannot be given by reference"; return; }
         if (!byref && (!seq || !comp)) { o.error = "sequence text missing"; return; }
-        codes.resize(byref ? 0 : L);
         std::vector<uint32_t> bad;
-        for (uint32_t i = 0; i < L && !byref; i++) {
-            codes[i] = (int8_t)code_of((unsigned char)seq[i]);
-            if (codes[i] < 0) bad.push_back(i);
-            else if (code_of((unsigned char)comp[i]) != 3 - codes[i]) {
-                o.error = "compsequence is not the complement of sequence";
-                return;
+        if (!byref) {
+            // nearly every sequence is pure A/C/G/T with the right complement: one branch-free pass says so; only the
+            // others are looked at base by base (where the non-ACGT letters are, whether the complement is wrong)
+            unsigned acc = 0;
+            for (uint32_t i = 0; i < L; i++) acc |= (unsigned)(g_lut.u[(unsigned char)seq[i]] ^ g_lut.v[(unsigned char)comp[i]]);
+            if (acc) {
+                for (uint32_t i = 0; i < L; i++) {
+                    const int cs = code_of((unsigned char)seq[i]);
+                    if (cs < 0) bad.push_back(i);
+                    else if (code_of((unsigned char)comp[i]) != 3 - cs) {
+                        o.error = "compsequence is not the complement of sequence";
+                        return;
+                    }
+                }
             }
         }
         if (target) {
@@ -173,11 +199,19 @@ void pack_cluster(const pf_pack_in* in, uint32_t ci, ClusterOut& o) {
         o.seg_src_off.push_back(0); o.seg_src_start.push_back(0); o.seg_src_flags.push_back(1u);
         o.words.resize(w0 + nw, 0);
         const char* seq = in->seq[g.seq] + g.a;
-        for (uint32_t i0 = 0; i0 < g.len; i0 += 32) {
+        uint64_t* wp = o.words.data() + w0;
+        uint32_t i0 = 0;
+        for (; i0 + 32 <= g.len; i0 += 32) {                 // whole words: 32 lookups, no bounds inside
             uint64_t w = 0;
-            const uint32_t m = std::min<uint32_t>(32, g.len - i0);
-            for (uint32_t i = 0; i < m; i++) w = (w << 2) | (uint64_t)code_of((unsigned char)seq[i0 + i]);
-            o.words[w0 + (i0 >> 5)] = w << (2 * (32 - m));
+#pragma GCC unroll 8
+            for (uint32_t i = 0; i < 32; i++) w = (w << 2) | (uint64_t)g_lut.u[(unsigned char)seq[i0 + i]];
+            wp[i0 >> 5] = w;
+        }
+        if (i0 < g.len) {
+            uint64_t w = 0;
+            const uint32_t m = g.len - i0;
+            for (uint32_t i = 0; i < m; i++) w = (w << 2) | (uint64_t)g_lut.u[(unsigned char)seq[i0 + i]];
+            wp[i0 >> 5] = w << (2 * (32 - m));
         }
     }
     for (auto& x : o.t_seg_local) x = where[x];
@@ -218,6 +252,7 @@ int pf_pack_records(const pf_pack_in* in, pf_packed** out) {
             th.emplace_back([&, t] { for (uint32_t ci = t; ci < C; ci += nt) pack_cluster(in, ci, outs[ci]); });
         for (auto& x : th) x.join();
     }
+
     for (uint32_t ci = 0; ci < C; ci++)
         if (!outs[ci].error.empty()) return pk_fail(PF_ERR_ARG, "cluster %u: %s", ci, outs[ci].error.c_str());
     pf_packed* p = new pf_packed();

@@ -181,9 +181,9 @@ def build_batch_native(records, klength, canon, W, stroi=(), first_ordinal=0, wa
     L = _lib.load()
     k = int(klength)
     hb = HostBatch(k=k, canon=bool(canon), W=W)
-    # The sequences are handed over as ONE block per kind (all `sequence`s NUL-joined, all `compsequence`s) with their
-    # addresses worked out by numpy, not as one bytes object and one pointer per Seqinfo: the per-sequence Python work
-    # (two encodes, five appends) was what bounded the host-strings path.
+    # The sequences are handed over by address -- of the str objects' own bytes when they are ASCII, else of two NUL-joined
+    # latin-1 blocks -- with the per-sequence columns built by numpy, not as one bytes object and one pointer per Seqinfo:
+    # the per-sequence Python work (two encodes, five appends) was what bounded the host-strings path.
     flat_s = []                                   # Seqinfo per sequence, iteration order (panfeed.py:54-55)
     col_parts, tgt_parts, strain_parts = [], [], []
     cl_names = []
@@ -229,15 +229,23 @@ def build_batch_native(records, klength, canon, W, stroi=(), first_ordinal=0, wa
         q = int(np.flatnonzero(a_len != np.fromiter(map(len, comp_strs), dtype=np.int64, count=nseq))[0])
         ci = int(np.searchsorted(np.asarray(cl_off), q, side="right") - 1)
         raise ValueError(f"{hb.idx[ci]}: sequence and compsequence differ in length")
-    seq_blob = "\0".join(seq_strs).encode("latin-1")
-    comp_blob = "\0".join(comp_strs).encode("latin-1")
-    if len(seq_blob) != int(a_len.sum()) + max(nseq - 1, 0) or len(comp_blob) != len(seq_blob):
-        raise ValueError("a sequence with characters outside latin-1")
-    starts = np.zeros(max(nseq, 1), dtype=np.uint64)
-    if nseq > 1:
-        starts[1:nseq] = np.cumsum(a_len[:-1] + 1).astype(np.uint64)
-    a_seq = np.ascontiguousarray(starts + np.uint64(C.cast(C.c_char_p(seq_blob), C.c_void_p).value or 0))
-    a_comp = np.ascontiguousarray(starts + np.uint64(C.cast(C.c_char_p(comp_blob), C.c_void_p).value or 0))
+    if all(map(str.isascii, seq_strs)) and all(map(str.isascii, comp_strs)):
+        # an ASCII str keeps its bytes in the object itself: their address is all the packer needs (the strings stay alive
+        # in flat_s for the duration of the call) -- no copy of the batch's 300 MB of text at all
+        as_utf8 = C.pythonapi.PyUnicode_AsUTF8
+        as_utf8.restype, as_utf8.argtypes = C.c_void_p, [C.py_object]
+        a_seq = np.fromiter(map(as_utf8, seq_strs), dtype=np.uint64, count=nseq) if nseq else np.zeros(1, dtype=np.uint64)
+        a_comp = np.fromiter(map(as_utf8, comp_strs), dtype=np.uint64, count=nseq) if nseq else np.zeros(1, dtype=np.uint64)
+    else:
+        seq_blob = "\0".join(seq_strs).encode("latin-1")
+        comp_blob = "\0".join(comp_strs).encode("latin-1")
+        if len(seq_blob) != int(a_len.sum()) + max(nseq - 1, 0) or len(comp_blob) != len(seq_blob):
+            raise ValueError("a sequence with characters outside latin-1")
+        starts = np.zeros(max(nseq, 1), dtype=np.uint64)
+        if nseq > 1:
+            starts[1:nseq] = np.cumsum(a_len[:-1] + 1).astype(np.uint64)
+        a_seq = np.ascontiguousarray(starts + np.uint64(C.cast(C.c_char_p(seq_blob), C.c_void_p).value or 0))
+        a_comp = np.ascontiguousarray(starts + np.uint64(C.cast(C.c_char_p(comp_blob), C.c_void_p).value or 0))
     a_len = a_len.astype(np.uint32)
     a_col = np.concatenate(col_parts).astype(np.uint32) if col_parts else np.zeros(0, dtype=np.uint32)
     a_tgt = np.concatenate(tgt_parts).astype(np.uint8) if tgt_parts else np.zeros(0, dtype=np.uint8)
