@@ -179,11 +179,12 @@ class Engine:
         res = self.fetch()
         return self._render(hb, res)
 
-    def run_stream(self, records, batch_clusters=256, prefetch=2, defer_patterns=False):
+    def run_stream(self, records, batch_clusters=256, prefetch=2, defer_patterns=False, device_text=False):
         """Generator over BatchOutput: packs batch i+1 (host threads, pf_pack_records) while the GPU works on
         batch i and the caller writes batch i-1 -- the reference's reader / workers / writer pipeline
         (__main__.py:39-81,299-344) with the GPU in the workers' place and a deterministic order
-        (always the --cores 1 order, whatever finishes first)."""
+        (always the --cores 1 order, whatever finishes first).  device_text: the two big files' text written by the GPU
+        and handed over as bytes-like blocks (see run_batches) instead of `str`."""
         import itertools
         it = iter(records)
 
@@ -195,7 +196,7 @@ class Engine:
                     return
                 yield build_batch_native(chunk, self.k, self.canon, self.W, stroi=self.stroi, first_ordinal=ordinal)
                 ordinal += len(chunk)
-        return self.run_batches(host_batches(), prefetch, defer_patterns=defer_patterns)
+        return self.run_batches(host_batches(), prefetch, device_text, defer_patterns=defer_patterns)
 
     def run_pangenome(self, pangenome, batch_clusters=256, prefetch=2, device_text=False, defer_patterns=False):
         """run_stream fed by the native reader (native_input.Pangenome): table rows -> records -> packed batches

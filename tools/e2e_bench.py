@@ -49,6 +49,33 @@ def main():
                       "output_bytes": nbytes, "device_ms_total": dev_ms,
                       "note": "host strings -> three files; 1 target strain; record generation excluded"}))
     eng.close()
+    # the same with the two big files' text written by the GPU (bytes into binary files; kmers.tsv from the library's
+    # renderer, handed over without a copy)
+    from panfeed_amd.engine import OwnedText
+    eng = Engine(klength=k, max_strains=1024, stroi=stroi)
+    t0 = time.time()
+    nbytes = 0
+    with open(os.path.join(out, "kmers.tsv"), "wb") as ks, open(os.path.join(out, "kmers_to_hashes.tsv"), "wb") as kh, \
+            open(os.path.join(out, "hashes_to_patterns.tsv"), "wb") as hp:
+        ks.write(KMERS_TSV_HEADER.encode())
+        kh.write(KMERS_TO_HASHES_HEADER.encode())
+        hp.write(hashes_to_patterns_header(names).encode())
+        for o in eng.run_stream(iter(recs), batch_clusters=128, device_text=True):
+            kt = o.kmers_tsv
+            if isinstance(kt, OwnedText):
+                ks.write(kt.view)
+                nbytes += len(kt)
+                kt.release()
+            else:
+                ks.write(kt.encode() if isinstance(kt, str) else kt)
+                nbytes += len(kt)
+            kh.write(o.kmers_to_hashes)
+            hp.write(o.hashes_to_patterns)
+            nbytes += len(o.kmers_to_hashes) + len(o.hashes_to_patterns)
+    dt = time.time() - t0
+    print(json.dumps({"clusters": n, "samples": S, "instances": ninst, "seconds": dt, "instances_per_s": ninst / dt,
+                      "output_bytes": nbytes, "note": "the same, text of the two big files written on the device"}))
+    eng.close()
 
 
 if __name__ == "__main__":
