@@ -172,6 +172,36 @@ def _fill_from_packed(L, hb, handle, n_clusters, seq_ref):
         hb.targets.append(SeqMeta(ci, strain, s, 0, max(len(s.sequence) - k + 1, 0), segs, ambig))
 
 
+_ASCII_DATA_OFFSET = None      # bytes from a compact ASCII str object to its characters, found out once (see below)
+
+
+def _ascii_addresses(strings):
+    """addresses (uint64 array) of the character data of ASCII `str` objects, which must stay alive while they are used.
+    The supported way, PyUnicode_AsUTF8 per string through ctypes, costs 0.4 us a string -- at 2 000 strings per cluster
+    more than everything else in the packer's Python side -- so the addresses are taken in bulk: an object array holds the
+    objects' addresses, and for compact ASCII strings the characters sit at a fixed distance behind the object header.
+    That distance is not assumed: it is measured with PyUnicode_AsUTF8 on probe strings once per process and checked
+    against the API on the first and last string of every call; if anything disagrees, the API is used for all."""
+    import ctypes as C
+    global _ASCII_DATA_OFFSET
+    n = len(strings)
+    if n == 0:
+        return np.zeros(1, dtype=np.uint64)
+    as_utf8 = C.pythonapi.PyUnicode_AsUTF8
+    as_utf8.restype, as_utf8.argtypes = C.c_void_p, [C.py_object]
+    if _ASCII_DATA_OFFSET is None:
+        probes = ["ACGT", "A" * 1000, "".join("ACGT"[i & 3] for i in range(37))]
+        offs = {as_utf8(p) - id(p) for p in probes}
+        _ASCII_DATA_OFFSET = offs.pop() if len(offs) == 1 else -1
+    if _ASCII_DATA_OFFSET > 0:
+        objs = np.empty(n, dtype=object)
+        objs[:] = strings
+        addr = np.ctypeslib.as_array((C.c_uint64 * n).from_address(objs.ctypes.data)) + np.uint64(_ASCII_DATA_OFFSET)
+        if int(addr[0]) == as_utf8(strings[0]) and int(addr[-1]) == as_utf8(strings[-1]):
+            return np.ascontiguousarray(addr)
+    return np.fromiter(map(as_utf8, strings), dtype=np.uint64, count=n)
+
+
 def build_batch_native(records, klength, canon, W, stroi=(), first_ordinal=0, want_strand=True):
     """Same result as build_batch, with the per-base work (packing, non-ACGT splitting, slow-path grouping)
     done by the library's host threads (pf_pack_records, csrc/pf_pack.cpp)."""
@@ -232,10 +262,8 @@ def build_batch_native(records, klength, canon, W, stroi=(), first_ordinal=0, wa
     if all(map(str.isascii, seq_strs)) and all(map(str.isascii, comp_strs)):
         # an ASCII str keeps its bytes in the object itself: their address is all the packer needs (the strings stay alive
         # in flat_s for the duration of the call) -- no copy of the batch's 300 MB of text at all
-        as_utf8 = C.pythonapi.PyUnicode_AsUTF8
-        as_utf8.restype, as_utf8.argtypes = C.c_void_p, [C.py_object]
-        a_seq = np.fromiter(map(as_utf8, seq_strs), dtype=np.uint64, count=nseq) if nseq else np.zeros(1, dtype=np.uint64)
-        a_comp = np.fromiter(map(as_utf8, comp_strs), dtype=np.uint64, count=nseq) if nseq else np.zeros(1, dtype=np.uint64)
+        a_seq = _ascii_addresses(seq_strs)
+        a_comp = _ascii_addresses(comp_strs)
     else:
         seq_blob = "\0".join(seq_strs).encode("latin-1")
         comp_blob = "\0".join(comp_strs).encode("latin-1")
