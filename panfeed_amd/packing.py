@@ -181,7 +181,7 @@ def _ascii_addresses(strings):
     more than everything else in the packer's Python side -- so the addresses are taken in bulk: an object array holds the
     objects' addresses, and for compact ASCII strings the characters sit at a fixed distance behind the object header.
     That distance is not assumed: it is measured with PyUnicode_AsUTF8 on probe strings once per process and checked
-    against the API on the first and last string of every call; if anything disagrees, the API is used for all."""
+    against the API on sixteen strings spread over every call; if anything disagrees, the API is used for all."""
     import ctypes as C
     global _ASCII_DATA_OFFSET
     n = len(strings)
@@ -197,7 +197,9 @@ def _ascii_addresses(strings):
         objs = np.empty(n, dtype=object)
         objs[:] = strings
         addr = np.ctypeslib.as_array((C.c_uint64 * n).from_address(objs.ctypes.data)) + np.uint64(_ASCII_DATA_OFFSET)
-        if int(addr[0]) == as_utf8(strings[0]) and int(addr[-1]) == as_utf8(strings[-1]):
+        # exact type only (a subclass may add fields), and a spread of spot checks against the API
+        probe = sorted({0, n - 1, *(int(x) for x in np.linspace(0, n - 1, 16))})
+        if all(type(strings[i]) is str and int(addr[i]) == as_utf8(strings[i]) for i in probe):
             return np.ascontiguousarray(addr)
     return np.fromiter(map(as_utf8, strings), dtype=np.uint64, count=n)
 
