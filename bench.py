@@ -198,9 +198,11 @@ def targets_pass(args, local):
                     "side turning its per-sequence objects into the C structs"}
 
 
-def allele_sweep(args, local):
+def allele_sweep(args, local, allele_model="star"):
     """throughput against the number of distinct sequences per cluster (5 000 clusters x --samples, uniform allele
-    weights): where the identical-sequence shortcut changes regime"""
+    weights): where the identical-sequence shortcut changes regime.  "star" = SURVEY 8d's alleles (each with its own
+    random flanks and its own 1 % substitutions: the distinct k-mers of a cluster grow by ~480 per allele); "tree" =
+    alleles descending from one another by two substitutions at a time (~62 new k-mers per allele)"""
     import torch
     from panfeed_amd import _lib, devbatch, synth
     from panfeed_amd.engine import Engine
@@ -209,7 +211,8 @@ def allele_sweep(args, local):
     n = 5000
     for mean_alleles in (7, 30, 60, 70, 150, 500):
         eng = Engine(klength=k, max_strains=(S + 31) // 32 * 32, device=local, max_items=32768, pattern_capacity=1 << 24)
-        cl = synth.generate(n, S, first=0, flank=args.flank, n_rate=0.0, mean_alleles=mean_alleles, allele_decay=1.0)
+        cl = synth.generate(n, S, first=0, flank=args.flank, n_rate=0.0, mean_alleles=mean_alleles, allele_decay=1.0,
+                            allele_model=allele_model)
         distinct = float(np.mean([len(np.unique(c.seq_allele)) for c in cl]))
         db = devbatch.from_synth(eng, cl, k)
         del cl
@@ -441,6 +444,7 @@ def main():
             out["targets_second_pass"] = targets_pass(args, local)
         if args.sweep_alleles:
             out["allele_sweep"] = allele_sweep(args, local)
+            out["allele_sweep_tree"] = allele_sweep(args, local, "tree")
         if world == 1 and not args.no_cpu_baseline:
             threads = min(len(os.sched_getaffinity(0)), 16)   # a 1-GPU box's CPU share
             out["cpu_baseline"] = cpu_baseline(args, threads)

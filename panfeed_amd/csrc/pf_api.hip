@@ -882,7 +882,12 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
                 const double D = (double)h_vnstr[i], L = (double)(vinst[i] * mult) / D;
                 const double est = L * (1.0 + share * (D - 1.0));
                 const double room = 0.9 * (double)pf::insert_limit(NS);
-                if (est > room) nparts[i] = (uint32_t)std::min<double>(std::ceil(est / room), 64.0);
+                // The estimate is right for SURVEY 8d's alleles, each with its own substitutions and flanks.  The many
+                // alleles of a population descend from one another and share far more (tens of new k-mers each, not
+                // hundreds): past 24 distinct sequences the cluster starts as ONE item instead, and if that overflows
+                // the scan reports how far it came and the retry gets the partitions it needs.  A failed first attempt
+                // costs 1/P of the P scans that follow; an over-partitioned cluster costs every surplus scan in full.
+                if (est > room) nparts[i] = D > 24.0 ? 1u : (uint32_t)std::min<double>(std::ceil(est / room), 64.0);
             }
         }
         return PF_OK;
@@ -1262,7 +1267,14 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         for (uint32_t ci : todo)
             if (ovf[ci]) {
                 next.push_back(ci);
-                nparts[ci] = nparts[ci] * 2;
+                // ovf = 64 * (the item's units / the units scanned when its table was full): that many times the keys
+                // of one partition are to be expected (an overestimate: a cluster's first sequence brings more new keys
+                // than its later ones), and key hashing spreads them evenly: a small margin is enough
+                // (a view of distinct sequences only: among the copies of an every-copy cluster new keys stop coming
+                // early and nothing can be extrapolated -- those double, as does a cluster that asks for more than 16x)
+                double want = std::ceil((double)nparts[ci] * ((double)ovf[ci] / 64.0) * 1.06);
+                if (!h_mode[ci] || want > 16.0 * nparts[ci]) want = 2.0 * nparts[ci];
+                nparts[ci] = (uint32_t)std::min<double>(std::max<double>(want, (double)nparts[ci] + 1.0), 65537.0);
                 if (nparts[ci] > 65536) return fail(PF_ERR_CAPACITY, "cluster %u does not fit 65536 key partitions", ci);
             }
         if (!next.empty()) {

@@ -61,6 +61,9 @@ constexpr uint32_t M_TMP_EXP = 2300;
 #ifndef PF_FIN_EXP
 #define PF_FIN_EXP 0            // 1..7: finish_kernel cut off after its phase n - 1 (timing experiments, never shipped)
 #endif
+#ifndef PF_ROWS_EXP
+#define PF_ROWS_EXP 0           // 1..4: rows_kernel's wide path cut off after its phase n (timing experiments, never shipped)
+#endif
 #ifndef PF_SCAN_LAZY_CLEAR
 #define PF_SCAN_LAZY_CLEAR (PF_SCAN_EXP == 0)     // the timing experiments leave slots behind that no dump visits
 #endif
@@ -158,7 +161,8 @@ struct ScanParams {
     uint32_t* chunkbits;              // [slice][W][NS]
     uint32_t* chunkmask;              // [slice][8]  bit ch set: chunk ch was flushed
     uint32_t* item_count;             // [item] unique keys in the item's table
-    uint32_t* cluster_overflow;       // [cluster] |= 1 when any partition overflowed
+    uint32_t* cluster_overflow;       // [cluster] nonzero when a partition overflowed: 64 * (units of the item / units
+                                      // scanned when the table was full), the largest over its partitions (>= 64)
     const uint32_t* work;             // [n_work] item ids of this launch
     const struct ScanDesc* desc;      // [n_work] what a workgroup needs to start on work[i] (scan_desc_kernel)
     uint32_t n_work;
@@ -407,6 +411,7 @@ constexpr uint32_t M_ORDB = M_NINST + SEG_TILE;
 constexpr uint32_t M_SAMPLE = M_ORDB + SEG_TILE;
 constexpr uint32_t M_UPREF = M_SAMPLE + SEG_TILE;                        // [SEG_TILE + 1] unit prefix
 constexpr uint32_t M_TMP = M_UPREF + SEG_TILE + 2;                       // one scratch word
+constexpr uint32_t M_PROG = M_TMP + 1;                                   // unit index at which the table was found full
 constexpr uint32_t M_DESC = M_TMP + 2;                                   // [16] the current item's ScanDesc
 constexpr uint32_t M_NDESC = M_DESC + 16;                                // [16] the next item's
 static_assert(M_NDESC + 16 <= MISC_WORDS, "misc area too small");
@@ -479,6 +484,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
     }
 #endif
     if (tid < 2) misc[tid] = 0;
+    if (tid == 2) misc[M_PROG] = 0xFFFFFFFFu;
+    uint32_t ubefore = 0;     // units of the tiles already walked
     const bool one_tile = seg1 - seg0 <= SEG_TILE;
     if (!one_tile) {
         for (uint32_t ch = tid; ch <= nchunks; ch += SCAN_THREADS)
@@ -620,7 +627,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
                     // 4.55 ms) -- so after the limit trips every wave finishes at most the unit it is in:
                     // 16 waves x 64 lanes x 2 keys < INSERT_SLACK.
                     if (scan_unit<KW, CANON>(keys, ord, bits, misc, NS, ns, limit, k, lane, part, nparts, cw,
-                                             u, ninst, ordb, bit)) break;
+                                             u, ninst, ordb, bit)) {
+                        if (lane == 0) atomicMin(&misc[M_PROG], ubefore + g);
+                        break;
+                    }
 #pragma unroll
                     for (int j = 0; j <= KW; j++) cw[j] = nw[j];
                     q = qn; s = sn; send = sendn; u = un; ninst = ninstn; ordb = ordbn; bit = bitn;
@@ -633,6 +643,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
             PF_PROF_STAMP(18);
             if (misc[M_OVERFLOW]) { overflow = true; break; }
         }
+        ubefore += misc[M_UPREF + SEG_TILE];       // (rewritten only after the next tile's first barrier)
         // the next tile overwrites the staged metadata: everyone is past the barrier above
     }
     if (!overflow && chunk_dirty && !compact) { flush_chunk(); }
@@ -644,7 +655,25 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
     PF_PROF_STAMP(19);
 
     if (overflow) {
-        if (tid == 0) { atomicOr(&p.cluster_overflow[c], 1u); p.item_count[item] = 0; }
+        // How far the item had come when its table was full tells the host how many key partitions the cluster needs:
+        // the same keys arrive at about the same rate in every partition and all through the item (the first sequence
+        // of a cluster brings more new keys than the later ones: the extrapolation errs on the safe side).
+        uint32_t tot = 0;
+        for (uint32_t s = seg0 + tid; s < seg1; s += SCAN_THREADS) {
+            const uint32_t len = p.seg_len[s];
+            tot += len >= k ? (len - k + 64) >> 6 : 0;
+        }
+        for (int d = 1; d < 64; d <<= 1) tot += __shfl_xor(tot, d);
+        if (tid == 0) misc[M_TMP] = 0;
+        __syncthreads();
+        if (lane == 0 && tot) atomicAdd(&misc[M_TMP], tot);
+        __syncthreads();
+        if (tid == 0) {
+            const uint64_t all = misc[M_TMP], done = min(misc[M_PROG], (uint32_t)all) + 1;
+            const uint64_t ratio = min((all * 64 + done - 1) / done, (uint64_t)0x7FFFFFFFu);
+            atomicMax(&p.cluster_overflow[c], (uint32_t)max(ratio, (uint64_t)64));
+            p.item_count[item] = 0;
+        }
 #if PF_SCAN_LAZY_CLEAR
         for (uint32_t i = tid; i < ns; i += SCAN_THREADS) {      // nothing is dumped: the table is emptied as a whole
 #pragma unroll
@@ -1450,6 +1479,10 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
             slot_tag[i] = tag;
         }
         __syncthreads();
+#if PF_ROWS_EXP == 1
+        if (tid == 0) { p.item_unique[item] = 0; p.item_kept[item] = 0; }
+        return;
+#endif
         // one half-wave per mask: lane j gathers row word 32 r + j in round r, the 32 words of a round then go through
         // the row hash in order (eight blocks), every lane running it on the shuffled words
         const uint32_t hw = tid >> 5, hl = tid & 31u, hbase = (tid & 63u) & 32u;
@@ -1502,6 +1535,11 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
             const bool keep = eval_slot((uint32_t)key & 0x3FFFu, h);
             if (hl == 0) { at_hash[t] = h; at_keep[t] = keep ? 1u : 0u; }
         }
+#if PF_ROWS_EXP == 2
+        __syncthreads();
+        if (tid == 0) { p.item_unique[item] = 0; p.item_kept[item] = 0; }
+        return;
+#endif
         // slots whose mask found no room in the table (rare): one evaluation each, result straight to where the
         // main loop below would put it
         for (uint32_t i = hw; i < ns; i += ROWS_THREADS / 32) {
@@ -1511,6 +1549,10 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
             if (hl == 0) { p.slot_hash[(size_t)slice * NS + i] = h; slot_tag[i] = keep ? WIDE_UNTABLED_KEEP : WIDE_UNTABLED_DROP; }
         }
         __syncthreads();
+#if PF_ROWS_EXP == 3
+        if (tid == 0) { p.item_unique[item] = 0; p.item_kept[item] = 0; }
+        return;
+#endif
         // segd is no longer needed: its place is the bitmaps' or the pairs'
         if (bitmaps) { for (uint32_t i = tid; i < 2 * DENSE_WORDS; i += ROWS_THREADS) occ[i] = 0; }
         else { for (uint32_t i = tid; i < SORT_MAX; i += ROWS_THREADS) pairs[i] = EMPTY64; }
@@ -1584,6 +1626,10 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         }
     }
     __syncthreads();
+#if PF_ROWS_EXP == 4
+    if (tid == 0) { p.item_unique[item] = 0; p.item_kept[item] = 0; }
+    return;
+#endif
 
     if (bitmaps) {
         // ranks come from the ordinal bitmaps: prefix popcounts per word, stored for emit_kernel

@@ -12,6 +12,10 @@ with allele-specific 1 % substitutions and allele-specific random flanks; allele
 of distinct sequences per cluster); cluster frequency 0.99 (60 % "core") or U(0.02, 0.9); 1 % of present samples
 carry a paralog copy; strand +-1 (affects coordinates only); `n_rate` of the sequences
 get one 'N'.
+
+`allele_model="tree"` (not SURVEY's; bench.py's second allele sweep): the alleles of a cluster descend from one
+another the way a population's do -- allele i is a copy of a random earlier allele, flanks included, with
+`tree_mutations` point substitutions -- so that many distinct sequences share most of their k-mers.
 """
 from dataclasses import dataclass, field
 
@@ -96,14 +100,29 @@ def sample_names(n, shuffle_seed=None):
 
 
 def generate_cluster(c, names, flank=0, mean_len=900, min_len=150, max_len=6000, n_rate=0.001,
-                     paralog_rate=0.01, sub_rate=0.01, mean_alleles=7.0, seed=0x9E3779B9, allele_decay=0.5):
+                     paralog_rate=0.01, sub_rate=0.01, mean_alleles=7.0, seed=0x9E3779B9, allele_decay=0.5,
+                     allele_model="star", tree_mutations=2):
     rng = np.random.Generator(np.random.PCG64(seed ^ c))
     S = len(names)
     L = int(np.clip(np.rint(rng.lognormal(np.log(mean_len), 0.5)), min_len, max_len))
     H = 1 + int(rng.poisson(mean_alleles))
     anc = rng.integers(0, 4, size=L, dtype=np.uint8)
     alleles = []
-    for i in range(H):
+    if allele_model == "tree":
+        root = anc if not flank else np.concatenate([rng.integers(0, 4, size=flank, dtype=np.uint8), anc,
+                                                     rng.integers(0, 4, size=flank, dtype=np.uint8)])
+        alleles.append(root)
+        seen = {root.tobytes()}
+        while len(alleles) < H:
+            a = alleles[int(rng.integers(0, len(alleles)))].copy()
+            at = rng.integers(0, len(a), size=tree_mutations)
+            a[at] = (a[at] + rng.integers(1, 4, size=tree_mutations, dtype=np.uint8)) & 3
+            if a.tobytes() not in seen:
+                seen.add(a.tobytes())
+                alleles.append(a)
+    elif allele_model != "star":
+        raise ValueError(f"allele_model {allele_model!r}")
+    for i in range(H if allele_model == "star" else 0):
         a = anc.copy()
         if i > 0:
             mut = rng.random(L) < sub_rate

@@ -615,6 +615,26 @@ def test_many_distinct_sequences_vs_oracle(D, S, L, k, canon, kw, missing):
     eng.close()
 
 
+@pytest.mark.parametrize("mean_alleles,S", [(40, 300), (250, 800)], ids=["D40", "D250"])
+def test_alleles_descending_from_one_another_vs_oracle(mean_alleles, S):
+    """many distinct sequences that share most of their k-mers (synth's "tree" alleles, the population-like case of
+    bench.py's second allele sweep): long allele masks over few k-mers"""
+    from panfeed_amd import synth
+    from panfeed_amd.engine import Engine
+    cl = synth.generate(4, S, first=11, flank=100, n_rate=0.002, mean_alleles=mean_alleles, allele_decay=1.0,
+                        allele_model="tree")
+    assert max(len(np.unique(c.seq_allele)) for c in cl) > (64 if mean_alleles > 64 else 20)
+    recs = [c.record() for c in cl]
+    stroi = {cl[0].names[1], cl[0].names[S - 2]}
+    eng = Engine(klength=31, max_strains=(S + 31) // 32 * 32, stroi=stroi)
+    out = eng.run(recs)
+    (ek, ekh, ehp), st = _oracle_texts(recs, stroi=stroi, klength=31)
+    assert out.kmers_to_hashes == ekh
+    assert out.hashes_to_patterns == ehp
+    assert out.kmers_tsv == ek
+    eng.close()
+
+
 def test_wide_dedup_with_5000_samples():
     """configs[4] shape: at 5 000 samples the sample-set matrix only fits 25 distinct sequences: clusters with more
     go through the wide class instead of scanning all 5 000 copies"""
