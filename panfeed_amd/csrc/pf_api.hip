@@ -1179,6 +1179,17 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             PFCHK(mark_begin(c, 2));
             hipLaunchKernelGGL(pf::cluster_base_kernel, dim3(1), dim3(1024), 0, c->stream, bp);
             HIPCHK(hipGetLastError());
+            if (sb.nitems > sb.ncl) {     // some cluster of this sub-batch has several items
+                pf::BitmapMergeParams bm{};
+                bm.sub_cluster = bp.sub_cluster; bm.cluster_item0 = bp.cluster_item0; bm.cluster_nitems = bp.cluster_nitems;
+                bm.item_scratch = c->it_slice.as<uint32_t>(); bm.cluster_overflow = bp.cluster_overflow;
+                bm.v_mode = c->v_mode.as<uint32_t>(); bm.v_dense = c->v_dense.as<uint32_t>();
+                bm.item_fused = c->it_compact.as<uint32_t>();
+                bm.bm_occ = c->bm_occ.as<uint32_t>(); bm.bm_keep = c->bm_keep.as<uint32_t>();
+                bm.pre_occ = c->pre_occ.as<uint32_t>(); bm.pre_keep = c->pre_keep.as<uint32_t>();
+                hipLaunchKernelGGL(pf::bitmap_merge_kernel, dim3(sb.ncl), dim3(256), 0, c->stream, bm);
+                HIPCHK(hipGetLastError());
+            }
 
             pf::EmitParams em{};
             em.item_cluster = c->it_cluster.as<uint32_t>(); em.item_scratch = c->it_slice.as<uint32_t>();

@@ -1141,7 +1141,8 @@ void cluster_dedup_kernel(DedupParams p) {
             }
         __syncthreads();
         const uint32_t D = sh_nrep;
-        const bool worth = 2 * D <= n;                    // at least half of the segments are copies
+        const bool worth = 2 * D <= n;                    // at least half of the segments are copies (a lower bar was
+                                                          // measured on clusters of 140 and 370 related alleles: no gain)
         if (CFG::MODE == 1) {
             // what the wide class can still do for this cluster: more distinct sequences, no sample-set matrix, no
             // ordinal bitmap; (a hash collision or too few copies stay mode 0)
@@ -1320,7 +1321,8 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
     __shared__ uint32_t at_keep[AT_SLOTS];
     // mode 2 ("wide": up to 1024 distinct sequences, a k-mer's allele mask is up to 32 words)
     __shared__ uint16_t slot_tag[9600];        // per slot: table position of its mask, WIDE_UNTABLED when it has none
-    __shared__ uint32_t mstage[ROWS_THREADS / 32][32];   // the mask being expanded, per half-wave
+    __shared__ uint32_t mstage[ROWS_THREADS / 32][33];   // the mask being expanded, per half-wave; word 32 stays zero
+    __shared__ __align__(16) uint32_t rowst[ROWS_THREADS / 32][32];   // 32 words of the row on their way into the hash
     __shared__ uint32_t wstart[MAX_CHUNKS + 1];          // first segment of every 32-sample word
 
     const uint32_t tid = threadIdx.x;
@@ -1358,9 +1360,11 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         for (uint32_t w = 0; w < W; w++) np += __popc(presab[w]);
         sh_npres = np;
     }
-    if (bitmaps && !wide) {
+    if (wide) {
+        for (uint32_t w = tid; w <= MAX_CHUNKS; w += ROWS_THREADS) wstart[w] = 0;
+    } else if (bitmaps) {
         for (uint32_t i = tid; i < DEDUP_MROWS + 2 * DENSE_WORDS; i += ROWS_THREADS) rsh[i] = 0;
-    } else if (!wide) {
+    } else {
         for (uint32_t i = tid; i < SORT_MAX; i += ROWS_THREADS) pairs[i] = EMPTY64;
     }
     __syncthreads();
@@ -1441,18 +1445,52 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         // words; its presence row is gathered through the segment list: sample s carries the k-mer iff one of its
         // segments is a copy of a distinct sequence of the mask.  Distinct masks are evaluated once (table keyed by a
         // 50-bit hash of the words, verified word for word against the slot that opened the entry).
+#if PF_ROWS_EXP == 5
+        if (tid == 0) { p.item_unique[item] = 0; p.item_kept[item] = 0; }
+        return;
+#endif
         const uint32_t s0 = p.cluster_seg_off[c], s1 = p.cluster_seg_off[c + 1], nsegs = s1 - s0;
         const uint32_t D = p.v_nstr[c], nmw = (D + 31) >> 5;
-        for (uint32_t s = tid; s < nsegs; s += ROWS_THREADS)
-            segd[s] = (uint16_t)((p.seg_distinct[s0 + s] << 5) | (p.seg_sample[s0 + s] & 31u));
-        for (uint32_t w = tid; w <= nchunks; w += ROWS_THREADS)
-            wstart[w] = seg_lower_bound(p.seg_sample, s0, s1, w << 5) - s0;
+        // (the segments are sorted by sample: the first segment of a 32-sample word is the count of those before it)
+        for (uint32_t s = tid; s < nsegs; s += ROWS_THREADS) {
+            const uint32_t smp = p.seg_sample[s0 + s];
+            segd[s] = (uint16_t)((p.seg_distinct[s0 + s] << 5) | (smp & 31u));
+            atomicAdd(&wstart[(smp >> 5) + 1], 1u);
+        }
         for (uint32_t t = tid; t < AT_SLOTS; t += ROWS_THREADS) at_key[t] = 0;
         if (tid == 0) at_count = 0;
         __syncthreads();
+        if (tid < 64) {
+            constexpr uint32_t PL = (MAX_CHUNKS + 1 + 63) / 64;          // entries per lane
+            uint32_t v[PL], sum = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < PL; j++) {
+                const uint32_t w = tid * PL + j;
+                v[j] = w <= MAX_CHUNKS ? wstart[w] : 0;
+                sum += v[j];
+            }
+            uint32_t x = sum;
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = __shfl_up(x, d);
+                if ((int)tid >= d) x += y;
+            }
+            uint32_t run = x - sum;
+#pragma unroll
+            for (uint32_t j = 0; j < PL; j++) {
+                const uint32_t w = tid * PL + j;
+                run += v[j];
+                if (w <= MAX_CHUNKS) wstart[w] = run;
+            }
+        }
+        __syncthreads();
+        const uint32_t cm0 = cmask[0];                    // nmw <= 32: the flushed-chunk flags of the mask words
         auto mask_word = [&](uint32_t j, uint32_t i) -> uint32_t {
-            return ((cmask[j >> 5] >> (j & 31)) & 1) ? cb[(size_t)j * NS + i] : 0u;
+            return ((cm0 >> j) & 1) ? cb[(size_t)j * NS + i] : 0u;
         };
+#if PF_ROWS_EXP == 6
+        if (tid == 0) { p.item_unique[item] = 0; p.item_kept[item] = 0; }
+        return;
+#endif
         for (uint32_t i = tid; i < ns; i += ROWS_THREADS) {
             if (ordp[i] == NO_ORD) { slot_tag[i] = 0; continue; }
             uint64_t h = 0x9E3779B97F4A7C15ull;
@@ -1470,9 +1508,11 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
                 }
                 if ((cur >> 14) == h50) {
                     const uint32_t rep = (uint32_t)cur & 0x3FFFu;     // the claim is one word: nothing to wait for
-                    bool same = true;
-                    for (uint32_t j = 0; j < nmw && same; j++) same = mask_word(j, i) == mask_word(j, rep);
-                    if (same) { tag = (uint16_t)a; break; }
+                    // every word, no early way out: the loads go out together (a mask that gets this far is almost
+                    // always the same one, and a chain of dependent round trips was most of this loop's time)
+                    uint32_t diff = 0;
+                    for (uint32_t j = 0; j < nmw; j++) diff |= mask_word(j, i) ^ mask_word(j, rep);
+                    if (!diff) { tag = (uint16_t)a; break; }
                 }
                 a = (a + 1) & (AT_SLOTS - 1);
             }
@@ -1484,33 +1524,71 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         return;
 #endif
         // one half-wave per mask: lane j gathers row word 32 r + j in round r, the 32 words of a round then go through
-        // the row hash in order (eight blocks), every lane running it on the shuffled words
-        const uint32_t hw = tid >> 5, hl = tid & 31u, hbase = (tid & 63u) & 32u;
-        auto eval_slot = [&](uint32_t rep, uint4& hout) -> bool {
-            if (hl < nmw) mstage[hw][hl] = mask_word(hl, rep);
+        // the row hash in order (eight blocks), every lane running it on the words read back from LDS (one broadcast
+        // 128-bit read per block).  The segments a lane looks at in round 0 are the same for every mask: they are
+        // held in registers (two to a register, the unused places point at a distinct index whose mask word is the
+        // zero word 32), so that a mask costs WIDE_SEGREG independent LDS reads per lane and no dependent pair.
+        const uint32_t hw = tid >> 5, hl = tid & 31u;
+        constexpr uint32_t WIDE_SEGREG = 32;
+        uint32_t sg[WIDE_SEGREG / 2];
+        uint32_t my_q0 = 0, my_q1 = 0;
+        if (hl < nchunks) { my_q0 = wstart[hl]; my_q1 = wstart[hl + 1]; }
+#pragma unroll
+        for (uint32_t j = 0; j < WIDE_SEGREG / 2; j++) {
+            const uint32_t q = my_q0 + 2 * j;
+            const uint32_t e0 = q < my_q1 ? segd[q] : 0x8000u, e1 = q + 1 < my_q1 ? segd[q + 1] : 0x8000u;
+            sg[j] = e0 | (e1 << 16);
+        }
+        uint32_t sg_used = min(my_q1 - my_q0, WIDE_SEGREG);          // the most any lane of the wave holds
+        for (int dd = 1; dd < 64; dd <<= 1) sg_used = max(sg_used, (uint32_t)__shfl_xor(sg_used, dd));
+        if (hl == 0) mstage[hw][32] = 0;
+        auto eval_slot = [&](uint32_t my_mask_word, uint4& hout) -> bool {     // lane hl < nmw brings word hl of the mask
+            if (hl < nmw) mstage[hw][hl] = my_mask_word;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             H128 st;
             st.h1 = 0x9747b28cu ^ nstr; st.h2 = 0x1b873593u; st.h3 = 0xe6546b64u; st.h4 = 0x85ebca6bu;
             if (p.multiple_files) { st.h2 ^= (uint32_t)ordinal; st.h3 ^= (uint32_t)(ordinal >> 32); }
             uint32_t cnt = 0, ne = 0;
+            const uint32_t* ms = mstage[hw];
             for (uint32_t w0 = 0; w0 < nchunks; w0 += 32) {
                 const uint32_t w = w0 + hl;
                 uint32_t word = 0;
-                if (w < nchunks) {
+                if (w0 == 0) {
+#pragma unroll
+                    for (uint32_t j = 0; j < WIDE_SEGREG / 2; j++) {
+                        if (2 * j >= sg_used) break;                          // wave-uniform
+                        // (opaque copy: decoded here, every time -- the compiler would otherwise keep three decoded
+                        // values per segment alive across the loop over the masks, 96 registers and a spill)
+                        uint32_t pr = sg[j];
+                        asm volatile("" : "+v"(pr));
+                        const uint32_t e0 = pr & 0xFFFFu, e1 = pr >> 16;
+                        word |= ((ms[e0 >> 10] >> ((e0 >> 5) & 31u)) & 1u) << (e0 & 31u);
+                        word |= ((ms[e1 >> 10] >> ((e1 >> 5) & 31u)) & 1u) << (e1 & 31u);
+                    }
+                    for (uint32_t q = my_q0 + WIDE_SEGREG; q < my_q1; q++) {   // a word with more segments than that
+                        const uint32_t e = segd[q], d = e >> 5;
+                        word |= ((ms[d >> 5] >> (d & 31u)) & 1u) << (e & 31u);
+                    }
+                } else if (w < nchunks) {
                     for (uint32_t q = wstart[w], qe = wstart[w + 1]; q < qe; q++) {
                         const uint32_t e = segd[q], d = e >> 5;
-                        word |= ((mstage[hw][d >> 5] >> (d & 31u)) & 1u) << (e & 31u);
+                        word |= ((ms[d >> 5] >> (d & 31u)) & 1u) << (e & 31u);
                     }
+                }
+                if (w < nchunks) {
                     cnt += __popc(word);
                     ne |= word != presab[w] ? 1u : 0u;
                 }
+                rowst[hw][hl] = word;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
                 const uint32_t nb = min(8u, (nchunks - w0 + 3) >> 2);
                 for (uint32_t b = 0; b < nb; b++) {
-                    const uint32_t b0 = __shfl(word, hbase + 4 * b), b1 = __shfl(word, hbase + 4 * b + 1);
-                    const uint32_t b2 = __shfl(word, hbase + 4 * b + 2), b3 = __shfl(word, hbase + 4 * b + 3);
-                    mm3_block(st, b0, b1, b2, b3);
+                    const uint4 v = *reinterpret_cast<const uint4*>(&rowst[hw][4 * b]);
+                    mm3_block(st, v.x, v.y, v.z, v.w);
                 }
+                __builtin_amdgcn_wave_barrier();                    // rowst[hw] is rewritten by the next round
             }
             if (p.consider_missing) {
                 for (uint32_t ch = 0; ch < nchunks; ch += 4) {
@@ -1528,12 +1606,21 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
             __builtin_amdgcn_wave_barrier();                    // mstage[hw] is rewritten by the next call
             return keep;
         };
-        for (uint32_t t = hw; t < AT_SLOTS; t += ROWS_THREADS / 32) {
-            const uint64_t key = at_key[t];
-            if (!key) continue;
-            uint4 h;
-            const bool keep = eval_slot((uint32_t)key & 0x3FFFu, h);
-            if (hl == 0) { at_hash[t] = h; at_keep[t] = keep ? 1u : 0u; }
+        {   // the words of the next mask are on their way from global memory while this one is evaluated
+            uint32_t t = hw;
+            uint64_t key = at_key[t];
+            uint32_t word = key && hl < nmw ? mask_word(hl, (uint32_t)key & 0x3FFFu) : 0u;
+            while (t < AT_SLOTS) {
+                const uint32_t tn = t + ROWS_THREADS / 32;
+                const uint64_t nkey = tn < AT_SLOTS ? at_key[tn] : 0ull;
+                const uint32_t nword = nkey && hl < nmw ? mask_word(hl, (uint32_t)nkey & 0x3FFFu) : 0u;
+                if (key) {
+                    uint4 h;
+                    const bool keep = eval_slot(word, h);
+                    if (hl == 0) { at_hash[t] = h; at_keep[t] = keep ? 1u : 0u; }
+                }
+                t = tn; key = nkey; word = nword;
+            }
         }
 #if PF_ROWS_EXP == 2
         __syncthreads();
@@ -1545,7 +1632,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         for (uint32_t i = hw; i < ns; i += ROWS_THREADS / 32) {
             if (slot_tag[i] != WIDE_UNTABLED) continue;
             uint4 h;
-            const bool keep = eval_slot(i, h);
+            const bool keep = eval_slot(hl < nmw ? mask_word(hl, i) : 0u, h);
             if (hl == 0) { p.slot_hash[(size_t)slice * NS + i] = h; slot_tag[i] = keep ? WIDE_UNTABLED_KEEP : WIDE_UNTABLED_DROP; }
         }
         __syncthreads();
@@ -1701,6 +1788,58 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         kp[n] = total;
         p.item_unique[item] = n;
         p.item_kept[item] = total;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bitmap_merge_kernel: one ordinal bitmap per cluster out of its items'
+// ---------------------------------------------------------------------------------------------
+// A cluster of several items (key partitions, slow-path rows) whose ranks come from ordinal bitmaps: every item marked
+// the ordinals of ITS k-mers; a k-mer's rank in the cluster counts the ordinals below its own in all of them.  The items'
+// bitmaps are disjoint, so their OR with one prefix count per word answers that with one look instead of one per item
+// (emit_kernel asked every sibling, four loads each, for every kept k-mer).  The result replaces the first item's arrays.
+struct BitmapMergeParams {
+    const uint32_t* sub_cluster; const uint32_t* cluster_item0; const uint32_t* cluster_nitems;   // as BaseParams
+    const uint32_t* item_scratch; const uint32_t* cluster_overflow; const uint32_t* v_mode; const uint32_t* v_dense;
+    const uint32_t* item_fused;        // [item] nonzero: finished by finish_kernel, which keeps its bitmaps in LDS
+    uint32_t* bm_occ; uint32_t* bm_keep; uint32_t* pre_occ; uint32_t* pre_keep;                   // [slice][DENSE_WORDS]
+};
+__global__ __launch_bounds__(256) void bitmap_merge_kernel(BitmapMergeParams p) {
+    __shared__ uint32_t wt_o[5], wt_k[5];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t c = p.sub_cluster[blockIdx.x];
+    const uint32_t i0 = p.cluster_item0[blockIdx.x], ni = p.cluster_nitems[blockIdx.x];
+    if (ni < 2 || p.item_fused[i0] || p.cluster_overflow[c] || !ranks_by_bitmap(p.v_mode[c] & 3u, p.v_dense[c])) return;
+    const uint32_t dense_words = (p.v_dense[c] + 31) >> 5;
+    const size_t g0 = (size_t)p.item_scratch[i0] * DENSE_WORDS;
+    uint32_t run_o = 0, run_k = 0;                       // ordinals / kept ordinals in the words before this round's
+    for (uint32_t w0 = 0; w0 < dense_words; w0 += 256) {
+        const uint32_t w = w0 + tid;
+        uint32_t o = 0, k = 0;
+        if (w < dense_words)
+            for (uint32_t q = 0; q < ni; q++) {
+                const size_t g = (size_t)p.item_scratch[i0 + q] * DENSE_WORDS + w;
+                o |= p.bm_occ[g]; k |= p.bm_keep[g];
+            }
+        uint32_t xo = __popc(o), xk = __popc(k);
+        const uint32_t so = xo, sk = xk;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t yo = __shfl_up(xo, d), yk = __shfl_up(xk, d);
+            if ((int)lane >= d) { xo += yo; xk += yk; }
+        }
+        if (lane == 63) { wt_o[wave] = xo; wt_k[wave] = xk; }
+        __syncthreads();
+        uint32_t bo = run_o, bk = run_k, to = 0, tk = 0;
+        for (uint32_t v = 0; v < 4; v++) {
+            if (v < wave) { bo += wt_o[v]; bk += wt_k[v]; }
+            to += wt_o[v]; tk += wt_k[v];
+        }
+        if (w < dense_words) {
+            p.bm_occ[g0 + w] = o; p.bm_keep[g0 + w] = k;
+            p.pre_occ[g0 + w] = bo + xo - so; p.pre_keep[g0 + w] = bk + xk - sk;
+        }
+        run_o += to; run_k += tk;
+        __syncthreads();
     }
 }
 
@@ -1902,8 +2041,16 @@ __device__ __forceinline__ uint32_t pair_lower_bound(const uint64_t* sp, uint32_
 }
 
 constexpr uint32_t EMIT_THREADS = 1024;
-constexpr uint32_t LT_SLOTS = 4096;      // per-item pattern table in LDS
-constexpr uint32_t LT_LIMIT = 3072;
+#ifndef PF_LT_SLOTS
+#define PF_LT_SLOTS 1024
+#endif
+// Per-item pattern table in LDS.  1024 slots = 28 KiB: two 1024-thread workgroups per CU instead of the one that 4096
+// slots (114 KiB) allowed -- the kernel is a chain of dependent global loads per k-mer, and twice the waves hide twice
+// the latency (2 000 clusters of ~140 related alleles: emit 3.33 -> 2.12 ms at 2048 slots, 1.68 at 1024, where the three
+// passes over the table shrink too; 370 alleles: 11.4 -> 7.2 ms; tools/lt_exp.sh).  An item with more than LT_LIMIT
+// distinct patterns sends the rest straight to the run-global table.
+constexpr uint32_t LT_SLOTS = PF_LT_SLOTS;
+constexpr uint32_t LT_LIMIT = LT_SLOTS / 4 * 3;
 
 __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
     // The item's patterns are first deduplicated in LDS (identity: the 128-bit row hash) so that the run-global
@@ -1950,7 +2097,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
     const uint32_t ns = p.item_nslots[item];
     const uint32_t dense_words = (p.v_dense[c] + 31) >> 5;
     const uint32_t* ordp = p.tab_ord + (size_t)slice * NS;
-    const size_t gb = (size_t)slice * DENSE_WORDS;
+    const size_t gb0 = (size_t)p.item_scratch[sib0] * DENSE_WORDS;
     const uint64_t* sp = p.sorted_pair + (size_t)slice * NS;
     const uint32_t* kp = p.kept_prefix + (size_t)slice * (NS + 1);
     uint32_t* sout = p.slot_out + (size_t)slice * NS;    // per entry (slot / sorted position): index of its k-mer in
@@ -1994,13 +2141,13 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
                 slot = i;
                 if (o != NO_ORD && (o >> 5) < dense_words) {
                     const uint32_t w = o >> 5, below = (1u << (o & 31)) - 1;
-                    if ((p.bm_keep[gb + w] >> (o & 31)) & 1) {
-                        uint32_t rank = 0, kept_before = 0;
-                        for (uint32_t q = 0; q < nsib; q++) {
-                            const size_t g2 = (size_t)p.item_scratch[sib0 + q] * DENSE_WORDS + w;
-                            rank += p.pre_occ[g2] + __popc(p.bm_occ[g2] & below);
-                            kept_before += p.pre_keep[g2] + __popc(p.bm_keep[g2] & below);
-                        }
+                    // the cluster's bitmaps: this item's own, or (several items) their union, which
+                    // bitmap_merge_kernel left in the first item's place
+                    const size_t g2 = gb0 + w;
+                    const uint32_t kw = p.bm_keep[g2];
+                    if ((kw >> (o & 31)) & 1) {
+                        const uint32_t rank = p.pre_occ[g2] + __popc(p.bm_occ[g2] & below);
+                        const uint32_t kept_before = p.pre_keep[g2] + __popc(kw & below);
                         res = kept_before;
                         fs = (ordinal << 32) | (uint64_t)(rank + 1);
                     }
