@@ -1235,7 +1235,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             pr.pat_n = c->pat_n.as<uint32_t>();
             pr.out_base = ar->base; pr.out_cap = ar->cap; pr.pool = c->pt.pool;
             pr.work = em.work; pr.W = W; pr.NS = NS; pr.consider_missing = c->o.consider_missing;
-            hipLaunchKernelGGL(pf::pattern_rows_kernel, dim3(n_rows), dim3(256), 0, c->stream, pr);
+            hipLaunchKernelGGL(pf::pattern_rows_kernel, dim3(n_rows), dim3(pf::PR_THREADS), 0, c->stream, pr);
             HIPCHK(hipGetLastError());
             PFCHK(mark_end(c));
         }

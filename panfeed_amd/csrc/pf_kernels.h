@@ -2863,8 +2863,16 @@ struct PatRowsParams {
     uint32_t consider_missing;
 };
 constexpr uint32_t PR_LIST = 2048;   // winners collected per round
+#ifndef PF_PR_THREADS
+#define PF_PR_THREADS 512
+#endif
+// 512 threads: three workgroups = 24 waves per CU (the 50 KiB of LDS allow three; with 256 threads that was 12 waves, with
+// 1024 two workgroups = 32 waves but longer barriers).  Phase 1 is three dependent global loads per slot and nothing else:
+// the waves in flight are all that hides them.  2 000 clusters of ~140 related alleles: 2.05 ms at 256, 1.45 at 512,
+// 1.89 at 1024 (tools/pr_exp.sh).
+constexpr uint32_t PR_THREADS = PF_PR_THREADS;
 
-__global__ __launch_bounds__(256) void pattern_rows_kernel(PatRowsParams p) {
+__global__ __launch_bounds__(PR_THREADS) void pattern_rows_kernel(PatRowsParams p) {
     // phase 1: every thread looks for k-mers whose first_seen won their pattern and appends (slot, pid) to an
     // LDS list; phase 2: one wave per list entry builds the row with its lanes spread over the words.
     __shared__ uint32_t l_slot[PR_LIST];
@@ -2874,7 +2882,7 @@ __global__ __launch_bounds__(256) void pattern_rows_kernel(PatRowsParams p) {
     // the mask a wave is expanding
     __shared__ uint16_t segd[DEDUP_MAX_SEGS];
     __shared__ uint32_t wstart[MAX_CHUNKS + 1];
-    __shared__ uint32_t mstage[4][32];
+    __shared__ uint32_t mstage[PR_THREADS / 64][32];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const uint32_t item = p.work[blockIdx.x];
@@ -2937,7 +2945,7 @@ __global__ __launch_bounds__(256) void pattern_rows_kernel(PatRowsParams p) {
         if (tid == 0) l_count = 0;
         __syncthreads();
         // PR_LIST / stride rounds fit the list even if every thread appends in every round
-        for (uint32_t r8 = 0; r8 < PR_LIST / 256 && round < rounds_total; r8++, round++) {
+        for (uint32_t r8 = 0; r8 < PR_LIST / PR_THREADS && round < rounds_total; r8++, round++) {
             const uint32_t i = round * stride + tid;
             uint32_t slot = 0xFFFFFFFFu, kept_before = 0;
             if (i < total) {
