@@ -22,7 +22,8 @@ for case in range(n_cases):
     gen = dict(flank=int(rng.choice([0, 0, 10, 60])), mean_len=int(rng.choice([60, 150, 400, 1500])), min_len=int(rng.choice([5, 40])),
                max_len=int(rng.choice([300, 2500])), n_rate=float(rng.choice([0.0, 0.02, 0.2])),
                paralog_rate=float(rng.choice([0.0, 0.05, 0.3])), sub_rate=float(rng.choice([0.0, 0.01, 0.1])),
-               mean_alleles=float(rng.choice([1.0, 7.0, 40.0])))
+               mean_alleles=float(rng.choice([1.0, 7.0, 40.0, 120.0] if big else [1.0, 7.0, 40.0])),
+               allele_decay=float(rng.choice([0.5, 1.0])), allele_model=str(rng.choice(["star", "tree"])))
     if gen["min_len"] > gen["max_len"]:
         gen["min_len"] = gen["max_len"]
     shuffle = int(rng.integers(0, 99)) if rng.random() < 0.5 else None
