@@ -119,10 +119,10 @@ struct pf_ctx {
     // host scratch of pf_submit, kept between calls (capacity persists: no allocation / page faults in steady state)
     std::vector<Item> hs_items;
     std::vector<uint8_t> hs_fused;
-    std::vector<uint32_t> hs_v[10], hs_w[6], hs_sub[3];
+    std::vector<uint32_t> hs_v[10], hs_w[7], hs_sub[3];
     int n_cu = 256;
     DevBuf it_cluster, it_part, it_nparts, it_nslots, it_slice, it_sib0, it_nsib, it_extra_first, it_count,
-        it_unique, it_kept, work_scan, work_extra, work_fin, work_fin2, work_fin3, work_rows, sub_cluster, sub_item0, sub_nitems;
+        it_unique, it_kept, work_scan, work_extra, work_fin, work_fin2, work_fin3, work_fin5, work_rows, sub_cluster, sub_item0, sub_nitems;
     std::vector<Arena*> arenas;
     uint32_t n_passes = 0;                 // arenas the last pf_submit used (arenas[] itself only ever grows)
     DevBuf rp_order, rp_rlen, rp_rowoff;   // pf_render_pattern_rows: the id list, row lengths, row offsets
@@ -415,7 +415,7 @@ void pf_destroy(pf_ctx* c) {
                       &c->cmask_lo, &c->cmask_hi, &c->it_compact, &c->cl_overflow, &c->cl_kmer_off, &c->cl_kmer_cnt, &c->cl_unique, &c->cl_pattern,
                       &c->cl_first, &c->cursor, &c->strand_bits, &c->it_cluster, &c->it_part, &c->it_nparts,
                       &c->it_nslots, &c->it_slice, &c->it_sib0, &c->it_nsib, &c->it_extra_first, &c->it_count,
-                      &c->it_unique, &c->it_kept, &c->work_scan, &c->work_extra, &c->work_fin, &c->work_fin2, &c->work_fin3, &c->work_rows, &c->sub_cluster, &c->sub_item0,
+                      &c->it_unique, &c->it_kept, &c->work_scan, &c->work_extra, &c->work_fin, &c->work_fin2, &c->work_fin3, &c->work_fin5, &c->work_rows, &c->sub_cluster, &c->sub_item0,
                       &c->sub_nitems};
     for (DevBuf* b : bufs) b->release();
     for (Arena* a : c->arenas) { a->key.release(); a->pid.release(); a->first.release(); delete a; }
@@ -926,13 +926,19 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             // a deduplicated cluster that is one work item (or a few key partitions) is finished by one fused kernel
             // (rows + emit in LDS); its slow-path rows (a few k-mers around an 'N') are folded in by that kernel
             const uint32_t mwords = h_vnstr[ci] * ((W + 3) & ~3u);
-            uint8_t fused = 0;   // 1/2: single item, small/large class; 3: first of several partitions; 4: the others
+            uint8_t fused = 0;   // 1/2: single item, small/large class; 3: first of several partitions; 4: the others;
+                                 // 5: single item, huge class
             if (h_mode[ci] == 1 && nex <= pf::FUSED_MAX_EXTRA && NS <= 9600) {
                 const bool fits_large = h_dense[ci] < pf::FinLarge::DW * 32 - 1 && mwords <= pf::FinLarge::MR;
+                const bool fits_huge = h_dense[ci] < pf::FinHuge::DW * 32 - 1 && mwords <= pf::FinHuge::MR;
                 if (np == 1) {
                     if (h_dense[ci] < pf::FinSmall::DW * 32 - 1 && mwords <= pf::FinSmall::MR) fused = 1;
                     else if (fits_large) fused = 2;
+                    else if (fits_huge) fused = 5;
                 } else if (fits_large) fused = 3;
+                // (several partitions of a cluster that large stay on the general path, one workgroup each: the one
+                // workgroup of the fused kernel took 15.9 ms where rows + emit + pattern rows take 4.5, 2 000 clusters
+                // of 60 SURVEY alleles)
             }
             const uint32_t nex_items = fused ? 0 : (nex + lim_full - 1) / lim_full;
             const uint32_t nit = np + nex_items;
@@ -986,7 +992,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         std::vector<uint32_t>&v_cluster = c->hs_v[0], &v_part = c->hs_v[1], &v_nparts = c->hs_v[2], &v_nslots = c->hs_v[3],
             &v_slice = c->hs_v[4], &v_sib0 = c->hs_v[5], &v_nsib = c->hs_v[6], &v_exfirst = c->hs_v[7], &v_isex = c->hs_v[8],
             &v_compact = c->hs_v[9], &w_scan = c->hs_w[0], &w_extra = c->hs_w[1], &w_fin = c->hs_w[2], &w_fin2 = c->hs_w[3],
-            &w_fin3 = c->hs_w[4], &w_rows = c->hs_w[5];
+            &w_fin3 = c->hs_w[4], &w_rows = c->hs_w[5], &w_fin5 = c->hs_w[6];
         for (auto& v : c->hs_v) v.resize(NI);
         for (auto& v : c->hs_w) { v.clear(); v.reserve(NI); }
         for (size_t i = 0; i < NI; i++) {
@@ -1000,7 +1006,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         PFCHK(c->it_kept.ensure(std::max<size_t>(NI, 1) * 4));
         // work lists per sub-batch, concatenated; scan items heaviest first (the grid drains evenly)
         std::vector<uint32_t> scan_off(subs.size() + 1, 0), extra_off(subs.size() + 1, 0), fin_off(subs.size() + 1, 0),
-            fin2_off(subs.size() + 1, 0), fin3_off(subs.size() + 1, 0), rows_off(subs.size() + 1, 0);
+            fin2_off(subs.size() + 1, 0), fin3_off(subs.size() + 1, 0), fin5_off(subs.size() + 1, 0), rows_off(subs.size() + 1, 0);
         // heaviest items first inside each launch (the grid then drains evenly): a coarse O(n) order by
         // log2(scan instances) is enough
         auto wclass = [&](uint32_t it) -> int {
@@ -1027,6 +1033,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
                 if (item_fused[i] == 1) tmp_fin.push_back(i);
                 else if (item_fused[i] == 2) tmp_fin2.push_back(i);
                 else if (item_fused[i] == 3) w_fin3.push_back(i);
+                else if (item_fused[i] == 5) w_fin5.push_back(i);
                 else if (item_fused[i] == 0) w_rows.push_back(i);
             }
             append_by_weight(tmp_scan, w_scan);
@@ -1037,6 +1044,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             fin_off[s + 1] = (uint32_t)w_fin.size();
             fin2_off[s + 1] = (uint32_t)w_fin2.size();
             fin3_off[s + 1] = (uint32_t)w_fin3.size();
+            fin5_off[s + 1] = (uint32_t)w_fin5.size();
             rows_off[s + 1] = (uint32_t)w_rows.size();
         }
         {
@@ -1046,7 +1054,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
                 {&c->it_extra_first, &v_exfirst}, {&c->it_is_extra, &v_isex}, {&c->it_compact, &v_compact},
                 {&c->sub_cluster, &sub_cluster},
                 {&c->sub_item0, &sub_item0}, {&c->sub_nitems, &sub_nitems}, {&c->work_scan, &w_scan},
-                {&c->work_extra, &w_extra}, {&c->work_fin, &w_fin}, {&c->work_fin2, &w_fin2}, {&c->work_fin3, &w_fin3}, {&c->work_rows, &w_rows}};
+                {&c->work_extra, &w_extra}, {&c->work_fin, &w_fin}, {&c->work_fin2, &w_fin2}, {&c->work_fin3, &w_fin3}, {&c->work_fin5, &w_fin5}, {&c->work_rows, &w_rows}};
             PFCHK(staged_upload(c, arrs));
         }
         // the cursor's next free index restarts at this arena's base
@@ -1095,8 +1103,9 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
                 c->timing.scan_launches++;
             }
             const uint32_t n_fin = fin_off[s + 1] - fin_off[s], n_fin2 = fin2_off[s + 1] - fin2_off[s],
-                           n_fin3 = fin3_off[s + 1] - fin3_off[s], n_rows = rows_off[s + 1] - rows_off[s];
-            if (n_fin || n_fin2 || n_fin3) {
+                           n_fin3 = fin3_off[s + 1] - fin3_off[s], n_fin5 = fin5_off[s + 1] - fin5_off[s],
+                           n_rows = rows_off[s + 1] - rows_off[s];
+            if (n_fin || n_fin2 || n_fin3 || n_fin5) {
                 pf::FinishParams fp{};
                 fp.work = c->work_fin.as<uint32_t>() + fin_off[s];
                 fp.item_cluster = c->it_cluster.as<uint32_t>(); fp.item_nslots = c->it_nslots.as<uint32_t>();
@@ -1123,7 +1132,12 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
                 fp.out_base = ar->base; fp.out_cap = ar->cap; fp.W = W; fp.NS = NS; fp.KW = KW;
                 fp.consider_missing = c->o.consider_missing; fp.patfilt = c->o.patfilt; fp.multiple_files = c->o.multiple_files;
                 PFCHK(mark_begin(c, 6));
-                if (n_fin3) {   // the heaviest clusters first
+                if (n_fin5) {   // the heaviest clusters first
+                    fp.work = c->work_fin5.as<uint32_t>() + fin5_off[s];
+                    hipLaunchKernelGGL((pf::finish_kernel<pf::FinHuge, true>), dim3(n_fin5), dim3(pf::FinHuge::THREADS), 0, c->stream, fp);
+                    HIPCHK(hipGetLastError());
+                }
+                if (n_fin3) {
                     fp.work = c->work_fin3.as<uint32_t>() + fin3_off[s];
                     hipLaunchKernelGGL((pf::finish_kernel<pf::FinLarge, true>), dim3(n_fin3), dim3(pf::FinLarge::THREADS), 0, c->stream, fp);
                     HIPCHK(hipGetLastError());

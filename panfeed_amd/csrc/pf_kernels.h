@@ -2239,7 +2239,11 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
 // what hides the latency of the global atomics and dependent loads this kernel is made of.
 struct FinSmall { static constexpr uint32_t THREADS = 512, DW = 1024, MR = 1024, AT = 256, ATL = 192; typedef uint8_t tag_t; };
 struct FinLarge { static constexpr uint32_t THREADS = 1024, DW = 2048, MR = 2048, AT = 512, ATL = 384; typedef uint16_t tag_t; };
-constexpr uint32_t FUSED_DENSE_WORDS = FinLarge::DW;   // < 65536 dense ordinals (prefix counts are 16-bit)
+// A third class for clusters whose distinct sequences carry up to 131 071 windows (60 sequences of 1 100 bases + flanks, or
+// 30 of 2 500): always in the MULTI form (no per-slot tags), 75 KiB, two workgroups per CU.  The 16-bit prefix counts are
+// kept: those of the upper half of the bitmap are relative to its first word (sh_half_*).
+struct FinHuge { static constexpr uint32_t THREADS = 1024, DW = 4096, MR = 2048, AT = 512, ATL = 384; typedef uint16_t tag_t; };
+constexpr uint32_t FUSED_DENSE_WORDS = FinHuge::DW;    // dense ordinals of a fused cluster / 32
 constexpr uint32_t FUSED_MROWS = FinLarge::MR;         // D * ceil4(W) words of M
 constexpr uint32_t FUSED_MAX_EXTRA = 1024;             // slow-path rows of a cluster the fused kernel takes along
 static_assert(nslots_max(1) <= 9600, "slot_at too small");
@@ -2287,7 +2291,9 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
     __shared__ tag_t slot_at[MULTI ? 1 : 9600];                  // per occupied slot: its mask's table position
     __shared__ uint32_t wave_tot[T / 64 + 1];
     __shared__ uint32_t sh_npres, at_count, wl_count;
+    __shared__ uint32_t sh_half_o, sh_half_k;                    // DW > 2048: the prefix counts at word 2048
     __shared__ uint64_t sh_base;
+    static_assert(DW <= 4096 && (DW <= 2048 || (DW / T) * (T / 2) == 2048), "prefix counts are 16-bit per half");
 
     const uint32_t tid = threadIdx.x;
     PF_PROF_BEGIN();
@@ -2621,6 +2627,11 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
         for (uint32_t j = 0; j < PW; j++) { so += __popc(occ[tid * PW + j]); sk += __popc(keepbm[tid * PW + j]); }
         uint32_t bo = block_exscan(so, wave_tot, &tot_o);
         uint32_t bk = block_exscan(sk, wave_tot, &tot_k);
+        if (DW > 2048) {
+            if (tid * PW == 2048) { sh_half_o = bo; sh_half_k = bk; }
+            __syncthreads();
+            if (tid * PW >= 2048) { bo -= sh_half_o; bk -= sh_half_k; }
+        }
 #pragma unroll
         for (uint32_t j = 0; j < PW; j++) {
             const uint32_t w = tid * PW + j;
@@ -2634,8 +2645,13 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
 #if PF_FIN_EXP == 5
     return;                                   // timing experiment: the kernel up to here
 #endif
-    auto rank_of = [&](uint32_t o) -> uint32_t { return pocc[o >> 5] + __popc(occ[o >> 5] & ((1u << (o & 31)) - 1)); };
-    auto kept_before = [&](uint32_t o) -> uint32_t { return pkeep[o >> 5] + __popc(keepbm[o >> 5] & ((1u << (o & 31)) - 1)); };
+    const uint32_t half_o = DW > 2048 ? sh_half_o : 0, half_k = DW > 2048 ? sh_half_k : 0;
+    auto rank_of = [&](uint32_t o) -> uint32_t {
+        return pocc[o >> 5] + __popc(occ[o >> 5] & ((1u << (o & 31)) - 1)) + (DW > 2048 && (o >> 5) >= 2048 ? half_o : 0u);
+    };
+    auto kept_before = [&](uint32_t o) -> uint32_t {
+        return pkeep[o >> 5] + __popc(keepbm[o >> 5] & ((1u << (o & 31)) - 1)) + (DW > 2048 && (o >> 5) >= 2048 ? half_k : 0u);
+    };
     // ---- run-global pattern table, bulk protocol.  Entry AT-1 of the mask table (never a hash position) stands
     // for the cluster's own row.  Step 1: every entry finds its pattern or claims a free slot (no waiting, no id);
     // the output range is reserved meanwhile.  Step 2: ONE atomicAdd on the global id counter for all claims of

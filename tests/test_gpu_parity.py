@@ -573,6 +573,11 @@ def _allele_cluster(rng, idx, names, D, L, sub=0.02, flank=0, paralogs=0, n_ever
     (65, 200, 260, 31, True, {"paralogs": 9, "n_every": 40}),       # + paralogs of other alleles, slow-path rows
     (200, 600, 300, 31, True, {"paralogs": 11}),
     (150, 500, 300, 31, True, {"paralogs": 7, "n_every": 25}),      # key partitions + slow-path rows: one merged bitmap
+    (60, 300, 1500, 31, True, {}),                                  # 88 000 windows over 60 sequences, several key
+                                                                    # partitions: the general path with bitmaps
+    (40, 300, 1800, 31, True, {"n_every": 30, "sub": 0.001}),       # 70 000+ windows, one partition: the fused kernel's
+                                                                    # third class, with slow-path rows
+    (25, 300, 1500, 21, False, {"sub": 0.001}),                     # the same class, both strands (twice the ordinals)
     (200, 600, 300, 51, False, {"flank": 30}),                      # two-word keys, both strands, key partitions
     (300, 1000, 150, 21, True, {"absent": 37}),                     # 32-word rows; some samples without the cluster
     (1024, 2100, 90, 15, True, {}),                                 # the largest wide cluster
@@ -580,7 +585,7 @@ def _allele_cluster(rng, idx, names, D, L, sub=0.02, flank=0, paralogs=0, n_ever
     (300, 700, 1000, 31, True, {}),                                 # 291 000 windows over the distinct sequences: more than
                                                                     # the ordinal bitmaps hold -> ranks by sorting (the
                                                                     # shorter wide cases above rank from bitmaps)
-], ids=["D64", "D65", "D65_paralogs_N", "D200", "D150_partitions_N", "D200_k51_noncanon", "D300_1000s", "D1024", "D1025", "D300_long_sorted"])
+], ids=["D64", "D65", "D65_paralogs_N", "D200", "D150_partitions_N", "D60_long", "D40_long_fused_N", "D25_long_noncanon", "D200_k51_noncanon", "D300_1000s", "D1024", "D1025", "D300_long_sorted"])
 @pytest.mark.parametrize("missing", [False, True], ids=["", "consider_missing"])
 def test_many_distinct_sequences_vs_oracle(D, S, L, k, canon, kw, missing):
     """clusters with more distinct sequences than the 64 an allele-mask pair of words holds: representatives are
@@ -616,7 +621,7 @@ def test_many_distinct_sequences_vs_oracle(D, S, L, k, canon, kw, missing):
     eng.close()
 
 
-@pytest.mark.parametrize("mean_alleles,S", [(40, 300), (250, 800)], ids=["D40", "D250"])
+@pytest.mark.parametrize("mean_alleles,S", [(40, 300), (70, 500), (250, 800)], ids=["D40", "D60_fused_third_class", "D250"])
 def test_alleles_descending_from_one_another_vs_oracle(mean_alleles, S):
     """many distinct sequences that share most of their k-mers (synth's "tree" alleles, the population-like case of
     bench.py's second allele sweep): long allele masks over few k-mers"""
