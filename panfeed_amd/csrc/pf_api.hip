@@ -95,6 +95,11 @@ struct pf_ctx {
     // pattern table + pool
     pf::PatternTable pt{};
     DevBuf pt_lo, pt_val, pt_first, pt_counters, pat_bits, pat_nan, pat_n, pat_md5;
+    // what this context has seen of its clusters of many distinct sequences: g = new k-mers per further sequence against
+    // L = windows of one sequence, as running sums for the line g = a + b L (related alleles: a few tens whatever L is;
+    // SURVEY 8d's: flanks + a share of L) -- see the key-partition estimate
+    double reg_n = 0, reg_x = 0, reg_y = 0, reg_xx = 0, reg_xy = 0, reg_yy = 0;
+    std::vector<uint32_t> hs_count;
     uint32_t n_patterns = 0;       // patterns allocated after the last submit
     uint32_t pid0 = 0;             // first pattern id of the last submit
     // scratch slices
@@ -887,7 +892,20 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
                 // hundreds): past 24 distinct sequences the cluster starts as ONE item instead, and if that overflows
                 // the scan reports how far it came and the retry gets the partitions it needs.  A failed first attempt
                 // costs 1/P of the P scans that follow; an over-partitioned cluster costs every surplus scan in full.
-                if (est > room) nparts[i] = D > 24.0 ? 1u : (uint32_t)std::min<double>(std::ceil(est / room), 64.0);
+                // Once the context has scanned enough such clusters it knows what a further sequence brings in THIS
+                // pangenome (the line through what it observed, plus one residual standard deviation) and the first
+                // attempt is sized by that.
+                if (D > 24.0 && c->reg_n >= 16) {
+                    const double n = c->reg_n, den = n * c->reg_xx - c->reg_x * c->reg_x;
+                    double a = c->reg_y / n, b = 0.0;
+                    if (den > 1e-6 * n * c->reg_xx) { b = (n * c->reg_xy - c->reg_x * c->reg_y) / den; a = (c->reg_y - b * c->reg_x) / n; }
+                    const double ss = std::max(0.0, c->reg_yy - a * c->reg_y - b * c->reg_xy);     // residual sum of squares
+                    const double g = std::max(0.0, a + b * L) + std::sqrt(ss / std::max(1.0, n - 2.0));
+                    const double est2 = L + g * (D - 1.0);
+                    if (est2 > room) nparts[i] = (uint32_t)std::min<double>(std::ceil(est2 / room), 4096.0);
+                } else if (est > room) {
+                    nparts[i] = D > 24.0 ? 1u : (uint32_t)std::min<double>(std::ceil(est / room), 64.0);
+                }
             }
         }
         return PF_OK;
@@ -1269,6 +1287,13 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         // ---- who overflowed?
         std::vector<uint32_t> ovf(C);
         uint64_t cur3[3];
+        // clusters of this pass the key-partition estimate can learn from: their items' key counts come along
+        bool learn = false;
+        for (uint32_t ci : todo) if (h_mode[ci] && h_vnstr[ci] > 24) { learn = true; break; }
+        if (learn) {
+            c->hs_count.resize(NI);
+            HIPCHK(hipMemcpyAsync(c->hs_count.data(), c->it_count.p, NI * 4, hipMemcpyDeviceToHost, c->stream));
+        }
         HIPCHK(hipMemcpyAsync(ovf.data(), c->cl_overflow.p, (size_t)C * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(cur3, c->cursor.p, 24, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -1287,6 +1312,19 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             deferred.clear();
             todo.resize(C);                        // every cluster has been through its first pass now
             std::iota(todo.begin(), todo.end(), 0u);
+        }
+        if (learn) {
+            for (size_t i = 0; i < NI; i++) {
+                const Item& it = items[i];
+                if (it.is_extra || it.part != 0) continue;
+                const uint32_t ci = it.cluster;
+                if (ovf[ci] || !h_mode[ci] || h_vnstr[ci] <= 24 || !vinst[ci]) continue;
+                uint64_t keys = 0;
+                for (uint32_t q = 0; q < it.nparts; q++) keys += c->hs_count[i + q];
+                const double D = (double)h_vnstr[ci], L = (double)(vinst[ci] * mult) / D;
+                const double g = std::max(0.0, ((double)keys - L) / (D - 1.0));
+                c->reg_n += 1; c->reg_x += L; c->reg_y += g; c->reg_xx += L * L; c->reg_xy += L * g; c->reg_yy += g * g;
+            }
         }
         std::vector<uint32_t> next;
         for (uint32_t ci : todo)

@@ -641,6 +641,26 @@ def test_alleles_descending_from_one_another_vs_oracle(mean_alleles, S):
     eng.close()
 
 
+def test_key_partitions_learned_from_earlier_batches():
+    """a context that has scanned 16 clusters of many related alleles sizes the next ones' key partitions by what those
+    brought (first attempts of several partitions, few failures); the files stay the oracle's"""
+    from panfeed_amd import synth
+    from panfeed_amd.engine import Engine
+    S = 400
+    cl = synth.generate(60, S, first=500, flank=100, mean_len=300, min_len=200, max_len=500, n_rate=0.0,
+                        mean_alleles=170, allele_decay=1.0, allele_model="tree")
+    recs = [c.record() for c in cl]
+    eng = Engine(klength=31, max_strains=(S + 31) // 32 * 32)
+    out1 = eng.run(recs[:44])
+    out2 = eng.run(recs[44:])
+    (ek, ekh, ehp), st = _oracle_texts(recs, klength=31)
+    assert out1.kmers_to_hashes + out2.kmers_to_hashes == ekh
+    assert out1.hashes_to_patterns + out2.hashes_to_patterns == ehp
+    assert out1.timing["n_retried"] >= 16           # the first batch had to find out
+    assert out2.timing["n_retried"] <= 3 and out2.timing["n_items"] >= 24     # the second knew
+    eng.close()
+
+
 def test_wide_dedup_with_5000_samples():
     """configs[4] shape: at 5 000 samples the sample-set matrix only fits 25 distinct sequences: clusters with more
     go through the wide class instead of scanning all 5 000 copies"""
