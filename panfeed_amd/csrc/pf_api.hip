@@ -702,19 +702,22 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         PFCHK(upload(c, c->b_extra_bits, b->extra_bits, (size_t)b->n_extra * W, &d.extra_bits));
         if (b->seg_strand_off) PFCHK(upload(c, c->b_seg_strand_off, b->seg_strand_off, NSEG, &d.seg_strand_off));
         if (b->n_extra) h_extra_cluster.assign(b->extra_cluster, b->extra_cluster + b->n_extra);
-    } else if (b->n_extra) {
-        h_extra_cluster.resize(b->n_extra);
-        HIPCHK(hipMemcpy(h_extra_cluster.data(), b->extra_cluster, (size_t)b->n_extra * 4, hipMemcpyDeviceToHost));
     }
-    for (uint32_t e = 0; e < b->n_extra; e++) {
-        if (h_extra_cluster[e] >= C || (e && h_extra_cluster[e] < h_extra_cluster[e - 1]))
-            return fail(PF_ERR_ARG, "extra_cluster must be non-decreasing and < n_clusters");
-    }
-    // extras per cluster (CSR)
+    // extras per cluster (CSR).  A batch that is in device memory already has its list checked and counted there
+    // (extra_csr_kernel); the counts come back with the first dedup results -- reading the list back and walking it here
+    // was 1 ms in front of the first kernel with SURVEY 8d's share of 'N's (1.5 M rows per 50 000 clusters).
+    const bool ex_on_device = b->on_device && b->n_extra;
+    if (ex_on_device && !C) return fail(PF_ERR_ARG, "extra_cluster must be non-decreasing and < n_clusters");
     std::vector<uint32_t> ex_first(C + 1, 0);
-    for (uint32_t e = 0; e < b->n_extra; e++) ex_first[h_extra_cluster[e] + 1]++;
-    for (uint32_t i = 0; i < C; i++) ex_first[i + 1] += ex_first[i];
-    PFCHK(upload_vec(c, c->extra_off, ex_first));
+    if (!ex_on_device) {
+        for (uint32_t e = 0; e < b->n_extra; e++) {
+            if (h_extra_cluster[e] >= C || (e && h_extra_cluster[e] < h_extra_cluster[e - 1]))
+                return fail(PF_ERR_ARG, "extra_cluster must be non-decreasing and < n_clusters");
+        }
+        for (uint32_t e = 0; e < b->n_extra; e++) ex_first[h_extra_cluster[e] + 1]++;
+        for (uint32_t i = 0; i < C; i++) ex_first[i + 1] += ex_first[i];
+        PFCHK(upload_vec(c, c->extra_off, ex_first));
+    }
 
     // ---- per batch outputs
     const size_t C1 = std::max(C, 1u), NSEG1 = std::max(NSEG, 1u), NEX1 = std::max(b->n_extra, 1u);
@@ -749,7 +752,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
     // second half's while the first half's scan runs -- otherwise the GPU idles for the ~1.2 ms that takes.
     const size_t C8 = ((size_t)C + 1) & ~(size_t)1;
     {
-        const size_t need = C8 * 36 + 64;
+        const size_t need = C8 * 36 + 64 + ((size_t)C + 2) * 4;
         if (need > c->pin_dedup_cap) {
             if (c->pin_dedup) (void)hipHostFree(c->pin_dedup);
             c->pin_dedup = nullptr; c->pin_dedup_cap = 0;
@@ -764,6 +767,16 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
     uint32_t* h_mode = reinterpret_cast<uint32_t*>(words + C8);
     uint32_t* h_dense = h_mode + C8;
     uint32_t* h_vnstr = h_dense + C8;
+    uint32_t* h_exfirst = h_vnstr + C8;         // [C + 1] + the "bad list" flag (device-side CSR only)
+    if (ex_on_device) {
+        PFCHK(c->extra_off.ensure(((size_t)C + 2) * 4));
+        uint32_t* exo = c->extra_off.as<uint32_t>();
+        HIPCHK(hipMemsetAsync(exo + C + 1, 0, 4, c->stream));
+        hipLaunchKernelGGL(pf::extra_csr_kernel, dim3(std::min<uint32_t>((std::max(C + 1, b->n_extra) + 255) / 256, 2048u)), dim3(256), 0,
+                           c->stream, b->extra_cluster, b->n_extra, C, exo, exo + C + 1);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(h_exfirst, exo, ((size_t)C + 2) * 4, hipMemcpyDeviceToHost, c->stream));
+    }
     // A large batch goes through in parts, all queued without a host sync in between: the host builds and launches a
     // part's work items while the GPU is on earlier parts (otherwise it idles for the ~1.2 ms that takes).  Two parts,
     // a quarter first: enough GPU work to hide building the rest.  (More, equal parts with the MD5 of part i on a second
@@ -921,6 +934,13 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             // this part's dedup results (queued with the others up front) have to be here; its clusters are the pass
             HIPCHK(hipEventSynchronize(c->ev_part[pass]));
             if (pass == 0) lap("first part's dedup results");
+            if (pass == 0 && ex_on_device) {
+                if (h_exfirst[C + 1]) {
+                    HIPCHK(hipStreamSynchronize(c->stream));
+                    return fail(PF_ERR_ARG, "extra_cluster must be non-decreasing and < n_clusters");
+                }
+                ex_first.assign(h_exfirst, h_exfirst + C + 1);
+            }
             PFCHK(prep_half((int)pass));
             const uint32_t c0 = pass ? part_end[pass - 1] : 0;
             todo.resize(part_end[pass] - c0);

@@ -1230,6 +1230,23 @@ void cluster_dedup_kernel(DedupParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// extra_csr_kernel: first slow-path row of every cluster, for a batch whose arrays are already in device memory
+// ---------------------------------------------------------------------------------------------
+// extra_cluster is non-decreasing: ex_first[c] = rows of clusters below c = lower bound of c (c = 0 .. C).  bad != 0 when
+// the list is out of order or names a cluster >= C (the host checks the list itself when it has it).
+__global__ __launch_bounds__(256) void extra_csr_kernel(const uint32_t* extra_cluster, uint32_t n_extra, uint32_t C,
+                                                        uint32_t* ex_first, uint32_t* bad) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    for (uint32_t c = t; c <= C; c += stride) {
+        uint32_t a = 0, b = n_extra;
+        while (a < b) { const uint32_t m = (a + b) >> 1; if (extra_cluster[m] < c) a = m + 1; else b = m; }
+        ex_first[c] = a;
+    }
+    for (uint32_t e = t; e < n_extra; e += stride)
+        if (extra_cluster[e] >= C || (e && extra_cluster[e] < extra_cluster[e - 1])) *bad = 1u;
+}
+
+// ---------------------------------------------------------------------------------------------
 // slow-path rows -> a prebuilt table in an item's scratch slice (same layout the scan kernel leaves)
 // ---------------------------------------------------------------------------------------------
 struct ExtraParams {
