@@ -906,14 +906,17 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
                 // the scan reports how far it came and the retry gets the partitions it needs.  A failed first attempt
                 // costs 1/P of the P scans that follow; an over-partitioned cluster costs every surplus scan in full.
                 // Once the context has scanned enough such clusters it knows what a further sequence brings in THIS
-                // pangenome (the line through what it observed, plus one residual standard deviation) and the first
+                // pangenome (the line through what it observed, plus a margin) and the first
                 // attempt is sized by that.
-                if (D > 24.0 && c->reg_n >= 16) {
+                if (D >= 2.0 && c->reg_n >= 16) {
                     const double n = c->reg_n, den = n * c->reg_xx - c->reg_x * c->reg_x;
                     double a = c->reg_y / n, b = 0.0;
                     if (den > 1e-6 * n * c->reg_xx) { b = (n * c->reg_xy - c->reg_x * c->reg_y) / den; a = (c->reg_y - b * c->reg_x) / n; }
                     const double ss = std::max(0.0, c->reg_yy - a * c->reg_y - b * c->reg_xy);     // residual sum of squares
-                    const double g = std::max(0.0, a + b * L) + std::sqrt(ss / std::max(1.0, n - 2.0));
+                    // (half a residual standard deviation on top: with `room` at 0.9 of the table's limit that left no
+                    // cluster of the headline workload, with or without 'N's, to overflow; 0 left 6, 1 to 3 standard
+                    // deviations cost 0.5 % to 5 % in surplus partitions -- profiles/r02/partition_margin_experiment.txt)
+                    const double g = std::max(0.0, a + b * L) + 0.5 * std::sqrt(ss / std::max(1.0, n - 2.0));
                     const double est2 = L + g * (D - 1.0);
                     if (est2 > room) nparts[i] = (uint32_t)std::min<double>(std::ceil(est2 / room), 4096.0);
                 } else if (est > room) {
@@ -1309,7 +1312,8 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         uint64_t cur3[3];
         // clusters of this pass the key-partition estimate can learn from: their items' key counts come along
         bool learn = false;
-        for (uint32_t ci : todo) if (h_mode[ci] && h_vnstr[ci] > 24) { learn = true; break; }
+        if (c->reg_n < 8192)         // (then the line is settled: no more read-backs)
+            for (uint32_t ci : todo) if (h_mode[ci] && h_vnstr[ci] >= 2) { learn = true; break; }
         if (learn) {
             c->hs_count.resize(NI);
             HIPCHK(hipMemcpyAsync(c->hs_count.data(), c->it_count.p, NI * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1338,7 +1342,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
                 const Item& it = items[i];
                 if (it.is_extra || it.part != 0) continue;
                 const uint32_t ci = it.cluster;
-                if (ovf[ci] || !h_mode[ci] || h_vnstr[ci] <= 24 || !vinst[ci]) continue;
+                if (ovf[ci] || !h_mode[ci] || h_vnstr[ci] < 2 || !vinst[ci]) continue;
                 uint64_t keys = 0;
                 for (uint32_t q = 0; q < it.nparts; q++) keys += c->hs_count[i + q];
                 const double D = (double)h_vnstr[ci], L = (double)(vinst[ci] * mult) / D;
