@@ -4,7 +4,7 @@ mkdir -p gpurun_out/ab
 for r in $(seq 1 ${3:-2}); do
   for v in "$1" "$2"; do
     cp "$v" panfeed_amd/libpanfeed_hip.so
-    timeout -k 10 200 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-every-copy-leg > gpurun_out/ab/out.json 2> gpurun_out/ab/err
+    timeout -k 10 200 python bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-every-copy-leg > gpurun_out/ab/out.json 2> gpurun_out/ab/err
     python - "$v" <<'PY'
 import json, sys
 d = json.loads(open("gpurun_out/ab/out.json").read().strip().splitlines()[-1])
