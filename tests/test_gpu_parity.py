@@ -641,6 +641,33 @@ def test_alleles_descending_from_one_another_vs_oracle(mean_alleles, S):
     eng.close()
 
 
+def test_device_batch_with_a_bad_slow_path_list_is_refused():
+    """the slow-path rows of a batch in device memory are checked where they are (extra_csr_kernel): a list out of order
+    or naming a cluster that does not exist is PF_ERR_ARG, as for a host batch, and the context stays usable"""
+    from panfeed_amd import _lib, devbatch, synth
+    from panfeed_amd.engine import Engine
+    import ctypes as C
+    cl = synth.generate(10, 64, first=5, flank=10, mean_len=300, min_len=60, max_len=600, n_rate=0.1)
+    eng = Engine(klength=31, max_strains=64)
+    db = devbatch.from_synth(eng, cl, 31)
+    assert db.n_extra > 3
+    good = db.download("extra_cluster", np.uint32, db.n_extra)
+    ref = db.submit()
+    for bad in (good[::-1].copy(), np.where(np.arange(db.n_extra) == db.n_extra - 1, 10, good).astype(np.uint32)):
+        if (bad == good).all():
+            continue
+        _lib.check(eng.L.pf_dev_upload(eng.ctx, db.ptrs["extra_cluster"], bad.ctypes.data_as(C.c_void_p), bad.nbytes))
+        with pytest.raises(_lib.PanfeedHipError) as e:
+            db.submit()
+        assert "extra_cluster" in str(e.value)
+    _lib.check(eng.L.pf_dev_upload(eng.ctx, db.ptrs["extra_cluster"], good.ctypes.data_as(C.c_void_p), good.nbytes))
+    _lib.check(eng.L.pf_reset_patterns(eng.ctx))
+    again = db.submit()
+    assert (int(again.n_kept), int(again.n_unique), int(again.n_new_patterns)) == (int(ref.n_kept), int(ref.n_unique), int(ref.n_new_patterns))
+    db.free()
+    eng.close()
+
+
 def test_key_partitions_learned_from_earlier_batches():
     """a context that has scanned 16 clusters of many related alleles sizes the next ones' key partitions by what those
     brought (first attempts of several partitions, few failures); the files stay the oracle's"""
