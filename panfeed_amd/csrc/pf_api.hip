@@ -132,7 +132,7 @@ struct pf_ctx {
     uint32_t n_passes = 0;                 // arenas the last pf_submit used (arenas[] itself only ever grows)
     DevBuf rp_order, rp_rlen, rp_rowoff;   // pf_render_pattern_rows: the id list, row lengths, row offsets
     uint32_t n_grown = 0;                  // times the pattern table / pool were enlarged
-    DevBuf mg_lo, mg_hi, mg_min, mg_cnt;   // pf_merge_patterns scratch table
+    DevBuf mg_lo, mg_cnt;   // pf_merge_patterns scratch table ([cap][4] words) and its counter
     // the small per-pass arrays: one device block + its pinned host mirror, two of each because the two halves of a
     // batch's first pass are in flight together (stage_slot picks the pair)
     DevBuf stage_devs[2];
@@ -435,7 +435,7 @@ void pf_destroy(pf_ctx* c) {
     c->rp_order.release(); c->rp_rlen.release(); c->rp_rowoff.release(); c->wide_list.release();
     for (int i = 0; i < 2; i++) if (c->txt_pins[i]) (void)hipHostFree(c->txt_pins[i]); c->md5_list.release();
     c->g_store.release(); c->b_literal.release(); c->g_src_off.release(); c->g_src_start.release(); c->g_src_flags.release();
-    c->mg_lo.release(); c->mg_hi.release(); c->mg_min.release(); c->mg_cnt.release();
+    c->mg_lo.release(); c->mg_cnt.release();
     if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
     if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1823,17 +1823,13 @@ int merge_impl(pf_ctx* c, const void* d_gathered, uint64_t n_total, uint64_t my_
     if (!d_gathered || (my_count && !d_keep) || my_first + my_count > n_total) return fail(PF_ERR_ARG, "pf_merge_patterns: bad range");
     uint64_t cap = 1024;
     while (cap < 2 * n_total) cap <<= 1;
-    PFCHK(c->mg_lo.ensure(cap * 8));
-    PFCHK(c->mg_hi.ensure(cap * 8));
-    PFCHK(c->mg_min.ensure(cap * 8));
+    PFCHK(c->mg_lo.ensure(cap * 32));
     PFCHK(c->mg_cnt.ensure(8));
-    PFCHK(fill_u64(c, c->mg_lo.p, pf::EMPTY64, cap));
-    PFCHK(fill_u64(c, c->mg_hi.p, pf::EMPTY64, cap));
-    PFCHK(fill_u64(c, c->mg_min.p, pf::EMPTY64, cap));
+    PFCHK(fill_u64(c, c->mg_lo.p, pf::EMPTY64, cap * 4));
     HIPCHK(hipMemsetAsync(c->mg_cnt.p, 0, 8, c->stream));
     pf::MergeParams mp{};
     mp.gathered = (const uint64_t*)d_gathered; mp.n = n_total;
-    mp.t_lo = c->mg_lo.as<uint64_t>(); mp.t_hi = c->mg_hi.as<uint64_t>(); mp.t_min = c->mg_min.as<uint64_t>();
+    mp.tab = c->mg_lo.as<uint64_t>();
     mp.cap = cap; mp.my_first = my_first; mp.my_count = my_count; mp.keep = (uint8_t*)d_keep;
     mp.slot_counts = (const int64_t*)d_slot_counts; mp.slot_rows = d_slot_counts ? slot_rows : 0;
     mp.n_global = c->mg_cnt.as<unsigned long long>();

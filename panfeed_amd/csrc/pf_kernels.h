@@ -3269,7 +3269,8 @@ __global__ __launch_bounds__(256) void result_checksum_kernel(const uint64_t* co
 struct MergeParams {
     const uint64_t* gathered;   // [n][3]
     uint64_t n;
-    uint64_t* t_lo; uint64_t* t_hi; uint64_t* t_min;   // [cap], t_lo/t_hi EMPTY64-filled, t_min EMPTY64-filled
+    uint64_t* tab;              // [cap][4] = {digest lo, digest hi, min first_seen, -}, EMPTY64-filled: an entry is one
+                                // 32-byte line segment (three parallel arrays were three cache lines per row)
     uint64_t cap;               // power of two
     uint64_t my_first, my_count;
     const int64_t* slot_counts; // padded layout: rows come in equal slots of `slot_rows` per rank, only the first
@@ -3289,19 +3290,19 @@ __device__ __forceinline__ uint64_t merge_slot(const MergeParams& p, uint64_t lo
         if (st == 2) {
             st = 0;
             for (uint64_t probes = 0; probes < p.cap; probes++) {
-                uint64_t cur = __hip_atomic_load(&p.t_lo[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint64_t cur = __hip_atomic_load(&p.tab[4 * slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (cur == EMPTY64) {
                     if (!insert) break;
-                    cur = atomicCAS((unsigned long long*)&p.t_lo[slot], (unsigned long long)EMPTY64, (unsigned long long)lo);
+                    cur = atomicCAS((unsigned long long*)&p.tab[4 * slot], (unsigned long long)EMPTY64, (unsigned long long)lo);
                     if (cur == EMPTY64) {
-                        __hip_atomic_store(&p.t_hi[slot], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&p.tab[4 * slot + 1], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         ++*claimed;
                         res = slot;
                         break;
                     }
                 }
                 if (cur == lo) {
-                    const uint64_t h = __hip_atomic_load(&p.t_hi[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint64_t h = __hip_atomic_load(&p.tab[4 * slot + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (h == EMPTY64) { st = 2; break; }            // claimed, not yet published
                     if (h == hi) { res = slot; break; }
                 }
@@ -3319,7 +3320,7 @@ __global__ __launch_bounds__(256) void merge_insert_kernel(MergeParams p) {
         if (p.slot_rows && (int64_t)(i % p.slot_rows) >= p.slot_counts[i / p.slot_rows]) continue;   // padding
         const uint64_t lo = p.gathered[3 * i], hi = p.gathered[3 * i + 1], fs = p.gathered[3 * i + 2];
         const uint64_t slot = merge_slot(p, lo, hi, true, &claimed);
-        if (slot != EMPTY64) atomicMin((unsigned long long*)&p.t_min[slot], (unsigned long long)fs);
+        if (slot != EMPTY64) atomicMin((unsigned long long*)&p.tab[4 * slot + 2], (unsigned long long)fs);
     }
     for (int d = 32; d > 0; d >>= 1) claimed += __shfl_down(claimed, d);
     if ((threadIdx.x & 63) == 0 && claimed) atomicAdd(p.n_global, (unsigned long long)claimed);   // one per wave
@@ -3330,7 +3331,7 @@ __global__ __launch_bounds__(256) void merge_lookup_kernel(MergeParams p) {
         const uint64_t lo = p.gathered[3 * i], hi = p.gathered[3 * i + 1], fs = p.gathered[3 * i + 2];
         uint32_t unused = 0;
         const uint64_t slot = merge_slot(p, lo, hi, false, &unused);
-        p.keep[j] = (slot != EMPTY64 && p.t_min[slot] == fs) ? 1 : 0;
+        p.keep[j] = (slot != EMPTY64 && p.tab[4 * slot + 2] == fs) ? 1 : 0;
     }
 }
 
