@@ -219,3 +219,22 @@ def test_parallel_gzip_writer_roundtrip(tmp_path):
     ParallelGzipWriter(q).close()
     with gzip.open(q, "rt") as fh:
         assert fh.read() == ""
+
+
+def test_synth_allele_models():
+    """the generator of the benchmark inputs: SURVEY 8d's alleles by default (the stream of random numbers the goldens and
+    the bench were made with must not move), related alleles on request: distinct, flanks inherited, two substitutions
+    away from some earlier allele"""
+    from panfeed_amd import synth
+    a = synth.generate(3, 40, first=7, flank=10)
+    b = synth.generate(3, 40, first=7, flank=10, allele_model="star")
+    assert all(len(x.alleles) == len(y.alleles) and all((p == q).all() for p, q in zip(x.alleles, y.alleles)) for x, y in zip(a, b))
+    assert [x.seq_allele.tolist() for x in a] == [y.seq_allele.tolist() for y in b]
+    for c in synth.generate(4, 300, first=3, flank=50, mean_alleles=60, allele_decay=1.0, allele_model="tree"):
+        al = c.alleles
+        assert len({x.tobytes() for x in al}) == len(al) > 20
+        assert len({len(x) for x in al}) == 1
+        for i in range(1, len(al)):
+            assert min(int((al[i] != al[j]).sum()) for j in range(i)) in (1, 2)
+    with pytest.raises(ValueError):
+        synth.generate(1, 10, allele_model="bush")
