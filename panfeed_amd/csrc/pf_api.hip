@@ -99,6 +99,7 @@ struct pf_ctx {
     // L = windows of one sequence, as running sums for the line g = a + b L (related alleles: a few tens whatever L is;
     // SURVEY 8d's: flanks + a share of L) -- see the key-partition estimate
     double reg_n = 0, reg_x = 0, reg_y = 0, reg_xx = 0, reg_xy = 0, reg_yy = 0;
+    uint64_t n_submits = 0;
     std::vector<uint32_t> hs_count;
     uint32_t n_patterns = 0;       // patterns allocated after the last submit
     uint32_t pid0 = 0;             // first pattern id of the last submit
@@ -848,6 +849,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
     uint64_t total_inst = 0;
 
     c->pid0 = c->n_patterns;
+    c->n_submits++;
     c->cluster_arena.assign(C, 0);
 
     std::vector<uint32_t> nparts(C, 1);
@@ -1312,7 +1314,9 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         uint64_t cur3[3];
         // clusters of this pass the key-partition estimate can learn from: their items' key counts come along
         bool learn = false;
-        if (c->reg_n < 8192)         // (then the line is settled: no more read-backs)
+        // (8 192 clusters settle the line; after that every 16th submit still looks, at half the old weight, so that a
+        // pangenome whose later clusters differ from its first is followed -- the read-back is not free)
+        if (c->reg_n < 8192 || (c->n_submits & 15) == 0)
             for (uint32_t ci : todo) if (h_mode[ci] && h_vnstr[ci] >= 2) { learn = true; break; }
         if (learn) {
             c->hs_count.resize(NI);
@@ -1338,6 +1342,9 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             std::iota(todo.begin(), todo.end(), 0u);
         }
         if (learn) {
+            if (c->reg_n >= 8192) {
+                c->reg_n *= 0.5; c->reg_x *= 0.5; c->reg_y *= 0.5; c->reg_xx *= 0.5; c->reg_xy *= 0.5; c->reg_yy *= 0.5;
+            }
             for (size_t i = 0; i < NI; i++) {
                 const Item& it = items[i];
                 if (it.is_extra || it.part != 0) continue;
