@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--mean-alleles", type=float, default=7.0)
     ap.add_argument("--allele-decay", type=float, default=0.5, help="allele weights decay^i (1.0: uniform)")
+    ap.add_argument("--allele-model", default="star", choices=["star", "tree"],
+                    help="star: SURVEY 8d's alleles (default); tree: alleles that descend from one another (synth.py)")
     ap.add_argument("--n-rate", type=float, default=0.0, help="share of the sequences that carry one 'N' (SURVEY 8d: 0.001)")
     ap.add_argument("--max-items", type=int, default=65536)
     ap.add_argument("--cpu-clusters", type=int, default=0, help="clusters in the CPU-baseline sample (0 = auto)")
@@ -84,7 +86,7 @@ def cpu_baseline(args, threads):
     per_cluster = max(1, args.samples // 1000)
     n = args.cpu_clusters or max(8, min(args.clusters, 80 * threads // per_cluster))   # ~15-25 s at ~5e6 instances/s/thread
     cl = synth.generate(n, args.samples, first=0, flank=args.flank, n_rate=args.n_rate, mean_alleles=args.mean_alleles,
-                        allele_decay=args.allele_decay)
+                        allele_decay=args.allele_decay, allele_model=args.allele_model)
     recs = [c.record() for c in cl]
     ninst = sum(c.n_instances(args.k) for c in cl)
     run = po.OracleRun(klength=args.k, want_kmers_tsv=False, threads=threads)
@@ -164,7 +166,7 @@ def targets_pass(args, local):
     from panfeed_amd.packing import build_batch_native
     S, k = args.samples, args.k
     cl = synth.generate(args.targets_clusters, S, first=10 ** 6, flank=args.flank, n_rate=0.0,
-                        mean_alleles=args.mean_alleles, allele_decay=args.allele_decay)
+                        mean_alleles=args.mean_alleles, allele_decay=args.allele_decay, allele_model=args.allele_model)
     recs = [c.record() for c in cl]
     stroi = set(cl[0].names)
     eng = Engine(klength=k, max_strains=(S + 31) // 32 * 32, stroi=stroi, device=local)
@@ -279,7 +281,7 @@ def main():
     dbs = []
     for s0 in range(0, n_mine, slab):
         cl = synth.generate(min(slab, n_mine - s0), S, first=first + s0, flank=args.flank, n_rate=args.n_rate,
-                            mean_alleles=args.mean_alleles, allele_decay=args.allele_decay)
+                            mean_alleles=args.mean_alleles, allele_decay=args.allele_decay, allele_model=args.allele_model)
         dbs.append(devbatch.from_synth(eng, cl, k, first_ordinal=first + s0))
         del cl
     t_gen = time.time() - t_gen
@@ -356,7 +358,8 @@ def main():
             pk["algorithmic_GBps"] = packed_bytes / (pk["ms"] / 1e3) / 1e9     # it has to read the packed input once
             pk["frac_of_hbm_peak"] = pk["algorithmic_GBps"] / HBM_PEAK_GBS
         default_cmd = (args.clusters, S, k, args.flank, world, args.no_dedup, strong, args.mean_alleles,
-                       args.allele_decay, args.n_rate) == (50000, 1000, 31, 100, 1, False, False, 7.0, 0.5, 0.0)
+                       args.allele_decay, args.n_rate, args.allele_model) == (50000, 1000, 31, 100, 1, False, False, 7.0, 0.5, 0.0,
+                                                                               "star")
         pmc, pmc_rel = load_pmc() if default_cmd else (None, None)
         if pmc:
             tot = 0.0
@@ -405,7 +408,7 @@ def main():
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": workload,
                        "clusters_this_gpu": n_mine, "samples": S, "k": k, "flank": args.flank,
-                       "mean_alleles": args.mean_alleles, "allele_decay": args.allele_decay,
+                       "mean_alleles": args.mean_alleles, "allele_decay": args.allele_decay, "allele_model": args.allele_model,
                        "instances_this_gpu": n_inst, "packed_bytes_this_gpu": packed_bytes,
                        "unique_kmers": last["unique"], "kept_kmers": last["kept"], "patterns": last["global_patterns"],
                        "sharding": f"{world} x contiguous cluster ranges" + (
