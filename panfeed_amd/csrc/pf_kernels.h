@@ -2915,7 +2915,7 @@ __global__ __launch_bounds__(PR_THREADS) void pattern_rows_kernel(PatRowsParams 
     // the mask a wave is expanding
     __shared__ uint16_t segd[DEDUP_MAX_SEGS];
     __shared__ uint32_t wstart[MAX_CHUNKS + 1];
-    __shared__ uint32_t mstage[PR_THREADS / 64][32];
+    __shared__ uint32_t mstage[PR_THREADS / 64][33];          // word 32 stays zero (the place unused segment registers point at)
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const uint32_t item = p.work[blockIdx.x];
@@ -2967,8 +2967,23 @@ __global__ __launch_bounds__(PR_THREADS) void pattern_rows_kernel(PatRowsParams 
             segd[s] = (uint16_t)((p.seg_distinct[s0 + s] << 5) | (p.seg_sample[s0 + s] & 31u));
         for (uint32_t w = tid; w <= nchunks; w += blockDim.x)
             wstart[w] = seg_lower_bound(p.seg_sample, s0, s1, w << 5) - s0;
+        if (lane == 0) mstage[wave][32] = 0;
         __syncthreads();
     }
+    // mode 2: the segments lane `lane` looks at for row word `lane` are the same for every pattern: held in registers as in
+    // rows_kernel (two to a register, unused places = distinct index 1024, whose mask word is the zero word 32)
+    constexpr uint32_t PR_SEGREG = 32;
+    uint32_t sg[PR_SEGREG / 2];
+    uint32_t my_q0 = 0, my_q1 = 0;
+    if (wide && lane < nchunks) { my_q0 = wstart[lane]; my_q1 = wstart[lane + 1]; }
+#pragma unroll
+    for (uint32_t j = 0; j < PR_SEGREG / 2; j++) {
+        const uint32_t q = my_q0 + 2 * j;
+        const uint32_t e0 = q < my_q1 ? segd[q] : 0x8000u, e1 = q + 1 < my_q1 ? segd[q + 1] : 0x8000u;
+        sg[j] = e0 | (e1 << 16);
+    }
+    uint32_t sg_used = min(my_q1 - my_q0, PR_SEGREG);
+    for (int dd = 1; dd < 64; dd <<= 1) sg_used = max(sg_used, (uint32_t)__shfl_xor(sg_used, dd));
     const bool sorted = !ranks_by_bitmap(mode, p.v_dense[c]);      // entries = sorted positions, or slots (emit_kernel)
     const uint32_t total = sorted ? U : ns;
     const uint32_t stride = blockDim.x;
@@ -3016,9 +3031,25 @@ __global__ __launch_bounds__(PR_THREADS) void pattern_rows_kernel(PatRowsParams 
                 uint32_t v = 0;
                 if (w < nchunks) {
                     if (wide) {
-                        for (uint32_t q = wstart[w], qe = wstart[w + 1]; q < qe; q++) {
+                        const uint32_t* ms = mstage[wave];
+                        uint32_t q = wstart[w];
+                        const uint32_t qe = wstart[w + 1];
+                        if (w == lane) {                            // the first 64 words: from the registers
+#pragma unroll
+                            for (uint32_t j = 0; j < PR_SEGREG / 2; j++) {
+                                if (2 * j < sg_used) {              // wave-uniform
+                                    uint32_t pr2 = sg[j];
+                                    asm volatile("" : "+v"(pr2));   // decoded here, every time (see rows_kernel)
+                                    const uint32_t e0 = pr2 & 0xFFFFu, e1 = pr2 >> 16;
+                                    v |= ((ms[e0 >> 10] >> ((e0 >> 5) & 31u)) & 1u) << (e0 & 31u);
+                                    v |= ((ms[e1 >> 10] >> ((e1 >> 5) & 31u)) & 1u) << (e1 & 31u);
+                                }
+                            }
+                            q += PR_SEGREG;
+                        }
+                        for (; q < qe; q++) {
                             const uint32_t e = segd[q], d = e >> 5;
-                            v |= ((mstage[wave][d >> 5] >> (d & 31u)) & 1u) << (e & 31u);
+                            v |= ((ms[d >> 5] >> (d & 31u)) & 1u) << (e & 31u);
                         }
                     } else if (expand) {
                         uint64_t t = amask;
