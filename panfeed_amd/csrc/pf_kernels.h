@@ -11,9 +11,12 @@
 //   finish_kernel      deduplicated clusters: everything after the scan in one workgroup (sample sets, allele-mask
 //                      table, MAF / same-as-cluster filter, ranks from ordinal bitmaps, run-global pattern table,
 //                      outputs).
-//   rows_kernel -> cluster_base_kernel -> emit_kernel -> pattern_rows_kernel   the general path: popcount / MAF +
-//                      same-as-cluster filter (panfeed.py:190-204), 128-bit row hash, ordinal order (dict insertion
-//                      order, :189), run-global pattern table (first-seen rule, :179-187, 210-223), pattern rows.
+//   rows_kernel -> cluster_base_kernel (+ bitmap_merge_kernel) -> emit_kernel -> pattern_rows_kernel   the general
+//                      path: popcount / MAF + same-as-cluster filter (panfeed.py:190-204), 128-bit row hash, ordinal
+//                      order (dict insertion order, :189; one merged ordinal bitmap per cluster of several items),
+//                      run-global pattern table (first-seen rule, :179-187, 210-223), pattern rows.
+//   extra_csr_kernel   slow-path rows (k-mers around a non-ACGT base) of a batch already in device memory: per-cluster
+//                      counts and the check of their list.
 //   md5_kernel         MD5 of the int64 / float64 image of each new pattern (panfeed.py:175, 206).
 #pragma once
 #include <hip/hip_runtime.h>
