@@ -1345,11 +1345,13 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             if (c->reg_n >= 8192) {
                 c->reg_n *= 0.5; c->reg_x *= 0.5; c->reg_y *= 0.5; c->reg_xx *= 0.5; c->reg_xy *= 0.5; c->reg_yy *= 0.5;
             }
-            for (size_t i = 0; i < NI; i++) {
+            uint32_t looked = 0;               // (the GPU waits while this runs: a few thousand clusters say enough)
+            for (size_t i = 0; i < NI && looked < 4096; i++) {
                 const Item& it = items[i];
                 if (it.is_extra || it.part != 0) continue;
                 const uint32_t ci = it.cluster;
                 if (ovf[ci] || !h_mode[ci] || h_vnstr[ci] < 2 || !vinst[ci]) continue;
+                looked++;
                 uint64_t keys = 0;
                 for (uint32_t q = 0; q < it.nparts; q++) keys += c->hs_count[i + q];
                 const double D = (double)h_vnstr[ci], L = (double)(vinst[ci] * mult) / D;
