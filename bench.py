@@ -4,14 +4,17 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment launches the N ranks itself (torch.distributed.run as a
+child process; this parent never touches HIP) and fails loudly when the box has fewer than N devices.
+
 One "step" = one pass of cluster_cutter + pattern_hasher (device path: pf_submit) over the rank's synthetic
 pangenome, packed input already resident in HBM, results left in HBM, followed (N > 1) by the exchange of
 {md5, first_seen} for the run-global pattern dedup (inside the timed region).
 
-Workload (default): BASELINE.json configs[2] -- 50k clusters x 1k samples, k=31, +-100 bp flanks (SURVEY 8d generator,
-pure-ACGT variant) -- PER GPU: "weak" scaling, every rank owns a contiguous range of the processing order.
-`--total-clusters T` splits T clusters over the ranks instead (BASELINE configs[3] as written: 50k x 1k sharded over
-8 GPUs, "strong" scaling); kernels and the merge are then timed separately as well.
+Workload: BASELINE.json configs[2] -- 50k clusters x 1k samples, k=31, +-100 bp flanks (SURVEY 8d generator,
+pure-ACGT variant).  N = 1: that workload on the one GPU.  N > 1 (default): BASELINE configs[3] as written, the SAME
+50k clusters sharded over the N GPUs with the RCCL pattern merge -- "strong" scaling, `value`; the weak figure (50k
+clusters PER GPU) is measured too and reported under `weak_scaling`.  `--scaling weak` makes the weak figure `value`.
 `--samples 5000 --k 21|51` is BASELINE configs[4]'s shape; `--targets-clusters M` adds its --targets second pass
 (positional rows of kmers.tsv for M clusters with every sample a target strain), timed on its own.
 `--sweep-alleles` runs a 5 000-cluster pass for several numbers of distinct sequences per cluster.
@@ -20,7 +23,10 @@ Prints ONE JSON line on rank 0.  `value` = k-mer instances/s over all ranks (tri
 /root/reference/panfeed/panfeed.py:64); `patterns_per_s` = unique patterns/s (rows of hashes_to_patterns.tsv).
 `roofline` prices the chain of kernels one pf_submit runs (dedup -> scan -> finish -> md5) against HBM with SURVEY
 8(d)'s algorithmic bytes, and lists every kernel with the roof that actually bounds it; `cpu_baseline` is the CPU
-oracle (a port, not the reference) on a bounded sample of the same workload, rank 0 at N=1 only.
+oracle (a port, not the reference) on a bounded sample of the same workload, rank 0 at N=1 only; `parity_sample` is
+that sample's kmers_to_hashes / hashes_to_patterns text, oracle against GPU, byte for byte; `with_N` is the same
+workload with SURVEY 8d's share of 'N's (0.1 % of the sequences); `end_to_end` is files on disk -> the three files
+(pipeline.run_files) and Seqinfo records -> the three files, with the stage split.
 """
 import argparse
 import json
@@ -44,13 +50,17 @@ VALU_PEAK_WAVE_INSTS = 256 * 4 * 0.5 * 2.4e9
 INT_MIX_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 4.05
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU); default 1, or WORLD_SIZE under a launcher")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--clusters", type=int, default=50000, help="gene clusters per GPU (weak scaling)")
-    ap.add_argument("--total-clusters", type=int, default=0, help="gene clusters over ALL GPUs (strong scaling)")
+    ap.add_argument("--clusters", type=int, default=50000, help="gene clusters of the workload (per GPU when scaling is weak)")
+    ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
+                    help="auto: strong at N > 1 (BASELINE configs[3]: the same --clusters split over the GPUs, the weak "
+                         "figure as a sub-key); weak: --clusters per GPU")
+    ap.add_argument("--total-clusters", type=int, default=0, help="strong scaling over this many clusters (same as "
+                                                                   "--scaling strong --clusters T)")
     ap.add_argument("--samples", type=int, default=1000)
     ap.add_argument("--flank", type=int, default=100)
     ap.add_argument("--k", type=int, default=31)
@@ -64,10 +74,41 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dedup", action="store_true", help="scan every copy of identical sequences (PF_FLAG_NO_DEDUP)")
     ap.add_argument("--no-every-copy-leg", action="store_true", help="skip the extra scan-every-copy step")
+    ap.add_argument("--no-n-leg", action="store_true", help="skip the leg with SURVEY 8d's share of 'N's")
+    ap.add_argument("--no-e2e-leg", action="store_true", help="skip the end-to-end (files -> files) leg")
+    ap.add_argument("--no-weak-leg", action="store_true", help="N > 1, strong scaling: skip the weak-scaling sub-leg")
+    ap.add_argument("--e2e-clusters", type=int, default=1000, help="clusters of the end-to-end leg's on-disk pangenome")
+    ap.add_argument("--e2e-records-clusters", type=int, default=400, help="clusters of the records -> files figure")
     ap.add_argument("--targets-clusters", type=int, default=0, help="clusters of the --targets second pass leg")
     ap.add_argument("--sweep-alleles", action="store_true", help="extra leg: throughput vs distinct sequences per cluster")
     ap.add_argument("--merge-method", default="owner", choices=["owner", "allgather"])
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: N fresh ranks through torch.distributed.run, as a child process.
+    This parent has made no HIP call (torch.cuda.device_count() does not initialise the GPU on this image) and
+    makes none: it passes the children's output through and exits with their code."""
+    import socket
+    import subprocess
+
+    import torch
+    shared = os.environ.get("PANFEED_BENCH_SHARED_GPU") == "1"
+    ndev = torch.cuda.device_count()
+    if ndev < n and not shared:
+        sys.stderr.write(f"bench.py: {n} ranks requested, {ndev} device{'s' if ndev != 1 else ''} on this box -- one rank "
+                         f"per GPU; nothing was run.  (PANFEED_BENCH_SHARED_GPU=1 rehearses the control flow with every "
+                         f"rank on cuda:0 and gloo collectives; its numbers are not multi-GPU numbers.)\n")
+        sys.exit(2)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
 def algorithmic_bytes(packed_bytes, n_kept, n_new_patterns, S, k):
@@ -79,31 +120,58 @@ def algorithmic_bytes(packed_bytes, n_kept, n_new_patterns, S, k):
     return full, full - n_kept * w8
 
 
-def cpu_baseline(args, threads):
-    """the CPU oracle on the first clusters of the same workload, ~10-30 s of CPU work"""
+def synth_kw(args, n_rate=None):
+    return dict(flank=args.flank, n_rate=args.n_rate if n_rate is None else n_rate, mean_alleles=args.mean_alleles,
+                allele_decay=args.allele_decay, allele_model=args.allele_model)
+
+
+def oracle_sample(args, local, threads, n, n_rate, timed):
+    """The CPU oracle on the first `n` clusters of the workload (oracle/: the checker), and the same clusters through the
+    HIP path: kmers_to_hashes.tsv and hashes_to_patterns.tsv bodies compared byte for byte.  Returns (cpu_baseline dict
+    or None, parity dict)."""
     from oracle import oracle as po
-    from panfeed_amd import synth
-    per_cluster = max(1, args.samples // 1000)
-    n = args.cpu_clusters or max(8, min(args.clusters, 80 * threads // per_cluster))   # ~15-25 s at ~5e6 instances/s/thread
-    cl = synth.generate(n, args.samples, first=0, flank=args.flank, n_rate=args.n_rate, mean_alleles=args.mean_alleles,
-                        allele_decay=args.allele_decay, allele_model=args.allele_model)
+    from panfeed_amd import devbatch, synth
+    from panfeed_amd.engine import Engine
+    S, k = args.samples, args.k
+    cl = synth.generate(n, S, first=0, **synth_kw(args, n_rate))
     recs = [c.record() for c in cl]
-    ninst = sum(c.n_instances(args.k) for c in cl)
-    run = po.OracleRun(klength=args.k, want_kmers_tsv=False, threads=threads)
+    ninst = sum(c.n_instances(k) for c in cl)
+    run = po.OracleRun(klength=k, want_kmers_tsv=False, threads=threads)
     prep = run.prepare(recs)
     t0 = time.time()
     run.run_prepared(prep)
     dt = time.time() - t0
     st = run.stats()
     assert st["instances"] == ninst
-    return {"value": ninst / dt, "unit": "kmer_instances/s", "cores": threads, "kind": "port",
-            "sample": f"first {n} clusters of the workload ({ninst} instances, {st['patterns']} patterns) in {dt:.1f} s",
-            "patterns_per_s": st["patterns"] / dt}
+    del prep, recs
+    base = None
+    if timed:
+        base = {"value": ninst / dt, "unit": "kmer_instances/s", "cores": threads, "kind": "port",
+                "sample": f"first {n} clusters of the workload ({ninst} instances, {st['patterns']} patterns) in {dt:.1f} s",
+                "patterns_per_s": st["patterns"] / dt}
+    ekh, ehp = run.text(1).encode(), run.text(2).encode()
+    run.close()
+    eng = Engine(klength=k, max_strains=(S + 31) // 32 * 32, device=local, max_items=min(args.max_items, 8192),
+                 dedup=not args.no_dedup)
+    db = devbatch.from_synth(eng, cl, k)
+    res = db.submit(eng)
+    kh, hp = eng.render_device(db)
+    eq_kh, eq_hp = bytes(kh) == ekh, bytes(hp) == ehp
+    par = {"clusters": n, "equal": bool(eq_kh and eq_hp), "kmers_to_hashes_equal": bool(eq_kh),
+           "hashes_to_patterns_equal": bool(eq_hp), "kmers_to_hashes_bytes": len(ekh), "hashes_to_patterns_bytes": len(ehp),
+           "kept_kmers": int(res.n_kept), "patterns": int(res.n_new_patterns), "n_rate": n_rate,
+           "note": "oracle (CPU restatement of panfeed.py:16-235) vs the HIP path on the first clusters of this workload: "
+                   "the bodies of kmers_to_hashes.tsv and hashes_to_patterns.tsv, byte for byte"}
+    db.free()
+    eng.close()
+    if not par["equal"]:
+        raise AssertionError(f"GPU text differs from the oracle's on the first {n} clusters: {par}")
+    return base, par
 
 
 def load_pmc():
     """committed rocprofv3 --pmc summary of the default command (tools/profile_round.sh): HBM bytes and SQ counters"""
-    for rel in ("profiles/r02/final_pmc_summary.json", "profiles/r01/final_pmc_traffic.json"):
+    for rel in ("profiles/r03/final_pmc_summary.json", "profiles/r02/final_pmc_summary.json"):
         path = os.path.join(REPO, rel)
         if os.path.exists(path):
             with open(path) as fh:
@@ -242,17 +310,116 @@ def allele_sweep(args, local, allele_model="star"):
     return rows
 
 
+# ------------------------------------------------------------------------------------------------ end to end
+def end_to_end(args, local):
+    """What a user of the drop-in runs (the reference's whole run: __main__.py:299-356): files on disk -> the three
+    files through pipeline.run_files (native reader -> genomes resident in HBM -> batches -> kernels -> text -> writer
+    thread), with the text of the two big files rendered by the host threads ("plain") and written on the device
+    ("device_text"); and Seqinfo records (the tuples input.py:468 yields, in host memory) -> the three files through
+    Engine.run_stream.  The synthetic pangenome (SURVEY 8d's generator with its share of 'N's, +-flank) is written to a
+    scratch directory first, untimed; its files are read back from the page cache."""
+    import shutil
+    import tempfile
+
+    from panfeed_amd import synth
+    from panfeed_amd.engine import (KMERS_TO_HASHES_HEADER, KMERS_TSV_HEADER, Engine, OwnedText,
+                                    hashes_to_patterns_header)
+    from panfeed_amd.pipeline import run_files
+    S, k, up = args.samples, args.k, args.flank
+    n = args.e2e_clusters
+    out = {"shape": f"{n} clusters x {S} samples, k={k}, --upstream {up} --downstream {up}, SURVEY 8d generator with "
+                    f"0.1 % of the sequences carrying an 'N' (the shape of BASELINE configs[2], a subset of its clusters)"}
+    scratch = tempfile.mkdtemp(prefix="pf_bench_e2e_")
+    try:
+        t0 = time.time()
+        cl = synth.generate(n, S, first=0, flank=up, n_rate=0.001, mean_alleles=args.mean_alleles,
+                            allele_decay=args.allele_decay, allele_model=args.allele_model)
+        ninst = sum(c.n_instances(k) for c in cl)
+        csvp, gffs, _fas = synth.write_pangenome(scratch, cl, missing_gene_rate=0.0)
+        in_bytes = sum(os.path.getsize(p) for p in gffs.values()) + os.path.getsize(csvp)
+        out["setup_write_inputs_s"] = time.time() - t0
+        out["input_bytes"] = in_bytes
+        del cl
+        for name, device_text in (("files_to_files_plain", False), ("files_to_files_device_text", True)):
+            od = os.path.join(scratch, "out_" + name)
+            t0 = time.time()
+            st = run_files(csvp, os.path.join(scratch, "gffs"), od, klength=k, upstream=up, downstream=up,
+                           batch_clusters=256, device_text=device_text, device=local)
+            dt = time.time() - t0
+            assert st["instances"] == ninst, (st["instances"], ninst)
+            fbytes = sum(os.path.getsize(os.path.join(od, f)) for f in os.listdir(od))
+            out[name] = {"seconds": dt, "inst_per_s": ninst / dt, "output_bytes": fbytes, "output_GBps": fbytes / dt / 1e9,
+                         "input_GBps": in_bytes / dt / 1e9, "instances": ninst, "kept_kmers": st["kept_kmers"],
+                         "patterns": st["patterns"], "stages_s": {a: round(b, 4) for a, b in st["stages"].items()}}
+            shutil.rmtree(od)
+        out["stages_note"] = ("open_parse_s: table + GFFs + FASTA read and indexed; context_s: pf_create; genome_upload_s: "
+                              "contigs -> 2 bit/base in HBM; then per batch, overlapped: pack_busy_s (reader + packer "
+                              "thread; pack_wait_s = what of it the GPU thread waited for), submit_s (coordinates + "
+                              "literals H2D, gather, the kernel chain; device_ms of it on the device), text_s (device "
+                              "text + D2H, or pf_fetch + host renderers), write_busy_s (writer thread); total_s: the call")
+    finally:
+        shutil.rmtree(scratch, ignore_errors=True)
+    # ---- records -> files: the boundary as the reference's callers use it (host strings in, three files out)
+    n2 = args.e2e_records_clusters
+    cl = synth.generate(n2, S, first=0, flank=up, n_rate=0.001, mean_alleles=args.mean_alleles,
+                        allele_decay=args.allele_decay, allele_model=args.allele_model)
+    names = cl[0].names
+    recs = [c.record() for c in cl]
+    ninst = sum(c.n_instances(k) for c in cl)
+    del cl
+    stroi = {names[10 % len(names)]}
+    scratch = tempfile.mkdtemp(prefix="pf_bench_e2e_")
+    try:
+        for name, device_text in (("records_to_files_plain", False), ("records_to_files_device_text", True)):
+            eng = Engine(klength=k, max_strains=(S + 31) // 32 * 32, stroi=stroi, device=local)
+            t0 = time.time()
+            nbytes = 0
+            with open(os.path.join(scratch, "kmers.tsv"), "wb") as ks, open(os.path.join(scratch, "kmers_to_hashes.tsv"), "wb") as kh, \
+                    open(os.path.join(scratch, "hashes_to_patterns.tsv"), "wb") as hp:
+                ks.write(KMERS_TSV_HEADER.encode())
+                kh.write(KMERS_TO_HASHES_HEADER.encode())
+                hp.write(hashes_to_patterns_header(names).encode())
+                for o in eng.run_stream(iter(recs), batch_clusters=128, device_text=device_text):
+                    for fh, data in ((ks, o.kmers_tsv), (kh, o.kmers_to_hashes), (hp, o.hashes_to_patterns)):
+                        if isinstance(data, OwnedText):
+                            fh.write(data.view)
+                            nbytes += len(data)
+                            data.release()
+                        else:
+                            nbytes += fh.write(data.encode() if isinstance(data, str) else data)
+            dt = time.time() - t0
+            out[name] = {"clusters": n2, "seconds": dt, "inst_per_s": ninst / dt, "output_bytes": nbytes,
+                         "output_GBps": nbytes / dt / 1e9, "instances": ninst,
+                         "stages_s": {a: round(b, 4) for a, b in eng.stages.items()}}
+            eng.close()
+    finally:
+        shutil.rmtree(scratch, ignore_errors=True)
+    out["records_note"] = ("Seqinfo records (Python strings, one target strain: kmers.tsv rows included) -> pf_pack_records -> "
+                           "H2D -> kernels -> text -> three files; the records are made before the clock starts")
+    return out
+
+
 def main():
     args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and (args.gpus or 1) > 1:
+        launch_ranks(args.gpus)                       # does not return
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(env_world or "1")
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus is not None and args.gpus != world:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); nothing was run\n")
+        sys.exit(2)
     import torch
     dist = None
     # rehearsal mode for a 1-GPU box: every rank on cuda:0, gloo collectives on host tensors (control flow only)
     shared = os.environ.get("PANFEED_BENCH_SHARED_GPU") == "1"
     if shared:
         local = 0
+    elif torch.cuda.device_count() < max(world, local + 1):
+        sys.stderr.write(f"bench.py: {world} ranks requested, {torch.cuda.device_count()} device(s) on this box -- one rank "
+                         f"per GPU; nothing was run\n")
+        sys.exit(2)
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
@@ -261,55 +428,83 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     dev = torch.device("cpu") if shared else torch.device("cuda", local)
+    backend = dist.get_backend() if world > 1 else None
+    n_ranks_seen = dist.get_world_size() if world > 1 else 1      # the ranks the collective backend actually has
 
     from panfeed_amd import devbatch, synth
     from panfeed_amd.distributed import shard_range
     from panfeed_amd.engine import Engine
 
     S, k = args.samples, args.k
-    strong = args.total_clusters > 0
-    if strong:
-        first, stop = shard_range(args.total_clusters, rank, world)
-        n_mine = stop - first
-    else:
-        first, n_mine = rank * args.clusters, args.clusters
-    t_gen = time.time()
+    if args.total_clusters > 0:
+        args.scaling, args.clusters = "strong", args.total_clusters
+    strong = args.scaling == "strong" or (args.scaling == "auto" and world > 1)
     eng = Engine(klength=k, max_strains=(S + 31) // 32 * 32, device=local, max_items=args.max_items,
                  pattern_capacity=1 << 25, dedup=not args.no_dedup)
-    # generate + upload in slabs so the host never holds more than a slab of cluster objects
-    slab = max(1, 50000 * 1000 // max(S, 1))
-    dbs = []
-    for s0 in range(0, n_mine, slab):
-        cl = synth.generate(min(slab, n_mine - s0), S, first=first + s0, flank=args.flank, n_rate=args.n_rate,
-                            mean_alleles=args.mean_alleles, allele_decay=args.allele_decay, allele_model=args.allele_model)
-        dbs.append(devbatch.from_synth(eng, cl, k, first_ordinal=first + s0))
-        del cl
-    t_gen = time.time() - t_gen
-    n_inst = sum(d.n_instances for d in dbs)
-    packed_bytes = sum(d.packed_bytes for d in dbs)
-    step = make_step(eng, dbs, world, dist, dev, args.merge_method)
+
+    def build(first, n_mine, n_rate=None):
+        # generate + upload in slabs so the host never holds more than a slab of cluster objects
+        slab = max(1, 50000 * 1000 // max(S, 1))
+        out = []
+        for s0 in range(0, n_mine, slab):
+            cl = synth.generate(min(slab, n_mine - s0), S, first=first + s0, **synth_kw(args, n_rate))
+            out.append(devbatch.from_synth(eng, cl, k, first_ordinal=first + s0))
+            del cl
+        return out
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.time()
-    last = None
-    for _ in range(args.steps):
-        last = step()
-    fence()
-    dt = time.time() - t0
-    tmax = torch.tensor([dt, last["total_ms"], last["merge_ms"]], dtype=torch.float64, device=dev)
-    agg = torch.tensor([float(n_inst), float(last["kept"]), float(packed_bytes)], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-    dt, max_kernel_ms, max_merge_ms = (float(x) for x in tmax.tolist())
-    tot_inst, tot_kept, tot_packed = (float(x) for x in agg.tolist())
+    def timed(step, steps, warmup):
+        for _ in range(warmup):
+            step()
+        fence()
+        t0 = time.time()
+        last = None
+        for _ in range(steps):
+            last = step()
+        fence()
+        return time.time() - t0, last
+
+    def reduce_max_sum(maxes, sums):
+        tmax = torch.tensor(maxes, dtype=torch.float64, device=dev)
+        agg = torch.tensor(sums, dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        return [float(x) for x in tmax.tolist()], [float(x) for x in agg.tolist()]
+
+    if strong:
+        first, stop = shard_range(args.clusters, rank, world)
+        n_mine = stop - first
+    else:
+        first, n_mine = rank * args.clusters, args.clusters
+    t_gen = time.time()
+    dbs = build(first, n_mine)
+    t_gen = time.time() - t_gen
+    n_inst = sum(d.n_instances for d in dbs)
+    packed_bytes = sum(d.packed_bytes for d in dbs)
+    step = make_step(eng, dbs, world, dist, dev, args.merge_method)
+    dt, last = timed(step, args.steps, args.warmup)
+    (dt, max_kernel_ms, max_merge_ms), (tot_inst, tot_kept, tot_packed) = reduce_max_sum(
+        [dt, last["total_ms"], last["merge_ms"]], [float(n_inst), float(last["kept"]), float(packed_bytes)])
+
+    # N > 1, strong scaling: the weak figure beside it (--clusters per GPU, rank r owns [r * clusters, (r + 1) * clusters))
+    weak = None
+    if world > 1 and strong and not args.no_weak_leg:
+        wdbs = build(rank * args.clusters, args.clusters)
+        wstep = make_step(eng, wdbs, world, dist, dev, args.merge_method)
+        wdt, wlast = timed(wstep, args.steps, args.warmup)
+        (wdt, wk, wm), (winst,) = reduce_max_sum([wdt, wlast["total_ms"], wlast["merge_ms"]],
+                                                  [float(sum(d.n_instances for d in wdbs))])
+        weak = {"value": winst * args.steps / wdt, "unit": "kmer_instances/s", "scaling": "weak",
+                "ms_per_step": wdt / args.steps * 1e3, "clusters_per_gpu": args.clusters,
+                "patterns_per_s": wlast["global_patterns"] * args.steps / wdt,
+                "max_kernel_chain_ms": wk, "max_merge_ms": wm}
+        for d in wdbs:
+            d.free()
 
     # transparency leg (untimed for `value`): the same pass with the identical-sequence shortcut off
     every = None
@@ -334,6 +529,31 @@ def main():
                          "checksum over every k-mer row and cluster row, pf_result_checksum, equal to the timed path's)"}
         eng2.close()
 
+    default_shape = (args.clusters, S, k, args.flank, args.no_dedup, args.mean_alleles, args.allele_decay,
+                     args.allele_model) == (50000, 1000, 31, 100, False, 7.0, 0.5, "star")
+    # SURVEY 8d's generator proper: 0.1 % of the sequences carry one 'N' (the value above is its pure-ACGT variant)
+    with_n = None
+    if world == 1 and default_shape and args.n_rate == 0.0 and not args.no_n_leg:
+        for d in dbs:
+            d.free()
+        dbs = []
+        ndbs = build(first, n_mine, n_rate=0.001)
+        nstep = make_step(eng, ndbs, world, dist, dev, args.merge_method)
+        ndt, nlast = timed(nstep, args.steps, args.warmup)
+        ninst_n = sum(d.n_instances for d in ndbs)
+        with_n = {"value": ninst_n * args.steps / ndt, "unit": "kmer_instances/s", "ms_per_step": ndt / args.steps * 1e3,
+                  "n_rate": 0.001, "instances": ninst_n, "slow_path_rows": sum(d.n_extra for d in ndbs),
+                  "kept_kmers": nlast["kept"], "patterns": nlast["global_patterns"],
+                  "patterns_per_s": nlast["global_patterns"] * args.steps / ndt,
+                  "device_ms_per_step": {"cluster_dedup_kernel": nlast["dedup_ms"], "kmer_scan_kernel": nlast["scan_ms"],
+                                         "finish_kernel": nlast["finish_ms"], "md5_kernel": nlast["md5_ms"],
+                                         "rows_kernel": nlast["rows_ms"], "emit_kernel": nlast["emit_ms"],
+                                         "submit_total": nlast["total_ms"]},
+                  "note": "the same workload from SURVEY 8d's generator as written: 0.1 % of the sequences carry one 'N' "
+                          "(their windows around it are slow-path rows, panfeed.py:65-79 string semantics)"}
+        for d in ndbs:
+            d.free()
+
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         alg, alg_must = algorithmic_bytes(packed_bytes, last["kept"], last["new"], S, k)   # this rank, one step
@@ -357,9 +577,7 @@ def main():
             pk = per_kernel["cluster_dedup_kernel"]
             pk["algorithmic_GBps"] = packed_bytes / (pk["ms"] / 1e3) / 1e9     # it has to read the packed input once
             pk["frac_of_hbm_peak"] = pk["algorithmic_GBps"] / HBM_PEAK_GBS
-        default_cmd = (args.clusters, S, k, args.flank, world, args.no_dedup, strong, args.mean_alleles,
-                       args.allele_decay, args.n_rate, args.allele_model) == (50000, 1000, 31, 100, 1, False, False, 7.0, 0.5, 0.0,
-                                                                               "star")
+        default_cmd = default_shape and world == 1 and not strong and args.n_rate == 0.0
         pmc, pmc_rel = load_pmc() if default_cmd else (None, None)
         if pmc:
             tot = 0.0
@@ -386,15 +604,15 @@ def main():
             if tot:
                 traffic, traffic_src = tot, pmc_rel
         workload = (f"synthetic {n_mine} clusters x {S} samples on this GPU"
-                    + (f" ({args.total_clusters} over {world} GPUs)" if strong else " per GPU")
+                    + (f" ({args.clusters} over {world} GPUs)" if strong and world > 1 else (" per GPU" if world > 1 else ""))
                     + f", k={k}, +-{args.flank} bp flanks, canonical, maf 0.01")
         if args.n_rate:
             workload += f", {args.n_rate:g} of the sequences with one 'N'"
-        if default_cmd:
+        if default_shape and world == 1 and args.n_rate == 0.0:
             workload += " (BASELINE.json configs[2], pure-ACGT)"
-        elif (args.clusters, S, k, args.flank, world, strong, args.n_rate) == (50000, 1000, 31, 100, 1, False, 0.001):
+        elif default_shape and world == 1 and args.n_rate == 0.001:
             workload += " (BASELINE.json configs[2] with SURVEY 8d's share of 'N's)"
-        elif strong and (args.total_clusters, S, k, args.flank) == (50000, 1000, 31, 100):
+        elif default_shape and strong:
             workload += " (BASELINE.json configs[3]: configs[2] sharded)"
         elif S == 5000:
             workload += " (BASELINE.json configs[4] shape)"
@@ -403,8 +621,9 @@ def main():
             "value": tot_inst * args.steps / dt,
             "unit": "kmer_instances/s",
             "patterns_per_s": last["global_patterns"] * args.steps / dt,
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "n_gpus": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True,
+            "scaling": "strong" if strong and world > 1 else "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": workload,
                        "clusters_this_gpu": n_mine, "samples": S, "k": k, "flank": args.flank,
@@ -424,7 +643,8 @@ def main():
                          "kernel_ms_per_step": chain_ms, "longest_kernel": dom, "per_kernel": per_kernel,
                          "kernels_ms_summed": sum(kern_ms.values()),
                          "note": "achieved = SURVEY 8d algorithmic bytes of the clusters one pf_submit processes / device "
-                                 "time of its kernel chain (first start to last end, HIP events on the library's stream). "
+                                 "time of its kernel chain (first start to last end, HIP events on the library's stream, "
+                                 "measured live in this run). "
                                  "U*ceil(S/8) of those bytes (one bit row per kept k-mer) are never materialised by this "
                                  "design -- a k-mer carries a pattern id -- so must_move_* prices only the bytes the path "
                                  "has to move (packed input, key + pattern id per kept k-mer, one row per new pattern). "
@@ -433,19 +653,25 @@ def main():
                                  "SQ_INSTS_VALU / time vs the chip's vector issue rate, 256 CU x 4 SIMD x 1 "
                                  "wave-instruction / 2 cycles x 2.4 GHz (valu_frac_of_issue_peak), latency / lds-latency "
                                  "= share of wave cycles spent waiting, SQ_WAIT_ANY / SQ_WAVE_CYCLES "
-                                 "(wave_cycles_waiting_frac).  traffic = HBM bytes of "
-                                 "every pf:: kernel of a step (FETCH_SIZE x 2 + WRITE_SIZE, fill and count kernels "
-                                 "included) from the committed PMC passes of this same command."},
+                                 "(wave_cycles_waiting_frac).  traffic (and the per-kernel counter figures) are NOT "
+                                 "measured by this run: they are the HBM bytes of every pf:: kernel of a step (FETCH_SIZE "
+                                 "x 2 on the 16-byte-per-lane reads + WRITE_SIZE, fill and count kernels included) from the "
+                                 "committed rocprofv3 --pmc passes of this same command (traffic_source)."},
             "device_ms_per_step": dict(kern_ms, submit_total=last["total_ms"]),
             "work_items": last["items"], "clusters_repartitioned": last["retried"],
             "clusters_deduplicated": last["dedup_clusters"], "scan_packed_bytes": last["scan_bytes"],
             "scan_every_copy": every,
             "setup_s": {"generate_and_upload": t_gen},
         }
+        if with_n is not None:
+            out["with_N"] = with_n
         if world > 1:
             out["multi_gpu"] = {"max_kernel_chain_ms": max_kernel_ms, "max_merge_ms": max_merge_ms,
-                                "merge_method": args.merge_method,
+                                "merge_method": args.merge_method, "backend": backend,
+                                "ranks_in_process_group": n_ranks_seen,
                                 "note": "slowest rank's device chain and host-timed digest exchange of the last step"}
+            if weak is not None:
+                out["weak_scaling"] = weak
         if args.targets_clusters:
             out["targets_second_pass"] = targets_pass(args, local)
         if args.sweep_alleles:
@@ -453,7 +679,13 @@ def main():
             out["allele_sweep_tree"] = allele_sweep(args, local, "tree")
         if world == 1 and not args.no_cpu_baseline:
             threads = min(len(os.sched_getaffinity(0)), 16)   # a 1-GPU box's CPU share
-            out["cpu_baseline"] = cpu_baseline(args, threads)
+            per_cluster = max(1, S // 1000)
+            n = args.cpu_clusters or max(8, min(args.clusters, 80 * threads // per_cluster))   # ~15-25 s at ~5e6 instances/s/thread
+            out["cpu_baseline"], out["parity_sample"] = oracle_sample(args, local, threads, n, args.n_rate, True)
+            if with_n is not None:
+                _, with_n["parity_sample"] = oracle_sample(args, local, threads, max(8, n // 4), 0.001, False)
+        if world == 1 and default_shape and not args.no_e2e_leg:
+            out["end_to_end"] = end_to_end(args, local)
         print(json.dumps(out), flush=True)
     for d in dbs:
         d.free()

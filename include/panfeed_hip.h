@@ -292,6 +292,11 @@ typedef struct {
 } pf_packed_view_t;
 
 int pf_pack_records(const pf_pack_in* in, pf_packed** out);
+/* Binding helper for a CPython host side (panfeed_amd/packing.py hands Seqinfo.sequence / .compsequence,
+ * classes.py:11-18, to pf_pack_records by address): out[i] = as_utf8(objs[i]) for an array of n object pointers, where
+ * as_utf8 is the interpreter's PyUnicode_AsUTF8 -- one C loop instead of one FFI call per string, no assumption about the
+ * object layout.  Call it with the GIL held (ctypes.PyDLL).  out[i] == 0: the API refused that object. */
+int pf_py_str_addresses(void* const* objs, uint64_t n, const char* (*as_utf8)(void*), uint64_t* out);
 int pf_packed_view(const pf_packed* p, pf_packed_view_t* view);
 void pf_packed_free(pf_packed* p);
 

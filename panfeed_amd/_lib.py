@@ -138,7 +138,8 @@ EXPORTS = ["pf_last_error", "pf_version", "pf_device_count", "pf_create", "pf_de
            "pf_pangenome_take_log", "pf_pangenome_next", "pf_records_free", "pf_pangenome_contigs",
            "pf_pangenome_set_store", "pf_genomes_upload", "pf_genomes_clear", "pf_submit_gather", "pf_gzip_members", "pf_render_device",
            "pf_render_device_ex", "pf_render_pattern_rows", "pf_pangenome_weights", "pf_pangenome_set_range",
-           "pf_rowfilter_create", "pf_rowfilter_scan", "pf_rowfilter_stats", "pf_rowfilter_destroy"]
+           "pf_rowfilter_create", "pf_rowfilter_scan", "pf_rowfilter_stats", "pf_rowfilter_destroy",
+           "pf_py_str_addresses"]
 
 RENDER_NO_PATTERN_ROWS = 1
 ERR_ARG, ERR_OOM, ERR_HIP, ERR_CAPACITY, ERR_STATE = -1, -2, -3, -4, -5
@@ -238,6 +239,22 @@ def load():
     L.pf_free_text.restype = None
     _lib = L
     return L
+
+
+_pydll = None
+
+
+def load_pydll():
+    """the same library through a handle whose calls keep the GIL (ctypes.PyDLL): for pf_py_str_addresses, which calls
+    back into the interpreter's C API"""
+    global _pydll
+    if _pydll is None:
+        load()
+        P = C.PyDLL(LIB_PATH)
+        P.pf_py_str_addresses.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        P.pf_py_str_addresses.restype = C.c_int
+        _pydll = P
+    return _pydll
 
 
 def check(status):

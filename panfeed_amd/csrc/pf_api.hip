@@ -133,6 +133,7 @@ struct pf_ctx {
     uint32_t n_passes = 0;                 // arenas the last pf_submit used (arenas[] itself only ever grows)
     DevBuf rp_order, rp_rlen, rp_rowoff;   // pf_render_pattern_rows: the id list, row lengths, row offsets
     uint32_t n_grown = 0;                  // times the pattern table / pool were enlarged
+    bool pt_stale = false;                 // a batch failed and its patterns could not be dropped (growth failed): reset first
     DevBuf mg_lo, mg_cnt;   // pf_merge_patterns scratch table ([cap][4] words) and its counter
     // the small per-pass arrays: one device block + its pinned host mirror, two of each because the two halves of a
     // batch's first pass are in flight together (stage_slot picks the pair)
@@ -214,6 +215,7 @@ int reset_patterns(pf_ctx* c) {
     c->n_patterns = 0;
     c->pid0 = 0;
     c->b64_done = 0;
+    c->pt_stale = false;
     c->h_pat_bits.clear(); c->h_pat_nan.clear(); c->h_pat_n.clear(); c->h_pat_md5.clear(); c->h_first_seen.clear();
     c->h_b64.clear();
     return PF_OK;
@@ -256,75 +258,97 @@ int staged_upload(pf_ctx* c, std::vector<std::pair<DevBuf*, const std::vector<ui
 }
 
 // the run-global pattern table (`slots` = power of two) and the pool arrays indexed by pattern id (slots / 2 ids)
-int alloc_patterns(pf_ctx* c, uint64_t slots) {
-    c->pt.cap = slots;
-    c->pt.pool = (uint32_t)std::min<uint64_t>(slots / 2, 0x7FFFFFF0ull);
-    const size_t W = c->W, pool = c->pt.pool;
-    PFCHK(c->pt_lo.ensure(slots * 8));
-    PFCHK(c->pt_val.ensure(slots * 8));
-    PFCHK(c->pt_first.ensure(pool * 8));
-    PFCHK(c->pt_counters.ensure(16));
-    PFCHK(c->pat_bits.ensure(pool * W * 4));
-    PFCHK(c->pat_n.ensure(pool * 4));
-    PFCHK(c->pat_md5.ensure(pool * 16));
-    if (c->o.consider_missing) PFCHK(c->pat_nan.ensure(pool * W * 4));
+struct PatternBufs {
+    DevBuf lo, val, first, bits, nan, n, md5, b64;
+    uint64_t cap = 0;
+    uint32_t pool = 0;
+    void release() { lo.release(); val.release(); first.release(); bits.release(); nan.release(); n.release(); md5.release(); b64.release(); }
+};
+int alloc_pattern_bufs(pf_ctx* c, uint64_t slots, bool with_b64, PatternBufs& pb) {
+    pb.cap = slots;
+    pb.pool = (uint32_t)std::min<uint64_t>(slots / 2, 0x7FFFFFF0ull);
+    const size_t W = c->W, pool = pb.pool;
+    PFCHK(pb.lo.ensure(slots * 8));
+    PFCHK(pb.val.ensure(slots * 8));
+    PFCHK(pb.first.ensure(pool * 8));
+    PFCHK(pb.bits.ensure(pool * W * 4));
+    PFCHK(pb.n.ensure(pool * 4));
+    PFCHK(pb.md5.ensure(pool * 16));
+    if (c->o.consider_missing) PFCHK(pb.nan.ensure(pool * W * 4));
+    if (with_b64) PFCHK(pb.b64.ensure(pool * 24));
+    return PF_OK;
+}
+// the context takes the buffers over (its old ones, if any, are the caller's to release: they are moved into `pb`)
+void adopt_pattern_bufs(pf_ctx* c, PatternBufs& pb) {
+    std::swap(c->pt_lo, pb.lo); std::swap(c->pt_val, pb.val); std::swap(c->pt_first, pb.first);
+    std::swap(c->pat_bits, pb.bits); std::swap(c->pat_nan, pb.nan); std::swap(c->pat_n, pb.n);
+    std::swap(c->pat_md5, pb.md5); std::swap(c->pat_b64, pb.b64);
+    std::swap(c->pt.cap, pb.cap); std::swap(c->pt.pool, pb.pool);
     c->pt.lo = c->pt_lo.as<uint64_t>();
     c->pt.val = c->pt_val.as<uint64_t>();
     c->pt.first_seen = c->pt_first.as<uint64_t>();
+}
+int alloc_patterns(pf_ctx* c, uint64_t slots) {
+    PatternBufs pb;
+    int rc = alloc_pattern_bufs(c, slots, false, pb);
+    if (rc == PF_OK) rc = c->pt_counters.ensure(16);
+    if (rc != PF_OK) { pb.release(); return rc; }
+    adopt_pattern_bufs(c, pb);
     c->pt.counters = c->pt_counters.as<uint32_t>();
+    pb.release();
     return PF_OK;
 }
 
 // The reference's `patterns` is an unbounded set (panfeed.py:146-150): when a batch runs out of pattern ids (or
 // comes close), the table and the pool are re-made larger, the patterns of earlier batches re-inserted
-// (pattern_rehash_kernel; whatever the failed batch added is dropped) and the batch is run again.
+// (pattern_rehash_kernel; whatever the failed batch added is dropped) and the batch is run again.  The new table is
+// built beside the old one and takes its place only when every step has succeeded: on a failure (out of memory with
+// both resident, a failed copy) the context keeps the table it had and the error is returned.
 int grow_patterns(pf_ctx* c, uint64_t min_pool) {
     uint64_t slots = c->pt.cap * 2;
     while (slots / 2 < min_pool + min_pool / 4) slots <<= 1;
     if (slots / 2 > 0x7FFFFFF0ull) return fail(PF_ERR_CAPACITY, "more than 2^31 distinct patterns");
     const uint32_t keep = c->n_patterns;            // ids of the batches that completed
     const size_t W = c->W;
-    DevBuf o_lo = c->pt_lo, o_val = c->pt_val, o_first = c->pt_first, o_bits = c->pat_bits, o_nan = c->pat_nan,
-           o_n = c->pat_n, o_md5 = c->pat_md5, o_b64 = c->pat_b64;
-    const uint64_t old_cap = c->pt.cap;
-    c->pt_lo = DevBuf(); c->pt_val = DevBuf(); c->pt_first = DevBuf(); c->pat_bits = DevBuf(); c->pat_nan = DevBuf();
-    c->pat_n = DevBuf(); c->pat_md5 = DevBuf(); c->pat_b64 = DevBuf();
-    int rc = alloc_patterns(c, slots);
-    if (rc == PF_OK && o_b64.p) rc = c->pat_b64.ensure((size_t)c->pt.pool * 24);
+    PatternBufs nb;
+    int rc = alloc_pattern_bufs(c, slots, c->pat_b64.p != nullptr, nb);
     auto copy = [&](DevBuf& dst, DevBuf& src, size_t bytes) -> int {
         if (bytes && src.p) HIPCHK(hipMemcpyAsync(dst.p, src.p, bytes, hipMemcpyDeviceToDevice, c->stream));
         return PF_OK;
     };
-    if (rc == PF_OK) rc = fill_u64(c, c->pt_lo.p, pf::EMPTY64, slots);
-    if (rc == PF_OK) rc = fill_u64(c, c->pt_val.p, pf::EMPTY64, slots);
-    if (rc == PF_OK) rc = fill_u64(c, c->pt_first.p, pf::EMPTY64, c->pt.pool);
-    if (rc == PF_OK) rc = copy(c->pt_first, o_first, (size_t)keep * 8);
-    if (rc == PF_OK) rc = copy(c->pat_bits, o_bits, (size_t)keep * W * 4);
-    if (rc == PF_OK && c->o.consider_missing) rc = copy(c->pat_nan, o_nan, (size_t)keep * W * 4);
-    if (rc == PF_OK) rc = copy(c->pat_n, o_n, (size_t)keep * 4);
-    if (rc == PF_OK) rc = copy(c->pat_md5, o_md5, (size_t)keep * 16);
-    if (rc == PF_OK && o_b64.p) rc = copy(c->pat_b64, o_b64, (size_t)std::min(c->b64_done, keep) * 24);
+    if (rc == PF_OK) rc = fill_u64(c, nb.lo.p, pf::EMPTY64, slots);
+    if (rc == PF_OK) rc = fill_u64(c, nb.val.p, pf::EMPTY64, slots);
+    if (rc == PF_OK) rc = fill_u64(c, nb.first.p, pf::EMPTY64, nb.pool);
+    if (rc == PF_OK) rc = copy(nb.first, c->pt_first, (size_t)keep * 8);
+    if (rc == PF_OK) rc = copy(nb.bits, c->pat_bits, (size_t)keep * W * 4);
+    if (rc == PF_OK && c->o.consider_missing) rc = copy(nb.nan, c->pat_nan, (size_t)keep * W * 4);
+    if (rc == PF_OK) rc = copy(nb.n, c->pat_n, (size_t)keep * 4);
+    if (rc == PF_OK) rc = copy(nb.md5, c->pat_md5, (size_t)keep * 16);
+    if (rc == PF_OK && nb.b64.p) rc = copy(nb.b64, c->pat_b64, (size_t)std::min(c->b64_done, keep) * 24);
     if (rc == PF_OK) {
         pf::RehashParams rp{};
-        rp.old_lo = o_lo.as<uint64_t>(); rp.old_val = o_val.as<uint64_t>(); rp.old_cap = old_cap;
-        rp.new_lo = c->pt.lo; rp.new_val = c->pt.val; rp.new_cap = slots; rp.keep_below = keep;
-        const uint32_t blocks = (uint32_t)std::min<uint64_t>((old_cap + 255) / 256, 8192);
+        rp.old_lo = c->pt_lo.as<uint64_t>(); rp.old_val = c->pt_val.as<uint64_t>(); rp.old_cap = c->pt.cap;
+        rp.new_lo = nb.lo.as<uint64_t>(); rp.new_val = nb.val.as<uint64_t>(); rp.new_cap = slots; rp.keep_below = keep;
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((c->pt.cap + 255) / 256, 8192);
         hipLaunchKernelGGL(pf::pattern_rehash_kernel, dim3(blocks), dim3(256), 0, c->stream, rp);
         if (hipGetLastError() != hipSuccess) rc = fail(PF_ERR_HIP, "pattern_rehash_kernel launch failed");
     }
-    if (rc == PF_OK) {
+    if (rc == PF_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(PF_ERR_HIP, "growing the pattern table failed");
+    if (rc != PF_OK) {
+        (void)hipStreamSynchronize(c->stream);       // nothing queued above may still touch the buffers released here
+        nb.release();
+        // the failed batch's additions are still in the old table: forget them, as the successful path does
         const uint32_t cnt[4] = {keep, 0, 0, 0};
-        if (hipMemcpyAsync(c->pt_counters.p, cnt, 16, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-            hipStreamSynchronize(c->stream) != hipSuccess)
-            rc = fail(PF_ERR_HIP, "growing the pattern table failed");
-    } else {
-        (void)hipStreamSynchronize(c->stream);
+        (void)hipMemcpy(c->pt_counters.p, cnt, 16, hipMemcpyHostToDevice);
+        return rc;
     }
-    o_lo.release(); o_val.release(); o_first.release(); o_bits.release(); o_nan.release(); o_n.release();
-    o_md5.release(); o_b64.release();
+    adopt_pattern_bufs(c, nb);                       // nb now holds the old buffers
+    nb.release();
+    const uint32_t cnt[4] = {keep, 0, 0, 0};
+    HIPCHK(hipMemcpy(c->pt_counters.p, cnt, 16, hipMemcpyHostToDevice));
     c->b64_done = std::min(c->b64_done, keep);
     c->n_grown++;
-    return rc;
+    return PF_OK;
 }
 
 template <int KW, bool CANON>
@@ -600,7 +624,7 @@ void pf_b64_digest(const uint8_t d[16], char out[24]) {
 namespace {
 constexpr int PF_RETRY_PATTERNS = 1;   // internal: the batch ran out of pattern ids, *need = ids it asked for
 
-int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* counters, uint64_t* need) {
+int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* counters, uint64_t* need, bool rerun) {
     c->have_batch = false;
     // whatever way this call ends, nothing it queued is still reading the caller's arrays or the pinned staging
     // blocks afterwards (the successful path has waited already; an error return may come with work in flight)
@@ -849,7 +873,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
     uint64_t total_inst = 0;
 
     c->pid0 = c->n_patterns;
-    c->n_submits++;
+    if (!rerun) c->n_submits++;
     c->cluster_arena.assign(C, 0);
 
     std::vector<uint32_t> nparts(C, 1);
@@ -920,9 +944,12 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
                     // deviations cost 0.5 % to 5 % in surplus partitions -- profiles/r02/partition_margin_experiment.txt)
                     const double g = std::max(0.0, a + b * L) + 0.5 * std::sqrt(ss / std::max(1.0, n - 2.0));
                     const double est2 = L + g * (D - 1.0);
-                    if (est2 > room) nparts[i] = (uint32_t)std::min<double>(std::ceil(est2 / room), 4096.0);
+                    // (an estimate never asks for more items than a sub-batch holds: the cluster then starts with what
+                    // fits and an overflowing scan says how many partitions it really needs)
+                    if (est2 > room)
+                        nparts[i] = (uint32_t)std::min<double>(std::ceil(est2 / room), (double)std::min(4096u, std::max(1u, c->max_items / 2)));
                 } else if (est > room) {
-                    nparts[i] = D > 24.0 ? 1u : (uint32_t)std::min<double>(std::ceil(est / room), 64.0);
+                    nparts[i] = D > 24.0 ? 1u : (uint32_t)std::min<double>(std::ceil(est / room), (double)std::min(64u, std::max(1u, c->max_items / 2)));
                 }
             }
         }
@@ -1316,7 +1343,8 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         bool learn = false;
         // (8 192 clusters settle the line; after that every 16th submit still looks, at half the old weight, so that a
         // pangenome whose later clusters differ from its first is followed -- the read-back is not free)
-        if (c->reg_n < 8192 || (c->n_submits & 15) == 0)
+        // (not in the re-run of a batch after the pattern table grew: its clusters have been counted)
+        if (!rerun && (c->reg_n < 8192 || (c->n_submits & 15) == 0))
             for (uint32_t ci : todo) if (h_mode[ci] && h_vnstr[ci] >= 2) { learn = true; break; }
         if (learn) {
             c->hs_count.resize(NI);
@@ -1462,15 +1490,22 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
         // the pattern set starts empty in every cluster (panfeed.py:165) and ids are salted by the cluster ordinal:
         // nothing of an earlier batch can ever be matched again
         PFCHK(reset_patterns(c));
+    } else if (c->pt_stale) {
+        return fail(PF_ERR_STATE, "the pattern table holds entries of a batch that failed while it was being enlarged; "
+                                  "pf_reset_patterns (a new run) first");
     } else if ((uint64_t)c->n_patterns * 2 > c->pt.pool) {
-        PFCHK(grow_patterns(c, (uint64_t)c->n_patterns * 2));     // ahead of need: a re-run costs a whole batch
+        // ahead of need: a re-run costs a whole batch.  No batch has failed here, so a growth that does not succeed
+        // (out of memory with both tables resident) leaves a table that is whole: carry on with it.
+        const int rc = grow_patterns(c, (uint64_t)c->n_patterns * 2);
+        if (rc != PF_OK && rc != PF_ERR_OOM) return rc;
     }
     for (int attempt = 0;; attempt++) {
         uint64_t need = 0;
-        const int rc = submit_once(c, b, gth, counters, &need);
+        const int rc = submit_once(c, b, gth, counters, &need, attempt > 0);
         if (rc != PF_RETRY_PATTERNS) return rc;
-        if (attempt >= 8) return fail(PF_ERR_CAPACITY, "pattern table still too small after %d enlargements", attempt);
-        PFCHK(grow_patterns(c, std::max<uint64_t>(need, (uint64_t)c->pt.pool + 1)));
+        int rg = attempt >= 8 ? fail(PF_ERR_CAPACITY, "pattern table still too small after %d enlargements", attempt)
+                              : grow_patterns(c, std::max<uint64_t>(need, (uint64_t)c->pt.pool + 1));
+        if (rg != PF_OK) { c->pt_stale = true; return rg; }     // the failed batch's patterns are still in the table
     }
 }
 

@@ -57,23 +57,7 @@ __host__ __device__ inline uint32_t insert_limit(uint32_t ns) {
     return a < b ? a : b;
 }
 
-#ifndef PF_SCAN_EXP
-#define PF_SCAN_EXP 0          // 1..3: destructive timing experiments on the scan's window loop (never shipped)
-#endif
-constexpr uint32_t M_TMP_EXP = 2300;
-#ifndef PF_FIN_EXP
-#define PF_FIN_EXP 0            // 1..7: finish_kernel cut off after its phase n - 1 (timing experiments, never shipped)
-#endif
-#ifndef PF_ROWS_EXP
-#define PF_ROWS_EXP 0           // 1..4: rows_kernel's wide path cut off after its phase n (timing experiments, never shipped)
-#endif
-#ifndef PF_SCAN_LAZY_CLEAR
-#define PF_SCAN_LAZY_CLEAR (PF_SCAN_EXP == 0)     // the timing experiments leave slots behind that no dump visits
-#endif
-#ifndef PF_SCAN_BUCKET
-#define PF_SCAN_BUCKET 4
-#endif
-constexpr uint32_t SCAN_BUCKET = PF_SCAN_BUCKET;   // slots per bucket of the one-word-key table (ns is a multiple of 64)
+constexpr uint32_t SCAN_BUCKET = 4;   // slots per bucket of the one-word-key table (ns is a multiple of 64)
 template <int KW>
 struct Key {
     uint64_t w[KW];
@@ -215,7 +199,7 @@ __device__ __forceinline__ bool table_update(uint64_t* keys, uint32_t* ord, uint
         // issued together, a new key takes the first empty slot of the first bucket that has one.  The loop runs as long
         // as the slowest of the 64 lanes, so what counts is how often ANY lane has to go past its home bucket: with
         // two-slot buckets (round 1) a unit took ~3.5 trips at the usual fill and the trips after the first were 38 % of
-        // the kernel's time (PF_SCAN_EXP=4 against 0).  ONE loop for the wave, its condition uniform (`__any`), the
+        // the kernel's time (profiles/r02/scan_time_breakdown_experiments.txt).  ONE loop for the wave, its condition uniform (`__any`), the
         // lanes predicated inside it.
         bool pending = active;
         uint32_t bucket = home;
@@ -243,9 +227,6 @@ __device__ __forceinline__ bool table_update(uint64_t* keys, uint32_t* ord, uint
             }
             if (got) { slot = cand; pending = false; }
             if (pending && !emp) bucket = bucket + 1 == nb ? 0 : bucket + 1;    // full of other keys: next bucket
-#if PF_SCAN_EXP == 4
-            if (pending) { active = false; pending = false; }                  // one trip only (timing experiment)
-#endif
         } while (__any(pending));
     } else {
         // word 0 is claimed by CAS, word 1 published right after.  A lane that sees word 0 match while word 1 is
@@ -283,10 +264,6 @@ __device__ __forceinline__ bool table_update(uint64_t* keys, uint32_t* ord, uint
         }
     }
     bool over = false;
-#if PF_SCAN_EXP == 1
-    if (active && slot == 0xFFFFFFF0u) misc[M_TMP_EXP] = 1;
-    active = false;
-#endif
     if (active) {
         atomicMin(&ord[slot], myord);
         atomicOr(&bits[slot], bit);
@@ -374,17 +351,6 @@ __device__ __forceinline__ bool scan_unit(uint64_t* keys, uint32_t* ord, uint32_
     const bool rc_smaller = window_keys<KW>(k, lane, cw, fwd, rc);
     const uint32_t nhome = KW == 1 ? ns / SCAN_BUCKET : ns;
     bool over;
-#if PF_SCAN_EXP == 2
-    {   // keys and hash only
-        Key<KW> key = rc_smaller ? rc : fwd;
-        const uint32_t h = key_hash<KW>(key);
-        if (valid && __umulhi(h, nhome) == 0xFFFFFFF0u) misc[M_TMP_EXP] = 1;
-        return false;
-    }
-#elif PF_SCAN_EXP == 3
-    if (valid && cw[0] == 0x123456789ull && cw[1] == 77) misc[M_TMP_EXP] = 1;
-    return false;
-#endif
     if (CANON) {
         Key<KW> key = rc_smaller ? rc : fwd;          // specseq <= revspecseq -> forward (panfeed.py:70)
         const uint32_t h = key_hash<KW>(key);
@@ -450,7 +416,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
         fetch_tile0(misc[M_DESC + 6], misc[M_DESC + 7]);
     }
 
-#if PF_SCAN_LAZY_CLEAR
     // The table is emptied ONCE here; after that every item leaves it empty behind itself -- the dump looks at every slot
     // anyway and resets the occupied ones (a third of them) as it goes, where a clearing pass over all slots at the start
     // of every item was 8 % of the kernel.
@@ -460,7 +425,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
         ord[i] = NO_ORD;
         bits[i] = 0;
     }
-#endif
     PF_PROF_BEGIN();
     uint32_t dcur = M_DESC, dnxt = M_NDESC;      // the two descriptor slots take turns: nothing is copied between items
     for (uint32_t wi = blockIdx.x; wi < p.n_work; wi += gridDim.x) {
@@ -478,14 +442,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
     uint32_t nd_word = 0;
     if (wn < p.n_work && tid < 16) nd_word = reinterpret_cast<const uint32_t*>(p.desc + wn)[tid];
 
-#if !PF_SCAN_LAZY_CLEAR
-    for (uint32_t i = tid; i < ns; i += SCAN_THREADS) {
-#pragma unroll
-        for (int j = 0; j < KW; j++) keys[(size_t)j * NS + i] = EMPTY64;
-        ord[i] = NO_ORD;
-        bits[i] = 0;
-    }
-#endif
     if (tid < 2) misc[tid] = 0;
     if (tid == 2) misc[M_PROG] = 0xFFFFFFFFu;
     uint32_t ubefore = 0;     // units of the tiles already walked
@@ -677,14 +633,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
             atomicMax(&p.cluster_overflow[c], (uint32_t)max(ratio, (uint64_t)64));
             p.item_count[item] = 0;
         }
-#if PF_SCAN_LAZY_CLEAR
         for (uint32_t i = tid; i < ns; i += SCAN_THREADS) {      // nothing is dumped: the table is emptied as a whole
 #pragma unroll
             for (int j = 0; j < KW; j++) keys[(size_t)j * NS + i] = EMPTY64;
             ord[i] = NO_ORD;
             bits[i] = 0;
         }
-#endif
     } else if (compact) {
         // chunk 0 words were flushed to global memory iff a chunk 1 followed; the last chunk is still in bits[]
         const bool last_live = chunk_dirty;
@@ -728,12 +682,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
             p.tab_ord[(size_t)slice * NS + e] = o;
             p.cmask_lo[(size_t)slice * NS + e] = lo;
             p.cmask_hi[(size_t)slice * NS + e] = hi;
-#if PF_SCAN_LAZY_CLEAR
 #pragma unroll
             for (int j = 0; j < KW; j++) keys[(size_t)j * NS + i] = EMPTY64;
             ord[i] = NO_ORD;
             bits[i] = 0;
-#endif
         }
         __syncthreads();
         if (tid == 0) p.item_count[item] = misc[M_COUNT];
@@ -742,11 +694,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
 #pragma unroll
             for (int j = 0; j < KW; j++) p.tab_key[((size_t)slice * KW + j) * NS + i] = keys[(size_t)j * NS + i];
             p.tab_ord[(size_t)slice * NS + i] = ord[i];
-#if PF_SCAN_LAZY_CLEAR
 #pragma unroll
             for (int j = 0; j < KW; j++) keys[(size_t)j * NS + i] = EMPTY64;
             ord[i] = NO_ORD;                                    // (bits[] went out, and to zero, with the last chunk)
-#endif
         }
         if (tid < 8) p.chunkmask[slice * 8 + tid] = mask_word;
         if (tid == 0) p.item_count[item] = misc[M_COUNT];
@@ -837,12 +787,6 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     return x;
 }
 
-#ifndef PF_DEDUP_HASH
-#define PF_DEDUP_HASH 1
-#endif
-#ifndef PF_DEDUP_NT
-#define PF_DEDUP_NT 0
-#endif
 // Contribution of 64-bit word `x` at word index idx of a segment to the segment's content hash.  Summed over the
 // words (any order: eight lanes hold different words), then finalised once per segment with mix64.  A multiply of the
 // two salted halves ("mum" folding): one v_mad_u64_u32 instead of the two 64-bit multiplies of a mix64 -- the pass is
@@ -855,27 +799,12 @@ __device__ __forceinline__ uint32_t dedup_salt_lo(uint32_t idx) { return 0x9E377
 __device__ __forceinline__ uint32_t dedup_salt_hi(uint32_t idx) { return 0x85EBCA77u * (2u * idx + 1u) + 0x165667B1u; }
 typedef uint32_t pf_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ ulonglong2 dedup_load16(const ulonglong2* p) {
-#if PF_DEDUP_NT
-    // read once, never again by this kernel: non-temporal
-    const pf_u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const pf_u32x4*>(p));
-    return make_ulonglong2(((uint64_t)t.y << 32) | t.x, ((uint64_t)t.w << 32) | t.z);
-#else
     return *p;
-#endif
 }
 
 constexpr uint32_t DEDUP_THREADS = 512;
 constexpr uint32_t DEDUP_CH = 4;              // 16-byte chunks per lane kept in registers (CH * GL * 64 bases per segment)
-#ifndef PF_DEDUP_U
-#define PF_DEDUP_U 1
-#endif
-#ifndef PF_DEDUP_EXP
-#define PF_DEDUP_EXP 0          // 1..3: destructive timing experiments on the pass over the bytes (never shipped)
-#endif
-#ifndef PF_DEDUP_WAVES
-#define PF_DEDUP_WAVES 6
-#endif
-constexpr uint32_t DEDUP_U = PF_DEDUP_U;       // segments in flight per 8-lane group
+constexpr uint32_t DEDUP_U = 1;       // segments in flight per 8-lane group
 constexpr uint32_t DEDUP_GL = 8;              // lanes that share one segment
 constexpr uint32_t DEDUP_UNSET = 0xFFFFFFFFu;
 constexpr uint32_t DEDUP_EX_LDS = 1024;       // slow-path rows of a cluster whose ordinals are staged in LDS
@@ -888,7 +817,7 @@ struct DedupSmall { static constexpr uint32_t GTAB = 256, MAXD = DEDUP_MAX_D, PO
 struct DedupWide { static constexpr uint32_t GTAB = 2048, MAXD = DEDUP_MAX_D_WIDE, POOL = 1024, MODE = 2; typedef uint16_t slot_t; };
 
 template <class CFG>
-__global__ __launch_bounds__(DEDUP_THREADS) __attribute__((amdgpu_waves_per_eu(CFG::MODE == 1 ? PF_DEDUP_WAVES : 2, CFG::MODE == 1 ? PF_DEDUP_WAVES : 4)))
+__global__ __launch_bounds__(DEDUP_THREADS) __attribute__((amdgpu_waves_per_eu(CFG::MODE == 1 ? 6 : 2, CFG::MODE == 1 ? 6 : 4)))
 void cluster_dedup_kernel(DedupParams p) {
     constexpr uint32_t GTAB = CFG::GTAB, MAXD = CFG::MAXD, POOL = CFG::POOL;
     typedef typename CFG::slot_t slot_t;
@@ -992,32 +921,18 @@ void cluster_dedup_kernel(DedupParams p) {
                 for (uint32_t q = 0; q < DEDUP_CH; q++) {
                     const uint32_t j = gl + DEDUP_GL * q;
                     if (j < pc[u]) {
-#if PF_DEDUP_HASH
                         // salts of words 2j and 2j + 1: lane part + a compile-time step per q
                         acc[u] += dedup_word_hash(v[u][q].x, salt_lo0 + q * (4u * DEDUP_GL * 0x9E3779B1u), salt_hi0 + q * (4u * DEDUP_GL * 0x85EBCA77u)) +
                                   dedup_word_hash(v[u][q].y, salt_lo0 + q * (4u * DEDUP_GL * 0x9E3779B1u) + 2u * 0x9E3779B1u,
                                                   salt_hi0 + q * (4u * DEDUP_GL * 0x85EBCA77u) + 2u * 0x85EBCA77u);
-#else
-                        acc[u] += mix64(v[u][q].x + 0x9E3779B97F4A7C15ull * (2 * j + 1)) ^
-                                  mix64(v[u][q].y + 0xC2B2AE3D27D4EB4Full * (2 * j + 2));
-#endif
                     }
                 }
                 for (uint32_t j = gl + DEDUP_GL * DEDUP_CH; j < pc[u]; j += DEDUP_GL) {      // longer than the registers hold
                     const ulonglong2 x = w[u][j];
-#if PF_DEDUP_HASH
                     acc[u] += dedup_word_hash(x.x, dedup_salt_lo(2 * j), dedup_salt_hi(2 * j)) +
                               dedup_word_hash(x.y, dedup_salt_lo(2 * j + 1), dedup_salt_hi(2 * j + 1));
-#else
-                    acc[u] += mix64(x.x + 0x9E3779B97F4A7C15ull * (2 * j + 1)) ^ mix64(x.y + 0xC2B2AE3D27D4EB4Full * (2 * j + 2));
-#endif
                 }
             }
-#if PF_DEDUP_EXP == 1 || PF_DEDUP_EXP == 4
-            if (acc[0] == 0x123456789abcdefull) sh_total = 1;   // timing experiment: loads and hash only
-            sh_bad = 1;
-            continue;
-#endif
             // claim: lane 0 of the group finds or opens the hash group
 #pragma unroll
             for (int u = 0; u < (int)DEDUP_U; u++) {
@@ -1055,10 +970,6 @@ void cluster_dedup_kernel(DedupParams p) {
                 registrar[u] = __shfl(reg, lane & ~(DEDUP_GL - 1)) != 0;
                 if (slot[u] >= GTAB) has[u] = false;      // cluster given up by this class
             }
-#if PF_DEDUP_EXP == 2
-            sh_bad = 1;                                          // timing experiment: no publish, no compare
-            continue;
-#endif
             // publish: the first segment of a group leaves its words in the pool
 #pragma unroll
             for (int u = 0; u < (int)DEDUP_U; u++) {
@@ -1086,10 +997,6 @@ void cluster_dedup_kernel(DedupParams p) {
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
-#if PF_DEDUP_EXP == 3
-            sh_bad = 1;                                          // timing experiment: no compare
-            continue;
-#endif
             // compare: every other segment of the group against the pool (or against the first one's global words)
 #pragma unroll
             for (int u = 0; u < (int)DEDUP_U; u++) {
@@ -1130,11 +1037,6 @@ void cluster_dedup_kernel(DedupParams p) {
                 }
             }
         }
-#if PF_DEDUP_EXP >= 4
-        // timing experiment: the pass over the bytes alone -- an empty view, no epilogue
-        if (tid == 0) { p.v_nseg[c] = 0; p.v_nstr[c] = p.cluster_nstrains[c]; p.v_dense[c] = 0; p.v_mode[c] = 0; }
-        return;
-#endif
         __syncthreads();
         // ---- 4. hash groups -> distinct indices in the ordinal order of their representatives
         for (uint32_t t = tid; t < GTAB; t += DEDUP_THREADS)
@@ -1465,10 +1367,6 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         // words; its presence row is gathered through the segment list: sample s carries the k-mer iff one of its
         // segments is a copy of a distinct sequence of the mask.  Distinct masks are evaluated once (table keyed by a
         // 50-bit hash of the words, verified word for word against the slot that opened the entry).
-#if PF_ROWS_EXP == 5
-        if (tid == 0) { p.item_unique[item] = 0; p.item_kept[item] = 0; }
-        return;
-#endif
         const uint32_t s0 = p.cluster_seg_off[c], s1 = p.cluster_seg_off[c + 1], nsegs = s1 - s0;
         const uint32_t D = p.v_nstr[c], nmw = (D + 31) >> 5;
         // (the segments are sorted by sample: the first segment of a 32-sample word is the count of those before it)
@@ -1507,10 +1405,6 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         auto mask_word = [&](uint32_t j, uint32_t i) -> uint32_t {
             return ((cm0 >> j) & 1) ? cb[(size_t)j * NS + i] : 0u;
         };
-#if PF_ROWS_EXP == 6
-        if (tid == 0) { p.item_unique[item] = 0; p.item_kept[item] = 0; }
-        return;
-#endif
         for (uint32_t i = tid; i < ns; i += ROWS_THREADS) {
             if (ordp[i] == NO_ORD) { slot_tag[i] = 0; continue; }
             uint64_t h = 0x9E3779B97F4A7C15ull;
@@ -1539,10 +1433,6 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
             slot_tag[i] = tag;
         }
         __syncthreads();
-#if PF_ROWS_EXP == 1
-        if (tid == 0) { p.item_unique[item] = 0; p.item_kept[item] = 0; }
-        return;
-#endif
         // one half-wave per mask: lane j gathers row word 32 r + j in round r, the 32 words of a round then go through
         // the row hash in order (eight blocks), every lane running it on the words read back from LDS (one broadcast
         // 128-bit read per block).  The segments a lane looks at in round 0 are the same for every mask: they are
@@ -1642,11 +1532,6 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
                 t = tn; key = nkey; word = nword;
             }
         }
-#if PF_ROWS_EXP == 2
-        __syncthreads();
-        if (tid == 0) { p.item_unique[item] = 0; p.item_kept[item] = 0; }
-        return;
-#endif
         // slots whose mask found no room in the table (rare): one evaluation each, result straight to where the
         // main loop below would put it
         for (uint32_t i = hw; i < ns; i += ROWS_THREADS / 32) {
@@ -1656,10 +1541,6 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
             if (hl == 0) { p.slot_hash[(size_t)slice * NS + i] = h; slot_tag[i] = keep ? WIDE_UNTABLED_KEEP : WIDE_UNTABLED_DROP; }
         }
         __syncthreads();
-#if PF_ROWS_EXP == 3
-        if (tid == 0) { p.item_unique[item] = 0; p.item_kept[item] = 0; }
-        return;
-#endif
         // segd is no longer needed: its place is the bitmaps' or the pairs'
         if (bitmaps) { for (uint32_t i = tid; i < 2 * DENSE_WORDS; i += ROWS_THREADS) occ[i] = 0; }
         else { for (uint32_t i = tid; i < SORT_MAX; i += ROWS_THREADS) pairs[i] = EMPTY64; }
@@ -1733,10 +1614,6 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         }
     }
     __syncthreads();
-#if PF_ROWS_EXP == 4
-    if (tid == 0) { p.item_unique[item] = 0; p.item_kept[item] = 0; }
-    return;
-#endif
 
     if (bitmaps) {
         // ranks come from the ordinal bitmaps: prefix popcounts per word, stored for emit_kernel
@@ -2061,15 +1938,12 @@ __device__ __forceinline__ uint32_t pair_lower_bound(const uint64_t* sp, uint32_
 }
 
 constexpr uint32_t EMIT_THREADS = 1024;
-#ifndef PF_LT_SLOTS
-#define PF_LT_SLOTS 1024
-#endif
 // Per-item pattern table in LDS.  1024 slots = 28 KiB: two 1024-thread workgroups per CU instead of the one that 4096
 // slots (114 KiB) allowed -- the kernel is a chain of dependent global loads per k-mer, and twice the waves hide twice
 // the latency (2 000 clusters of ~140 related alleles: emit 3.33 -> 2.12 ms at 2048 slots, 1.68 at 1024, where the three
 // passes over the table shrink too; 370 alleles: 11.4 -> 7.2 ms; tools/lt_exp.sh).  An item with more than LT_LIMIT
 // distinct patterns sends the rest straight to the run-global table.
-constexpr uint32_t LT_SLOTS = PF_LT_SLOTS;
+constexpr uint32_t LT_SLOTS = 1024;
 constexpr uint32_t LT_LIMIT = LT_SLOTS / 4 * 3;
 
 __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
@@ -2370,9 +2244,6 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
         }
     }
     PF_PROF_STAMP(0);
-#if PF_FIN_EXP == 1
-    return;                                   // timing experiment: the kernel up to here
-#endif
     // phase A: distinct allele masks
     for (uint32_t q = 0; q < nparts; q++) {
     set_part(q);
@@ -2409,9 +2280,6 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
     }
     __syncthreads();
     PF_PROF_STAMP(1);
-#if PF_FIN_EXP == 2
-    return;                                   // timing experiment: the kernel up to here
-#endif
     const uint32_t npresent = sh_npres;
     const uint32_t n_eff = p.consider_missing ? npresent : nstr;               // panfeed.py:191 / :196
     const uint32_t lo = p.maf_lo[n_eff], hi = p.maf_hi[n_eff];
@@ -2579,9 +2447,6 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
     }
     __syncthreads();
     PF_PROF_STAMP(2);
-#if PF_FIN_EXP == 3
-    return;                                   // timing experiment: the kernel up to here
-#endif
     // phase C: ordinal bitmaps, lowest ordinal per mask.  Slots whose mask did not fit the table (rare) are left to
     // a second, plain loop so that the batched one stays small.
     bool saw_untabled = false;
@@ -2635,9 +2500,6 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
     }
     __syncthreads();
     PF_PROF_STAMP(3);
-#if PF_FIN_EXP == 4
-    return;                                   // timing experiment: the kernel up to here
-#endif
     // prefix popcounts over the bitmap words
     uint32_t tot_o, tot_k;
     {
@@ -2662,9 +2524,6 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
     if (tid == 0) at_count = 0;      // from here on: number of pattern-table slots this workgroup claims
     __syncthreads();
     PF_PROF_STAMP(4);
-#if PF_FIN_EXP == 5
-    return;                                   // timing experiment: the kernel up to here
-#endif
     const uint32_t half_o = DW > 2048 ? sh_half_o : 0, half_k = DW > 2048 ? sh_half_k : 0;
     auto rank_of = [&](uint32_t o) -> uint32_t {
         return pocc[o >> 5] + __popc(occ[o >> 5] & ((1u << (o & 31)) - 1)) + (DW > 2048 && (o >> 5) >= 2048 ? half_o : 0u);
@@ -2725,9 +2584,6 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
     }
     __syncthreads();
     PF_PROF_STAMP(5);
-#if PF_FIN_EXP == 6
-    return;                                   // timing experiment: the kernel up to here
-#endif
     if (tid == 0) {
         const uint32_t nnew = at_count;
         uint32_t base = 0;
@@ -2767,9 +2623,6 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
     }
     __syncthreads();
     PF_PROF_STAMP(6);
-#if PF_FIN_EXP == 7
-    return;                                   // timing experiment: the kernel up to here
-#endif
     const uint64_t obase = sh_base - p.out_base;
     // rows of the patterns whose first_seen this workgroup lowered (at_minord is free by now: the list of their
     // mask-table positions)
@@ -2899,14 +2752,11 @@ struct PatRowsParams {
     uint32_t consider_missing;
 };
 constexpr uint32_t PR_LIST = 2048;   // winners collected per round
-#ifndef PF_PR_THREADS
-#define PF_PR_THREADS 512
-#endif
 // 512 threads: three workgroups = 24 waves per CU (the 50 KiB of LDS allow three; with 256 threads that was 12 waves, with
 // 1024 two workgroups = 32 waves but longer barriers).  Phase 1 is three dependent global loads per slot and nothing else:
 // the waves in flight are all that hides them.  2 000 clusters of ~140 related alleles: 2.05 ms at 256, 1.45 at 512,
 // 1.89 at 1024 (tools/pr_exp.sh).
-constexpr uint32_t PR_THREADS = PF_PR_THREADS;
+constexpr uint32_t PR_THREADS = 512;
 
 __global__ __launch_bounds__(PR_THREADS) void pattern_rows_kernel(PatRowsParams p) {
     // phase 1: every thread looks for k-mers whose first_seen won their pattern and appends (slot, pid) to an

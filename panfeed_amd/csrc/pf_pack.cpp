@@ -360,4 +360,14 @@ int pf_packed_view(const pf_packed* p, pf_packed_view_t* v) {
     return PF_OK;
 }
 
+// Binding helper for CPython callers (panfeed_amd/packing.py): the UTF-8 address of every `str` of an object array, through
+// the interpreter's own PyUnicode_AsUTF8 handed in as a function pointer (this library does not link against libpython).
+// One C loop instead of one ctypes call per string; the caller holds the GIL (ctypes.PyDLL).  out[i] = 0 where the API
+// returned NULL (not a str / not encodable): the caller falls back to copying.
+int pf_py_str_addresses(void* const* objs, uint64_t n, const char* (*as_utf8)(void*), uint64_t* out) {
+    if ((n && (!objs || !out)) || !as_utf8) return pk_fail(PF_ERR_ARG, "pf_py_str_addresses: null argument");
+    for (uint64_t i = 0; i < n; i++) out[i] = (uint64_t)(uintptr_t)as_utf8(objs[i]);
+    return PF_OK;
+}
+
 }  // extern "C"

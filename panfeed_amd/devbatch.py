@@ -23,6 +23,9 @@ class DeviceBatch:
         self.packed_bytes = 0
         self.n_clusters = 0
         self.n_segs = 0
+        self.n_extra = 0
+        self.idx = []            # cluster names (batch order) and the k-mer text of the slow-path rows: what the
+        self.extra_keys = []     # text renderers need beside the device results (Engine.render_device)
 
     def _alloc(self, name, nbytes):
         p = C.c_void_p()
@@ -77,6 +80,7 @@ def from_host_batch(engine, hb):
     db.n_instances = hb.n_instances
     db.packed_bytes = int(((hb.seg_len.astype(np.int64) + 3) // 4).sum())
     db.n_clusters, db.n_segs = hb.n_clusters, len(hb.seg_len)
+    db.idx, db.extra_keys = list(hb.idx), list(hb.extra_keys)
     return db
 
 
@@ -96,7 +100,7 @@ def from_synth(engine, clusters, k, canon=True, first_ordinal=0):
     cl_seg_off = np.zeros(len(clusters) + 1, dtype=np.int64)
     cl_nstr = np.zeros(len(clusters), dtype=np.uint32)
     cl_presab = np.zeros((len(clusters), W), dtype=np.uint32)
-    ex_cluster, ex_ord, ex_bits = [], [], []
+    ex_cluster, ex_ord, ex_bits, ex_keys = [], [], [], []
     n_inst = 0
 
     def add_allele(codes):
@@ -154,6 +158,7 @@ def from_synth(engine, clusters, k, canon=True, first_ordinal=0):
                 ex_cluster.append(ci)
                 ex_ord.append(o)
                 ex_bits.append(row)
+                ex_keys.append(key.decode())
         al = np.concatenate([r[0] for r in rows])
         ln = np.concatenate([r[1] for r in rows])
         sm = np.concatenate([r[2] for r in rows])
@@ -209,4 +214,5 @@ def from_synth(engine, clusters, k, canon=True, first_ordinal=0):
     db.n_extra = int(b.n_extra)
     db.packed_bytes = int(((seg_len.astype(np.int64) + 3) // 4).sum())
     db.n_clusters, db.n_segs = len(clusters), len(seg_len)
+    db.idx, db.extra_keys = [cl.idx for cl in clusters], ex_keys
     return db

@@ -136,6 +136,11 @@ def _ordered_unique(series):
     return list(dict.fromkeys(series.tolist()))
 
 
+def _first_fields(rows):
+    """the literal first field of every line of `rows` (bytes), in order"""
+    return [ln.split(b"\t", 1)[0] for ln in rows.split(b"\n") if ln]
+
+
 def get_clusters(argv=None, out=None):
     """panfeed-get-clusters: the gene clusters that have a k-mer whose pattern passes the threshold, one per line"""
     out = out or sys.stdout
@@ -164,11 +169,18 @@ def get_kmers(argv=None, out=None):
         f.close()
     h = _table(header, rows).set_index("hashed_pattern")
     clusters = _ordered_unique(h["cluster"])
+    # The device filter compares the TEXT of a row's cluster field, the reference the values pandas parsed on both sides
+    # (get_kmers.py:131-134): a cluster named '007' or '1e3' parses as a number whose str() is not the file's bytes.  The
+    # keys given to the filter are therefore the literal fields of the kept kmers_to_hashes rows, grouped by the value
+    # pandas made of them (row i of `h` is line i of `rows`).
+    literal = {}
+    for val, lit in zip(h["cluster"].tolist(), _first_fields(rows)):
+        literal.setdefault(val, {})[lit] = None
     first = True
     b = a.join(h, how="inner") if clusters else None                       # get_kmers.py:136
     for idx in range(0, len(clusters), args.clusters_per_iteration):
         bunch = clusters[idx: idx + args.clusters_per_iteration]
-        fk = RowFilter([str(c) for c in bunch], first_field=True, device=args.device)
+        fk = RowFilter([lit for c in bunch for lit in literal[c]], first_field=True, device=args.device)
         try:
             kheader, krows = fk.filter_file(args.kmers)
         finally:

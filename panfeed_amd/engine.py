@@ -215,20 +215,35 @@ class Engine:
         defer_patterns: leave hashes_to_patterns empty -- a rank of a sharded run renders its pattern rows after the
         run-global merge (`render_pattern_rows`)."""
         from concurrent.futures import ThreadPoolExecutor
+        import time as _time
         it = iter(host_batches)
+        # where the wall time of this run goes (seconds; bench.py's end-to-end leg): the packer thread's busy time
+        # (read + pack, overlapped with the GPU), the time this thread waited for it, pf_submit (upload + kernels),
+        # the text stage (device text + its copy to the host, or pf_fetch + the host renderers)
+        st = self.stages = {"pack_busy_s": 0.0, "pack_wait_s": 0.0, "submit_s": 0.0, "device_ms": 0.0, "text_s": 0.0,
+                            "batches": 0}
 
         def pack_next():
-            return next(it, None)
+            t0 = _time.perf_counter()
+            hb = next(it, None)
+            st["pack_busy_s"] += _time.perf_counter() - t0
+            return hb
 
         with ThreadPoolExecutor(max_workers=1) as pool:      # one packer thread keeps the record order
             pending = [pool.submit(pack_next) for _ in range(max(1, prefetch))]
             while pending:
+                t0 = _time.perf_counter()
                 hb = pending.pop(0).result()
+                st["pack_wait_s"] += _time.perf_counter() - t0
                 if hb is None:
                     break
                 pending.append(pool.submit(pack_next))
                 self.next_ordinal = int(hb.cluster_ordinal[-1]) + 1 if hb.n_clusters else self.next_ordinal
+                t0 = _time.perf_counter()
                 res = self.submit_host_batch(hb)
+                t1 = _time.perf_counter()
+                st["submit_s"] += t1 - t0
+                st["batches"] += 1
                 texts = None
                 if device_text and not self.multiple_files:
                     try:
@@ -248,9 +263,11 @@ class Engine:
                                  "kept_kmers": int(res.n_kept), "new_patterns": int(res.n_new_patterns),
                                  "patterns": self.pattern_count()}
                     out.timing = self.timing()
-                    yield out
-                    continue
-                yield self._render(hb, self.fetch(), defer_patterns)
+                else:
+                    out = self._render(hb, self.fetch(), defer_patterns)
+                st["text_s"] += _time.perf_counter() - t1
+                st["device_ms"] += out.timing.get("total_ms", 0.0)
+                yield out
 
     def result_checksum(self):
         """(k-mer rows, cluster rows, kept) checksums of the last submit, computed on the device (pf_result_checksum)"""

@@ -172,36 +172,29 @@ def _fill_from_packed(L, hb, handle, n_clusters, seq_ref):
         hb.targets.append(SeqMeta(ci, strain, s, 0, max(len(s.sequence) - k + 1, 0), segs, ambig))
 
 
-_ASCII_DATA_OFFSET = None      # bytes from a compact ASCII str object to its characters, found out once (see below)
-
-
 def _ascii_addresses(strings):
     """addresses (uint64 array) of the character data of ASCII `str` objects, which must stay alive while they are used.
-    The supported way, PyUnicode_AsUTF8 per string through ctypes, costs 0.4 us a string -- at 2 000 strings per cluster
-    more than everything else in the packer's Python side -- so the addresses are taken in bulk: an object array holds the
-    objects' addresses, and for compact ASCII strings the characters sit at a fixed distance behind the object header.
-    That distance is not assumed: it is measured with PyUnicode_AsUTF8 on probe strings once per process and checked
-    against the API on sixteen strings spread over every call; if anything disagrees, the API is used for all."""
+    PyUnicode_AsUTF8 per string through ctypes costs 0.4 us a string -- at 2 000 strings per cluster more than everything
+    else in the packer's Python side -- so the library walks the object array itself and calls the interpreter's
+    PyUnicode_AsUTF8 (handed over as a function pointer) for EVERY string: no assumption about how a str lays out its
+    bytes, nothing sampled.  The call goes through a GIL-holding handle (ctypes.PyDLL)."""
     import ctypes as C
-    global _ASCII_DATA_OFFSET
+    import sys
+
+    from . import _lib
     n = len(strings)
     if n == 0:
         return np.zeros(1, dtype=np.uint64)
-    as_utf8 = C.pythonapi.PyUnicode_AsUTF8
-    as_utf8.restype, as_utf8.argtypes = C.c_void_p, [C.py_object]
-    if _ASCII_DATA_OFFSET is None:
-        probes = ["ACGT", "A" * 1000, "".join("ACGT"[i & 3] for i in range(37))]
-        offs = {as_utf8(p) - id(p) for p in probes}
-        _ASCII_DATA_OFFSET = offs.pop() if len(offs) == 1 else -1
-    if _ASCII_DATA_OFFSET > 0:
-        objs = np.empty(n, dtype=object)
-        objs[:] = strings
-        addr = np.ctypeslib.as_array((C.c_uint64 * n).from_address(objs.ctypes.data)) + np.uint64(_ASCII_DATA_OFFSET)
-        # exact type only (a subclass may add fields), and a spread of spot checks against the API
-        probe = sorted({0, n - 1, *(int(x) for x in np.linspace(0, n - 1, 16))})
-        if all(type(strings[i]) is str and int(addr[i]) == as_utf8(strings[i]) for i in probe):
-            return np.ascontiguousarray(addr)
-    return np.fromiter(map(as_utf8, strings), dtype=np.uint64, count=n)
+    if sys.implementation.name != "cpython":
+        raise RuntimeError("handing str data over by address needs CPython")
+    objs = np.empty(n, dtype=object)
+    objs[:] = strings                              # the array holds the objects' addresses (and a reference each)
+    out = np.zeros(n, dtype=np.uint64)
+    as_utf8 = C.cast(C.pythonapi.PyUnicode_AsUTF8, C.c_void_p)
+    _lib.check(_lib.load_pydll().pf_py_str_addresses(C.c_void_p(objs.ctypes.data), n, as_utf8, C.c_void_p(out.ctypes.data)))
+    if not out.all():
+        raise ValueError("a sequence that is not a str")
+    return out
 
 
 def build_batch_native(records, klength, canon, W, stroi=(), first_ordinal=0, want_strand=True):

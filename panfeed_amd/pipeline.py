@@ -30,6 +30,8 @@ def run_files(presence_absence, gffdir, output, fastadir=None, klength=31, canon
     starting empty in each: `panfeed.py:35-43,153-167`) from a panaroo table and a directory (or file of files) of GFFs.  Option names and meaning follow
     the reference's (`__main__.py:86-186`); `patfilt` is what `pattern_hasher` receives (`--no-filter` inverted,
     `__main__.py:283-297`).  Returns a dict of counters."""
+    import time as _time
+    t_start = _time.perf_counter()
     if os.path.isdir(output):                       # the reference refuses an existing directory (input.py:213-216)
         raise FileExistsError(f"Output directory {output} already exists; remove it or change the output path")
     os.makedirs(output)
@@ -38,13 +40,18 @@ def run_files(presence_absence, gffdir, output, fastadir=None, klength=31, canon
                    genes=genes)
     eng = None
     stats = {"clusters": 0, "instances": 0, "kept_kmers": 0, "patterns": 0, "device_ms": 0.0, "bytes": 0}
+    stages = {"open_parse_s": _time.perf_counter() - t_start, "write_busy_s": 0.0}
     try:
+        t0 = _time.perf_counter()
         eng = Engine(klength=klength, canon=canon, consider_missing=consider_missing, patfilt=patfilt, maf=maf,
                      multiple_files=multiple_files, max_strains=max(32, (pg.n_strains + 31) // 32 * 32),
                      stroi=set(targets), device=device,
                      max_items=max_items, pattern_capacity=pattern_capacity)
+        stages["context_s"] = _time.perf_counter() - t0
+        t0 = _time.perf_counter()
         if resident:
             pg.make_resident(eng)
+        stages["genome_upload_s"] = _time.perf_counter() - t0
         cols = _Columns(pg.strains)
         if multiple_files:
             kmer_stroi = hash_pat = kmer_hash = None
@@ -101,7 +108,9 @@ def run_files(presence_absence, gffdir, output, fastadir=None, klength=31, canon
                     return
                 try:
                     if not failed:
+                        tw = _time.perf_counter()
                         write_one(o)
+                        stages["write_busy_s"] += _time.perf_counter() - tw
                 except Exception as e:          # keep draining so that the producer never blocks on a dead writer
                     failed.append(e)
                 finally:
@@ -132,6 +141,12 @@ def run_files(presence_absence, gffdir, output, fastadir=None, klength=31, canon
         if failed:
             raise failed[0]
         stats["log"] = pg.take_log()
+        # where the wall time went: opening + parsing the inputs, creating the context, uploading the genomes, then the
+        # overlapped stages of the batches (Engine.run_batches: read + pack on its thread, pf_submit = upload + kernels,
+        # text = device text + D2H or fetch + host renderers) and the writer thread's busy time
+        stages.update(getattr(eng, "stages", {}))
+        stages["total_s"] = _time.perf_counter() - t_start
+        stats["stages"] = stages
         return stats
     finally:
         pg.close()

@@ -106,9 +106,11 @@ def kept_pattern_ids(md5, first_seen, dist=None, engine=None, device=None, metho
     return ids.astype(np.uint32), int(n_global)
 
 
-def check_first_seen_disjoint(first_seen, dist):
+def check_first_seen_disjoint(first_seen, dist, device=None):
     """Ranks must not share cluster ordinals (every rank running with ordinals from 0 would make ties that keep a
-    digest twice): the ordinal ranges [min, max] of the ranks have to be disjoint and ascending with the rank."""
+    digest twice): the ordinal ranges [min, max] of the ranks have to be disjoint and ascending with the rank.
+    `device`: this rank's GPU -- under RCCL the gathered tensors have to live on it (every rank on cuda:0 is a
+    duplicate-GPU communicator error or a hang)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return
     import torch
@@ -119,7 +121,7 @@ def check_first_seen_disjoint(first_seen, dist):
     allr = [torch.zeros(2, dtype=torch.int64) for _ in range(dist.get_world_size())]
     backend = dist.get_backend()
     if backend == "nccl":
-        dev = torch.device("cuda", torch.cuda.current_device())
+        dev = device if device is not None and device.type == "cuda" else torch.device("cuda", torch.cuda.current_device())
         allr = [t.to(dev) for t in allr]
         mine = mine.to(dev)
     dist.all_gather(allr, mine)
@@ -138,7 +140,7 @@ def finish_shard(source, writer, dist=None, device=None, method="owner"):
     """After the shard's batches: exchange digests, write this rank's pattern rows.  `source`: export_patterns() and
     render_pattern_rows(ids) (an Engine).  Returns (rows written by this rank, run-global pattern count)."""
     md5, fs = source.export_patterns()
-    check_first_seen_disjoint(fs, dist)
+    check_first_seen_disjoint(fs, dist, device)
     eng = source if hasattr(source, "ctx") else None
     ids, n_global = kept_pattern_ids(md5, fs, dist, engine=eng, device=device, method=method)
     writer.write_patterns(source.render_pattern_rows(ids))
@@ -164,9 +166,19 @@ def assemble(output, world, strains, compress=False, keep_parts=False):
         shutil.rmtree(os.path.join(output, ".parts"), ignore_errors=True)
 
 
-def _barrier(dist):
+def _barrier(dist, device=None):
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        if device is not None and device.type == "cuda" and dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[device.index if device.index is not None else 0])
+        else:
+            dist.barrier()
+
+
+def _bind_device(device):
+    """one process per GPU: collectives of this process run on `device` (RCCL picks torch's current device)"""
+    if device is not None and device.type == "cuda":
+        import torch
+        torch.cuda.set_device(device)
 
 
 def run_records_sharded(records, output, strains, rank, world, dist=None, device=None, klength=31, canon=True,
@@ -177,6 +189,7 @@ def run_records_sharded(records, output, strains, rank, world, dist=None, device
     is given the same list).  Returns a dict of counters; the files are complete once rank 0 returns."""
     from .distributed import shard_range
     from .engine import Engine
+    _bind_device(device)
     records = list(records)
     start, stop = shard_range(len(records), rank, world, weights)
     max_strains = max([len(strains)] + [max(len(r[0]), len(r[2])) for r in records] + [1])
@@ -203,14 +216,15 @@ def run_files_sharded(presence_absence, gffdir, output, rank, world, dist=None, 
     from .distributed import shard_range
     from .engine import Engine
     from .native_input import Pangenome
+    _bind_device(device)
     targets = tuple(targets or ())
     exists = os.path.isdir(output)
-    _barrier(dist)                                        # every rank has looked before rank 0 creates it
+    _barrier(dist, device)                                        # every rank has looked before rank 0 creates it
     if exists:                                            # input.py:213-216
         raise FileExistsError(f"Output directory {output} already exists; remove it or change --output")
     if rank == 0:
         os.makedirs(output)
-    _barrier(dist)
+    _barrier(dist, device)
     pg = Pangenome(presence_absence, gffdir, fastadir, upstream, downstream, downstream_start_codon, targets=targets,
                    genes=genes)
     eng = None
@@ -259,7 +273,7 @@ def _drive(eng, batches, output, strains, rank, world, dist, device, compress, m
                 f_kh.close()
             stats["clusters"] += o.stats.get("clusters", 0)
             stats["instances"] += o.stats.get("instances", 0)
-        _barrier(dist)
+        _barrier(dist, device)
         return stats
     writer = ShardWriter(output, rank, compress)
     try:
@@ -273,9 +287,9 @@ def _drive(eng, batches, output, strains, rank, world, dist, device, compress, m
         stats["pattern_rows"], stats["patterns"] = finish_shard(eng, writer, dist, device, method)
     finally:
         writer.close()
-    _barrier(dist)
+    _barrier(dist, device)
     if rank == 0:
         assemble(output, world, strains, compress)
-    _barrier(dist)
+    _barrier(dist, device)
     stats["bytes"] = writer.bytes
     return stats

@@ -48,7 +48,18 @@ for method in ("owner", "allgather"):
     good = bool(torch.equal(keep.cpu(), exp)) and n == len(all_ids)
     ok = ok and good
     print(f"rank {rank}/{world} {method}: n_global {n} (expected {len(all_ids)}), keep marks {'ok' if good else 'WRONG'}", flush=True)
-dist.barrier()
+# the end of a shard (sharded.finish_shard) through RCCL on THIS rank's device: the ordinal-range check's all-gather and
+# the id selection
+import numpy as np  # noqa: E402
+from panfeed_amd import sharded  # noqa: E402
+fs_np = fs.cpu().numpy().view(np.uint64)
+sharded.check_first_seen_disjoint(fs_np, dist, dev)
+ids, n_glob = sharded.kept_pattern_ids(md5.cpu().numpy(), fs_np, dist if world > 1 else None, engine=eng, device=dev)
+good = n_glob == (len(all_ids) if world > 1 else 3000) and len(ids) == int(exp.sum() if world > 1 else 3000)
+ok = ok and good
+print(f"rank {rank}/{world} finish_shard path on {dev}: {len(ids)} rows kept of {n_glob} run-global patterns "
+      f"{'ok' if good else 'WRONG'}", flush=True)
+dist.barrier(device_ids=[local])
 dist.destroy_process_group()
 eng.close()
 sys.exit(0 if ok else 1)

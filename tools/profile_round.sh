@@ -1,13 +1,15 @@
 # bench line + rocprofv3 kernel stats + PMC passes (HBM bytes, SQ counters) of the default bench command.
-# usage (on a GPU box): bash tools/profile_round.sh [--prof-only] ; results under gpurun_out/r02/, to be copied into profiles/r02/
+# usage (on a GPU box): bash tools/profile_round.sh [--prof-only] [ROUND] ; results under gpurun_out/ROUND/ (default r03), to be
+# copied into profiles/ROUND/
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/r02
+PROF_ONLY=0; if [ "$1" = "--prof-only" ]; then PROF_ONLY=1; shift; fi
+OUT=gpurun_out/${1:-r03}
 rm -rf $OUT && mkdir -p $OUT
-if [ "$1" != "--prof-only" ]; then
+if [ "$PROF_ONLY" = 0 ]; then
 timeout -k 10 500 python bench.py --steps 5 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
 fi
-B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-every-copy-leg"
+B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-every-copy-leg --no-n-leg --no-e2e-leg"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- $B > $OUT/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o run -- $B > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o run -- $B > $OUT/write.log 2>&1
