@@ -73,6 +73,7 @@ def parse(argv=None):
     ap.add_argument("--cpu-clusters", type=int, default=0, help="clusters in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dedup", action="store_true", help="scan every copy of identical sequences (PF_FLAG_NO_DEDUP)")
+    ap.add_argument("--no-unit-dedup", action="store_true", help="scan every unit of every distinct sequence (PF_FLAG_NO_UNIT_DEDUP)")
     ap.add_argument("--no-every-copy-leg", action="store_true", help="skip the extra scan-every-copy step")
     ap.add_argument("--no-n-leg", action="store_true", help="skip the leg with SURVEY 8d's share of 'N's")
     ap.add_argument("--no-e2e-leg", action="store_true", help="skip the end-to-end (files -> files) leg")
@@ -282,7 +283,8 @@ def allele_sweep(args, local, allele_model="star"):
     rows = []
     n = 5000
     for mean_alleles in (7, 30, 60, 70, 150, 500):
-        eng = Engine(klength=k, max_strains=(S + 31) // 32 * 32, device=local, max_items=32768, pattern_capacity=1 << 24)
+        eng = Engine(klength=k, max_strains=(S + 31) // 32 * 32, device=local, max_items=32768, pattern_capacity=1 << 24,
+                     unit_dedup=not args.no_unit_dedup)
         cl = synth.generate(n, S, first=0, flank=args.flank, n_rate=0.0, mean_alleles=mean_alleles, allele_decay=1.0,
                             allele_model=allele_model)
         distinct = float(np.mean([len(np.unique(c.seq_allele)) for c in cl]))
@@ -439,8 +441,10 @@ def main():
     if args.total_clusters > 0:
         args.scaling, args.clusters = "strong", args.total_clusters
     strong = args.scaling == "strong" or (args.scaling == "auto" and world > 1)
-    eng = Engine(klength=k, max_strains=(S + 31) // 32 * 32, device=local, max_items=args.max_items,
-                 pattern_capacity=1 << 25, dedup=not args.no_dedup)
+    # (rehearsal with every rank on one GPU: the ranks share its memory, a work item's scratch slice is ~1.9 MB)
+    max_items = args.max_items if not shared else max(2048, args.max_items // (4 * world))
+    eng = Engine(klength=k, max_strains=(S + 31) // 32 * 32, device=local, max_items=max_items,
+                 pattern_capacity=1 << 25, dedup=not args.no_dedup, unit_dedup=not args.no_unit_dedup)
 
     def build(first, n_mine, n_rate=None):
         # generate + upload in slabs so the host never holds more than a slab of cluster objects
@@ -494,6 +498,9 @@ def main():
     # N > 1, strong scaling: the weak figure beside it (--clusters per GPU, rank r owns [r * clusters, (r + 1) * clusters))
     weak = None
     if world > 1 and strong and not args.no_weak_leg:
+        for d in dbs:
+            d.free()
+        dbs = []
         wdbs = build(rank * args.clusters, args.clusters)
         wstep = make_step(eng, wdbs, world, dist, dev, args.merge_method)
         wdt, wlast = timed(wstep, args.steps, args.warmup)

@@ -61,6 +61,10 @@ typedef struct {
 /* Scan every segment even when a cluster holds identical copies of a sequence (same output, slower:
    by default only one representative per distinct sequence is scanned). */
 #define PF_FLAG_NO_DEDUP 1u
+/* With the shortcut above on: scan every 64-window unit of every distinct sequence even when distinct sequences of a
+   cluster share it (same output, slower on clusters of many alleles: by default a unit that several alleles of a gene
+   hold unchanged at the same place is scanned once for all of them). */
+#define PF_FLAG_NO_UNIT_DEDUP 2u
 
 /*
  * One batch of gene clusters = the records iter_gene_clusters yields

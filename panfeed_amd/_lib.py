@@ -125,6 +125,7 @@ class Timing(C.Structure):
                 ("n_wide_clusters", C.c_uint32), ("reserved", C.c_uint32)]
 
 FLAG_NO_DEDUP = 1
+FLAG_NO_UNIT_DEDUP = 2
 
 
 # every symbol include/panfeed_hip.h declares

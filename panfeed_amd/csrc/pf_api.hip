@@ -114,6 +114,10 @@ struct pf_ctx {
     DevBuf v_word_off, v_len, v_sample, v_ord, seg_distinct, v_nseg, v_nstr, v_mode, v_dense, extra_off, extra_dense;
     DevBuf bm_occ, bm_keep, pre_occ, pre_keep, mrows, slot_out, it_is_extra, cmask_lo, cmask_hi, it_compact;
     DevBuf strand_bits, scan_desc, md5_list, wide_list;
+    DevBuf v_bits, view_off;
+    // unit view (unit_class_kernel): one pool of view entries per part of a batch's first pass, and the list
+    // {clusters, their places in the pool} that goes up with it
+    struct UPool { DevBuf word_off, len, sample, ord, bits, list; uint32_t* pin = nullptr; size_t pin_cap = 0; };
     DevBuf pat_b64, txt_dev, txt_meta;   // device-side rendering: base64 of every digest, the text, its per-row tables
     uint32_t b64_done = 0;               // patterns whose base64 is in pat_b64
     char* txt_pins[2] = {nullptr, nullptr};   // pinned host copies of the rendered text, used alternately so that a
@@ -145,6 +149,7 @@ struct pf_ctx {
     size_t pin_dedup_cap = 0;
     uint64_t* pin_small = nullptr; // pinned scratch: cursor values going up, cursor read-backs of a deferred pass
     static constexpr int MAX_PARTS = 8;
+    UPool upool[MAX_PARTS];
     hipEvent_t ev_part[MAX_PARTS] = {};    // a part's dedup results have arrived in pinned memory
     hipEvent_t ev_stage[2] = {nullptr, nullptr};   // a staging slot's upload has left the pinned block
 
@@ -454,6 +459,11 @@ void pf_destroy(pf_ctx* c) {
     for (int i = 0; i < 2; i++) { if (c->stage_pins[i]) (void)hipHostFree(c->stage_pins[i]); c->stage_devs[i].release(); if (c->ev_stage[i]) (void)hipEventDestroy(c->ev_stage[i]); }
     for (auto e : c->ev_part) if (e) (void)hipEventDestroy(e);
 
+    for (auto& u : c->upool) {
+        u.word_off.release(); u.len.release(); u.sample.release(); u.ord.release(); u.bits.release(); u.list.release();
+        if (u.pin) (void)hipHostFree(u.pin);
+    }
+    c->v_bits.release(); c->view_off.release();
     if (c->pin_dedup) (void)hipHostFree(c->pin_dedup);
     if (c->pin_small) (void)hipHostFree(c->pin_small);
     c->scan_desc.release(); c->pat_b64.release(); c->txt_dev.release(); c->txt_meta.release();
@@ -759,6 +769,8 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
     PFCHK(c->v_len.ensure(NSEG1 * 4));
     PFCHK(c->v_sample.ensure(NSEG1 * 4));
     PFCHK(c->v_ord.ensure(NSEG1 * 4));
+    PFCHK(c->v_bits.ensure(NSEG1 * 4));
+    PFCHK(c->view_off.ensure(C1 * 4));
     PFCHK(c->seg_distinct.ensure(NSEG1 * 4));
     PFCHK(c->v_nseg.ensure(C1 * 4));
     PFCHK(c->v_nstr.ensure(C1 * 4));
@@ -818,6 +830,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         dp.v_word_off = c->v_word_off.as<uint64_t>(); dp.v_len = c->v_len.as<uint32_t>();
         dp.v_sample = c->v_sample.as<uint32_t>(); dp.v_ord = c->v_ord.as<uint32_t>();
         dp.seg_distinct = c->seg_distinct.as<uint32_t>();
+        dp.v_bits = c->v_bits.as<uint32_t>(); dp.view_off = c->view_off.as<uint32_t>();
         dp.v_nseg = c->v_nseg.as<uint32_t>(); dp.v_nstr = c->v_nstr.as<uint32_t>();
         dp.v_mode = c->v_mode.as<uint32_t>(); dp.v_dense = c->v_dense.as<uint32_t>();
         dp.extra_dense = c->extra_dense.as<uint32_t>();
@@ -953,6 +966,65 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
                 }
             }
         }
+        // ---- unit view: identical 64-window units among the distinct sequences of a cluster are scanned once
+        // (unit_class_kernel).  A cluster's pieces number at most the units of its plain view: that is its room in
+        // this part's pool.
+        if (!(c->o.flags & PF_FLAG_NO_UNIT_DEDUP)) {
+            pf_ctx::UPool& up = c->upool[h];
+            const size_t need_pin = (size_t)(c1 - c0) * 8 + 64;
+            if (need_pin > up.pin_cap) {
+                if (up.pin) (void)hipHostFree(up.pin);
+                up.pin = nullptr; up.pin_cap = 0;
+                hipError_t e = hipHostMalloc((void**)&up.pin, need_pin + need_pin / 4, hipHostMallocDefault);
+                if (e != hipSuccess) return fail(PF_ERR_OOM, "hipHostMalloc(%zu) failed: %s", need_pin, hipGetErrorString(e));
+                up.pin_cap = need_pin + need_pin / 4;
+            }
+            // clusters of up to 64 distinct sequences first (one wave each, no table), then the wider ones
+            uint32_t nu = 0, nsmall = 0;
+            uint64_t room = 0;
+            uint32_t* lc = up.pin;
+            auto takes = [&](uint32_t i) { return h_mode[i] && h_vnstr[i] >= 2 && words[i] && room + words[i] / 2 < 0x7FFFFFF0ull; };
+            for (uint32_t i = c0; i < c1; i++)
+                if (h_vnstr[i] <= pf::UNIT_SMALL_MAX_D && takes(i)) { lc[nu++] = i; room += words[i] / 2; }
+            nsmall = nu;
+            for (uint32_t i = c0; i < c1; i++)
+                if (h_vnstr[i] > pf::UNIT_SMALL_MAX_D && takes(i)) { lc[nu++] = i; room += words[i] / 2; }
+            uint32_t* lb = up.pin + nu;
+            room = 0;
+            for (uint32_t j = 0; j < nu; j++) { lb[j] = (uint32_t)room; room += words[lc[j]] / 2; }
+            if (nu) {
+                const size_t R = (size_t)room + 1;
+                PFCHK(up.word_off.ensure(R * 8)); PFCHK(up.len.ensure(R * 4)); PFCHK(up.sample.ensure(R * 4));
+                PFCHK(up.ord.ensure(R * 4)); PFCHK(up.bits.ensure(R * 4)); PFCHK(up.list.ensure((size_t)nu * 8));
+                HIPCHK(hipMemcpyAsync(up.list.p, up.pin, (size_t)nu * 8, hipMemcpyHostToDevice, c->stream));
+                pf::UnitParams q{};
+                q.packed = d.packed; q.cluster_seg_off = d.cluster_seg_off; q.v_nstr = c->v_nstr.as<uint32_t>();
+                q.list_cluster = up.list.as<uint32_t>(); q.list_base = up.list.as<uint32_t>() + nu;
+                q.v_word_off = c->v_word_off.as<uint64_t>(); q.v_len = c->v_len.as<uint32_t>(); q.v_ord = c->v_ord.as<uint32_t>();
+                q.u_word_off = up.word_off.as<uint64_t>(); q.u_len = up.len.as<uint32_t>(); q.u_sample = up.sample.as<uint32_t>();
+                q.u_ord = up.ord.as<uint32_t>(); q.u_bits = up.bits.as<uint32_t>();
+                q.v_nseg = c->v_nseg.as<uint32_t>(); q.view_off = c->view_off.as<uint32_t>(); q.k = c->o.klength;
+                PFCHK(mark_begin(c, 3));
+                if (nsmall) {
+                    const dim3 g((nsmall + 3) / 4), b(256);
+                    switch ((63 + c->o.klength + 31) / 32) {       // words a unit's 63 + k bases take
+                        case 2: hipLaunchKernelGGL(pf::unit_class_small_kernel<2>, g, b, 0, c->stream, q, nsmall); break;
+                        case 3: hipLaunchKernelGGL(pf::unit_class_small_kernel<3>, g, b, 0, c->stream, q, nsmall); break;
+                        case 4: hipLaunchKernelGGL(pf::unit_class_small_kernel<4>, g, b, 0, c->stream, q, nsmall); break;
+                        case 5: hipLaunchKernelGGL(pf::unit_class_small_kernel<5>, g, b, 0, c->stream, q, nsmall); break;
+                        default: hipLaunchKernelGGL(pf::unit_class_small_kernel<6>, g, b, 0, c->stream, q, nsmall); break;
+                    }
+                    HIPCHK(hipGetLastError());
+                }
+                if (nu > nsmall) {
+                    pf::UnitParams qw = q;
+                    qw.list_cluster += nsmall; qw.list_base += nsmall;
+                    hipLaunchKernelGGL(pf::unit_class_kernel, dim3(nu - nsmall), dim3(pf::UNIT_THREADS), 0, c->stream, qw);
+                    HIPCHK(hipGetLastError());
+                }
+                PFCHK(mark_end(c));
+            }
+        }
         return PF_OK;
     };
     uint32_t pass = 0;
@@ -984,12 +1056,13 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         std::vector<uint8_t>& item_fused = c->hs_fused;      // 0 unfused, 1 fused small class, 2 fused large class
         items.clear(); item_fused.clear();
         items.reserve(todo.size() + 64); item_fused.reserve(todo.size() + 64);
-        struct Sub { uint32_t item0, nitems, cl0, ncl; };
+        struct Sub { uint32_t item0, nitems, cl0, ncl, part; };
+        auto part_of = [&](uint32_t ci) { uint32_t q = 0; while (q + 1 < P && ci >= part_end[q]) q++; return q; };
         std::vector<Sub> subs;
         std::vector<uint32_t>&sub_cluster = c->hs_sub[0], &sub_item0 = c->hs_sub[1], &sub_nitems = c->hs_sub[2];
         sub_cluster.clear(); sub_item0.clear(); sub_nitems.clear();
         uint64_t arena_cap = 0;
-        Sub cur{0, 0, 0, 0};
+        Sub cur{0, 0, 0, 0, todo.empty() ? 0u : part_of(todo[0])};
         for (uint32_t ci : todo) {
             const uint32_t np = nparts[ci];
             const uint32_t nex = ex_first[ci + 1] - ex_first[ci];
@@ -1014,10 +1087,12 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             const uint32_t nit = np + nex_items;
             if (nit > c->max_items)
                 return fail(PF_ERR_CAPACITY, "cluster %u needs %u work items; raise max_items (%u)", ci, nit, c->max_items);
-            if (cur.nitems + nit > c->max_items) {
+            // (a launch reads one part's unit-view pool: a re-run pass does not mix the parts' clusters in a sub-batch)
+            if (cur.nitems + nit > c->max_items || (cur.nitems && part_of(ci) != cur.part)) {
                 subs.push_back(cur);
-                cur = Sub{(uint32_t)items.size(), 0, (uint32_t)sub_cluster.size(), 0};
+                cur = Sub{(uint32_t)items.size(), 0, (uint32_t)sub_cluster.size(), 0, part_of(ci)};
             }
+            if (!cur.nitems) cur.part = part_of(ci);
             const uint32_t sib0 = (uint32_t)items.size();
             // table size: a cluster that cannot overflow a small table gets one (less flush traffic)
             uint32_t ns = NS;
@@ -1156,7 +1231,13 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
                 pf::ScanParams sp{};
                 sp.packed = d.packed; sp.seg_word_off = c->v_word_off.as<uint64_t>(); sp.seg_len = c->v_len.as<uint32_t>();
                 sp.seg_sample = c->v_sample.as<uint32_t>(); sp.seg_ord_base = c->v_ord.as<uint32_t>();
-                sp.cluster_seg_off = d.cluster_seg_off; sp.cluster_vnseg = c->v_nseg.as<uint32_t>();
+                sp.seg_bits = c->v_bits.as<uint32_t>();
+                {
+                    const pf_ctx::UPool& up = c->upool[sb.part];
+                    sp.u_word_off = up.word_off.as<uint64_t>(); sp.u_len = up.len.as<uint32_t>(); sp.u_sample = up.sample.as<uint32_t>();
+                    sp.u_ord_base = up.ord.as<uint32_t>(); sp.u_bits = up.bits.as<uint32_t>();
+                }
+                sp.cluster_seg_off = c->view_off.as<uint32_t>(); sp.cluster_vnseg = c->v_nseg.as<uint32_t>();
                 sp.cluster_vnstr = c->v_nstr.as<uint32_t>();
                 sp.item_cluster = c->it_cluster.as<uint32_t>(); sp.item_part = c->it_part.as<uint32_t>();
                 sp.item_nparts = c->it_nparts.as<uint32_t>(); sp.item_nslots = c->it_nslots.as<uint32_t>();

@@ -130,7 +130,11 @@ struct ScanParams {
     const uint32_t* seg_len;          // view
     const uint32_t* seg_sample;       // view: sample column (mode 0) / distinct index (mode 1)
     const uint32_t* seg_ord_base;     // view: instance ordinal of the segment's first window
-    const uint32_t* cluster_seg_off;  // first view segment of the cluster
+    const uint32_t* seg_bits;         // view: presence bits a window of the segment sets in its chunk's word
+    // the unit view (unit_class_kernel) of the clusters that have one: same five arrays in a pool of their own;
+    // cluster_seg_off[c] carries VIEW_IN_POOL then
+    const uint64_t* u_word_off; const uint32_t* u_len; const uint32_t* u_sample; const uint32_t* u_ord_base; const uint32_t* u_bits;
+    const uint32_t* cluster_seg_off;  // first view segment of the cluster (view_off)
     const uint32_t* cluster_vnseg;    // view segments of the cluster
     const uint32_t* cluster_vnstr;    // columns of the view (len(cluster) / distinct sequences)
     // per item (item = work[blockIdx.x])
@@ -161,6 +165,7 @@ struct ScanParams {
 // One 64-byte record per work entry, so that a workgroup starts an item with one load instead of a chain of
 // four dependent ones (work -> item arrays -> cluster arrays); the scan kernel requests the next one while it
 // works on the current item.
+constexpr uint32_t VIEW_IN_POOL = 0x80000000u;   // view_off flag: the cluster's view is in the unit-view pool
 struct ScanDesc { uint32_t item, c, part, nparts, ns, slice, seg0, nseg, nstr, compact, pad[6]; };
 static_assert(sizeof(ScanDesc) == 64, "ScanDesc is read as 16 words");
 
@@ -383,7 +388,8 @@ constexpr uint32_t M_TMP = M_UPREF + SEG_TILE + 2;                       // one 
 constexpr uint32_t M_PROG = M_TMP + 1;                                   // unit index at which the table was found full
 constexpr uint32_t M_DESC = M_TMP + 2;                                   // [16] the current item's ScanDesc
 constexpr uint32_t M_NDESC = M_DESC + 16;                                // [16] the next item's
-static_assert(M_NDESC + 16 <= MISC_WORDS, "misc area too small");
+constexpr uint32_t M_BITS = M_NDESC + 16;                                // [SEG_TILE] presence bits of the staged segments
+static_assert(M_BITS + SEG_TILE <= MISC_WORDS, "misc area too small");
 
 // Persistent: gridDim.x workgroups (one per CU: the table takes the whole LDS) walk work entries
 // blockIdx.x, blockIdx.x + gridDim.x, ...  With one workgroup per CU nothing else hides the dependent global
@@ -402,12 +408,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
     const uint32_t k = p.k;
 
     // first-tile metadata of the item about to start, one segment per thread (tid < SEG_TILE)
-    uint32_t pm_len = 0, pm_ordb = 0, pm_sample = 0;
+    uint32_t pm_len = 0, pm_ordb = 0, pm_sample = 0, pm_bits = 0;
     uint64_t pm_wo = 0;
-    auto fetch_tile0 = [&](uint32_t seg0, uint32_t nseg) {
+    auto fetch_tile0 = [&](uint32_t seg0raw, uint32_t nseg) {
         if (tid < min(nseg, SEG_TILE)) {
-            const uint32_t s = seg0 + tid;
-            pm_len = p.seg_len[s]; pm_wo = p.seg_word_off[s]; pm_ordb = p.seg_ord_base[s]; pm_sample = p.seg_sample[s];
+            const uint32_t s = (seg0raw & ~VIEW_IN_POOL) + tid;
+            if (seg0raw & VIEW_IN_POOL) {
+                pm_len = p.u_len[s]; pm_wo = p.u_word_off[s]; pm_ordb = p.u_ord_base[s]; pm_sample = p.u_sample[s];
+                pm_bits = p.u_bits[s];
+            } else {
+                pm_len = p.seg_len[s]; pm_wo = p.seg_word_off[s]; pm_ordb = p.seg_ord_base[s]; pm_sample = p.seg_sample[s];
+                pm_bits = p.seg_bits[s];
+            }
         }
     };
     if (blockIdx.x < p.n_work) {
@@ -432,7 +444,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
     const uint32_t item = misc[dcur + 0], c = misc[dcur + 1];
     const uint32_t part = misc[dcur + 2], nparts = misc[dcur + 3];
     const uint32_t ns = misc[dcur + 4], slice = misc[dcur + 5];
-    const uint32_t seg0 = misc[dcur + 6], seg1 = seg0 + misc[dcur + 7];
+    const bool in_pool = (misc[dcur + 6] & VIEW_IN_POOL) != 0;
+    const uint32_t seg0 = misc[dcur + 6] & ~VIEW_IN_POOL, seg1 = seg0 + misc[dcur + 7];
+    const uint64_t* const a_woff = in_pool ? p.u_word_off : p.seg_word_off;
+    const uint32_t* const a_len = in_pool ? p.u_len : p.seg_len;
+    const uint32_t* const a_sample = in_pool ? p.u_sample : p.seg_sample;
+    const uint32_t* const a_ordb = in_pool ? p.u_ord_base : p.seg_ord_base;
+    const uint32_t* const a_bits = in_pool ? p.u_bits : p.seg_bits;
     const uint32_t nstr = misc[dcur + 8];
     const bool compact = misc[dcur + 9] != 0;  // view has <= 64 columns: at most chunks 0 and 1
     const uint32_t nchunks = (nstr + 31) >> 5;
@@ -448,7 +466,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
     const bool one_tile = seg1 - seg0 <= SEG_TILE;
     if (!one_tile) {
         for (uint32_t ch = tid; ch <= nchunks; ch += SCAN_THREADS)
-            misc[M_CHUNK + ch] = seg_lower_bound(p.seg_sample, seg0, seg1, ch << 5);
+            misc[M_CHUNK + ch] = seg_lower_bound(a_sample, seg0, seg1, ch << 5);
     }
     {   // tile 0 from the registers filled during the previous item
         const uint32_t nseg = min(SEG_TILE, seg1 - seg0);
@@ -458,6 +476,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
             misc[M_NINST + tid] = pm_len >= k ? pm_len - k + 1 : 0;
             misc[M_ORDB + tid] = pm_ordb;
             misc[M_SAMPLE + tid] = pm_sample;
+            misc[M_BITS + tid] = pm_bits;
         }
     }
     __syncthreads();
@@ -493,13 +512,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
         // ---- stage this tile's segment metadata (coalesced; tile 0 is there already), then unit prefix by wave 0
         if (t0 != seg0 && tid < nseg) {
             const uint32_t s = t0 + tid;
-            const uint32_t len = p.seg_len[s];
-            const uint64_t wo = p.seg_word_off[s];
+            const uint32_t len = a_len[s];
+            const uint64_t wo = a_woff[s];
             misc[M_WOFF + 2 * tid] = (uint32_t)wo;
             misc[M_WOFF + 2 * tid + 1] = (uint32_t)(wo >> 32);
             misc[M_NINST + tid] = len >= k ? len - k + 1 : 0;
-            misc[M_ORDB + tid] = p.seg_ord_base[s];
-            misc[M_SAMPLE + tid] = p.seg_sample[s];
+            misc[M_ORDB + tid] = a_ordb[s];
+            misc[M_SAMPLE + tid] = a_sample[s];
+            misc[M_BITS + tid] = a_bits[s];
         }
         __syncthreads();
         if (wave == 0) {
@@ -548,11 +568,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
             uint32_t g = ubase + wave;
             const uint32_t gend = ubase + utot;
             if (g < gend) {
-                uint32_t s = lo;
+                uint32_t s = in_pool ? lo + (g - ubase) : lo;      // (a piece of the unit view holds exactly one unit)
                 while (g >= misc[M_UPREF + s + 1]) s++;
                 uint32_t send = misc[M_UPREF + s + 1];      // first unit past segment s
                 uint32_t u = g - misc[M_UPREF + s];
-                uint32_t ninst = misc[M_NINST + s], ordb = misc[M_ORDB + s], bit = 1u << (misc[M_SAMPLE + s] & 31);
+                uint32_t ninst = misc[M_NINST + s], ordb = misc[M_ORDB + s], bit = misc[M_BITS + s];
                 const uint64_t* q = p.packed + (((uint64_t)misc[M_WOFF + 2 * s + 1] << 32) | misc[M_WOFF + 2 * s]) +
                                     2 * (size_t)u + (lane >> 5);
                 uint64_t cw[KW + 1];
@@ -567,12 +587,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
                     if (gn < gend) {
                         if (gn < send) { qn = q + 2 * SCAN_WAVES; un = u + SCAN_WAVES; }
                         else {
-                            sn = s + 1;
+                            sn = in_pool ? lo + (gn - ubase) : s + 1;
                             while (gn >= misc[M_UPREF + sn + 1]) sn++;
                             sendn = misc[M_UPREF + sn + 1];
                             un = gn - misc[M_UPREF + sn];
                             ninstn = misc[M_NINST + sn]; ordbn = misc[M_ORDB + sn];
-                            bitn = 1u << (misc[M_SAMPLE + sn] & 31);
+                            bitn = misc[M_BITS + sn];
                             qn = p.packed + (((uint64_t)misc[M_WOFF + 2 * sn + 1] << 32) | misc[M_WOFF + 2 * sn]) +
                                  2 * (size_t)un + (lane >> 5);
                         }
@@ -619,7 +639,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
         // of a cluster brings more new keys than the later ones: the extrapolation errs on the safe side).
         uint32_t tot = 0;
         for (uint32_t s = seg0 + tid; s < seg1; s += SCAN_THREADS) {
-            const uint32_t len = p.seg_len[s];
+            const uint32_t len = a_len[s];
             tot += len >= k ? (len - k + 64) >> 6 : 0;
         }
         for (int d = 1; d < 64; d <<= 1) tot += __shfl_xor(tot, d);
@@ -775,7 +795,9 @@ struct DedupParams {
     const uint32_t* extra_ord;        // [n_extra]
     uint64_t* v_word_off; uint32_t* v_len; uint32_t* v_sample; uint32_t* v_ord;   // view, [n_segs]
     uint32_t* seg_distinct;           // [n_segs] distinct index of every original segment (modes 1, 2)
+    uint32_t* v_bits;                 // view, [n_segs]: the presence bits a window of the segment sets in its chunk's word
     uint32_t* v_nseg; uint32_t* v_nstr; uint32_t* v_mode; uint32_t* v_dense;       // [C]
+    uint32_t* view_off;               // [C] first entry of the cluster's view in the view arrays
     uint32_t* extra_dense;            // [n_extra] ordinal of the extra row in the cluster's (dense) numbering
     uint32_t k, W, canon, enable;
     uint32_t cluster_base;            // first cluster of this launch (the batch's clusters may be launched in two halves)
@@ -1046,8 +1068,11 @@ void cluster_dedup_kernel(DedupParams p) {
             }
         __syncthreads();
         const uint32_t D = sh_nrep;
-        const bool worth = 2 * D <= n;                    // at least half of the segments are copies (a lower bar was
-                                                          // measured on clusters of 140 and 370 related alleles: no gain)
+        // The view of distinct sequences is taken whenever it fits.  (Rounds 1-2 asked for at least half of the segments
+        // to be copies: with fewer, mode 0's direct sample columns were as fast.  With the unit view the scan of the
+        // distinct sequences is several times cheaper than the scan of every copy, and the rule only kept a third of the
+        // accessory clusters of a many-allele pangenome on the every-copy path: profiles/r03/worth_rule_experiment.txt.)
+        const bool worth = true;
         if (CFG::MODE == 1) {
             // what the wide class can still do for this cluster: more distinct sequences, no sample-set matrix, no
             // ordinal bitmap; (a hash collision or too few copies stay mode 0)
@@ -1095,6 +1120,7 @@ void cluster_dedup_kernel(DedupParams p) {
                     p.v_word_off[seg0 + d] = p.seg_word_off[seg0 + s];
                     p.v_len[seg0 + d] = p.seg_len[seg0 + s];
                     p.v_sample[seg0 + d] = d;
+                    p.v_bits[seg0 + d] = 1u << (d & 31);
                     p.v_ord[seg0 + d] = r_dense[d];
                 }
                 for (uint32_t e = ex0 + tid; e < ex1; e += DEDUP_THREADS) {
@@ -1111,6 +1137,7 @@ void cluster_dedup_kernel(DedupParams p) {
                     p.extra_dense[e] = (below + er) * mult;
                 }
                 if (tid == 0) {
+                    p.view_off[c] = seg0;
                     p.v_nseg[c] = D; p.v_nstr[c] = D; p.v_mode[c] = CFG::MODE;
                     p.v_dense[c] = (uint32_t)min(dense_bits, (uint64_t)0xFFFFFFFFu);
                 }
@@ -1122,16 +1149,269 @@ void cluster_dedup_kernel(DedupParams p) {
         for (uint32_t s = tid; s < n; s += DEDUP_THREADS) {
             p.v_word_off[seg0 + s] = p.seg_word_off[seg0 + s];
             p.v_len[seg0 + s] = p.seg_len[seg0 + s];
-            p.v_sample[seg0 + s] = p.seg_sample[seg0 + s];
+            const uint32_t smp = p.seg_sample[seg0 + s];
+            p.v_sample[seg0 + s] = smp;
+            p.v_bits[seg0 + s] = 1u << (smp & 31);
             p.v_ord[seg0 + s] = p.seg_ord_base[seg0 + s];
         }
         for (uint32_t e = ex0 + tid; e < ex1; e += DEDUP_THREADS) p.extra_dense[e] = p.extra_ord[e];
         if (tid == 0) {
+            p.view_off[c] = seg0;
             p.v_nseg[c] = n; p.v_nstr[c] = p.cluster_nstrains[c]; p.v_dense[c] = 0;
             p.v_mode[c] = retry_wide ? MODE_RETRY_WIDE : 0;
         }
     }
     (void)lane;
+}
+
+// ---------------------------------------------------------------------------------------------
+// unit_class_kernel: identical 64-window units among the distinct sequences of a cluster
+// ---------------------------------------------------------------------------------------------
+// The distinct sequences of a cluster are alleles of one gene: they differ in a few positions, so most of their
+// 64-window units -- the 64 + k - 1 bases that the windows starting at bases 64u .. 64u + 63 cover -- are the same
+// bases at the same place in many of them.  Units of different distinct sequences with the same u and the same
+// content form a class: its windows are the same k-mers at the same offsets, so ONE scan of the class's first member
+// (lowest distinct index = lowest ordinals: the view is in ordinal order, so its windows are the first occurrences,
+// panfeed.py:77-79) with ALL the members' column bits gives what scanning every member would.  Exact: members are
+// compared with the class's first member word for word; two different contents with one hash send the cluster back to
+// the plain view.  The scan view of such a cluster becomes a list of one-unit pieces {words, bases, ordinal of the
+// first window, chunk of 32 columns, the members' bits in that chunk}, sorted by chunk -- a class whose members spread
+// over several chunks is listed once per chunk.
+struct UnitParams {
+    const uint64_t* packed;
+    const uint32_t* cluster_seg_off;       // the plain view of cluster c sits at [seg0, seg0 + D) of the view arrays
+    const uint32_t* v_nstr;                // [C] D
+    const uint32_t* list_cluster;          // [n] clusters of this launch
+    const uint32_t* list_base;             // [n] where the cluster's pieces go in the view arrays (room: its units)
+    const uint64_t* v_word_off; const uint32_t* v_len; const uint32_t* v_ord;     // the plain view
+    uint64_t* u_word_off; uint32_t* u_len; uint32_t* u_sample; uint32_t* u_ord; uint32_t* u_bits;   // the pool
+    uint32_t* v_nseg; uint32_t* view_off;  // [C] rewritten when the cluster takes the unit view
+    uint32_t k;
+};
+constexpr uint32_t UNIT_THREADS = 256;
+constexpr uint32_t UNIT_TAB = 4096;            // class-table slots per batch of unit positions
+constexpr uint32_t UNIT_PAIRS = 2048;          // (distinct sequence, unit) pairs per batch: half the table
+constexpr uint32_t UNIT_PER_THREAD = UNIT_PAIRS / UNIT_THREADS;
+constexpr uint32_t UNIT_MAX_WORDS = 6;         // ceil((63 + PF_MAX_K) / 32)
+
+__global__ __launch_bounds__(UNIT_THREADS) void unit_class_kernel(UnitParams p) {
+    __shared__ uint64_t t_hash[UNIT_TAB];
+    __shared__ uint32_t t_min[UNIT_TAB];                 // lowest pair index of the class = its first member
+    __shared__ uint32_t d_len[DEDUP_MAX_D_WIDE], d_ord[DEDUP_MAX_D_WIDE];
+    __shared__ uint32_t d_wlo[DEDUP_MAX_D_WIDE], d_whi[DEDUP_MAX_D_WIDE];
+    __shared__ uint32_t ch_cnt[DEDUP_MAX_D_WIDE / 32], ch_base[DEDUP_MAX_D_WIDE / 32 + 1];
+    __shared__ uint32_t sh_bad;
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, half = (lane >> 5) << 5;
+    const uint32_t c = p.list_cluster[blockIdx.x], base = p.list_base[blockIdx.x];
+    const uint32_t seg0 = p.cluster_seg_off[c], D = p.v_nstr[c], k = p.k;
+    if (D < 2 || D > DEDUP_MAX_D_WIDE) return;
+    const uint32_t Dp = (D + 31) & ~31u, nchunks = Dp >> 5;
+    uint32_t maxlen = 0;
+    for (uint32_t d = tid; d < D; d += UNIT_THREADS) {
+        const uint64_t wo = p.v_word_off[seg0 + d];
+        const uint32_t len = p.v_len[seg0 + d];
+        d_len[d] = len; d_ord[d] = p.v_ord[seg0 + d]; d_wlo[d] = (uint32_t)wo; d_whi[d] = (uint32_t)(wo >> 32);
+        maxlen = max(maxlen, len);
+    }
+    for (uint32_t i = tid; i < nchunks; i += UNIT_THREADS) ch_cnt[i] = 0;
+    if (tid == 0) sh_bad = 0;
+    for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o));
+    __shared__ uint32_t sh_max[UNIT_THREADS / 64];
+    if (lane == 0) sh_max[tid >> 6] = maxlen;
+    __syncthreads();
+    maxlen = max(max(sh_max[0], sh_max[1]), max(sh_max[2], sh_max[3]));
+    if (maxlen < k) return;                                          // no window anywhere: the plain view is empty work
+    const uint32_t nunits = (maxlen - k + 64) >> 6;                  // unit positions of the longest sequence
+    const uint32_t UB = max(1u, UNIT_PAIRS / Dp);                    // unit positions per batch (Dp <= 1024 <= UNIT_PAIRS)
+    const uint32_t span = 63 + k;                                    // bases a full unit covers
+
+    // pass 0 counts the pieces per chunk, pass 1 writes them behind the chunk's base
+    for (int pass = 0; pass < 2; pass++) {
+        for (uint32_t u0 = 0; u0 < nunits; u0 += UB) {
+            const uint32_t ub_n = min(UB, nunits - u0), npairs = ub_n * Dp;
+            for (uint32_t i = tid; i < UNIT_TAB; i += UNIT_THREADS) { t_hash[i] = EMPTY64; t_min[i] = 0xFFFFFFFFu; }
+            __syncthreads();
+            // ---- every pair finds or opens its class (hash of the unit's bases, its length and its position)
+            uint32_t my_slot[UNIT_PER_THREAD];
+#pragma unroll
+            for (uint32_t r = 0; r < UNIT_PER_THREAD; r++) {
+                my_slot[r] = 0xFFFFFFFFu;
+                const uint32_t pi = tid + r * UNIT_THREADS;
+                if (pi >= npairs) continue;
+                const uint32_t ub = pi / Dp, d = pi - ub * Dp, u = u0 + ub;
+                if (d >= D) continue;
+                const uint32_t len = d_len[d];
+                if (len < k || 64 * u + k > len) continue;            // the sequence has no window in this unit
+                const uint32_t nb = min(len - 64 * u, span), nw = (nb + 31) >> 5;
+                const uint64_t* w = p.packed + (((uint64_t)d_whi[d] << 32) | d_wlo[d]) + 2 * (size_t)u;
+                uint64_t h = 0x9E3779B97F4A7C15ull * (nb + 1) + u;
+                for (uint32_t j = 0; j < nw; j++) {
+                    uint64_t x = w[j];
+                    if (j + 1 == nw && (nb & 31)) x &= ~0ull << (64 - 2 * (nb & 31));      // bases past the unit's span
+                    h = mix64(h ^ x) + 0xC2B2AE3D27D4EB4Full * (j + 1);
+                }
+                if (h == EMPTY64) h = EMPTY64 - 1;
+                uint32_t sl = (uint32_t)(h >> 20) & (UNIT_TAB - 1);
+                for (;;) {
+                    uint64_t cur = __hip_atomic_load(&t_hash[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (cur == EMPTY64)
+                        cur = atomicCAS((unsigned long long*)&t_hash[sl], (unsigned long long)EMPTY64, (unsigned long long)h);
+                    if (cur == EMPTY64 || cur == h) break;
+                    sl = (sl + 1) & (UNIT_TAB - 1);                   // at most UNIT_PAIRS entries: an empty slot exists
+                }
+                atomicMin(&t_min[sl], pi);
+                my_slot[r] = sl;
+            }
+            __syncthreads();
+            // ---- exactness: every member against the class's first member, word for word
+#pragma unroll
+            for (uint32_t r = 0; r < UNIT_PER_THREAD; r++) {
+                if (my_slot[r] == 0xFFFFFFFFu || pass) continue;
+                const uint32_t pi = tid + r * UNIT_THREADS, fi = t_min[my_slot[r]];
+                if (fi == pi) continue;
+                const uint32_t ub = pi / Dp, d = pi - ub * Dp, u = u0 + ub, fd = fi - (fi / Dp) * Dp;
+                bool diff = fi / Dp != ub;
+                const uint32_t nb = min(d_len[d] - 64 * u, span), nw = (nb + 31) >> 5;
+                if (!diff) diff = min(d_len[fd] - 64 * u, span) != nb;
+                if (!diff) {
+                    const uint64_t* a = p.packed + (((uint64_t)d_whi[d] << 32) | d_wlo[d]) + 2 * (size_t)u;
+                    const uint64_t* b = p.packed + (((uint64_t)d_whi[fd] << 32) | d_wlo[fd]) + 2 * (size_t)u;
+                    for (uint32_t j = 0; j < nw; j++) {
+                        uint64_t x = a[j] ^ b[j];
+                        if (j + 1 == nw && (nb & 31)) x &= ~0ull << (64 - 2 * (nb & 31));
+                        diff = diff || x != 0;
+                    }
+                }
+                if (diff) sh_bad = 1;
+            }
+            // ---- the members of a class inside one chunk of 32 columns -> one piece.  Pair index = ub * Dp + d with Dp a
+            // multiple of 32: the 32 lanes of a half-wave hold the 32 columns of one (unit, chunk).
+#pragma unroll
+            for (uint32_t r = 0; r < UNIT_PER_THREAD; r++) {
+                const uint32_t pi0 = r * UNIT_THREADS + (tid & ~63u);            // first pair of this wave in round r
+                if (pi0 >= npairs) continue;                                      // wave-uniform
+                const uint32_t pi = tid + r * UNIT_THREADS;
+                const uint32_t ub = pi / Dp, d = pi - ub * Dp, u = u0 + ub, chunk = d >> 5;
+                bool todo = my_slot[r] != 0xFFFFFFFFu;
+                while (__any(todo)) {
+                    const uint64_t bal = __ballot(todo);
+                    const uint32_t mine = (uint32_t)(bal >> half);               // this half-wave's lanes
+                    uint32_t leader = mine ? (uint32_t)__builtin_ctz(mine) + half : lane;
+                    const uint32_t lslot = __shfl(my_slot[r], leader);
+                    const bool same = todo && my_slot[r] == lslot;
+                    const uint32_t members = (uint32_t)(__ballot(same) >> half);
+                    if (todo && lane == leader) {
+                        if (pass == 0) {
+                            atomicAdd(&ch_cnt[chunk], 1u);
+                        } else {
+                            const uint32_t fi = t_min[my_slot[r]], fd = fi - (fi / Dp) * Dp;
+                            const uint32_t at = base + ch_base[chunk] + atomicAdd(&ch_cnt[chunk], 1u);
+                            p.u_word_off[at] = (((uint64_t)d_whi[fd] << 32) | d_wlo[fd]) + 2 * (uint64_t)u;
+                            p.u_len[at] = min(d_len[fd] - 64 * u, span);
+                            p.u_ord[at] = d_ord[fd] + 64 * u;
+                            p.u_sample[at] = chunk << 5;
+                            p.u_bits[at] = members;
+                        }
+                    }
+                    if (same) todo = false;
+                }
+            }
+            __syncthreads();
+        }
+        if (sh_bad) return;                                          // (uniform) the cluster keeps its plain view
+        if (pass == 0) {
+            if (tid == 0) {
+                uint32_t run = 0;
+                for (uint32_t i = 0; i < nchunks; i++) { ch_base[i] = run; run += ch_cnt[i]; ch_cnt[i] = 0; }
+                ch_base[nchunks] = run;
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) { p.view_off[c] = base | VIEW_IN_POOL; p.v_nseg[c] = ch_base[nchunks]; }
+}
+
+// The same for a cluster of at most 64 distinct sequences (every mode-1 cluster: the usual case), without a table: one
+// WAVE per cluster, lane d holds distinct sequence d, and for every unit position the lanes are grouped by comparing
+// their unit's words with the lowest remaining lane's (v_readlane: the leader is wave-uniform) -- exact by
+// construction, no hash, no LDS, no barrier.  A class gives one piece per chunk of 32 columns it has members in; chunk-1
+// pieces go behind all chunk-0 pieces, so a cluster of more than 32 distinct sequences is walked twice (the first walk
+// only counts).
+constexpr uint32_t UNIT_SMALL_MAX_D = 64;
+template <int NW>     // 64-bit words a unit's 63 + k bases take: ceil((63 + k) / 32)
+__global__ __launch_bounds__(256) void unit_class_small_kernel(UnitParams p, uint32_t n) {
+    // One wave per cluster.  The wave's lanes are G = 4 .. 64 columns (the next power of two >= D) x 64 / G unit positions:
+    // with lane = distinct sequence alone, a cluster of 8 alleles left 56 lanes idle and the kernel was bound by
+    // instruction issue (9 000 wave-instructions per cluster, 0.7 ms per 50 000 clusters).  Classes inside a group of G
+    // lanes: the group's lowest remaining lane leads, everyone compares its unit with the leader's (ds_bpermute), the
+    // members leave; a class gives one piece per chunk of 32 columns it has members in.  Chunk-1 pieces go behind all
+    // chunk-0 pieces, so a cluster of more than 32 distinct sequences is walked twice (the first walk only counts).
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (wi >= n) return;                                             // (whole waves)
+    const uint32_t c = p.list_cluster[wi], base = p.list_base[wi];
+    const uint32_t seg0 = p.cluster_seg_off[c], D = p.v_nstr[c], k = p.k;
+    if (D < 2 || D > UNIT_SMALL_MAX_D) return;
+    const uint32_t G = D <= 4 ? 4u : D <= 8 ? 8u : D <= 16 ? 16u : D <= 32 ? 32u : 64u, UPR = 64 / G;
+    const uint32_t d = lane & (G - 1), gbase = lane & ~(G - 1), ug = lane / G;
+    const uint64_t gmask = G == 64 ? ~0ull : (1ull << G) - 1;
+    uint32_t len = 0, ordb = 0;
+    uint64_t wo = 0;
+    if (d < D) { len = p.v_len[seg0 + d]; ordb = p.v_ord[seg0 + d]; wo = p.v_word_off[seg0 + d]; }
+    uint32_t maxlen = len;
+    for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o));
+    if (maxlen < k) return;
+    const uint32_t nunits = (maxlen - k + 64) >> 6, span = 63 + k;
+    const uint64_t* w = p.packed + wo;
+    const uint64_t below = lane ? ~0ull >> (64 - lane) : 0ull;       // the lanes in front of this one
+    uint32_t n0 = 0;                                                 // pieces of chunk 0 (known after the counting walk)
+    for (int pass = D > 32 ? 0 : 1; pass < 2; pass++) {
+        uint32_t i0 = 0, i1 = 0;
+        for (uint32_t u0 = 0; u0 < nunits; u0 += UPR) {
+            const uint32_t u = u0 + ug;
+            const bool valid = u < nunits && len >= k && 64 * u + k <= len;
+            const uint32_t nb = valid ? min(len - 64 * u, span) : 0u, nw = (nb + 31) >> 5;
+            uint64_t x[NW];
+#pragma unroll
+            for (int j = 0; j < NW; j++) x[j] = (uint32_t)j < nw ? w[2 * (size_t)u + j] : 0ull;
+#pragma unroll
+            for (int j = 0; j < NW; j++)
+                if ((uint32_t)j + 1 == nw && (nb & 31)) x[j] &= ~0ull << (64 - 2 * (nb & 31));      // bases past the unit's span
+            bool todo = valid;
+            while (__any(todo)) {
+                const uint64_t grp = (__ballot(todo) >> gbase) & gmask;            // this group's remaining lanes
+                const uint32_t leader = gbase + (grp ? (uint32_t)__builtin_ctzll(grp) : 0u);
+                bool same = todo && (uint32_t)__shfl((int)nb, (int)leader) == nb;
+#pragma unroll
+                for (int j = 0; j < NW; j++) {
+                    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)x[j], (int)leader);
+                    const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(x[j] >> 32), (int)leader);
+                    same = same && x[j] == (((uint64_t)hi << 32) | lo);
+                }
+                const uint64_t members = (__ballot(same) >> gbase) & gmask;        // (the leader is one of them)
+                const uint32_t m0 = (uint32_t)members, m1 = (uint32_t)(members >> 32);
+                const bool lead = todo && lane == leader;
+                const uint64_t b0 = __ballot(lead && m0 != 0), b1 = __ballot(lead && m1 != 0);
+                if (pass && lead) {
+                    if (m0) {
+                        const uint32_t at = base + i0 + (uint32_t)__popcll(b0 & below);
+                        p.u_word_off[at] = wo + 2 * (uint64_t)u; p.u_len[at] = nb; p.u_ord[at] = ordb + 64 * u;
+                        p.u_sample[at] = 0; p.u_bits[at] = m0;
+                    }
+                    if (m1) {
+                        const uint32_t at = base + n0 + i1 + (uint32_t)__popcll(b1 & below);
+                        p.u_word_off[at] = wo + 2 * (uint64_t)u; p.u_len[at] = nb; p.u_ord[at] = ordb + 64 * u;
+                        p.u_sample[at] = 32; p.u_bits[at] = m1;
+                    }
+                }
+                i0 += (uint32_t)__popcll(b0); i1 += (uint32_t)__popcll(b1);
+                if (same) todo = false;
+            }
+        }
+        if (!pass) n0 = i0;
+        else if (lane == 0) { p.view_off[c] = base | VIEW_IN_POOL; p.v_nseg[c] = i0 + i1; }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
