@@ -12,6 +12,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <chrono>
 #include <cstdlib>
 #include <cstdio>
@@ -46,16 +49,42 @@ struct Genome {
     std::string error;
 };
 
+// the whole file in one string: one read() into a buffer of the file's size (a stream copy through a stringbuf was three
+// passes over every genome)
 bool read_file(const std::string& path, std::string& out) {
-    std::ifstream f(path, std::ios::binary);
-    if (!f) return false;
-    std::ostringstream ss;
-    ss << f.rdbuf();
-    out = ss.str();
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    size_t want = 0;
+    if (::fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) want = (size_t)st.st_size;
+    out.clear();
+    size_t have = 0;
+    for (;;) {
+        if (out.size() - have < (1u << 16)) out.resize(std::max(out.size() * 2, std::max<size_t>(want + 1, 1u << 16)));
+        const ssize_t r = ::read(fd, &out[have], out.size() - have);
+        if (r < 0) { ::close(fd); return false; }
+        if (r == 0) break;
+        have += (size_t)r;
+    }
+    ::close(fd);
+    out.resize(have);
     return true;
 }
 
 inline bool is_space(char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; }
+
+struct FastaLut {
+    unsigned char up[256], bad[256];       // letter -> upper case (a-z only, as before); 1 for anything but A/C/G/T after that
+    FastaLut() {
+        for (int i = 0; i < 256; i++) {
+            unsigned char c = (unsigned char)i;
+            if (c >= 'a' && c <= 'z') c = (unsigned char)(c - 32);
+            up[i] = c;
+            bad[i] = (c != 'A' && c != 'C' && c != 'G' && c != 'T') ? 1 : 0;
+        }
+    }
+};
+const FastaLut g_fasta;
 
 // FASTA text -> contigs (pyfaidx: name up to first whitespace, lines joined, upper case)
 void parse_fasta(const char* p, const char* end, Genome& g) {
@@ -72,13 +101,24 @@ void parse_fasta(const char* p, const char* end, Genome& g) {
             auto ins = g.contigs.emplace(name, Contig());
             cur = ins.second ? &ins.first->second : nullptr;      // a repeated name keeps its first record
         } else if (cur) {
-            const size_t o = cur->seq.size();
-            cur->seq.resize(o + (e - p));
-            for (const char* q = p; q < e; q++) {
-                char c = *q;
-                if (c >= 'a' && c <= 'z') c = (char)(c - 32);
-                cur->seq[o + (q - p)] = c;
-                if (c != 'A' && c != 'C' && c != 'G' && c != 'T') cur->bad.push_back((uint32_t)(o + (q - p)));
+            // upper-cased copy through a table, 8 bytes at a time; the positions of letters other than A/C/G/T are
+            // looked for only in a stretch that holds one (a genome is ~all A/C/G/T: this loop is what opening a
+            // pangenome spends its time in)
+            const size_t o = cur->seq.size(), n = (size_t)(e - p);
+            cur->seq.resize(o + n);
+            char* dst = &cur->seq[o];
+            const unsigned char* src = (const unsigned char*)p;
+            size_t i = 0;
+            for (; i + 8 <= n; i += 8) {
+                unsigned bad = 0;
+                for (int j = 0; j < 8; j++) { const unsigned char c = src[i + j]; dst[i + j] = (char)g_fasta.up[c]; bad |= g_fasta.bad[c]; }
+                if (bad)
+                    for (int j = 0; j < 8; j++) if (g_fasta.bad[src[i + j]]) cur->bad.push_back((uint32_t)(o + i + j));
+            }
+            for (; i < n; i++) {
+                const unsigned char c = src[i];
+                dst[i] = (char)g_fasta.up[c];
+                if (g_fasta.bad[c]) cur->bad.push_back((uint32_t)(o + i));
             }
         }
         p = nl ? nl + 1 : end;
@@ -103,56 +143,68 @@ bool py_int(const std::string& s, long long* out) {
     return true;
 }
 
-// input.py:274-332 (feature_types = {'CDS'})
+// input.py:274-332 (feature_types = {'CDS'}).  Fields are looked at where they lie in the file's text: a line becomes
+// strings only where the reference's result needs one (the feature's ID and contig; a warning's text).
 void parse_gff(const std::string& text, const std::string& file_name, Genome& g) {
     const char* p = text.data();
     const char* end = p + text.size();
     while (p < end) {
         const char* nl = (const char*)memchr(p, '\n', end - p);
         const char* le = nl ? nl + 1 : end;                      // the line keeps its newline, as in `for line in gff`
-        std::string line(p, le);
+        const char* ls = p;
         p = le;
-        size_t a = 0;
-        while (a < line.size() && is_space(line[a])) a++;       // line.lstrip()
-        if (line.compare(a, 7, "##FASTA") == 0) break;            // input.py:286-288
-        if (a < line.size() && line[a] == '#') continue;          // input.py:290-292
-        std::vector<std::string> e;                               // line.split('\t')
-        size_t s0 = 0;
+        const char* a = ls;
+        while (a < le && is_space(*a)) a++;                       // line.lstrip()
+        if (le - a >= 7 && memcmp(a, "##FASTA", 7) == 0) break;   // input.py:286-288
+        if (a < le && *a == '#') continue;                        // input.py:290-292
+        // line.split('\t'): the first nine fields' bounds, and how many there are
+        const char* fb[9]; const char* fe[9];
+        size_t nf = 0;
+        const char* q = ls;
         for (;;) {
-            size_t t = line.find('\t', s0);
-            if (t == std::string::npos) { e.push_back(line.substr(s0)); break; }
-            e.push_back(line.substr(s0, t - s0));
-            s0 = t + 1;
+            const char* t = (const char*)memchr(q, '\t', le - q);
+            if (nf < 9) { fb[nf] = q; fe[nf] = t ? t : le; }
+            nf++;
+            if (!t) break;
+            q = t + 1;
+            if (nf >= 9) {                                        // field 8 runs to the next tab or the line's end
+                break;
+            }
         }
+        if (nf >= 9) { const char* t = (const char*)memchr(fb[8], '\t', le - fb[8]); fe[8] = t ? t : le; }
         auto warn = [&](const char* what) {
-            std::string l = line;
+            std::string l(ls, le);
             while (!l.empty() && is_space(l.back())) l.pop_back();
             g.warnings += std::string(what) + ", skipping line \"" + l + "\" from " + file_name + "\n";
         };
-        if (e.size() < 3) { warn("list index out of range"); continue; }
-        if (e[2] != "CDS") continue;                              // input.py:300-301
-        if (e.size() < 9) { warn("list index out of range"); continue; }
+        if (nf < 3) { warn("list index out of range"); continue; }
+        if (!(fe[2] - fb[2] == 3 && memcmp(fb[2], "CDS", 3) == 0)) continue;      // input.py:300-301
+        if (nf < 9) { warn("list index out of range"); continue; }
         long long st, en;
-        if (!py_int(e[3], &st) || !py_int(e[4], &en)) { warn("invalid literal for int() with base 10"); continue; }
-        const int strand = e[6] == "+" ? 1 : -1;                  // input.py:309-312
+        if (!py_int(std::string(fb[3], fe[3]), &st) || !py_int(std::string(fb[4], fe[4]), &en)) {
+            warn("invalid literal for int() with base 10"); continue;
+        }
+        const int strand = (fe[6] - fb[6] == 1 && *fb[6] == '+') ? 1 : -1;       // input.py:309-312
         bool have = false;
-        std::string id;
-        size_t q0 = 0;
-        const std::string& attrs = e[8];
+        const char* idb = nullptr; const char* ide = nullptr;
+        const char* q0 = fb[8];
         for (;;) {                                                // entries[8].split(';')
-            size_t t = attrs.find(';', q0);
-            std::string ent = attrs.substr(q0, t == std::string::npos ? std::string::npos : t - q0);
-            if (ent.compare(0, 2, "ID") == 0 && ent.find('=') != std::string::npos) {      // input.py:317
-                size_t eq = ent.find('=');
-                size_t eq2 = ent.find('=', eq + 1);
-                id = ent.substr(eq + 1, eq2 == std::string::npos ? std::string::npos : eq2 - eq - 1);   // split('=')[1]
-                have = true;
+            const char* t = (const char*)memchr(q0, ';', fe[8] - q0);
+            const char* ee = t ? t : fe[8];
+            if (ee - q0 >= 2 && q0[0] == 'I' && q0[1] == 'D') {   // entry.startswith('ID') and '=' in entry (input.py:317)
+                const char* eq = (const char*)memchr(q0, '=', ee - q0);
+                if (eq) {
+                    const char* eq2 = (const char*)memchr(eq + 1, '=', ee - (eq + 1));
+                    idb = eq + 1; ide = eq2 ? eq2 : ee;           // split('=')[1]
+                    have = true;
+                }
             }
-            if (t == std::string::npos) break;
+            if (!t) break;
             q0 = t + 1;
         }
         if (!have) continue;                                      // input.py:321-322
-        g.features[id] = Feature{id, e[0], st, en, strand};       // input.py:325
+        std::string id(idb, ide);
+        g.features[id] = Feature{id, std::string(fb[0], fe[0]), st, en, strand};     // input.py:325
     }
 }
 
@@ -377,13 +429,60 @@ int pf_pangenome_open(const pf_pangenome_opts* o, pf_pangenome** out) {
     }
     if (!d1 || !d2) { delete P; return in_fail(PF_ERR_ARG, "presence/absence table lacks 'Non-unique Gene name' / 'Annotation' columns"); }
     std::unordered_set<std::string> na(std::begin(NA_STRINGS), std::end(NA_STRINGS));
-    while (next_csv_record(csv, pos, rec)) {
-        if (rec.size() == 1 && rec[0].empty()) continue;          // blank line
-        P->cluster_names.push_back(rec[0]);
-        std::vector<std::string> row(P->strains.size());
-        for (size_t c = 1; c < rec.size() && c - 1 < keep.size(); c++)
-            if (keep[c - 1] >= 0 && !na.count(rec[c])) row[keep[c - 1]] = rec[c];
-        P->cells.push_back(std::move(row));
+    {
+        // The table is one row per gene cluster with one cell per strain (16 MB per 1 000 clusters x 1 000 strains):
+        // record starts are found in one pass that only tracks quotes, the records are split on all host threads.
+        std::vector<size_t> starts;
+        bool inq = false;
+        size_t at = pos;
+        const char* base = csv.data();
+        const size_t n = csv.size();
+        if (at < n) starts.push_back(at);
+        while (at < n) {
+            if (!inq) {
+                const char* q = (const char*)memchr(base + at, '\n', n - at);
+                const char* dq = (const char*)memchr(base + at, '"', (q ? (size_t)(q - base) : n) - at);
+                if (dq) { inq = true; at = (size_t)(dq - base) + 1; continue; }
+                if (!q) break;
+                at = (size_t)(q - base) + 1;
+                if (at < n) starts.push_back(at);
+            } else {
+                const char* dq = (const char*)memchr(base + at, '"', n - at);
+                if (!dq) break;
+                at = (size_t)(dq - base) + 1;
+                if (at < n && base[at] == '"') at++;               // doubled quote inside a quoted cell
+                else inq = false;
+            }
+        }
+        const size_t nrec = starts.size();
+        std::vector<std::string> names(nrec);
+        std::vector<std::vector<std::string>> cells(nrec);
+        std::vector<uint8_t> blank(nrec, 0);
+        unsigned ntc = std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+        if (nrec < 64) ntc = 1;
+        std::atomic<size_t> nextrec{0};
+        auto work = [&] {
+            std::vector<std::string> r;
+            for (size_t i; (i = nextrec.fetch_add(1)) < nrec;) {
+                size_t ppos = starts[i];
+                if (!next_csv_record(csv, ppos, r)) { blank[i] = 1; continue; }
+                if (r.size() == 1 && r[0].empty()) { blank[i] = 1; continue; }      // blank line
+                names[i] = r[0];
+                std::vector<std::string> row(P->strains.size());
+                for (size_t c = 1; c < r.size() && c - 1 < keep.size(); c++)
+                    if (keep[c - 1] >= 0 && !na.count(r[c])) row[keep[c - 1]] = std::move(r[c]);
+                cells[i] = std::move(row);
+            }
+        };
+        std::vector<std::thread> thc;
+        for (unsigned t = 1; t < ntc; t++) thc.emplace_back(work);
+        work();
+        for (auto& x : thc) x.join();
+        for (size_t i = 0; i < nrec; i++) {
+            if (blank[i]) continue;
+            P->cluster_names.push_back(std::move(names[i]));
+            P->cells.push_back(std::move(cells[i]));
+        }
     }
     P->sorted_strains = P->strains;
     std::sort(P->sorted_strains.begin(), P->sorted_strains.end());
@@ -393,6 +492,8 @@ int pf_pangenome_open(const pf_pangenome_opts* o, pf_pangenome** out) {
     P->W = (uint32_t)(P->strains.size() + 31) / 32;
     // ---- genomes: GFF features + FASTA (embedded or separate), loaded in parallel
     std::vector<Genome> gs(o->n_genomes);
+    std::atomic<long long> dbg_ns[4] = {};
+    auto TA = std::chrono::steady_clock::now();
     unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
     std::vector<std::thread> th;
     for (unsigned t = 0; t < nt; t++)
@@ -400,8 +501,12 @@ int pf_pangenome_open(const pf_pangenome_opts* o, pf_pangenome** out) {
             for (uint32_t i = t; i < o->n_genomes; i += nt) {
                 Genome& g = gs[i];
                 std::string text;
+                auto T0 = std::chrono::steady_clock::now();
                 if (!read_file(o->gff_paths[i], text)) { g.error = std::string("cannot read ") + o->gff_paths[i]; continue; }
+                auto T1 = std::chrono::steady_clock::now();
                 parse_gff(text, o->gff_paths[i], g);
+                auto T2 = std::chrono::steady_clock::now();
+                dbg_ns[0] += (T1 - T0).count(); dbg_ns[1] += (T2 - T1).count();
                 if (o->fasta_paths && o->fasta_paths[i]) {
                     std::string fa;
                     if (!read_file(o->fasta_paths[i], fa)) { g.error = std::string("cannot read ") + o->fasta_paths[i]; continue; }
@@ -415,19 +520,25 @@ int pf_pangenome_open(const pf_pangenome_opts* o, pf_pangenome** out) {
                     if (b == std::string::npos) b = text.size();
                     parse_fasta(text.data() + a, text.data() + b, g);
                 }
+                auto T3 = std::chrono::steady_clock::now();
+                dbg_ns[2] += (T3 - T2).count();
+                for (auto& fv : g.features) {                      // feature -> contig, once (the maps keep their nodes when moved)
+                    auto cit = g.contigs.find(fv.second.chrom);
+                    fv.second.ctg = cit == g.contigs.end() ? nullptr : &cit->second;
+                }
             }
         });
     for (auto& x : th) x.join();
+    if (getenv("PF_DEBUG_TIMING")) {
+        auto TB = std::chrono::steady_clock::now();
+        fprintf(stderr, "[open] genomes wall %.3f s; thread-seconds: read %.3f gff %.3f fasta %.3f\n", (TB - TA).count() / 1e9,
+                dbg_ns[0] / 1e9, dbg_ns[1] / 1e9, dbg_ns[2] / 1e9);
+    }
     for (uint32_t i = 0; i < o->n_genomes; i++) {
         if (!gs[i].error.empty()) { std::string e = gs[i].error; delete P; return in_fail(PF_ERR_ARG, e); }
         P->log += gs[i].warnings;
         P->genomes.emplace(o->genome_names[i], std::move(gs[i]));
     }
-    for (auto& kv : P->genomes)                                    // feature -> contig, once
-        for (auto& fv : kv.second.features) {
-            auto cit = kv.second.contigs.find(fv.second.chrom);
-            fv.second.ctg = cit == kv.second.contigs.end() ? nullptr : &cit->second;
-        }
     for (auto& st : P->strains) {
         auto git = P->genomes.find(st);
         P->strain_genome.push_back(git == P->genomes.end() ? nullptr : &git->second);

@@ -149,6 +149,9 @@ def run_files(presence_absence, gffdir, output, fastadir=None, klength=31, canon
         stats["stages"] = stages
         return stats
     finally:
+        t0 = _time.perf_counter()
         pg.close()
         if eng is not None:
             eng.close()
+        if "stages" in stats:
+            stats["stages"]["close_s"] = _time.perf_counter() - t0        # reader and context given back
