@@ -70,6 +70,7 @@ def parse(argv=None):
                     help="star: SURVEY 8d's alleles (default); tree: alleles that descend from one another (synth.py)")
     ap.add_argument("--n-rate", type=float, default=0.0, help="share of the sequences that carry one 'N' (SURVEY 8d: 0.001)")
     ap.add_argument("--max-items", type=int, default=65536)
+    ap.add_argument("--pattern-capacity", type=int, default=1 << 25, help="initial slots of the run-global pattern table")
     ap.add_argument("--cpu-clusters", type=int, default=0, help="clusters in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dedup", action="store_true", help="scan every copy of identical sequences (PF_FLAG_NO_DEDUP)")
@@ -444,7 +445,7 @@ def main():
     # (rehearsal with every rank on one GPU: the ranks share its memory, a work item's scratch slice is ~1.9 MB)
     max_items = args.max_items if not shared else max(2048, args.max_items // (4 * world))
     eng = Engine(klength=k, max_strains=(S + 31) // 32 * 32, device=local, max_items=max_items,
-                 pattern_capacity=1 << 25, dedup=not args.no_dedup, unit_dedup=not args.no_unit_dedup)
+                 pattern_capacity=args.pattern_capacity, dedup=not args.no_dedup, unit_dedup=not args.no_unit_dedup)
 
     def build(first, n_mine, n_rate=None):
         # generate + upload in slabs so the host never holds more than a slab of cluster objects

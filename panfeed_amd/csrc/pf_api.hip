@@ -777,10 +777,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
     PFCHK(c->v_mode.ensure(C1 * 4));
     PFCHK(c->v_dense.ensure(C1 * 4));
     PFCHK(c->extra_dense.ensure(NEX1 * 4));
-    HIPCHK(hipMemsetAsync(c->cl_overflow.p, 0, C1 * 4, c->stream));
-    HIPCHK(hipMemsetAsync(c->cl_kmer_cnt.p, 0, C1 * 4, c->stream));
-    HIPCHK(hipMemsetAsync(c->cl_unique.p, 0, C1 * 4, c->stream));
-    HIPCHK(hipMemsetAsync(c->cl_pattern.p, 0xFF, C1 * 4, c->stream));
+    // (cl_overflow / cl_kmer_cnt / cl_unique / cl_pattern get their start values from the dedup kernel)
     HIPCHK(hipMemsetAsync(c->cursor.p, 0, 64, c->stream));
 
     // ---- identical segments -> scan view (mode 1) or the caller's list as it is (mode 0)
@@ -831,6 +828,8 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         dp.v_sample = c->v_sample.as<uint32_t>(); dp.v_ord = c->v_ord.as<uint32_t>();
         dp.seg_distinct = c->seg_distinct.as<uint32_t>();
         dp.v_bits = c->v_bits.as<uint32_t>(); dp.view_off = c->view_off.as<uint32_t>();
+        dp.cl_overflow = c->cl_overflow.as<uint32_t>(); dp.cl_kmer_cnt = c->cl_kmer_cnt.as<uint32_t>();
+        dp.cl_unique = c->cl_unique.as<uint32_t>(); dp.cl_pattern = c->cl_pattern.as<uint32_t>();
         dp.v_nseg = c->v_nseg.as<uint32_t>(); dp.v_nstr = c->v_nstr.as<uint32_t>();
         dp.v_mode = c->v_mode.as<uint32_t>(); dp.v_dense = c->v_dense.as<uint32_t>();
         dp.extra_dense = c->extra_dense.as<uint32_t>();
@@ -1028,6 +1027,8 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         return PF_OK;
     };
     uint32_t pass = 0;
+    uint32_t cnt2[3] = {0, 0, 0};          // pattern counters {ids handed out, pool overflow, arena overflow}
+    c->counters = pf_result{};
     const uint32_t lim_full = pf::insert_limit(NS);
     uint64_t arena_base = 0;
     struct Deferred { Arena* ar; uint32_t pin; };
@@ -1433,7 +1434,10 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         }
         HIPCHK(hipMemcpyAsync(ovf.data(), c->cl_overflow.p, (size_t)C * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(cur3, c->cursor.p, 24, hipMemcpyDeviceToHost, c->stream));
+        // (the pattern counters come along: when this was the last pass the MD5 launch needs no round trip of its own)
+        HIPCHK(hipMemcpyAsync(cnt2, c->pt_counters.p, 12, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
+        c->counters.n_unique = cur3[1]; c->counters.n_kept = cur3[2];
         lap("sync pass");
         ar->used = cur3[0] - ar->base;
         if (ar->used > ar->cap) return fail(PF_ERR_CAPACITY, "output arena overflow (%llu > %llu)",
@@ -1493,10 +1497,11 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
     for (size_t a = pass; a < c->arenas.size(); a++) c->arenas[a]->used = 0;   // arenas of an earlier, longer batch
     c->n_passes = pass;
 
-    // ---- MD5 of the patterns this batch created
-    uint32_t cnt2[3] = {0, 0, 0};
-    HIPCHK(hipMemcpyAsync(cnt2, c->pt_counters.p, 12, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    // ---- MD5 of the patterns this batch created (cnt2: read with the last pass's results)
+    if (!C) {
+        HIPCHK(hipMemcpyAsync(cnt2, c->pt_counters.p, 12, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
     if (cnt2[2]) return fail(PF_ERR_CAPACITY, "output arena overflow inside a kernel");
     if (cnt2[1] || cnt2[0] > c->pt.pool) { *need = cnt2[0]; return PF_RETRY_PATTERNS; }
     const uint32_t pid1 = cnt2[0];
@@ -1526,8 +1531,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         PFCHK(mark_end(c));
     }
     c->n_patterns = pid1;
-    uint64_t cur3[3];
-    HIPCHK(hipMemcpyAsync(cur3, c->cursor.p, 24, hipMemcpyDeviceToHost, c->stream));
+    const uint64_t n_unique_total = c->counters.n_unique, n_kept_total = c->counters.n_kept;   // the last pass's cursor
     HIPCHK(hipEventRecord(c->ev_t1, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
 
@@ -1549,8 +1553,8 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
     c->n_clusters = C;
     c->counters = pf_result{};
     c->counters.n_instances = total_inst;
-    c->counters.n_unique = cur3[1];
-    c->counters.n_kept = cur3[2];
+    c->counters.n_unique = n_unique_total;
+    c->counters.n_kept = n_kept_total;
     c->counters.n_new_patterns = pid1 - c->pid0;
     c->counters.n_patterns = pid1;
     c->counters.W = W;

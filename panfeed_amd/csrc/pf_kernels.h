@@ -798,6 +798,9 @@ struct DedupParams {
     uint32_t* v_bits;                 // view, [n_segs]: the presence bits a window of the segment sets in its chunk's word
     uint32_t* v_nseg; uint32_t* v_nstr; uint32_t* v_mode; uint32_t* v_dense;       // [C]
     uint32_t* view_off;               // [C] first entry of the cluster's view in the view arrays
+    // per-cluster outputs of the passes that follow, given their start values here (small class only: it sees every
+    // cluster of a batch first) instead of by four memsets in front of the batch
+    uint32_t* cl_overflow; uint32_t* cl_kmer_cnt; uint32_t* cl_unique; uint32_t* cl_pattern;
     uint32_t* extra_dense;            // [n_extra] ordinal of the extra row in the cluster's (dense) numbering
     uint32_t k, W, canon, enable;
     uint32_t cluster_base;            // first cluster of this launch (the batch's clusters may be launched in two halves)
@@ -865,6 +868,9 @@ void cluster_dedup_kernel(DedupParams p) {
     const uint32_t k = p.k;
     const uint32_t mult = p.canon ? 1u : 2u;
     const uint32_t Wp = (p.W + 3) & ~3u;
+    if (CFG::MODE == 1 && threadIdx.x == 0) {
+        p.cl_overflow[c] = 0; p.cl_kmer_cnt[c] = 0; p.cl_unique[c] = 0; p.cl_pattern[c] = 0xFFFFFFFFu;
+    }
 
     bool mode1 = p.enable && n >= 4 && n <= DEDUP_MAX_SEGS;
     bool retry_wide = false;                 // small class only: the wide class may still deduplicate this cluster

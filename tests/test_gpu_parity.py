@@ -409,7 +409,9 @@ def test_dedup_big_alleles_repartition(flags):
     kw.update(flags)
     eng = Engine(max_strains=96, stroi={names[4]}, **kw)
     out = eng.run(recs)
-    assert out.timing["n_dedup_clusters"] == 4 and out.timing["n_retried"] >= 1
+    # (all five: since round 3 the view of distinct sequences is taken whenever it fits -- "many", 70 distinct sequences
+    # among 80, goes through the wide class instead of staying on the every-copy path)
+    assert out.timing["n_dedup_clusters"] == 5 and out.timing["n_retried"] >= 1
     (ek, ekh, ehp), st = _oracle_texts(recs, stroi={names[4]}, **kw)
     assert out.kmers_to_hashes == ekh
     assert out.hashes_to_patterns == ehp
