@@ -701,7 +701,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
             for (int j = 0; j < KW; j++) p.tab_key[((size_t)slice * KW + j) * NS + e] = keys[(size_t)j * NS + i];
             p.tab_ord[(size_t)slice * NS + e] = o;
             p.cmask_lo[(size_t)slice * NS + e] = lo;
-            p.cmask_hi[(size_t)slice * NS + e] = hi;
+            if (nstr > 32) p.cmask_hi[(size_t)slice * NS + e] = hi;      // (at most 32 columns: nobody reads the upper word)
 #pragma unroll
             for (int j = 0; j < KW; j++) keys[(size_t)j * NS + i] = EMPTY64;
             ord[i] = NO_ORD;
@@ -2494,6 +2494,7 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
     const uint32_t* ordp = nullptr;
     const uint32_t* mlo = nullptr;
     const uint32_t* mhi = nullptr;
+    const bool has_hi = p.v_nstr[c] > 32;                       // more than 32 distinct sequences: the masks' upper word exists
     auto set_part = [&](uint32_t q) {
         slice = p.item_scratch[item + q];
         ns = p.item_count[item + q];
@@ -2539,7 +2540,7 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
 #pragma unroll
       for (uint32_t u = 0; u < 4; u++) {
           const uint32_t i = i0 + u * T;
-          ml_[u] = i < ns ? mlo[i] : 0; mh_[u] = i < ns ? mhi[i] : 0;
+          ml_[u] = i < ns ? mlo[i] : 0; mh_[u] = (has_hi && i < ns) ? mhi[i] : 0;
       }
 #pragma unroll
       for (uint32_t u = 0; u < 4; u++) {
@@ -2744,7 +2745,7 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
       for (uint32_t u = 0; u < 4; u++) {
           const uint32_t i = i0 + u * T;
           o_[u] = i < ns ? ordp[i] : 0xFFFFFFFFu;
-          if (MULTI) { ml_[u] = i < ns ? mlo[i] : 0; mh_[u] = i < ns ? mhi[i] : 0; }
+          if (MULTI) { ml_[u] = i < ns ? mlo[i] : 0; mh_[u] = (has_hi && i < ns) ? mhi[i] : 0; }
       }
 #pragma unroll
       for (uint32_t u = 0; u < 4; u++) {
@@ -2768,7 +2769,7 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
             for (uint32_t i = tid; i < ns; i += T) {
                 const uint32_t o = ordp[i];
                 if ((o >> 5) >= dense_words) continue;
-                const uint64_t amask = (uint64_t)mlo[i] | ((uint64_t)mhi[i] << 32);
+                const uint64_t amask = (uint64_t)mlo[i] | ((uint64_t)(has_hi ? mhi[i] : 0u) << 32);
                 if ((MULTI ? find_tag(amask) : slot_at[i]) != UNTABLED) continue;
                 uint4 h;
                 if (row_eval(amask, h)) atomicOr(&keepbm[o >> 5], 1u << (o & 31));
@@ -2933,7 +2934,7 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
           const uint32_t i = i0 + u * T, o = o_[u];
           kp_[u] = (o >> 5) < dense_words && ((keepbm[o >> 5] >> (o & 31)) & 1);
           k0_[u] = kp_[u] ? p.tab_key[((size_t)slice * KW) * NS + i] : 0;
-          if (MULTI) { ml_[u] = kp_[u] ? mlo[i] : 0; mh_[u] = kp_[u] ? mhi[i] : 0; }
+          if (MULTI) { ml_[u] = kp_[u] ? mlo[i] : 0; mh_[u] = (has_hi && kp_[u]) ? mhi[i] : 0; }
       }
 #pragma unroll
       for (uint32_t u = 0; u < 4; u++) {
@@ -2958,7 +2959,7 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
             for (uint32_t i = tid; i < ns; i += T) {
                 const uint32_t o = ordp[i];
                 if ((o >> 5) >= dense_words || !((keepbm[o >> 5] >> (o & 31)) & 1)) continue;
-                const uint64_t amask = (uint64_t)mlo[i] | ((uint64_t)mhi[i] << 32);
+                const uint64_t amask = (uint64_t)mlo[i] | ((uint64_t)(has_hi ? mhi[i] : 0u) << 32);
                 if ((MULTI ? find_tag(amask) : slot_at[i]) != UNTABLED) continue;
                 uint4 h;
                 row_eval(amask, h);
