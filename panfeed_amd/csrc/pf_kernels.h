@@ -1083,7 +1083,10 @@ void cluster_dedup_kernel(DedupParams p) {
             // what the wide class can still do for this cluster: more distinct sequences, no sample-set matrix, no
             // ordinal bitmap; (a hash collision or too few copies stay mode 0)
             retry_wide = sh_many != 0 || (!sh_bad && worth && D * Wp > DEDUP_MROWS);
-            mode1 = !sh_bad && D <= MAXD && D * Wp <= DEDUP_MROWS && worth;
+            // (the view's columns are swept in chunks of 32 whose words live in chunkbits[slice][W][NS]: more chunks than
+            // the W words of a sample row -- more distinct sequences than samples, through paralogs and sequences cut at
+            // an 'N' -- would run into the next slice; found by the randomised test once such clusters reached mode 1)
+            mode1 = !sh_bad && D <= MAXD && D * Wp <= DEDUP_MROWS && worth && ((D + 31) >> 5) <= p.W;
         } else {
             mode1 = !sh_bad && D <= MAXD && worth && ((D + 31) >> 5) <= p.W;
         }

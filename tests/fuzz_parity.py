@@ -32,11 +32,12 @@ for case in range(n_cases):
     names = cl[0].names
     stroi = set(rng.choice(names, size=min(len(names), int(rng.integers(0, 3))), replace=False).tolist())
     dedup = bool(rng.random() < 0.8)
+    unit_dedup = bool(rng.random() < 0.85)
     max_items = int(rng.choice([64, 2048]))
     cut = int(rng.integers(0, ncl + 1))
     try:
         for attempt in range(2):
-            eng = Engine(max_strains=(S + 31) // 32 * 32, stroi=stroi, dedup=dedup, max_items=max_items, **kw)
+            eng = Engine(max_strains=(S + 31) // 32 * 32, stroi=stroi, dedup=dedup, unit_dedup=unit_dedup, max_items=max_items, **kw)
             try:
                 outs = [eng.run(recs[:cut])] if cut else []
                 if cut < ncl:

@@ -100,3 +100,22 @@ def test_many_related_alleles_unit_view(D, S, k):
     names = [f"r{i:04d}" for i in range(S)]
     tms = _run_all([_cluster("g_rel", names, alleles), _cluster("g_rel2", names, alleles[::2])], k, S)
     assert tms[0]["n_dedup_clusters"] == 2
+
+
+def test_more_distinct_sequences_than_samples():
+    """17 samples, paralogs and sequences cut at an 'N': more than 32 distinct sequences with one 32-column word per
+    sample row (the case the randomised test found when every cluster with a copy started to take the view of distinct
+    sequences: the view's second chunk of columns has no room in the per-slot words, the cluster stays on the
+    every-copy path); non-canonical, two-word keys, several key partitions"""
+    from panfeed_amd import synth
+    from panfeed_amd.engine import Engine
+    cl = synth.generate(3, 17, first=946990, flank=60, mean_len=1500, min_len=5, max_len=2500, n_rate=0.2, paralog_rate=0.3,
+                        sub_rate=0.0, mean_alleles=40.0, allele_decay=1.0, allele_model="tree", shuffle_columns=94)
+    recs = [c.record() for c in cl]
+    for k, canon in ((64, False), (31, True)):
+        (ek, ekh, ehp), st = _oracle_texts(recs, klength=k, canon=canon, maf=0.0)
+        for kw in (dict(), dict(unit_dedup=False)):
+            eng = Engine(klength=k, canon=canon, maf=0.0, max_strains=32, **kw)
+            out = eng.run(recs)
+            assert out.kmers_to_hashes == ekh and out.hashes_to_patterns == ehp, (k, canon, kw)
+            eng.close()
