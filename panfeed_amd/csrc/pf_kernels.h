@@ -373,6 +373,83 @@ __device__ __forceinline__ bool scan_unit(uint64_t* keys, uint32_t* ord, uint32_
     return __any(over);
 }
 
+// ---- key partitions: a queue of "mine" windows per wave
+// An item that is one of P key partitions of its cluster looks at every window of the view and keeps the 1 / P whose key
+// hashes into its partition.  Going through the table's insert loop once per unit -- the loop is wave-uniform and runs
+// as long as its slowest lane -- made a partition's scan cost as much as a whole scan, for 64 / P inserts per trip.  The
+// windows a wave keeps are therefore gathered over several units in its lanes (lane i < n holds pending entry i; a
+// unit's kept windows are appended behind them, pulled from their lanes through a 64-byte list of lane numbers in LDS)
+// and go through the insert loop 64 at a time.
+template <int KW>
+struct ScanQueue { Key<KW> key; uint32_t ord, bit; };
+
+constexpr uint32_t M_WQ_WORDS = 16;            // 64 lane numbers per wave
+
+template <int KW>
+__device__ __forceinline__ bool queue_flush(uint64_t* keys, uint32_t* ord, uint32_t* bits, uint32_t* misc, uint32_t NS,
+                                            uint32_t ns, uint32_t limit, uint32_t lane, ScanQueue<KW>& pq, uint32_t& pn) {
+    if (!pn) return false;                                           // (uniform)
+    const uint32_t nhome = KW == 1 ? ns / SCAN_BUCKET : ns;
+    const uint32_t h = key_hash<KW>(pq.key);
+    const bool over = table_update<KW>(keys, ord, bits, misc, NS, ns, limit, lane < pn, pq.key, __umulhi(h, nhome), pq.ord, pq.bit);
+    pn = 0;
+    return __any(over);
+}
+
+template <int KW>
+__device__ __forceinline__ bool queue_push(uint64_t* keys, uint32_t* ord, uint32_t* bits, uint32_t* misc, uint32_t NS,
+                                           uint32_t ns, uint32_t limit, uint32_t lane, uint8_t* wq, ScanQueue<KW>& pq,
+                                           uint32_t& pn, bool mine, const Key<KW>& key, uint32_t myord, uint32_t bit) {
+    const uint64_t mm = __ballot(mine);
+    if (!mm) return false;                                           // (uniform)
+    const uint32_t m = (uint32_t)__popcll(mm);
+    bool over = false;
+    if (pn + m > 64) over = queue_flush<KW>(keys, ord, bits, misc, NS, ns, limit, lane, pq, pn);
+    const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+    if (mine) wq[r] = (uint8_t)lane;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const bool take = lane >= pn && lane < pn + m;
+    const uint32_t src = take ? (uint32_t)wq[lane - pn] : lane;
+    __builtin_amdgcn_wave_barrier();                                 // the list is rewritten by the next push
+#pragma unroll
+    for (int j = 0; j < KW; j++) {
+        const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)key.w[j], (int)src);
+        const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(key.w[j] >> 32), (int)src);
+        if (take) pq.key.w[j] = ((uint64_t)hi << 32) | lo;
+    }
+    const uint32_t o = (uint32_t)__shfl((int)myord, (int)src), b = (uint32_t)__shfl((int)bit, (int)src);
+    if (take) { pq.ord = o; pq.bit = b; }
+    pn += m;
+    return over;
+}
+
+// One 64-window unit of an item that is one key partition of several: this wave's kept windows join its queue.
+template <int KW, bool CANON>
+__device__ __forceinline__ bool scan_unit_queued(uint64_t* keys, uint32_t* ord, uint32_t* bits, uint32_t* misc, uint32_t NS,
+                                                 uint32_t ns, uint32_t limit, uint32_t k, uint32_t lane, uint32_t part,
+                                                 uint32_t nparts, const uint64_t (&cw)[KW + 1], uint32_t u, uint32_t ninst,
+                                                 uint32_t ordb, uint32_t bit, uint8_t* wq, ScanQueue<KW>& pq, uint32_t& pn) {
+    const uint32_t pos = (u << 6) + lane;
+    const bool valid = pos < ninst;
+    Key<KW> fwd, rc;
+    const bool rc_smaller = window_keys<KW>(k, lane, cw, fwd, rc);
+    if (CANON) {
+        Key<KW> key = rc_smaller ? rc : fwd;          // specseq <= revspecseq -> forward (panfeed.py:70)
+        const uint32_t h = key_hash<KW>(key);
+        const bool mine = valid && (((h & 0xFFFFu) * nparts) >> 16) == part;
+        return queue_push<KW>(keys, ord, bits, misc, NS, ns, limit, lane, wq, pq, pn, mine, key, ordb + pos, bit);
+    } else {
+        uint32_t h = key_hash<KW>(fwd);
+        bool mine = valid && (((h & 0xFFFFu) * nparts) >> 16) == part;
+        bool over = queue_push<KW>(keys, ord, bits, misc, NS, ns, limit, lane, wq, pq, pn, mine, fwd, 2 * (ordb + pos), bit);
+        h = key_hash<KW>(rc);
+        mine = valid && (((h & 0xFFFFu) * nparts) >> 16) == part;
+        over |= queue_push<KW>(keys, ord, bits, misc, NS, ns, limit, lane, wq, pq, pn, mine, rc, 2 * (ordb + pos) + 1, bit);
+        return over;
+    }
+}
+
 // chunkmask word 0 is accumulated by thread 0
 __device__ __forceinline__ uint32_t mask_word_any(uint32_t mask_word, uint32_t tid) { return tid == 0 ? mask_word : 0u; }
 
@@ -389,7 +466,8 @@ constexpr uint32_t M_PROG = M_TMP + 1;                                   // unit
 constexpr uint32_t M_DESC = M_TMP + 2;                                   // [16] the current item's ScanDesc
 constexpr uint32_t M_NDESC = M_DESC + 16;                                // [16] the next item's
 constexpr uint32_t M_BITS = M_NDESC + 16;                                // [SEG_TILE] presence bits of the staged segments
-static_assert(M_BITS + SEG_TILE <= MISC_WORDS, "misc area too small");
+constexpr uint32_t M_WQ = M_BITS + SEG_TILE;                             // [SCAN_WAVES][M_WQ_WORDS] lane lists of the waves' queues
+static_assert(M_WQ + SCAN_WAVES * M_WQ_WORDS <= MISC_WORDS, "misc area too small");
 
 // Persistent: gridDim.x workgroups (one per CU: the table takes the whole LDS) walk work entries
 // blockIdx.x, blockIdx.x + gridDim.x, ...  With one workgroup per CU nothing else hides the dependent global
@@ -578,6 +656,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
                 uint64_t cw[KW + 1];
 #pragma unroll
                 for (int j = 0; j <= KW; j++) cw[j] = q[j];
+                // one of several key partitions (one- and two-word keys: the wider kernels have no registers to spare):
+                // this wave's kept windows are queued and inserted 64 at a time
+                const bool queued = KW <= 2 && nparts > 1;
+                ScanQueue<KW> pq{};
+                uint32_t pn = 0;
+                uint8_t* const wq = reinterpret_cast<uint8_t*>(misc + M_WQ + wave * M_WQ_WORDS);
+                bool stopped = false;
                 while (g < gend) {
                     // unconditional prefetch (re-reads the current address past the end) so that the compiler
                     // keeps exactly one load in flight across the table work: s_waitcnt vmcnt(1), not 0
@@ -605,15 +690,23 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
                     // LDS round trip in front of every unit (looking every fourth unit was measured too: slower, 4.36 ->
                     // 4.55 ms) -- so after the limit trips every wave finishes at most the unit it is in:
                     // 16 waves x 64 lanes x 2 keys < INSERT_SLACK.
-                    if (scan_unit<KW, CANON>(keys, ord, bits, misc, NS, ns, limit, k, lane, part, nparts, cw,
-                                             u, ninst, ordb, bit)) {
+                    const bool over = queued
+                        ? scan_unit_queued<KW, CANON>(keys, ord, bits, misc, NS, ns, limit, k, lane, part, nparts, cw, u, ninst,
+                                                      ordb, bit, wq, pq, pn)
+                        : scan_unit<KW, CANON>(keys, ord, bits, misc, NS, ns, limit, k, lane, part, nparts, cw, u, ninst, ordb, bit);
+                    if (over) {
                         if (lane == 0) atomicMin(&misc[M_PROG], ubefore + g);
+                        stopped = true;
                         break;
                     }
 #pragma unroll
                     for (int j = 0; j <= KW; j++) cw[j] = nw[j];
                     q = qn; s = sn; send = sendn; u = un; ninst = ninstn; ordb = ordbn; bit = bitn;
                     g = gn;
+                }
+                // what is still queued belongs to this chunk's words: in before they are flushed
+                if (queued && !stopped && queue_flush<KW>(keys, ord, bits, misc, NS, ns, limit, lane, pq, pn)) {
+                    if (lane == 0) atomicMin(&misc[M_PROG], ubefore + gend - 1);
                 }
             }
             chunk_dirty = true;

@@ -46,7 +46,10 @@ def run_files(presence_absence, gffdir, output, fastadir=None, klength=31, canon
         eng = Engine(klength=klength, canon=canon, consider_missing=consider_missing, patfilt=patfilt, maf=maf,
                      multiple_files=multiple_files, max_strains=max(32, (pg.n_strains + 31) // 32 * 32),
                      stroi=set(targets), device=device,
-                     max_items=max_items, pattern_capacity=pattern_capacity)
+                     # work items in flight = scratch slices (1.9 MB each at 1 000 strains): sized for the batches of this
+                     # run, not the library's default of 2 048 -- creating and freeing 4 GB of scratch was a third of a
+                     # one-second run's time
+                     max_items=max_items or max(512, 2 * int(batch_clusters)), pattern_capacity=pattern_capacity)
         stages["context_s"] = _time.perf_counter() - t0
         t0 = _time.perf_counter()
         if resident:
@@ -151,7 +154,9 @@ def run_files(presence_absence, gffdir, output, fastadir=None, klength=31, canon
     finally:
         t0 = _time.perf_counter()
         pg.close()
+        t1 = _time.perf_counter()
         if eng is not None:
             eng.close()
-        if "stages" in stats:
-            stats["stages"]["close_s"] = _time.perf_counter() - t0        # reader and context given back
+        if "stages" in stats:                                             # reader and context given back
+            stats["stages"]["close_reader_s"] = t1 - t0
+            stats["stages"]["close_context_s"] = _time.perf_counter() - t1
