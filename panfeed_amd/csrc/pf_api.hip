@@ -2062,56 +2062,76 @@ int pf_genomes_upload(pf_ctx* c, uint32_t n, const char* const* ascii, const uin
     c->g_store.release();
     PFCHK(c->g_store.ensure((size_t)std::max<uint64_t>(total, 2) * 8));
     c->g_words = total;
-    // staged in blocks: pinned host block -> device ASCII block -> 2-bit words
+    // staged in blocks: pinned host block -> device ASCII block -> 2-bit words.  Two sets of staging buffers: the host
+    // threads copy block i + 1 into its pinned block while block i is on its way to the device and being packed there.
     const size_t BLOCK = 64u << 20;
-    char* pin = nullptr;
-    DevBuf dasc, dpieces;
+    struct Src { const char* p; size_t n, at; };
+    struct Blk { std::vector<pf::PackPiece> pieces; std::vector<Src> src; size_t fill = 0; uint32_t blocks = 0; };
+    std::vector<Blk> blks(1);
+    for (uint32_t i = 0; i < n; i++) {
+        uint64_t done = 0;
+        const uint64_t L = len[i];
+        do {
+            if (BLOCK - blks.back().fill < 64) blks.emplace_back();
+            Blk& bk = blks.back();
+            const uint64_t room = (BLOCK - bk.fill - 32) / 32 * 32;               // bases this block still takes
+            const uint64_t take = std::min<uint64_t>(L - done, room);
+            const bool last = done + take == L;
+            bk.src.push_back(Src{ascii[i] + done, (size_t)take, bk.fill});
+            const size_t padded = (take + 31) / 32 * 32;
+            pf::PackPiece pc{};
+            pc.ascii_off = bk.fill; pc.dst_word = word_off[i] + done / 32; pc.nbases = (uint32_t)take;
+            const uint64_t contig_words = 2 * ((L + 63) / 64) + 4;
+            pc.nwords = (uint32_t)(last ? contig_words - done / 32 : take / 32);
+            pc.block0 = bk.blocks;
+            bk.blocks += (pc.nwords + 255) / 256;
+            if (pc.nwords) bk.pieces.push_back(pc);
+            bk.fill += padded;
+            done += take;
+            if (!last) blks.emplace_back();
+        } while (done < L);
+    }
+    char* pin[2] = {nullptr, nullptr};
+    DevBuf dasc[2], dpieces[2];
+    hipEvent_t ev[2] = {nullptr, nullptr};
     int rc = PF_OK;
     do {
-        if (hipHostMalloc((void**)&pin, BLOCK, hipHostMallocDefault) != hipSuccess) { rc = fail(PF_ERR_OOM, "hipHostMalloc(%zu) failed", BLOCK); break; }
-        if ((rc = dasc.ensure(BLOCK)) != PF_OK) break;
-        std::vector<pf::PackPiece> pieces;
-        size_t fill = 0;
-        uint32_t blocks = 0;
-        auto flush = [&]() -> int {
-            if (pieces.empty()) return PF_OK;
-            PFCHK(dpieces.ensure(pieces.size() * sizeof(pf::PackPiece)));
-            HIPCHK(hipMemcpyAsync(dasc.p, pin, fill, hipMemcpyHostToDevice, c->stream));
-            HIPCHK(hipMemcpyAsync(dpieces.p, pieces.data(), pieces.size() * sizeof(pf::PackPiece), hipMemcpyHostToDevice, c->stream));
-            hipLaunchKernelGGL(pf::genome_pack_kernel, dim3(blocks), dim3(256), 0, c->stream, (const uint8_t*)dasc.p,
-                               (const pf::PackPiece*)dpieces.p, (uint32_t)pieces.size(), c->g_store.as<uint64_t>());
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(c->stream));        // the pinned block is reused
-            pieces.clear(); fill = 0; blocks = 0;
-            return PF_OK;
-        };
-        for (uint32_t i = 0; i < n && rc == PF_OK; i++) {
-            uint64_t done = 0;
-            const uint64_t L = len[i];
-            do {
-                if (BLOCK - fill < 64) { if ((rc = flush()) != PF_OK) break; }
-                const uint64_t room = (BLOCK - fill - 32) / 32 * 32;                  // bases this block still takes
-                const uint64_t take = std::min<uint64_t>(L - done, room);
-                const bool last = done + take == L;
-                memcpy(pin + fill, ascii[i] + done, take);
-                const size_t padded = (take + 31) / 32 * 32;
-                memset(pin + fill + take, 'A', padded - take);
-                pf::PackPiece pc{};
-                pc.ascii_off = fill; pc.dst_word = word_off[i] + done / 32; pc.nbases = (uint32_t)take;
-                const uint64_t contig_words = 2 * ((L + 63) / 64) + 4;
-                pc.nwords = (uint32_t)(last ? contig_words - done / 32 : take / 32);
-                pc.block0 = blocks;
-                blocks += (pc.nwords + 255) / 256;
-                if (pc.nwords) pieces.push_back(pc);
-                fill += padded;
-                done += take;
-                if (!last && (rc = flush()) != PF_OK) break;
-            } while (done < L);
+        for (int q = 0; q < 2 && rc == PF_OK; q++) {
+            if (hipHostMalloc((void**)&pin[q], BLOCK, hipHostMallocDefault) != hipSuccess) { rc = fail(PF_ERR_OOM, "hipHostMalloc(%zu) failed", BLOCK); break; }
+            if ((rc = dasc[q].ensure(BLOCK)) != PF_OK) break;
+            if (hipEventCreateWithFlags(&ev[q], hipEventDisableTiming) != hipSuccess) { rc = fail(PF_ERR_HIP, "hipEventCreate failed"); break; }
         }
-        if (rc == PF_OK) rc = flush();
+        if (rc != PF_OK) break;
+        for (size_t bi = 0; bi < blks.size() && rc == PF_OK; bi++) {
+            Blk& bk = blks[bi];
+            if (bk.pieces.empty()) continue;
+            const int q = (int)(bi & 1);
+            if (hipEventSynchronize(ev[q]) != hipSuccess) { rc = fail(PF_ERR_HIP, "hipEventSynchronize failed"); break; }   // the slot's last block has left it
+            // the block's pieces into the pinned block, on the host threads (padding bases are 'A')
+            char* dst = pin[q];
+            parallel_for(bk.fill, [&](uint64_t a, uint64_t e) {          // every thread takes a byte range of the block
+                for (const Src& sp : bk.src) {
+                    const uint64_t lo = std::max<uint64_t>(a, sp.at), hi = std::min<uint64_t>(e, sp.at + sp.n);
+                    if (lo < hi) memcpy(dst + lo, sp.p + (lo - sp.at), hi - lo);
+                }
+            });
+            for (const Src& sp : bk.src) { const size_t padded = (sp.n + 31) / 32 * 32; memset(dst + sp.at + sp.n, 'A', padded - sp.n); }
+            if ((rc = dpieces[q].ensure(bk.pieces.size() * sizeof(pf::PackPiece))) != PF_OK) break;
+            if (hipMemcpyAsync(dasc[q].p, pin[q], bk.fill, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                hipMemcpyAsync(dpieces[q].p, bk.pieces.data(), bk.pieces.size() * sizeof(pf::PackPiece), hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+                rc = fail(PF_ERR_HIP, "genome upload failed"); break;
+            }
+            hipLaunchKernelGGL(pf::genome_pack_kernel, dim3(bk.blocks), dim3(256), 0, c->stream, (const uint8_t*)dasc[q].p,
+                               (const pf::PackPiece*)dpieces[q].p, (uint32_t)bk.pieces.size(), c->g_store.as<uint64_t>());
+            if (hipGetLastError() != hipSuccess || hipEventRecord(ev[q], c->stream) != hipSuccess) { rc = fail(PF_ERR_HIP, "genome_pack_kernel launch failed"); break; }
+        }
     } while (0);
-    if (pin) (void)hipHostFree(pin);
-    dasc.release(); dpieces.release();
+    if (hipStreamSynchronize(c->stream) != hipSuccess && rc == PF_OK) rc = fail(PF_ERR_HIP, "genome upload failed");
+    for (int q = 0; q < 2; q++) {
+        if (pin[q]) (void)hipHostFree(pin[q]);
+        if (ev[q]) (void)hipEventDestroy(ev[q]);
+        dasc[q].release(); dpieces[q].release();
+    }
     return rc;
 }
 

@@ -555,7 +555,30 @@ int pf_pangenome_open(const pf_pangenome_opts* o, pf_pangenome** out) {
     return PF_OK;
 }
 
-void pf_pangenome_close(pf_pangenome* P) { delete P; }
+// The reader holds millions of small heap objects (a feature map and the contigs per genome, a string per table cell):
+// a plain `delete` walks them on one thread -- 0.16 s for 1 000 genomes x 1 000 clusters, as long as the run's whole GPU
+// part.  They are emptied on all host threads first.
+void pf_pangenome_close(pf_pangenome* P) {
+    if (!P) return;
+    std::vector<Genome*> gs;
+    gs.reserve(P->genomes.size());
+    for (auto& kv : P->genomes) gs.push_back(&kv.second);
+    const size_t ng = gs.size(), nr = P->cells.size();
+    unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+    if (ng + nr < 64) nt = 1;
+    std::atomic<size_t> next{0};
+    auto work = [&] {
+        for (size_t i; (i = next.fetch_add(1)) < ng + nr;) {
+            if (i < ng) { Genome dead; std::swap(dead.contigs, gs[i]->contigs); std::swap(dead.features, gs[i]->features); }
+            else { std::vector<std::string> dead; dead.swap(P->cells[i - ng]); }
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
+    delete P;
+}
 
 int pf_pangenome_info(pf_pangenome* P, pf_pangenome_info_t* info) {
     if (!P || !info) return in_fail(PF_ERR_ARG, "null argument");
