@@ -359,7 +359,9 @@ def end_to_end(args, local):
                               "contigs -> 2 bit/base in HBM; then per batch, overlapped: pack_busy_s (reader + packer "
                               "thread; pack_wait_s = what of it the GPU thread waited for), submit_s (coordinates + "
                               "literals H2D, gather, the kernel chain; device_ms of it on the device), text_s (device "
-                              "text + D2H, or pf_fetch + host renderers), write_busy_s (writer thread); total_s: the call")
+                              "text + D2H, or pf_fetch + host renderers), write_busy_s (writer thread); total_s: open to the last byte written; "
+                              "close_reader_s: the reader handed to its teardown thread (its memory goes back in the "
+                              "background, after the call), close_context_s: pf_destroy; seconds = the whole call")
     finally:
         shutil.rmtree(scratch, ignore_errors=True)
     # ---- records -> files: the boundary as the reference's callers use it (host strings in, three files out)

@@ -348,6 +348,9 @@ typedef struct {
 
 int pf_pangenome_open(const pf_pangenome_opts* opts, pf_pangenome** out);
 void pf_pangenome_close(pf_pangenome* p);
+/* The same on a thread of its own: returns at once, the reader's memory (tables, features, gigabytes of contigs) is
+ * given back in the background.  For a caller that has finished its run. */
+void pf_pangenome_close_async(pf_pangenome* p);
 int pf_pangenome_info(pf_pangenome* p, pf_pangenome_info_t* info);
 const char* pf_pangenome_strain(pf_pangenome* p, uint32_t i, int sorted);
 const char* pf_pangenome_take_log(pf_pangenome* p);   /* warnings the reference sends to logger.warning */

@@ -140,7 +140,7 @@ EXPORTS = ["pf_last_error", "pf_version", "pf_device_count", "pf_create", "pf_de
            "pf_pangenome_set_store", "pf_genomes_upload", "pf_genomes_clear", "pf_submit_gather", "pf_gzip_members", "pf_render_device",
            "pf_render_device_ex", "pf_render_pattern_rows", "pf_pangenome_weights", "pf_pangenome_set_range",
            "pf_rowfilter_create", "pf_rowfilter_scan", "pf_rowfilter_stats", "pf_rowfilter_destroy",
-           "pf_py_str_addresses"]
+           "pf_py_str_addresses", "pf_pangenome_close_async"]
 
 RENDER_NO_PATTERN_ROWS = 1
 ERR_ARG, ERR_OOM, ERR_HIP, ERR_CAPACITY, ERR_STATE = -1, -2, -3, -4, -5
@@ -206,6 +206,8 @@ def load():
     L.pf_pangenome_open.argtypes = [C.POINTER(PangenomeOpts), C.POINTER(C.c_void_p)]
     L.pf_pangenome_close.argtypes = [C.c_void_p]
     L.pf_pangenome_close.restype = None
+    L.pf_pangenome_close_async.argtypes = [C.c_void_p]
+    L.pf_pangenome_close_async.restype = None
     L.pf_pangenome_info.argtypes = [C.c_void_p, C.POINTER(PangenomeInfo)]
     L.pf_pangenome_strain.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
     L.pf_pangenome_strain.restype = C.c_char_p

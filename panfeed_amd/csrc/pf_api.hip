@@ -1516,6 +1516,8 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         HIPCHK(hipMemsetAsync(c->md5_list.p, 0, 4, c->stream));
         mp.int_list = c->md5_list.as<uint32_t>();
         PFCHK(mark_begin(c, 5));
+        // (one workgroup per CU -- one wave per SIMD -- already runs this kernel at 0.93 of its full-grid speed: 3.21 against
+        // 2.99 ms, profiles/r03/md5_occupancy_experiment.txt; it is a chain of dependent integer instructions)
         const dim3 g_float((pid1 - c->pid0 + pf::MD5_THREADS - 1) / pf::MD5_THREADS);
         const dim3 g_int(std::min<uint32_t>((C + pf::MD5_THREADS - 1) / pf::MD5_THREADS, 1024u));
         if (mp.pat_nan) {

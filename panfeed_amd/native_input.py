@@ -120,9 +120,10 @@ class Pangenome:
         """restrict the reader to processed clusters [first, first + count) and rewind it to `first`"""
         _lib.check(self.L.pf_pangenome_set_range(self.h, int(first), int(count)))
 
-    def close(self):
+    def close(self, wait=True):
+        """give the reader back; wait=False: on a thread of the library's own (the call returns at once)"""
         if self.h:
-            self.L.pf_pangenome_close(self.h)
+            (self.L.pf_pangenome_close if wait else self.L.pf_pangenome_close_async)(self.h)
             self.h = C.c_void_p()
 
     __del__ = close

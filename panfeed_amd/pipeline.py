@@ -153,7 +153,7 @@ def run_files(presence_absence, gffdir, output, fastadir=None, klength=31, canon
         return stats
     finally:
         t0 = _time.perf_counter()
-        pg.close()
+        pg.close(wait=False)                 # the run is over: the reader's memory goes back in the background
         t1 = _time.perf_counter()
         if eng is not None:
             eng.close()
