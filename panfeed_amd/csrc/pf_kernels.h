@@ -988,12 +988,17 @@ void cluster_dedup_kernel(DedupParams p) {
         // of the group it waits for.
         const uint64_t wbase = p.seg_word_off[seg0];
         const ulonglong2* cbase = reinterpret_cast<const ulonglong2*>(p.packed + wbase);
-        const uint32_t grp = tid / DEDUP_GL, gl = tid % DEDUP_GL, ngrp = DEDUP_THREADS / DEDUP_GL;
-        const uint32_t wave_grp0 = (tid >> 6) * (64 / DEDUP_GL);
+        // Lanes per segment: as many as the cluster's segments need at DEDUP_CH pieces per lane (the sequences of a cluster
+        // are alleles of one gene: about the same length) -- 5 for 1 200 bases.  With a fixed 8 (rounds 1-2) such a segment
+        // filled 19 of its group's 32 places: the pass had 38 bytes in flight per lane where it could have 61.
+        const uint32_t GL = min(DEDUP_GL, max(2u, (((p.seg_len[seg0] + 63) >> 6) + DEDUP_CH - 1) / DEDUP_CH));
+        const uint32_t gpw = 64 / GL;                              // groups per wave (lanes past gpw * GL stay idle)
+        const bool lane_used = lane < gpw * GL;
+        const uint32_t gl = lane % GL, gbase = lane - gl;
+        const uint32_t grp = (tid >> 6) * gpw + min(lane / GL, gpw - 1), ngrp = (DEDUP_THREADS / 64) * gpw;
+        const uint32_t wave_grp0 = (tid >> 6) * gpw;
         // segment metadata is read from global memory one trip ahead (no LDS copy: clusters of thousands of samples
         // have thousands of segments)
-        const uint32_t salt_lo0 = dedup_salt_lo(2 * gl), salt_hi0 = dedup_salt_hi(2 * gl);   // word 2 * gl (q = 0, first word)
-        (void)salt_lo0; (void)salt_hi0;
         uint32_t nx_len[DEDUP_U], nx_woff[DEDUP_U], nx_ord[DEDUP_U];
 #pragma unroll
         for (int u = 0; u < (int)DEDUP_U; u++) {
@@ -1015,9 +1020,9 @@ void cluster_dedup_kernel(DedupParams p) {
 #pragma unroll
             for (int u = 0; u < (int)DEDUP_U; u++) {
                 si[u] = s + u * ngrp;
-                has[u] = si[u] < n;
+                has[u] = lane_used && si[u] < n;
                 len[u] = nx_len[u];
-                pc[u] = (len[u] + 63) >> 6;
+                pc[u] = lane_used ? (len[u] + 63) >> 6 : 0;
                 w[u] = cbase + (nx_woff[u] >> 1);
             }
 #pragma unroll
@@ -1026,7 +1031,7 @@ void cluster_dedup_kernel(DedupParams p) {
             for (int u = 0; u < (int)DEDUP_U; u++)
 #pragma unroll
                 for (uint32_t q = 0; q < DEDUP_CH; q++) {
-                    const uint32_t j = gl + DEDUP_GL * q;
+                    const uint32_t j = gl + GL * q;
                     v[u][q] = j < pc[u] ? dedup_load16(&w[u][j]) : make_ulonglong2(0, 0);
                 }
 #pragma unroll
@@ -1040,15 +1045,12 @@ void cluster_dedup_kernel(DedupParams p) {
             for (int u = 0; u < (int)DEDUP_U; u++) {
 #pragma unroll
                 for (uint32_t q = 0; q < DEDUP_CH; q++) {
-                    const uint32_t j = gl + DEDUP_GL * q;
-                    if (j < pc[u]) {
-                        // salts of words 2j and 2j + 1: lane part + a compile-time step per q
-                        acc[u] += dedup_word_hash(v[u][q].x, salt_lo0 + q * (4u * DEDUP_GL * 0x9E3779B1u), salt_hi0 + q * (4u * DEDUP_GL * 0x85EBCA77u)) +
-                                  dedup_word_hash(v[u][q].y, salt_lo0 + q * (4u * DEDUP_GL * 0x9E3779B1u) + 2u * 0x9E3779B1u,
-                                                  salt_hi0 + q * (4u * DEDUP_GL * 0x85EBCA77u) + 2u * 0x85EBCA77u);
-                    }
+                    const uint32_t j = gl + GL * q;
+                    if (j < pc[u])
+                        acc[u] += dedup_word_hash(v[u][q].x, dedup_salt_lo(2 * j), dedup_salt_hi(2 * j)) +
+                                  dedup_word_hash(v[u][q].y, dedup_salt_lo(2 * j + 1), dedup_salt_hi(2 * j + 1));
                 }
-                for (uint32_t j = gl + DEDUP_GL * DEDUP_CH; j < pc[u]; j += DEDUP_GL) {      // longer than the registers hold
+                for (uint32_t j = gl + GL * DEDUP_CH; j < pc[u]; j += GL) {      // longer than the registers hold
                     const ulonglong2 x = w[u][j];
                     acc[u] += dedup_word_hash(x.x, dedup_salt_lo(2 * j), dedup_salt_hi(2 * j)) +
                               dedup_word_hash(x.y, dedup_salt_lo(2 * j + 1), dedup_salt_hi(2 * j + 1));
@@ -1057,8 +1059,8 @@ void cluster_dedup_kernel(DedupParams p) {
             // claim: lane 0 of the group finds or opens the hash group
 #pragma unroll
             for (int u = 0; u < (int)DEDUP_U; u++) {
-                uint64_t a = acc[u];
-                for (int d = 1; d < (int)DEDUP_GL; d <<= 1) a += __shfl_xor(a, d);
+                uint64_t a = 0;                                  // the group's sum (GL is not a power of two in general)
+                for (uint32_t i = 0; i < GL; i++) a += __shfl(acc[u], (int)(gbase + i));
                 uint64_t h = mix64(a ^ ((uint64_t)len[u] << 40));
                 if (h == EMPTY64) h = EMPTY64 - 1;
                 uint32_t sl = 0, reg = 0;
@@ -1087,8 +1089,8 @@ void cluster_dedup_kernel(DedupParams p) {
                         s_slot[si[u]] = (slot_t)sl;
                     }
                 }
-                slot[u] = __shfl(sl, lane & ~(DEDUP_GL - 1));
-                registrar[u] = __shfl(reg, lane & ~(DEDUP_GL - 1)) != 0;
+                slot[u] = __shfl(sl, (int)gbase);
+                registrar[u] = __shfl(reg, (int)gbase) != 0;
                 if (slot[u] >= GTAB) has[u] = false;      // cluster given up by this class
             }
             // publish: the first segment of a group leaves its words in the pool
@@ -1097,15 +1099,15 @@ void cluster_dedup_kernel(DedupParams p) {
                 if (has[u] && registrar[u]) {
                     uint32_t off = 0;
                     if (gl == 0) off = atomicAdd(&sh_pool_used, 2 * pc[u]);
-                    off = __shfl(off, lane & ~(DEDUP_GL - 1));
+                    off = __shfl(off, (int)gbase);
                     const bool fits = off + 2 * pc[u] <= POOL;
                     if (fits) {
 #pragma unroll
                         for (uint32_t q = 0; q < DEDUP_CH; q++) {
-                            const uint32_t j = gl + DEDUP_GL * q;
+                            const uint32_t j = gl + GL * q;
                             if (j < pc[u]) *reinterpret_cast<ulonglong2*>(&s_pool[off + 2 * j]) = v[u][q];     // off is even: 16-byte stores
                         }
-                        for (uint32_t j = gl + DEDUP_GL * DEDUP_CH; j < pc[u]; j += DEDUP_GL) {
+                        for (uint32_t j = gl + GL * DEDUP_CH; j < pc[u]; j += GL) {
                             const ulonglong2 x = w[u][j];
                             s_pool[off + 2 * j] = x.x; s_pool[off + 2 * j + 1] = x.y;
                         }
@@ -1132,10 +1134,10 @@ void cluster_dedup_kernel(DedupParams p) {
                         {
 #pragma unroll
                             for (uint32_t q = 0; q < DEDUP_CH; q++) {
-                                const uint32_t j = gl + DEDUP_GL * q;
+                                const uint32_t j = gl + GL * q;
                                 if (j < pc[u]) { const ulonglong2 y = b[j]; diff = diff || y.x != v[u][q].x || y.y != v[u][q].y; }
                             }
-                            for (uint32_t j = gl + DEDUP_GL * DEDUP_CH; j < pc[u]; j += DEDUP_GL) {
+                            for (uint32_t j = gl + GL * DEDUP_CH; j < pc[u]; j += GL) {
                                 const ulonglong2 x = w[u][j], y = b[j];
                                 diff = diff || x.x != y.x || x.y != y.y;
                             }
@@ -1143,13 +1145,13 @@ void cluster_dedup_kernel(DedupParams p) {
                     } else {
 #pragma unroll
                         for (uint32_t q = 0; q < DEDUP_CH; q++) {
-                            const uint32_t j = gl + DEDUP_GL * q;
+                            const uint32_t j = gl + GL * q;
                             if (j < pc[u]) {
                                 const ulonglong2 y = *reinterpret_cast<const ulonglong2*>(&s_pool[pp + 2 * j]);   // one 16-byte read
                                 diff = diff || y.x != v[u][q].x || y.y != v[u][q].y;
                             }
                         }
-                        for (uint32_t j = gl + DEDUP_GL * DEDUP_CH; j < pc[u]; j += DEDUP_GL) {
+                        for (uint32_t j = gl + GL * DEDUP_CH; j < pc[u]; j += GL) {
                             const ulonglong2 x = w[u][j];
                             diff = diff || s_pool[pp + 2 * j] != x.x || s_pool[pp + 2 * j + 1] != x.y;
                         }
