@@ -238,3 +238,25 @@ def test_synth_allele_models():
             assert min(int((al[i] != al[j]).sum()) for j in range(i)) in (1, 2)
     with pytest.raises(ValueError):
         synth.generate(1, 10, allele_model="bush")
+
+
+def test_bench_gpus_n_refuses_without_devices():
+    """`python bench.py --gpus N` launches its own ranks; on a box with fewer than N devices (here: none) it must say so
+    and run nothing -- not print an N = 1 line (round-2 review, item 2)"""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PANFEED_BENCH_SHARED_GPU")}
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two devices present: the launcher would start")
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 2, r.stderr
+    assert "2 ranks requested" in r.stderr and r.stdout.strip() == ""
+    # a launcher that started another number of ranks than --gpus says is refused as well
+    env2 = dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2"], env=env2, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 2 and "--gpus 2 but the launcher started 3" in r.stderr
