@@ -1,11 +1,13 @@
 // pf_api.hip -- C ABI (include/panfeed_hip.h) over the kernels in pf_kernels.h.
 //
 // Host orchestration of one batch (pf_submit):
-//   per-cluster instance counts -> work items (cluster x key partition, plus one prebuilt item per cluster
-//   for slow-path rows) -> sub-batches of <= max_items items, each: scan -> rows -> base -> emit -> pattern
-//   rows; clusters whose LDS table overflowed are re-run with 4x the partitions; MD5 of new patterns last.
-// Everything is stream-ordered on one HIP stream; the only host syncs are the instance-count read-back, the
-// overflow read-back per pass and the final counter read-back.
+//   dedup (identical sequences) -> per-cluster counts back to the host -> unit classes (identical units) ->
+//   work items (cluster x key partition, plus prebuilt items for slow-path rows) -> sub-batches of <= max_items
+//   items, each: scan -> fused finish, or rows -> base -> emit -> pattern rows; clusters whose LDS table overflowed are
+//   re-run with the partitions the failed scan asked for; MD5 of new patterns last.  A batch of >= 8 192 clusters goes
+//   through in two parts so that the host builds a part's items while the GPU is on the other.
+// Everything is stream-ordered on one HIP stream; the host syncs are the dedup results per part, the overflow / cursor /
+// pattern-counter read-back of the last pass and the end of the batch.
 #include "pf_kernels.h"
 #include "../../include/panfeed_hip.h"
 

@@ -4,6 +4,8 @@
 //   gather_segments_kernel  (optional) segments cut out of / reverse-complemented from genomes resident in HBM.
 //   cluster_dedup_kernel  per cluster: identical segments -> one representative per distinct sequence (exact,
 //                      one pass over the packed bytes).
+//   unit_class_small_kernel / unit_class_kernel   per cluster of several distinct sequences: 64-window units that
+//                      several of them hold unchanged at the same place -> one piece with all their column bits (exact).
 //   scan_desc_kernel + kmer_scan_kernel   persistent 1024-thread workgroups, one (cluster, key partition) at a
 //                      time: slide the k window over the 2-bit packed segments, canonicalise (panfeed.py:65-75),
 //                      group k-mers in an LDS hash table {key, first-occurrence ordinal, 32-column presence word};
