@@ -70,7 +70,9 @@ def parse(argv=None):
                     help="star: SURVEY 8d's alleles (default); tree: alleles that descend from one another (synth.py)")
     ap.add_argument("--n-rate", type=float, default=0.0, help="share of the sequences that carry one 'N' (SURVEY 8d: 0.001)")
     ap.add_argument("--max-items", type=int, default=65536)
-    ap.add_argument("--pattern-capacity", type=int, default=1 << 25, help="initial slots of the run-global pattern table")
+    ap.add_argument("--pattern-capacity", type=int, default=0,
+                    help="initial slots of the run-global pattern table (0 = by workload: 2^25 for the headline's 2.6 M patterns "
+                         "per pass, 2^22 for small workloads; the table grows on demand either way)")
     ap.add_argument("--cpu-clusters", type=int, default=0, help="clusters in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dedup", action="store_true", help="scan every copy of identical sequences (PF_FLAG_NO_DEDUP)")
@@ -446,6 +448,15 @@ def main():
     strong = args.scaling == "strong" or (args.scaling == "auto" and world > 1)
     # (rehearsal with every rank on one GPU: the ranks share its memory, a work item's scratch slice is ~1.9 MB)
     max_items = args.max_items if not shared else max(2048, args.max_items // (4 * world))
+    if strong:
+        first, stop = shard_range(args.clusters, rank, world)
+        n_mine = stop - first
+    else:
+        first, n_mine = rank * args.clusters, args.clusters
+    if not args.pattern_capacity:
+        # (every step starts from an empty pattern set -- pf_reset_patterns, inside the timed region: clearing a table sized
+        # for the headline costs 0.16 ms, a tenth of a 5 000 x 200 pass)
+        args.pattern_capacity = 1 << 25 if n_mine * max(S, 1) >= 20_000_000 else 1 << 22
     eng = Engine(klength=k, max_strains=(S + 31) // 32 * 32, device=local, max_items=max_items,
                  pattern_capacity=args.pattern_capacity, dedup=not args.no_dedup, unit_dedup=not args.no_unit_dedup)
 
@@ -483,11 +494,6 @@ def main():
             dist.all_reduce(agg, op=dist.ReduceOp.SUM)
         return [float(x) for x in tmax.tolist()], [float(x) for x in agg.tolist()]
 
-    if strong:
-        first, stop = shard_range(args.clusters, rank, world)
-        n_mine = stop - first
-    else:
-        first, n_mine = rank * args.clusters, args.clusters
     t_gen = time.time()
     dbs = build(first, n_mine)
     t_gen = time.time() - t_gen
