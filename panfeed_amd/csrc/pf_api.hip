@@ -111,7 +111,7 @@ struct pf_ctx {
     DevBuf b_packed, b_seg_word_off, b_seg_len, b_seg_sample, b_seg_ord, b_cl_seg_off, b_cl_nstr, b_cl_npres,
         b_cl_presab, b_cl_ordinal, b_extra_ord, b_extra_bits, b_seg_strand_off;
     // per batch device arrays
-    DevBuf cl_ninst, cl_vinst, cl_vwords, cl_overflow, cl_kmer_off, cl_kmer_cnt, cl_unique, cl_pattern, cl_first, cursor;
+    DevBuf cl_rec, cl_overflow, cl_kmer_off, cl_kmer_cnt, cl_unique, cl_pattern, cl_first, cursor;
     // scan view built by cluster_dedup_kernel
     DevBuf v_word_off, v_len, v_sample, v_ord, seg_distinct, v_nseg, v_nstr, v_mode, v_dense, extra_off, extra_dense;
     DevBuf bm_occ, bm_keep, pre_occ, pre_keep, mrows, slot_out, it_is_extra, cmask_lo, cmask_hi, it_compact;
@@ -446,7 +446,7 @@ void pf_destroy(pf_ctx* c) {
                       &c->pat_nan, &c->pat_n, &c->pat_md5, &c->tab_key, &c->tab_ord, &c->chunkbits, &c->chunkmask,
                       &c->slot_hash, &c->sorted_pair, &c->kept_prefix, &c->b_packed, &c->b_seg_word_off, &c->b_seg_len,
                       &c->b_seg_sample, &c->b_seg_ord, &c->b_cl_seg_off, &c->b_cl_nstr, &c->b_cl_npres, &c->b_cl_presab,
-                      &c->b_cl_ordinal, &c->b_extra_ord, &c->b_extra_bits, &c->b_seg_strand_off, &c->cl_ninst, &c->cl_vinst, &c->cl_vwords, &c->v_word_off, &c->v_len, &c->v_sample, &c->v_ord,
+                      &c->b_cl_ordinal, &c->b_extra_ord, &c->b_extra_bits, &c->b_seg_strand_off, &c->cl_rec, &c->v_word_off, &c->v_len, &c->v_sample, &c->v_ord,
                       &c->seg_distinct, &c->v_nseg, &c->v_nstr, &c->v_mode, &c->v_dense, &c->extra_off, &c->extra_dense,
                       &c->bm_occ, &c->bm_keep, &c->pre_occ, &c->pre_keep, &c->mrows, &c->slot_out, &c->it_is_extra,
                       &c->cmask_lo, &c->cmask_hi, &c->it_compact, &c->cl_overflow, &c->cl_kmer_off, &c->cl_kmer_cnt, &c->cl_unique, &c->cl_pattern,
@@ -764,9 +764,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
     PFCHK(c->cl_unique.ensure(C1 * 4));
     PFCHK(c->cl_pattern.ensure(C1 * 4));
     PFCHK(c->cl_first.ensure(C1 * 8));
-    PFCHK(c->cl_ninst.ensure(C1 * 8));
-    PFCHK(c->cl_vinst.ensure(C1 * 8));
-    PFCHK(c->cl_vwords.ensure(C1 * 8));
+    PFCHK(c->cl_rec.ensure(C1 * sizeof(pf::ClusterRec)));
     PFCHK(c->v_word_off.ensure(NSEG1 * 8));
     PFCHK(c->v_len.ensure(NSEG1 * 4));
     PFCHK(c->v_sample.ensure(NSEG1 * 4));
@@ -788,7 +786,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
     // second half's while the first half's scan runs -- otherwise the GPU idles for the ~1.2 ms that takes.
     const size_t C8 = ((size_t)C + 1) & ~(size_t)1;
     {
-        const size_t need = C8 * 36 + 64 + ((size_t)C + 2) * 4;
+        const size_t need = C8 * sizeof(pf::ClusterRec) + 64 + ((size_t)C + 2) * 4;
         if (need > c->pin_dedup_cap) {
             if (c->pin_dedup) (void)hipHostFree(c->pin_dedup);
             c->pin_dedup = nullptr; c->pin_dedup_cap = 0;
@@ -797,13 +795,11 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             c->pin_dedup_cap = need + need / 4;
         }
     }
-    uint64_t* ninst = reinterpret_cast<uint64_t*>(c->pin_dedup);
-    uint64_t* vinst = ninst + C8;
-    uint64_t* words = vinst + C8;
-    uint32_t* h_mode = reinterpret_cast<uint32_t*>(words + C8);
-    uint32_t* h_dense = h_mode + C8;
-    uint32_t* h_vnstr = h_dense + C8;
-    uint32_t* h_exfirst = h_vnstr + C8;         // [C + 1] + the "bad list" flag (device-side CSR only)
+    // what the host needs of the dedup pass per cluster, one 40-byte record each (pf::ClusterRec, written by
+    // cluster_ninst_kernel): ONE copy per part brings them over -- six small copies in a row were 40 us of the part's
+    // critical path
+    pf::ClusterRec* rec = reinterpret_cast<pf::ClusterRec*>(c->pin_dedup);
+    uint32_t* h_exfirst = reinterpret_cast<uint32_t*>(rec + C8);   // [C + 1] + the "bad list" flag (device-side CSR only)
     if (ex_on_device) {
         PFCHK(c->extra_off.ensure(((size_t)C + 2) * 4));
         uint32_t* exo = c->extra_off.as<uint32_t>();
@@ -850,14 +846,9 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             hipLaunchKernelGGL(pf::cluster_ninst_kernel, dim3((n + 3) / 4), dim3(256), 0, c->stream, d.cluster_seg_off,
                                d.seg_len, c->v_len.as<uint32_t>(), c->v_nseg.as<uint32_t>(), c->o.klength, c0, c1,
                                (const uint32_t*)nullptr,
-                               c->cl_ninst.as<uint64_t>(), c->cl_vinst.as<uint64_t>(), c->cl_vwords.as<uint64_t>());
+                               c->v_mode.as<uint32_t>(), c->v_dense.as<uint32_t>(), c->v_nstr.as<uint32_t>(), c->cl_rec.as<pf::ClusterRec>());
             HIPCHK(hipGetLastError());
-            HIPCHK(hipMemcpyAsync(ninst + c0, c->cl_ninst.as<uint64_t>() + c0, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipMemcpyAsync(vinst + c0, c->cl_vinst.as<uint64_t>() + c0, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipMemcpyAsync(words + c0, c->cl_vwords.as<uint64_t>() + c0, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipMemcpyAsync(h_mode + c0, c->v_mode.as<uint32_t>() + c0, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipMemcpyAsync(h_dense + c0, c->v_dense.as<uint32_t>() + c0, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipMemcpyAsync(h_vnstr + c0, c->v_nstr.as<uint32_t>() + c0, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(rec + c0, c->cl_rec.as<pf::ClusterRec>() + c0, (size_t)n * sizeof(pf::ClusterRec), hipMemcpyDeviceToHost, c->stream));
         }
         HIPCHK(hipEventRecord(c->ev_part[h], c->stream));
         return PF_OK;
@@ -906,7 +897,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         // clusters the small dedup class gave up on for lack of room (more than 64 distinct sequences, a sample-set
         // matrix or an ordinal bitmap that does not fit): the wide class on those alone, then their counts again
         wide_list.clear();
-        for (uint32_t i = c0; i < c1; i++) if (h_mode[i] & pf::MODE_RETRY_WIDE) wide_list.push_back(i);
+        for (uint32_t i = c0; i < c1; i++) if (rec[i].mode & pf::MODE_RETRY_WIDE) wide_list.push_back(i);
         if (!wide_list.empty()) {
             const uint32_t nw = (uint32_t)wide_list.size();
             PFCHK(c->wide_list.ensure((size_t)nw * 4));
@@ -920,24 +911,20 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             hipLaunchKernelGGL(pf::cluster_ninst_kernel, dim3((nw + 3) / 4), dim3(256), 0, c->stream, d.cluster_seg_off,
                                d.seg_len, c->v_len.as<uint32_t>(), c->v_nseg.as<uint32_t>(), c->o.klength, 0u, nw,
                                c->wide_list.as<uint32_t>(),
-                               c->cl_ninst.as<uint64_t>(), c->cl_vinst.as<uint64_t>(), c->cl_vwords.as<uint64_t>());
+                               c->v_mode.as<uint32_t>(), c->v_dense.as<uint32_t>(), c->v_nstr.as<uint32_t>(), c->cl_rec.as<pf::ClusterRec>());
             HIPCHK(hipGetLastError());
             const size_t n = c1 - c0;
-            HIPCHK(hipMemcpyAsync(vinst + c0, c->cl_vinst.as<uint64_t>() + c0, n * 8, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipMemcpyAsync(words + c0, c->cl_vwords.as<uint64_t>() + c0, n * 8, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipMemcpyAsync(h_mode + c0, c->v_mode.as<uint32_t>() + c0, n * 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipMemcpyAsync(h_dense + c0, c->v_dense.as<uint32_t>() + c0, n * 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipMemcpyAsync(h_vnstr + c0, c->v_nstr.as<uint32_t>() + c0, n * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(rec + c0, c->cl_rec.as<pf::ClusterRec>() + c0, n * sizeof(pf::ClusterRec), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
             c->timing.n_wide_clusters += nw;
         }
         for (uint32_t i = c0; i < c1; i++) {
-            h_mode[i] &= 3u;
-            if (ninst[i] * mult >= 0xFFFFFFF0ull) return fail(PF_ERR_ARG, "cluster %u has too many k-mer instances", i);
-            total_inst += ninst[i] * mult;
-            c->timing.n_dedup_clusters += h_mode[i] ? 1u : 0u;
-            if (h_mode[i] && h_vnstr[i]) {
-                const double D = (double)h_vnstr[i], L = (double)(vinst[i] * mult) / D;
+            rec[i].mode &= 3u;
+            if (rec[i].ninst * mult >= 0xFFFFFFF0ull) return fail(PF_ERR_ARG, "cluster %u has too many k-mer instances", i);
+            total_inst += rec[i].ninst * mult;
+            c->timing.n_dedup_clusters += rec[i].mode ? 1u : 0u;
+            if (rec[i].mode && rec[i].vnstr) {
+                const double D = (double)rec[i].vnstr, L = (double)(rec[i].vinst * mult) / D;
                 const double est = L * (1.0 + share * (D - 1.0));
                 const double room = 0.9 * (double)pf::insert_limit(NS);
                 // The estimate is right for SURVEY 8d's alleles, each with its own substitutions and flanks.  The many
@@ -984,15 +971,15 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             uint32_t nu = 0, nsmall = 0;
             uint64_t room = 0;
             uint32_t* lc = up.pin;
-            auto takes = [&](uint32_t i) { return h_mode[i] && h_vnstr[i] >= 2 && words[i] && room + words[i] / 2 < 0x7FFFFFF0ull; };
+            auto takes = [&](uint32_t i) { return rec[i].mode && rec[i].vnstr >= 2 && rec[i].words && room + rec[i].words / 2 < 0x7FFFFFF0ull; };
             for (uint32_t i = c0; i < c1; i++)
-                if (h_vnstr[i] <= pf::UNIT_SMALL_MAX_D && takes(i)) { lc[nu++] = i; room += words[i] / 2; }
+                if (rec[i].vnstr <= pf::UNIT_SMALL_MAX_D && takes(i)) { lc[nu++] = i; room += rec[i].words / 2; }
             nsmall = nu;
             for (uint32_t i = c0; i < c1; i++)
-                if (h_vnstr[i] > pf::UNIT_SMALL_MAX_D && takes(i)) { lc[nu++] = i; room += words[i] / 2; }
+                if (rec[i].vnstr > pf::UNIT_SMALL_MAX_D && takes(i)) { lc[nu++] = i; room += rec[i].words / 2; }
             uint32_t* lb = up.pin + nu;
             room = 0;
-            for (uint32_t j = 0; j < nu; j++) { lb[j] = (uint32_t)room; room += words[lc[j]] / 2; }
+            for (uint32_t j = 0; j < nu; j++) { lb[j] = (uint32_t)room; room += rec[lc[j]].words / 2; }
             if (nu) {
                 const size_t R = (size_t)room + 1;
                 PFCHK(up.word_off.ensure(R * 8)); PFCHK(up.len.ensure(R * 4)); PFCHK(up.sample.ensure(R * 4));
@@ -1071,14 +1058,14 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             const uint32_t nex = ex_first[ci + 1] - ex_first[ci];
             // a deduplicated cluster that is one work item (or a few key partitions) is finished by one fused kernel
             // (rows + emit in LDS); its slow-path rows (a few k-mers around an 'N') are folded in by that kernel
-            const uint32_t mwords = h_vnstr[ci] * ((W + 3) & ~3u);
+            const uint32_t mwords = rec[ci].vnstr * ((W + 3) & ~3u);
             uint8_t fused = 0;   // 1/2: single item, small/large class; 3: first of several partitions; 4: the others;
                                  // 5: single item, huge class
-            if (h_mode[ci] == 1 && nex <= pf::FUSED_MAX_EXTRA && NS <= 9600) {
-                const bool fits_large = h_dense[ci] < pf::FinLarge::DW * 32 - 1 && mwords <= pf::FinLarge::MR;
-                const bool fits_huge = h_dense[ci] < pf::FinHuge::DW * 32 - 1 && mwords <= pf::FinHuge::MR;
+            if (rec[ci].mode == 1 && nex <= pf::FUSED_MAX_EXTRA && NS <= 9600) {
+                const bool fits_large = rec[ci].dense < pf::FinLarge::DW * 32 - 1 && mwords <= pf::FinLarge::MR;
+                const bool fits_huge = rec[ci].dense < pf::FinHuge::DW * 32 - 1 && mwords <= pf::FinHuge::MR;
                 if (np == 1) {
-                    if (h_dense[ci] < pf::FinSmall::DW * 32 - 1 && mwords <= pf::FinSmall::MR) fused = 1;
+                    if (rec[ci].dense < pf::FinSmall::DW * 32 - 1 && mwords <= pf::FinSmall::MR) fused = 1;
                     else if (fits_large) fused = 2;
                     else if (fits_huge) fused = 5;
                 } else if (fits_large) fused = 3;
@@ -1099,7 +1086,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             const uint32_t sib0 = (uint32_t)items.size();
             // table size: a cluster that cannot overflow a small table gets one (less flush traffic)
             uint32_t ns = NS;
-            const uint64_t inst = vinst[ci] * mult;
+            const uint64_t inst = rec[ci].vinst * mult;
             if (np == 1 && NS > 4096 + pf::INSERT_SLACK && inst <= pf::insert_limit(4096)) ns = 4096;
             else if (np == 1 && NS > 6144 + pf::INSERT_SLACK && inst <= pf::insert_limit(6144)) ns = 6144;
             for (uint32_t q = 0; q < np; q++) {
@@ -1158,7 +1145,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         // heaviest items first inside each launch (the grid then drains evenly): a coarse O(n) order by
         // log2(scan instances) is enough
         auto wclass = [&](uint32_t it) -> int {
-            const uint64_t w = vinst[items[it].cluster];
+            const uint64_t w = rec[items[it].cluster].vinst;
             return w ? 63 - __builtin_clzll(w) : 0;
         };
         std::vector<uint32_t> tmp_scan, tmp_fin, tmp_fin2;
@@ -1408,7 +1395,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             PFCHK(mark_end(c));
         }
         c->timing.n_items += (uint32_t)NI;
-        for (uint32_t ci : todo) c->timing.scan_packed_bytes += words[ci] * 8 * nparts[ci];
+        for (uint32_t ci : todo) c->timing.scan_packed_bytes += rec[ci].words * 8 * nparts[ci];
 
         lap("launch pass");
         if (pass + 1 < P) {
@@ -1429,7 +1416,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         // pangenome whose later clusters differ from its first is followed -- the read-back is not free)
         // (not in the re-run of a batch after the pattern table grew: its clusters have been counted)
         if (!rerun && (c->reg_n < 8192 || (c->n_submits & 15) == 0))
-            for (uint32_t ci : todo) if (h_mode[ci] && h_vnstr[ci] >= 2) { learn = true; break; }
+            for (uint32_t ci : todo) if (rec[ci].mode && rec[ci].vnstr >= 2) { learn = true; break; }
         if (learn) {
             c->hs_count.resize(NI);
             HIPCHK(hipMemcpyAsync(c->hs_count.data(), c->it_count.p, NI * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1465,11 +1452,11 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
                 const Item& it = items[i];
                 if (it.is_extra || it.part != 0) continue;
                 const uint32_t ci = it.cluster;
-                if (ovf[ci] || !h_mode[ci] || h_vnstr[ci] < 2 || !vinst[ci]) continue;
+                if (ovf[ci] || !rec[ci].mode || rec[ci].vnstr < 2 || !rec[ci].vinst) continue;
                 looked++;
                 uint64_t keys = 0;
                 for (uint32_t q = 0; q < it.nparts; q++) keys += c->hs_count[i + q];
-                const double D = (double)h_vnstr[ci], L = (double)(vinst[ci] * mult) / D;
+                const double D = (double)rec[ci].vnstr, L = (double)(rec[ci].vinst * mult) / D;
                 const double g = std::max(0.0, ((double)keys - L) / (D - 1.0));
                 c->reg_n += 1; c->reg_x += L; c->reg_y += g; c->reg_xx += L * L; c->reg_xy += L * g; c->reg_yy += g * g;
             }
@@ -1484,7 +1471,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
                 // (a view of distinct sequences only: among the copies of an every-copy cluster new keys stop coming
                 // early and nothing can be extrapolated -- those double, as does a cluster that asks for more than 16x)
                 double want = std::ceil((double)nparts[ci] * ((double)ovf[ci] / 64.0) * 1.06);
-                if (!h_mode[ci] || want > 16.0 * nparts[ci]) want = 2.0 * nparts[ci];
+                if (!rec[ci].mode || want > 16.0 * nparts[ci]) want = 2.0 * nparts[ci];
                 nparts[ci] = (uint32_t)std::min<double>(std::max<double>(want, (double)nparts[ci] + 1.0), 65537.0);
                 if (nparts[ci] > 65536) return fail(PF_ERR_CAPACITY, "cluster %u does not fit 65536 key partitions", ci);
             }

@@ -3610,12 +3610,15 @@ __global__ __launch_bounds__(256) void merge_lookup_kernel(MergeParams p) {
 // misc kernels
 // ---------------------------------------------------------------------------------------------
 // per-cluster instance counts: the trip count of panfeed.py:64 over the caller's segments, and the
-// instances / packed words the scan will actually visit (the view); one wave per cluster
+// instances / packed words the scan will actually visit (the view); one wave per cluster.  With the cluster's mode,
+// dense ordinal space and number of view columns they make the 40-byte record the host plans the batch's work from.
+struct ClusterRec { uint64_t ninst, vinst, words; uint32_t mode, dense, vnstr, pad; };
+static_assert(sizeof(ClusterRec) == 40, "ClusterRec is copied to the host as 40-byte records");
 __global__ __launch_bounds__(256) void cluster_ninst_kernel(const uint32_t* cluster_seg_off, const uint32_t* seg_len,
                                                             const uint32_t* v_len, const uint32_t* v_nseg, uint32_t k,
                                                             uint32_t c_first, uint32_t c_end, const uint32_t* list,
-                                                            uint64_t* cluster_ninst,
-                                                            uint64_t* cluster_vinst, uint64_t* cluster_vwords) {
+                                                            const uint32_t* v_mode, const uint32_t* v_dense,
+                                                            const uint32_t* v_nstr, ClusterRec* rec) {
     // clusters c_first .. c_end - 1, or (list) list[c_first .. c_end - 1]
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t idx = c_first + ((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -3635,7 +3638,11 @@ __global__ __launch_bounds__(256) void cluster_ninst_kernel(const uint32_t* clus
     for (int d = 32; d > 0; d >>= 1) {
         n += __shfl_down(n, d); nv += __shfl_down(nv, d); wv += __shfl_down(wv, d);
     }
-    if (lane == 0) { cluster_ninst[c] = n; cluster_vinst[c] = nv; cluster_vwords[c] = wv; }
+    if (lane == 0) {
+        ClusterRec r;
+        r.ninst = n; r.vinst = nv; r.words = wv; r.mode = v_mode[c]; r.dense = v_dense[c]; r.vnstr = v_nstr[c]; r.pad = 0;
+        rec[c] = r;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
