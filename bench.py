@@ -701,7 +701,10 @@ def main():
             if with_n is not None:
                 _, with_n["parity_sample"] = oracle_sample(args, local, threads, max(8, n // 4), 0.001, False)
         if world == 1 and default_shape and not args.no_e2e_leg:
-            out["end_to_end"] = end_to_end(args, local)
+            try:
+                out["end_to_end"] = end_to_end(args, local)
+            except OSError as e:             # no room for the 1.2 GB scratch pangenome: the line is still worth printing
+                out["end_to_end"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     for d in dbs:
         d.free()
