@@ -509,7 +509,7 @@ int pf_create(pf_ctx** out, int device, const pf_opts* o) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b) {
             const uint64_t slice_bytes = (uint64_t)c->NS * (8ull * c->KW + 4 + 4ull * c->W + 16 + 8 + 4 + 4 + 4 + 4) +
-                                         (uint64_t)pf::DENSE_WORDS * 16 + (uint64_t)pf::DEDUP_MROWS * 4 + 64;
+                                         (uint64_t)pf::DENSE_WORDS_BIG * 16 + (uint64_t)pf::DEDUP_MROWS * 4 + 64;
             const uint64_t fit = (free_b / 2) / slice_bytes;
             if (c->max_items > fit) c->max_items = (uint32_t)std::max<uint64_t>(fit, 64);
         }
@@ -545,8 +545,8 @@ int pf_create(pf_ctx** out, int device, const pf_opts* o) {
             !guard(c->chunkbits.ensure(S * NS * W * 4)) || !guard(c->chunkmask.ensure(S * 8 * 4)) ||
             !guard(c->slot_hash.ensure(S * NS * 16)) || !guard(c->sorted_pair.ensure(S * NS * 8)) ||
             !guard(c->kept_prefix.ensure(S * (NS + 1) * 4)) || !guard(c->cursor.ensure(64)) ||
-            !guard(c->bm_occ.ensure(S * pf::DENSE_WORDS * 4)) || !guard(c->bm_keep.ensure(S * pf::DENSE_WORDS * 4)) ||
-            !guard(c->pre_occ.ensure(S * pf::DENSE_WORDS * 4)) || !guard(c->pre_keep.ensure(S * pf::DENSE_WORDS * 4)) ||
+            !guard(c->bm_occ.ensure(S * pf::DENSE_WORDS_BIG * 4)) || !guard(c->bm_keep.ensure(S * pf::DENSE_WORDS_BIG * 4)) ||
+            !guard(c->pre_occ.ensure(S * pf::DENSE_WORDS_BIG * 4)) || !guard(c->pre_keep.ensure(S * pf::DENSE_WORDS_BIG * 4)) ||
             !guard(c->mrows.ensure(S * pf::DEDUP_MROWS * 4)) || !guard(c->slot_out.ensure(S * NS * 4)) ||
             !guard(c->cmask_lo.ensure(S * NS * 4)) || !guard(c->cmask_hi.ensure(S * NS * 4)))
             break;

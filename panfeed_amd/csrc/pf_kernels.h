@@ -868,14 +868,16 @@ constexpr uint32_t DEDUP_MAX_SEGS = 16384;    // segments of a cluster (one tabl
 constexpr uint32_t DEDUP_MAX_D = 64;          // distinct sequences of a mode-1 cluster (two 32-bit presence words)
 constexpr uint32_t DEDUP_MAX_D_WIDE = 1024;   // ... of a mode-2 cluster (up to 32 presence words per k-mer)
 constexpr uint32_t DEDUP_MROWS = 4096;        // words of the M matrix: D * ceil4(W) <= this
-constexpr uint32_t DENSE_WORDS = 8192;        // ordinal bitmap words (262144 dense ordinals)
+constexpr uint32_t DENSE_WORDS = 8192;        // ordinal bitmap words held in LDS two at a time (262144 dense ordinals)
+constexpr uint32_t DENSE_WORDS_BIG = 16384;   // ... one at a time (wide clusters of up to 524288 windows over their distinct
+                                              // sequences), and the words an item's bitmaps take in the scratch arrays
 constexpr uint32_t MODE_RETRY_WIDE = 0x80u;   // v_mode flag: mode 0 only because the small class was too small
 // How a cluster's k-mers get their rank (position in dict insertion order): from bitmaps over the cluster's dense ordinal
 // space -- prefix popcounts, summed over the cluster's key partitions -- whenever that space fits (every mode-1 cluster, and
-// a mode-2 cluster of up to DENSE_WORDS * 32 windows over its distinct sequences); otherwise every partition sorts its
+// a mode-2 cluster of up to DENSE_WORDS_BIG * 32 windows over its distinct sequences); otherwise every partition sorts its
 // (ordinal, slot) pairs and a k-mer's rank is a binary search in each sibling partition.
 __host__ __device__ inline bool ranks_by_bitmap(uint32_t mode, uint32_t v_dense) {
-    return mode == 1 || (mode == 2 && v_dense <= DENSE_WORDS * 32);
+    return mode == 1 || (mode == 2 && v_dense <= DENSE_WORDS_BIG * 32);
 }
 
 // v_mode of a cluster: 0 = scan every segment (sample columns); 1 = scan one representative per distinct sequence,
@@ -1658,6 +1660,12 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
     uint32_t* occ = rsh + DEDUP_MROWS;
     uint32_t* keepbm = occ + DENSE_WORDS;
     const uint32_t dense_words = bitmaps ? (p.v_dense[c] + 31) >> 5 : 0;
+    // more dense ordinals than two LDS bitmaps hold (a wide cluster of up to 524 288 windows over its distinct sequences):
+    // ONE bitmap of DENSE_WORDS_BIG words, used twice -- occupied ordinals, then kept ones -- with the slots' keep flags
+    // parked in slot_tag meanwhile.  (Such clusters sorted their (ordinal, slot) pairs per item and searched every
+    // sibling item per k-mer before: 130 dependent global reads per kept k-mer at ten key partitions.)
+    const bool big = bitmaps && dense_words > DENSE_WORDS;
+    uint32_t* bigbm = rsh;
     uint16_t* segd = reinterpret_cast<uint16_t*>(rsh);   // mode 2: (distinct index << 5 | sample & 31) per segment;
                                                          // lives where `pairs` will be, until the rows are evaluated
 
@@ -1928,7 +1936,8 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         }
         __syncthreads();
         // segd is no longer needed: its place is the bitmaps' or the pairs'
-        if (bitmaps) { for (uint32_t i = tid; i < 2 * DENSE_WORDS; i += ROWS_THREADS) occ[i] = 0; }
+        if (big) { for (uint32_t i = tid; i < DENSE_WORDS_BIG; i += ROWS_THREADS) bigbm[i] = 0; }
+        else if (bitmaps) { for (uint32_t i = tid; i < 2 * DENSE_WORDS; i += ROWS_THREADS) occ[i] = 0; }
         else { for (uint32_t i = tid; i < SORT_MAX; i += ROWS_THREADS) pairs[i] = EMPTY64; }
         __syncthreads();
     }
@@ -1994,12 +2003,49 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
             keepf[i] = keep ? 1 : 0;
             const uint32_t at = atomicAdd(&sh_cnt, 1u);
             if (at < SORT_MAX) pairs[at] = ((uint64_t)o << 32) | i;
+        } else if (big) {
+            if ((o >> 5) < dense_words) atomicOr(&bigbm[o >> 5], 1u << (o & 31));
+            slot_tag[i] = keep ? 1 : 0;
         } else if ((o >> 5) < dense_words) {
             atomicOr(&occ[o >> 5], 1u << (o & 31));
             if (keep) atomicOr(&keepbm[o >> 5], 1u << (o & 31));
         }
     }
     __syncthreads();
+
+    if (big) {
+        constexpr uint32_t PWB = DENSE_WORDS_BIG / ROWS_THREADS;     // 16 words per thread
+        const size_t gb = (size_t)slice * DENSE_WORDS_BIG;
+        for (int round = 0; round < 2; round++) {
+            uint32_t sm = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < PWB; j++) sm += __popc(bigbm[tid * PWB + j]);
+            uint32_t tot;
+            uint32_t run = block_exscan(sm, wave_tot, &tot);
+            uint32_t* bm = round ? p.bm_keep : p.bm_occ;
+            uint32_t* pre = round ? p.pre_keep : p.pre_occ;
+#pragma unroll
+            for (uint32_t j = 0; j < PWB; j++) {
+                const uint32_t w = tid * PWB + j;
+                if (w < dense_words) {
+                    const uint32_t a = bigbm[w];
+                    bm[gb + w] = a; pre[gb + w] = run;
+                    run += __popc(a);
+                }
+            }
+            if (tid == 0) { if (round) p.item_kept[item] = tot; else p.item_unique[item] = tot; }
+            if (round) break;
+            __syncthreads();
+            for (uint32_t i = tid; i < DENSE_WORDS_BIG; i += ROWS_THREADS) bigbm[i] = 0;
+            __syncthreads();
+            for (uint32_t i = tid; i < ns; i += ROWS_THREADS) {
+                const uint32_t o = ordp[i];
+                if (o != NO_ORD && (o >> 5) < dense_words && slot_tag[i] == 1) atomicOr(&bigbm[o >> 5], 1u << (o & 31));
+            }
+            __syncthreads();
+        }
+        return;
+    }
 
     if (bitmaps) {
         // ranks come from the ordinal bitmaps: prefix popcounts per word, stored for emit_kernel
@@ -2014,7 +2060,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         uint32_t tot_o, tot_k;
         uint32_t bo = block_exscan(so, wave_tot, &tot_o);
         uint32_t bk = block_exscan(sk, wave_tot, &tot_k);
-        const size_t gb = (size_t)slice * DENSE_WORDS;
+        const size_t gb = (size_t)slice * DENSE_WORDS_BIG;
 #pragma unroll
         for (uint32_t j = 0; j < PW; j++) {
             const uint32_t w = tid * PW + j;
@@ -2094,14 +2140,14 @@ __global__ __launch_bounds__(256) void bitmap_merge_kernel(BitmapMergeParams p) 
     const uint32_t i0 = p.cluster_item0[blockIdx.x], ni = p.cluster_nitems[blockIdx.x];
     if (ni < 2 || p.item_fused[i0] || p.cluster_overflow[c] || !ranks_by_bitmap(p.v_mode[c] & 3u, p.v_dense[c])) return;
     const uint32_t dense_words = (p.v_dense[c] + 31) >> 5;
-    const size_t g0 = (size_t)p.item_scratch[i0] * DENSE_WORDS;
+    const size_t g0 = (size_t)p.item_scratch[i0] * DENSE_WORDS_BIG;
     uint32_t run_o = 0, run_k = 0;                       // ordinals / kept ordinals in the words before this round's
     for (uint32_t w0 = 0; w0 < dense_words; w0 += 256) {
         const uint32_t w = w0 + tid;
         uint32_t o = 0, k = 0;
         if (w < dense_words)
             for (uint32_t q = 0; q < ni; q++) {
-                const size_t g = (size_t)p.item_scratch[i0 + q] * DENSE_WORDS + w;
+                const size_t g = (size_t)p.item_scratch[i0 + q] * DENSE_WORDS_BIG + w;
                 o |= p.bm_occ[g]; k |= p.bm_keep[g];
             }
         uint32_t xo = __popc(o), xk = __popc(k);
@@ -2377,7 +2423,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
     const uint32_t ns = p.item_nslots[item];
     const uint32_t dense_words = (p.v_dense[c] + 31) >> 5;
     const uint32_t* ordp = p.tab_ord + (size_t)slice * NS;
-    const size_t gb0 = (size_t)p.item_scratch[sib0] * DENSE_WORDS;
+    const size_t gb0 = (size_t)p.item_scratch[sib0] * DENSE_WORDS_BIG;
     const uint64_t* sp = p.sorted_pair + (size_t)slice * NS;
     const uint32_t* kp = p.kept_prefix + (size_t)slice * (NS + 1);
     uint32_t* sout = p.slot_out + (size_t)slice * NS;    // per entry (slot / sorted position): index of its k-mer in

@@ -119,3 +119,22 @@ def test_more_distinct_sequences_than_samples():
             out = eng.run(recs)
             assert out.kmers_to_hashes == ekh and out.hashes_to_patterns == ehp, (k, canon, kw)
             eng.close()
+
+
+@pytest.mark.parametrize("D,L,S", [(260, 1250, 800), (500, 900, 1600), (600, 980, 1800)], ids=["dense_325k", "dense_450k", "dense_570k_sorted"])
+def test_wide_cluster_beyond_two_lds_bitmaps(D, L, S):
+    """a wide cluster whose distinct sequences carry more than 262 144 windows (two LDS ordinal bitmaps' worth) and at
+    most 524 288: ranks from ONE big bitmap used twice (round 3) instead of sorted pairs and a search in every sibling
+    item; several key partitions; against the oracle"""
+    rng = np.random.default_rng(D + L)
+    alleles = [np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, L)].tobytes()]
+    seen = set(alleles)
+    while len(alleles) < D:
+        a = _mut(alleles[int(rng.integers(0, len(alleles)))], [int(x) for x in rng.integers(0, L, 3)])
+        if a not in seen:
+            seen.add(a)
+            alleles.append(a)
+    assert 262144 < D * (L - 30) and (D * (L - 30) <= 524288) == (D < 600)      # the last case: beyond the big bitmap too
+    names = [f"b{i:04d}" for i in range(S)]
+    tms = _run_all([_cluster("g_big", names, alleles)], 31, S)
+    assert tms[0]["n_wide_clusters"] == 1 and tms[0]["n_dedup_clusters"] == 1
