@@ -23,6 +23,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace pf {
 
@@ -1625,16 +1626,16 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
     __shared__ __align__(16) uint32_t rsh[20480];
     __shared__ uint32_t cmask[8];
     __shared__ uint32_t wave_tot[ROWS_THREADS / 64 + 1];
-    __shared__ uint32_t sh_cnt, sh_npres, at_count;
+    __shared__ uint32_t sh_cnt, sh_npres, at_count, sh_more;
     __shared__ uint64_t at_key[AT_SLOTS];      // mode 1: distinct allele masks of the item; mode 2: hash50 << 14 | slot
     __shared__ uint4 at_hash[AT_SLOTS];
     __shared__ uint32_t at_keep[AT_SLOTS];
     // mode 2 ("wide": up to 1024 distinct sequences, a k-mer's allele mask is up to 32 words)
-    __shared__ uint16_t slot_tag[9600];        // per slot: table position of its mask, WIDE_UNTABLED when it has none
+    __shared__ uint16_t slot_tag[9600];        // per slot: table position of its mask in this round, or a WIDE_ state
     __shared__ uint32_t mstage[ROWS_THREADS / 32][33];   // the mask being expanded, per half-wave; word 32 stays zero
-    __shared__ __align__(16) uint32_t rowst[ROWS_THREADS / 32][32];   // 32 words of the row on their way into the hash
     __shared__ uint32_t wstart[MAX_CHUNKS + 1];          // first segment of every 32-sample word
 
+    PF_PROF_BEGIN();
     const uint32_t tid = threadIdx.x;
     const uint32_t item = p.work[blockIdx.x];
     const uint32_t c = p.item_cluster[item];
@@ -1753,14 +1754,14 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         return keep;
     };
 
-    // slot_tag of a slot whose mask found no room in the table: it is evaluated on its own, its hash goes straight to
-    // slot_hash and its keep flag into the tag
-    constexpr uint16_t WIDE_UNTABLED = 0xFFFFu, WIDE_UNTABLED_KEEP = 0xFFFEu, WIDE_UNTABLED_DROP = 0xFFFDu;
+    // slot_tag of a wide item's slot: position of its mask in the table of the round (< AT_SLOTS), or one of these
+    constexpr uint16_t WIDE_PENDING = 0xFFFFu, WIDE_KEEP = 0xFFFEu, WIDE_DROP = 0xFFFDu, WIDE_EMPTY = 0xFFFCu;
     if (wide) {
         // ---- mode 2.  A k-mer's allele mask (which distinct sequences contain it) is nmw = ceil(D / 32) chunk
         // words; its presence row is gathered through the segment list: sample s carries the k-mer iff one of its
         // segments is a copy of a distinct sequence of the mask.  Distinct masks are evaluated once (table keyed by a
-        // 50-bit hash of the words, verified word for word against the slot that opened the entry).
+        // 50-bit hash of the words, verified word for word against the slot that opened the entry), in rounds of up
+        // to AT_LIMIT distinct masks: a mask that finds the table full waits for the next round.
         const uint32_t s0 = p.cluster_seg_off[c], s1 = p.cluster_seg_off[c + 1], nsegs = s1 - s0;
         const uint32_t D = p.v_nstr[c], nmw = (D + 31) >> 5;
         // (the segments are sorted by sample: the first segment of a 32-sample word is the count of those before it)
@@ -1769,8 +1770,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
             segd[s] = (uint16_t)((p.seg_distinct[s0 + s] << 5) | (smp & 31u));
             atomicAdd(&wstart[(smp >> 5) + 1], 1u);
         }
-        for (uint32_t t = tid; t < AT_SLOTS; t += ROWS_THREADS) at_key[t] = 0;
-        if (tid == 0) at_count = 0;
+        for (uint32_t i = tid; i < ns; i += ROWS_THREADS) slot_tag[i] = ordp[i] == NO_ORD ? WIDE_EMPTY : WIDE_PENDING;
         __syncthreads();
         if (tid < 64) {
             constexpr uint32_t PL = (MAX_CHUNKS + 1 + 63) / 64;          // entries per lane
@@ -1795,80 +1795,59 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
             }
         }
         __syncthreads();
+        PF_PROF_STAMP(40);
         const uint32_t cm0 = cmask[0];                    // nmw <= 32: the flushed-chunk flags of the mask words
-        auto mask_word = [&](uint32_t j, uint32_t i) -> uint32_t {
-            return ((cm0 >> j) & 1) ? cb[(size_t)j * NS + i] : 0u;
+        // The words of a mask lie NS words apart in the scan's table dump; a slot asks for them eight at a time
+        // (unconditionally, with a clamped index), so that it costs one trip to memory per eight words and not one per
+        // word -- which, word after word through a hash chain, was 35-40 % of this kernel at 150 distinct sequences.
+        constexpr uint32_t MWB = 8, MWMAX = DEDUP_MAX_D_WIDE / 32;
+        // the round's table: at_key = hash50 << 14 | state (entry number once its words are written), the masks' words
+        // in LDS behind the segment list (entry e: tabw[e * nmw ..]), their rows in this slice's bitmap arrays (which
+        // are written at the very end of this kernel only), four entries to a stripe of RW words
+        constexpr uint32_t ENT_BUSY = 0x3FFEu, ENT_DEAD = 0x3FFFu;
+        uint32_t* tabw = rsh + ((nsegs + 1) >> 1);
+        const uint32_t RW = (nchunks + 3) & ~3u;
+        const uint32_t cap = min(min(AT_LIMIT, (20480u - ((nsegs + 1) >> 1)) / nmw), 4u * (DENSE_WORDS_BIG / RW));
+        auto row_of = [&](uint32_t e) -> uint32_t* {
+            uint32_t* arr = (e & 2u) ? ((e & 1u) ? p.pre_keep : p.pre_occ) : ((e & 1u) ? p.bm_keep : p.bm_occ);
+            return arr + (size_t)slice * DENSE_WORDS_BIG + (size_t)(e >> 2) * RW;
         };
-        for (uint32_t i = tid; i < ns; i += ROWS_THREADS) {
-            if (ordp[i] == NO_ORD) { slot_tag[i] = 0; continue; }
-            uint64_t h = 0x9E3779B97F4A7C15ull;
-            for (uint32_t j = 0; j < nmw; j++) h = mix64(h ^ mask_word(j, i)) + j;
-            uint64_t h50 = h >> 14;
-            if (!h50) h50 = 1;
-            uint16_t tag = WIDE_UNTABLED;
-            uint32_t a = (uint32_t)(h & (AT_SLOTS - 1));
-            for (uint32_t probes = 0; probes < AT_SLOTS; probes++) {
-                uint64_t cur = __hip_atomic_load(&at_key[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (cur == 0) {
-                    if (__hip_atomic_load(&at_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= AT_LIMIT) break;
-                    cur = atomicCAS((unsigned long long*)&at_key[a], 0ull, (unsigned long long)((h50 << 14) | i));
-                    if (cur == 0) { atomicAdd(&at_count, 1u); tag = (uint16_t)a; break; }
-                }
-                if ((cur >> 14) == h50) {
-                    const uint32_t rep = (uint32_t)cur & 0x3FFFu;     // the claim is one word: nothing to wait for
-                    // every word, no early way out: the loads go out together (a mask that gets this far is almost
-                    // always the same one, and a chain of dependent round trips was most of this loop's time)
-                    uint32_t diff = 0;
-                    for (uint32_t j = 0; j < nmw; j++) diff |= mask_word(j, i) ^ mask_word(j, rep);
-                    if (!diff) { tag = (uint16_t)a; break; }
-                }
-                a = (a + 1) & (AT_SLOTS - 1);
-            }
-            slot_tag[i] = tag;
-        }
-        __syncthreads();
         // one half-wave per mask: lane j gathers row word 32 r + j in round r, the 32 words of a round then go through
         // the row hash in order (eight blocks), every lane running it on the words read back from LDS (one broadcast
         // 128-bit read per block).  The segments a lane looks at in round 0 are the same for every mask: they are
         // held in registers (two to a register, the unused places point at a distinct index whose mask word is the
         // zero word 32), so that a mask costs WIDE_SEGREG independent LDS reads per lane and no dependent pair.
+        // (What one lane writes to LDS for the other lanes of ITS wave needs no wait: a wave's LDS operations run in
+        // the order they were issued.  The fences are of wavefront scope, for the compiler -- a workgroup-scope release
+        // waits for every memory operation of the wave, the next mask's words on their way from global memory among
+        // them, which is exactly what should stay in flight.)
         const uint32_t hw = tid >> 5, hl = tid & 31u;
         constexpr uint32_t WIDE_SEGREG = 32;
         uint32_t sg[WIDE_SEGREG / 2];
-        uint32_t my_q0 = 0, my_q1 = 0;
-        if (hl < nchunks) { my_q0 = wstart[hl]; my_q1 = wstart[hl + 1]; }
-#pragma unroll
-        for (uint32_t j = 0; j < WIDE_SEGREG / 2; j++) {
-            const uint32_t q = my_q0 + 2 * j;
-            const uint32_t e0 = q < my_q1 ? segd[q] : 0x8000u, e1 = q + 1 < my_q1 ? segd[q + 1] : 0x8000u;
-            sg[j] = e0 | (e1 << 16);
-        }
-        uint32_t sg_used = min(my_q1 - my_q0, WIDE_SEGREG);          // the most any lane of the wave holds
-        for (int dd = 1; dd < 64; dd <<= 1) sg_used = max(sg_used, (uint32_t)__shfl_xor(sg_used, dd));
+        uint32_t my_q0 = 0, my_q1 = 0, sg_used = 0;
         if (hl == 0) mstage[hw][32] = 0;
-        auto eval_slot = [&](uint32_t my_mask_word, uint4& hout) -> bool {     // lane hl < nmw brings word hl of the mask
+        auto gather_row = [&](uint32_t my_mask_word, uint32_t* row) {     // lane hl < nmw brings word hl of the mask
             if (hl < nmw) mstage[hw][hl] = my_mask_word;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            H128 st;
-            st.h1 = 0x9747b28cu ^ nstr; st.h2 = 0x1b873593u; st.h3 = 0xe6546b64u; st.h4 = 0x85ebca6bu;
-            if (p.multiple_files) { st.h2 ^= (uint32_t)ordinal; st.h3 ^= (uint32_t)(ordinal >> 32); }
-            uint32_t cnt = 0, ne = 0;
             const uint32_t* ms = mstage[hw];
-            for (uint32_t w0 = 0; w0 < nchunks; w0 += 32) {
+            for (uint32_t w0 = 0; w0 < RW; w0 += 32) {
                 const uint32_t w = w0 + hl;
                 uint32_t word = 0;
                 if (w0 == 0) {
 #pragma unroll
-                    for (uint32_t j = 0; j < WIDE_SEGREG / 2; j++) {
-                        if (2 * j >= sg_used) break;                          // wave-uniform
-                        // (opaque copy: decoded here, every time -- the compiler would otherwise keep three decoded
-                        // values per segment alive across the loop over the masks, 96 registers and a spill)
-                        uint32_t pr = sg[j];
-                        asm volatile("" : "+v"(pr));
-                        const uint32_t e0 = pr & 0xFFFFu, e1 = pr >> 16;
-                        word |= ((ms[e0 >> 10] >> ((e0 >> 5) & 31u)) & 1u) << (e0 & 31u);
-                        word |= ((ms[e1 >> 10] >> ((e1 >> 5) & 31u)) & 1u) << (e1 & 31u);
+                    for (uint32_t jb = 0; jb < WIDE_SEGREG / 2; jb += 4) {
+                        if (2 * jb >= sg_used) break;                         // wave-uniform; eight segments a step
+#pragma unroll
+                        for (uint32_t j = jb; j < jb + 4; j++) {
+                            // (opaque copy: decoded here, every time -- the compiler would otherwise keep three decoded
+                            // values per segment alive across the loop over the masks, 96 registers and a spill)
+                            uint32_t pr = sg[j];
+                            asm volatile("" : "+v"(pr));
+                            const uint32_t e0 = pr & 0xFFFFu, e1 = pr >> 16;
+                            word |= ((ms[e0 >> 10] >> ((e0 >> 5) & 31u)) & 1u) << (e0 & 31u);
+                            word |= ((ms[e1 >> 10] >> ((e1 >> 5) & 31u)) & 1u) << (e1 & 31u);
+                        }
                     }
                     for (uint32_t q = my_q0 + WIDE_SEGREG; q < my_q1; q++) {   // a word with more segments than that
                         const uint32_t e = segd[q], d = e >> 5;
@@ -1880,19 +1859,25 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
                         word |= ((ms[d >> 5] >> (d & 31u)) & 1u) << (e & 31u);
                     }
                 }
-                if (w < nchunks) {
-                    cnt += __popc(word);
-                    ne |= word != presab[w] ? 1u : 0u;
-                }
-                rowst[hw][hl] = word;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                const uint32_t nb = min(8u, (nchunks - w0 + 3) >> 2);
-                for (uint32_t b = 0; b < nb; b++) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(&rowst[hw][4 * b]);
-                    mm3_block(st, v.x, v.y, v.z, v.w);
-                }
-                __builtin_amdgcn_wave_barrier();                    // rowst[hw] is rewritten by the next round
+                if (w < RW) row[w] = word;                          // (words past nchunks: zero, as the row hash wants them)
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();                    // mstage[hw] is rewritten by the next call
+        };
+        // the row of one mask, read back by ONE lane: hash, count, comparison with the cluster's own row
+        auto row_hash = [&](const uint32_t* row, uint4& hout) -> bool {
+            H128 st;
+            st.h1 = 0x9747b28cu ^ nstr; st.h2 = 0x1b873593u; st.h3 = 0xe6546b64u; st.h4 = 0x85ebca6bu;
+            if (p.multiple_files) { st.h2 ^= (uint32_t)ordinal; st.h3 ^= (uint32_t)(ordinal >> 32); }
+            uint32_t cnt = 0;
+            bool eq = true;
+            for (uint32_t ch = 0; ch < nchunks; ch += 4) {
+                const uint4 v = *reinterpret_cast<const uint4*>(row + ch);
+                const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (ch + j < nchunks) { cnt += __popc(wv[j]); eq = eq && (wv[j] == presab[ch + j]); }
+                mm3_block(st, wv[0], wv[1], wv[2], wv[3]);
             }
             if (p.consider_missing) {
                 for (uint32_t ch = 0; ch < nchunks; ch += 4) {
@@ -1903,38 +1888,167 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
                 }
             }
             mm3_final(st, nchunks * 4);
-            for (int dd = 1; dd < 32; dd <<= 1) { cnt += __shfl_xor(cnt, dd); ne |= __shfl_xor(ne, dd); }
             bool keep = cnt >= lo && cnt <= hi;                 // panfeed.py:197-200
-            if (same_possible && !ne) keep = false;             // panfeed.py:202-204
+            if (same_possible && eq) keep = false;              // panfeed.py:202-204
             hout = make_uint4(st.h1, st.h2, st.h3, st.h4);
-            __builtin_amdgcn_wave_barrier();                    // mstage[hw] is rewritten by the next call
             return keep;
         };
-        {   // the words of the next mask are on their way from global memory while this one is evaluated
-            uint32_t t = hw;
-            uint64_t key = at_key[t];
-            uint32_t word = key && hl < nmw ? mask_word(hl, (uint32_t)key & 0x3FFFu) : 0u;
-            while (t < AT_SLOTS) {
-                const uint32_t tn = t + ROWS_THREADS / 32;
-                const uint64_t nkey = tn < AT_SLOTS ? at_key[tn] : 0ull;
-                const uint32_t nword = nkey && hl < nmw ? mask_word(hl, (uint32_t)nkey & 0x3FFFu) : 0u;
-                if (key) {
-                    uint4 h;
-                    const bool keep = eval_slot(word, h);
-                    if (hl == 0) { at_hash[t] = h; at_keep[t] = keep ? 1u : 0u; }
+        for (;;) {
+            for (uint32_t t = tid; t < AT_SLOTS; t += ROWS_THREADS) at_key[t] = 0;
+            if (tid == 0) { at_count = 0; sh_more = 0; }
+            __syncthreads();
+            PF_PROF_STAMP(55);
+            // A: every waiting slot finds its mask in the table (hash, then word for word against the entry's copy) or
+            // opens an entry for it.  Nobody waits in place for an entry whose words are still being written: the lane
+            // goes round the loop again, the writer -- which may be a lane of the same wave -- finishes within ITS turn.
+            // (The trips to memory are what this step waits for -- one workgroup per CU, sixteen waves: the words of four
+            // slots are asked for at a time where a mask is eight words at most, of two up to sixteen words.)
+            auto step_a = [&](auto nbc) {
+                constexpr uint32_t NWA = decltype(nbc)::value * MWB, U = NWA == MWB ? 4 : NWA == 2 * MWB ? 2 : 1;
+                for (uint32_t i0 = tid; i0 < ns; i0 += U * ROWS_THREADS) {
+                    uint32_t wu[U][NWA];
+                    bool pend[U], any = false;
+#pragma unroll
+                    for (uint32_t u = 0; u < U; u++) {
+                        const uint32_t i = i0 + u * ROWS_THREADS;
+                        pend[u] = i < ns && slot_tag[min(i, ns - 1)] == WIDE_PENDING;
+                        any = any || pend[u];
+                    }
+                    if (!any) continue;
+                    // (every load of the trip first, then an opaque use of every value: left to itself the compiler
+                    // turns "clamped index, then select" back into a branch around each load and waits for each one)
+#pragma unroll
+                    for (uint32_t u = 0; u < U; u++) {
+                        const uint32_t i = min(i0 + u * ROWS_THREADS, ns - 1);
+#pragma unroll
+                        for (uint32_t j = 0; j < NWA; j++) wu[u][j] = cb[min(j, nmw - 1) * NS + i];   // (32-bit index: a slice is W * NS words)
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < U; u++) {
+#pragma unroll
+                        for (uint32_t j = 0; j < NWA; j++) asm volatile("" : "+v"(wu[u][j]));
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < U; u++) {
+#pragma unroll
+                        for (uint32_t j = 0; j < NWA; j++)
+                            if (!(j < nmw && ((cm0 >> j) & 1))) wu[u][j] = 0;
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < U; u++) {
+                        if (!pend[u]) continue;
+                        const uint32_t i = i0 + u * ROWS_THREADS;
+                        const uint32_t (&w)[NWA] = wu[u];
+                        uint64_t a1 = 0x9E3779B97F4A7C15ull, a2 = 0xC2B2AE3D27D4EB4Full;
+#pragma unroll
+                        for (uint32_t j = 0; j < NWA; j++) {              // sums of word x odd constant of its place
+                            const uint32_t kj = (2 * j + 1) * 0x9E3779B1u;
+                            a1 += (uint64_t)w[j] * (kj | 1u);
+                            a2 += (uint64_t)w[j] * (((kj >> 9) | (kj << 23)) | 1u);
+                        }
+                        const uint64_t hsh = mix64(a1 ^ ((a2 << 32) | (a2 >> 32)));
+                        uint64_t h50 = hsh >> 14;
+                        if (!h50) h50 = 1;
+                        uint32_t a = (uint32_t)(hsh & (AT_SLOTS - 1));
+                        uint32_t tag = WIDE_PENDING, probes = 0, spins = 0;
+                        bool done = false;
+                        while (!done) {
+                            uint64_t cur = __hip_atomic_load(&at_key[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (cur == 0) {
+                                if (__hip_atomic_load(&at_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= cap) {
+                                    done = true;                                     // full: next round
+                                } else {
+                                    cur = atomicCAS((unsigned long long*)&at_key[a], 0ull, (unsigned long long)((h50 << 14) | ENT_BUSY));
+                                    if (cur == 0) {
+                                        const uint32_t e = atomicAdd(&at_count, 1u);
+                                        if (e >= cap) {
+                                            __hip_atomic_store(&at_key[a], (h50 << 14) | ENT_DEAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                        } else {
+#pragma unroll
+                                            for (uint32_t j = 0; j < NWA; j++)
+                                                if (j < nmw) tabw[e * nmw + j] = w[j];
+                                            __hip_atomic_store(&at_key[a], (h50 << 14) | e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                            tag = e;
+                                        }
+                                        done = true;
+                                    }
+                                }
+                            }
+                            if (!done) {                                             // cur: somebody's entry
+                                const uint32_t st = (uint32_t)cur & 0x3FFFu;
+                                uint32_t adv = 1;
+                                if ((cur >> 14) == h50) {
+                                    if (st == ENT_BUSY) { adv = 0; spins++; }        // look again on the next trip
+                                    else if (st == ENT_DEAD) done = true;
+                                    else {
+                                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                                        uint32_t diff = 0;
+#pragma unroll
+                                        for (uint32_t j = 0; j < NWA; j++)
+                                            if (j < nmw) diff |= tabw[st * nmw + j] ^ w[j];
+                                        if (!diff) { tag = st; done = true; }
+                                    }
+                                }
+                                a = (a + adv) & (AT_SLOTS - 1);
+                                probes += adv;
+                                if (probes >= AT_SLOTS || spins >= 4096u) done = true;   // (gives up for this round; never met)
+                            }
+                        }
+                        if (tag == WIDE_PENDING) sh_more = 1;
+                        else slot_tag[i] = (uint16_t)tag;
+                    }
                 }
-                t = tn; key = nkey; word = nword;
+            };
+            if (nmw <= MWB) step_a(std::integral_constant<uint32_t, 1>{});
+            else if (nmw <= 2 * MWB) step_a(std::integral_constant<uint32_t, 2>{});
+            else step_a(std::integral_constant<uint32_t, MWMAX / MWB>{});
+            PF_PROF_STAMP(56);
+            __syncthreads();
+            PF_PROF_STAMP(41);
+            const uint32_t n_ent = min(at_count, cap);
+            // (the lane's segments, decoded into registers for the round's gathers: not held across step A, which
+            // wants the registers for the words of its slots)
+            if (hl < nchunks) { my_q0 = wstart[hl]; my_q1 = wstart[hl + 1]; }
+#pragma unroll
+            for (uint32_t j = 0; j < WIDE_SEGREG / 2; j++) {
+                const uint32_t q = my_q0 + 2 * j;
+                const uint32_t e0 = q < my_q1 ? segd[q] : 0x8000u, e1 = q + 1 < my_q1 ? segd[q + 1] : 0x8000u;
+                sg[j] = e0 | (e1 << 16);
             }
+            sg_used = min(my_q1 - my_q0, WIDE_SEGREG);          // the most any lane of the wave holds
+            for (int dd = 1; dd < 64; dd <<= 1) sg_used = max(sg_used, (uint32_t)__shfl_xor(sg_used, dd));
+            // C: the rows of the round's masks, one half-wave per mask, into the row stripes ...
+            for (uint32_t e = hw; e < n_ent; e += ROWS_THREADS / 32)
+                gather_row(hl < nmw ? tabw[e * nmw + hl] : 0u, row_of(e));
+            __syncthreads();
+            PF_PROF_STAMP(42);
+            // ... and their hashes and keep flags, one LANE per mask (half-waves that ran the hash in step, as rounds 2-3
+            // had it, spent two thirds of their issue slots on 32 copies of the same quarter-rate multiplications)
+            for (uint32_t e = tid; e < n_ent; e += ROWS_THREADS) {
+                uint4 h;
+                const bool keep = row_hash(row_of(e), h);
+                at_hash[e] = h; at_keep[e] = keep ? 1u : 0u;
+            }
+            __syncthreads();
+            // D: every slot of the round takes its mask's result
+            for (uint32_t i = tid; i < ns; i += ROWS_THREADS) {
+                const uint32_t tag = slot_tag[i];
+                if (tag >= AT_SLOTS) continue;
+                p.slot_hash[(size_t)slice * NS + i] = at_hash[tag];
+                slot_tag[i] = at_keep[tag] ? WIDE_KEEP : WIDE_DROP;
+            }
+            __syncthreads();
+            const bool more = sh_more != 0;
+            PF_PROF_STAMP(43);
+#ifdef PF_PROF
+            if (tid == 0) { atomicAdd(&pf_prof[48], (unsigned long long)n_ent); atomicAdd(&pf_prof[50], 1ull); }
+#endif
+            __syncthreads();
+            if (!more) break;
         }
-        // slots whose mask found no room in the table (rare): one evaluation each, result straight to where the
-        // main loop below would put it
-        for (uint32_t i = hw; i < ns; i += ROWS_THREADS / 32) {
-            if (slot_tag[i] != WIDE_UNTABLED) continue;
-            uint4 h;
-            const bool keep = eval_slot(hl < nmw ? mask_word(hl, i) : 0u, h);
-            if (hl == 0) { p.slot_hash[(size_t)slice * NS + i] = h; slot_tag[i] = keep ? WIDE_UNTABLED_KEEP : WIDE_UNTABLED_DROP; }
-        }
-        __syncthreads();
+#ifdef PF_PROF
+        if (tid == 0) { atomicAdd(&pf_prof[47], 1ull); atomicAdd(&pf_prof[49], (unsigned long long)ns); }
+#endif
         // segd is no longer needed: its place is the bitmaps' or the pairs'
         if (big) { for (uint32_t i = tid; i < DENSE_WORDS_BIG; i += ROWS_THREADS) bigbm[i] = 0; }
         else if (bitmaps) { for (uint32_t i = tid; i < 2 * DENSE_WORDS; i += ROWS_THREADS) occ[i] = 0; }
@@ -1992,9 +2106,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
             if (found) { h = at_hash[a]; keep = at_keep[a] != 0; }
             else keep = row_eval(true, amask, i, h);          // table was full: evaluate this slot on its own
         } else if (wide) {
-            const uint32_t tag = slot_tag[i];
-            if (tag >= WIDE_UNTABLED_DROP) { keep = tag == WIDE_UNTABLED_KEEP; have_hash = true; }
-            else { h = at_hash[tag]; keep = at_keep[tag] != 0; }
+            keep = slot_tag[i] == WIDE_KEEP; have_hash = true;        // (hash and flag: round D above)
         } else {
             keep = row_eval(false, 0, i, h);
         }
@@ -2012,6 +2124,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         }
     }
     __syncthreads();
+    PF_PROF_STAMP(44);
 
     if (big) {
         constexpr uint32_t PWB = DENSE_WORDS_BIG / ROWS_THREADS;     // 16 words per thread
@@ -2044,6 +2157,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
             }
             __syncthreads();
         }
+        PF_PROF_STAMP(45);
         return;
     }
 
@@ -2072,6 +2186,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
             }
         }
         if (tid == 0) { p.item_unique[item] = tot_o; p.item_kept[item] = tot_k; }
+        PF_PROF_STAMP(45);
         return;
     }
 
@@ -2118,6 +2233,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         p.item_unique[item] = n;
         p.item_kept[item] = total;
     }
+    PF_PROF_STAMP(46);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,5 +1,5 @@
 """Cycles per phase inside the fused kernels (PF_PROF build).  On the GPU box:
-    PF_PROF=1 python -c "import __graft_entry__ as g; g.build(force=True)" && python tools/phase_prof.py [clusters]
+    PF_PROF=1 python -c "import __graft_entry__ as g; g.build(force=True)" && python tools/phase_prof.py [clusters [mean_alleles star|tree]]
 then rebuild without PF_PROF."""
 import ctypes as C
 import sys
@@ -10,8 +10,12 @@ from panfeed_amd.engine import Engine  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
 S, k = 1000, 31
-eng = Engine(klength=k, max_strains=1024, max_items=8192, pattern_capacity=1 << 23)
-cl = synth.generate(n, S, flank=100, n_rate=0.0)
+ma = float(sys.argv[2]) if len(sys.argv) > 2 else None
+eng = Engine(klength=k, max_strains=1024, max_items=32768 if ma else 8192, pattern_capacity=1 << 24 if ma else 1 << 23)
+if ma:
+    cl = synth.generate(n, S, flank=100, n_rate=0.0, mean_alleles=ma, allele_decay=1.0, allele_model=sys.argv[3])
+else:
+    cl = synth.generate(n, S, flank=100, n_rate=0.0)
 db = devbatch.from_synth(eng, cl, k)
 db.submit()
 eng.L.pf_reset_patterns(eng.ctx)
@@ -23,11 +27,19 @@ v = list(buf)
 names = {0: "finish: init + M", 1: "finish: A masks", 2: "finish: B row eval", 3: "finish: C bitmaps", 4: "finish: prefix",
          5: "finish: find/claim", 6: "finish: publish+rows", 7: "finish: outputs", 8: "finish: workgroups",
          16: "scan: clear + tile0", 17: "scan: unit prefix", 18: "scan: windows", 19: "scan: next desc/tile",
-         20: "scan: table dump", 21: "scan: desc swap", 24: "scan: items"}
-for lo, hi, cnt in ((0, 8, 8), (16, 24, 24)):
+         20: "scan: table dump", 21: "scan: desc swap", 24: "scan: items",
+         40: "rows(wide): segments", 41: "rows(wide): A mask table", 42: "rows(wide): C rows", 43: "rows(wide): C hashes + D",
+         44: "rows: slots", 45: "rows: bitmaps out", 46: "rows: sort + out", 47: "rows(wide): items",
+         48: "rows(wide): distinct masks", 49: "rows(wide): slots", 50: "rows(wide): rounds"}
+for lo, hi, cnt in ((0, 8, 8), (16, 24, 24), (40, 47, 47)):
     tot = sum(v[lo:hi])
     for i in list(range(lo, hi)) + [cnt]:
         if v[i]:
             print(f"{i:2d} {names.get(i, ''):24s} {v[i]:14d} {100.0 * v[i] / tot if i < hi else 0:6.1f}%"
                   + (f"  {v[i] / v[cnt]:9.0f} cyc/item" if i < hi and v[cnt] else ""))
+for i in (48, 49, 50):
+    if v[47]:
+        print(f"{i:2d} {names[i]:28s} {v[i] / v[47]:9.1f} per item")
+if v[47]:
+    print(f"step A (wave 0): clear {v[55] / v[47]:.0f}, own slots {v[56] / v[47]:.0f}, waiting for the others {v[41] / v[47]:.0f} cycles per item")
 print(eng.timing())
