@@ -65,6 +65,10 @@ typedef struct {
    cluster share it (same output, slower on clusters of many alleles: by default a unit that several alleles of a gene
    hold unchanged at the same place is scanned once for all of them). */
 #define PF_FLAG_NO_UNIT_DEDUP 2u
+/* A cluster whose distinct k-mers take three or more passes of the on-chip table (key partitions) has its windows sorted
+   by partition first, so that every pass reads its own windows only.  With this flag every pass walks the whole cluster
+   and keeps its share (same output, slower on clusters of many alleles). */
+#define PF_FLAG_NO_KEY_BINNING 4u
 
 /*
  * One batch of gene clusters = the records iter_gene_clusters yields
@@ -159,7 +163,7 @@ typedef struct {
     float md5_ms;      /* md5_kernel (emit_ms excludes it) */
     float finish_ms;   /* finish_kernel (fused rows+emit of single-item deduplicated clusters) */
     uint32_t n_wide_clusters;  /* clusters that went through the wide dedup class (more than 64 distinct sequences, ...) */
-    uint32_t reserved;
+    uint32_t n_binned_clusters;/* clusters whose windows were sorted by key partition before the scan, retries included */
 } pf_timing;
 
 const char* pf_last_error(void);

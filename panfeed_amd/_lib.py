@@ -122,10 +122,11 @@ class Timing(C.Structure):
                 ("scan_launches", C.c_uint32), ("n_items", C.c_uint32), ("n_retried", C.c_uint32),
                 ("n_dedup_clusters", C.c_uint32), ("scan_packed_bytes", C.c_uint64),
                 ("dedup_ms", C.c_float), ("patrows_ms", C.c_float), ("md5_ms", C.c_float), ("finish_ms", C.c_float),
-                ("n_wide_clusters", C.c_uint32), ("reserved", C.c_uint32)]
+                ("n_wide_clusters", C.c_uint32), ("n_binned_clusters", C.c_uint32)]
 
 FLAG_NO_DEDUP = 1
 FLAG_NO_UNIT_DEDUP = 2
+FLAG_NO_KEY_BINNING = 4
 
 
 # every symbol include/panfeed_hip.h declares

@@ -133,6 +133,8 @@ struct pf_ctx {
     std::vector<uint8_t> hs_fused;
     std::vector<uint32_t> hs_v[10], hs_w[7], hs_sub[3];
     int n_cu = 256;
+    DevBuf it_binned, bin_lists, q_key, q_ord, q_bit, q_off;      // key-partition queues of binned clusters (bin_kernel)
+    std::vector<uint32_t> hs_binned, hs_bin[4];
     DevBuf it_cluster, it_part, it_nparts, it_nslots, it_slice, it_sib0, it_nsib, it_extra_first, it_count,
         it_unique, it_kept, work_scan, work_extra, work_fin, work_fin2, work_fin3, work_fin5, work_rows, sub_cluster, sub_item0, sub_nitems;
     std::vector<Arena*> arenas;
@@ -391,6 +393,22 @@ int launch_scan_t(pf_ctx* c, const pf::ScanParams& sp, uint32_t n) {
     HIPCHK(hipGetLastError());
     return PF_OK;
 }
+int launch_bin(pf_ctx* c, const pf::ScanParams& sp, uint32_t n) {
+    const dim3 g(n), b(pf::BIN_THREADS);
+    switch (c->KW) {
+        case 1:
+            if (c->o.canon) hipLaunchKernelGGL((pf::bin_kernel<1, true>), g, b, 0, c->stream, sp);
+            else hipLaunchKernelGGL((pf::bin_kernel<1, false>), g, b, 0, c->stream, sp);
+            break;
+        case 2:
+            if (c->o.canon) hipLaunchKernelGGL((pf::bin_kernel<2, true>), g, b, 0, c->stream, sp);
+            else hipLaunchKernelGGL((pf::bin_kernel<2, false>), g, b, 0, c->stream, sp);
+            break;
+        default: return fail(PF_ERR_STATE, "bin_kernel: keys of more than two words are not binned");
+    }
+    HIPCHK(hipGetLastError());
+    return PF_OK;
+}
 int launch_scan(pf_ctx* c, const pf::ScanParams& sp, uint32_t n) {
     switch (c->KW) {
         case 1: return c->o.canon ? launch_scan_t<1, true>(c, sp, n) : launch_scan_t<1, false>(c, sp, n);
@@ -453,7 +471,7 @@ void pf_destroy(pf_ctx* c) {
                       &c->cl_first, &c->cursor, &c->strand_bits, &c->it_cluster, &c->it_part, &c->it_nparts,
                       &c->it_nslots, &c->it_slice, &c->it_sib0, &c->it_nsib, &c->it_extra_first, &c->it_count,
                       &c->it_unique, &c->it_kept, &c->work_scan, &c->work_extra, &c->work_fin, &c->work_fin2, &c->work_fin3, &c->work_fin5, &c->work_rows, &c->sub_cluster, &c->sub_item0,
-                      &c->sub_nitems};
+                      &c->sub_nitems, &c->it_binned, &c->bin_lists, &c->q_key, &c->q_ord, &c->q_bit, &c->q_off};
     for (DevBuf* b : bufs) b->release();
     for (Arena* a : c->arenas) { a->key.release(); a->pid.release(); a->first.release(); delete a; }
     for (auto& e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -1046,13 +1064,21 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         std::vector<uint8_t>& item_fused = c->hs_fused;      // 0 unfused, 1 fused small class, 2 fused large class
         items.clear(); item_fused.clear();
         items.reserve(todo.size() + 64); item_fused.reserve(todo.size() + 64);
-        struct Sub { uint32_t item0, nitems, cl0, ncl, part; };
+        struct Sub { uint32_t item0, nitems, cl0, ncl, part, bin0, nbin; uint64_t q_total; };
+        // A cluster of three or more key partitions (a dedup view, keys of up to two words) has its windows sorted by
+        // partition first (bin_kernel): its items then read their own windows instead of each walking the whole view.
+        // The entry arrays belong to a sub-batch; a sub-batch ends where they would pass BIN_MAX_ENTRIES.
+        constexpr uint32_t BIN_MIN_PARTS = 3;
+        constexpr uint64_t BIN_MAX_ENTRIES = 1ull << 28;
+        std::vector<uint32_t>& v_binned = c->hs_binned;
+        std::vector<uint32_t>&bin_cluster = c->hs_bin[0], &bin_item0 = c->hs_bin[1], &bin_nparts = c->hs_bin[2], &bin_base = c->hs_bin[3];
+        v_binned.clear(); bin_cluster.clear(); bin_item0.clear(); bin_nparts.clear(); bin_base.clear();
         auto part_of = [&](uint32_t ci) { uint32_t q = 0; while (q + 1 < P && ci >= part_end[q]) q++; return q; };
         std::vector<Sub> subs;
         std::vector<uint32_t>&sub_cluster = c->hs_sub[0], &sub_item0 = c->hs_sub[1], &sub_nitems = c->hs_sub[2];
         sub_cluster.clear(); sub_item0.clear(); sub_nitems.clear();
         uint64_t arena_cap = 0;
-        Sub cur{0, 0, 0, 0, todo.empty() ? 0u : part_of(todo[0])};
+        Sub cur{0, 0, 0, 0, todo.empty() ? 0u : part_of(todo[0]), 0, 0, 0};
         for (uint32_t ci : todo) {
             const uint32_t np = nparts[ci];
             const uint32_t nex = ex_first[ci + 1] - ex_first[ci];
@@ -1077,10 +1103,15 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             const uint32_t nit = np + nex_items;
             if (nit > c->max_items)
                 return fail(PF_ERR_CAPACITY, "cluster %u needs %u work items; raise max_items (%u)", ci, nit, c->max_items);
+            const uint64_t qn = rec[ci].vinst * mult;          // entries of the cluster's queue at most (its view's windows)
+            const uint32_t vch = (rec[ci].vnstr + 31) / 32;
+            const bool binned = !(c->o.flags & PF_FLAG_NO_KEY_BINNING) && np >= BIN_MIN_PARTS && KW <= 2 && rec[ci].mode != 0 &&
+                                vch <= pf::BIN_CHUNKS && (uint64_t)np * vch <= pf::BIN_CELLS && qn && qn <= BIN_MAX_ENTRIES;
             // (a launch reads one part's unit-view pool: a re-run pass does not mix the parts' clusters in a sub-batch)
-            if (cur.nitems + nit > c->max_items || (cur.nitems && part_of(ci) != cur.part)) {
+            if (cur.nitems + nit > c->max_items || (cur.nitems && part_of(ci) != cur.part) ||
+                (binned && cur.q_total + qn > BIN_MAX_ENTRIES)) {
                 subs.push_back(cur);
-                cur = Sub{(uint32_t)items.size(), 0, (uint32_t)sub_cluster.size(), 0, part_of(ci)};
+                cur = Sub{(uint32_t)items.size(), 0, (uint32_t)sub_cluster.size(), 0, part_of(ci), (uint32_t)bin_cluster.size(), 0, 0};
             }
             if (!cur.nitems) cur.part = part_of(ci);
             const uint32_t sib0 = (uint32_t)items.size();
@@ -1092,6 +1123,14 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             for (uint32_t q = 0; q < np; q++) {
                 items.push_back(Item{ci, q, np, ns, cur.nitems + q, sib0, nit, 0, 0});
                 item_fused.push_back(fused == 3 && q > 0 ? 4 : fused);
+            }
+            v_binned.resize(items.size() + nex_items, 0);
+            if (binned) {
+                for (uint32_t q = 0; q < np; q++) v_binned[sib0 + q] = 1;
+                bin_cluster.push_back(ci); bin_item0.push_back(sib0); bin_nparts.push_back(np);
+                bin_base.push_back((uint32_t)cur.q_total);
+                cur.q_total += qn; cur.nbin++;
+                c->timing.n_binned_clusters++;
             }
             for (uint32_t q = 0; q < nex_items; q++) {
                 const uint32_t first = ex_first[ci] + q * lim_full;
@@ -1129,6 +1168,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             &v_compact = c->hs_v[9], &w_scan = c->hs_w[0], &w_extra = c->hs_w[1], &w_fin = c->hs_w[2], &w_fin2 = c->hs_w[3],
             &w_fin3 = c->hs_w[4], &w_rows = c->hs_w[5], &w_fin5 = c->hs_w[6];
         for (auto& v : c->hs_v) v.resize(NI);
+        v_binned.resize(NI, 0);
         for (auto& v : c->hs_w) { v.clear(); v.reserve(NI); }
         for (size_t i = 0; i < NI; i++) {
             v_cluster[i] = items[i].cluster; v_part[i] = items[i].part; v_nparts[i] = items[i].nparts;
@@ -1182,11 +1222,22 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             fin5_off[s + 1] = (uint32_t)w_fin5.size();
             rows_off[s + 1] = (uint32_t)w_rows.size();
         }
+        // the four lists of the binned clusters travel as one block (cluster | first item | partitions | first entry)
+        const size_t NB = bin_cluster.size();
+        if (NB) {
+            std::vector<uint32_t>& all = c->hs_bin[0];
+            all.insert(all.end(), bin_item0.begin(), bin_item0.end());
+            all.insert(all.end(), bin_nparts.begin(), bin_nparts.end());
+            all.insert(all.end(), bin_base.begin(), bin_base.end());
+            PFCHK(c->q_off.ensure(NI * (pf::BIN_CHUNKS + 1) * 4));
+        }
         {
             std::vector<std::pair<DevBuf*, const std::vector<uint32_t>*>> arrs = {
+                {&c->bin_lists, &c->hs_bin[0]},
                 {&c->it_cluster, &v_cluster}, {&c->it_part, &v_part}, {&c->it_nparts, &v_nparts},
                 {&c->it_nslots, &v_nslots}, {&c->it_slice, &v_slice}, {&c->it_sib0, &v_sib0}, {&c->it_nsib, &v_nsib},
                 {&c->it_extra_first, &v_exfirst}, {&c->it_is_extra, &v_isex}, {&c->it_compact, &v_compact},
+                {&c->it_binned, &v_binned},
                 {&c->sub_cluster, &sub_cluster},
                 {&c->sub_item0, &sub_item0}, {&c->sub_nitems, &sub_nitems}, {&c->work_scan, &w_scan},
                 {&c->work_extra, &w_extra}, {&c->work_fin, &w_fin}, {&c->work_fin2, &w_fin2}, {&c->work_fin3, &w_fin3}, {&c->work_fin5, &w_fin5}, {&c->work_rows, &w_rows}};
@@ -1238,7 +1289,17 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
                 sp.item_count = c->it_count.as<uint32_t>(); sp.cluster_overflow = c->cl_overflow.as<uint32_t>();
                 sp.work = c->work_scan.as<uint32_t>() + scan_off[s];
                 sp.k = c->o.klength; sp.W = W; sp.NS = NS;
+                sp.item_binned = c->it_binned.as<uint32_t>();
                 PFCHK(mark_begin(c, 0));
+                if (sb.nbin) {
+                    const size_t qcap = (size_t)sb.q_total + 64;
+                    PFCHK(c->q_key.ensure(qcap * 8 * KW)); PFCHK(c->q_ord.ensure(qcap * 4)); PFCHK(c->q_bit.ensure(qcap * 4));
+                    sp.q_key = c->q_key.as<uint64_t>(); sp.q_ord = c->q_ord.as<uint32_t>(); sp.q_bit = c->q_bit.as<uint32_t>();
+                    sp.q_stride = qcap; sp.q_off = c->q_off.as<uint32_t>();
+                    sp.bin_cluster = c->bin_lists.as<uint32_t>() + sb.bin0; sp.bin_item0 = c->bin_lists.as<uint32_t>() + NB + sb.bin0;
+                    sp.bin_nparts = c->bin_lists.as<uint32_t>() + 2 * NB + sb.bin0; sp.bin_base = c->bin_lists.as<uint32_t>() + 3 * NB + sb.bin0;
+                    PFCHK(launch_bin(c, sp, sb.nbin));
+                }
                 PFCHK(launch_scan(c, sp, n_scan));
                 PFCHK(mark_end(c));
                 c->timing.scan_launches++;

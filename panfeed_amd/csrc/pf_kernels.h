@@ -159,6 +159,13 @@ struct ScanParams {
                                       // scanned when the table was full), the largest over its partitions (>= 64)
     const uint32_t* work;             // [n_work] item ids of this launch
     const struct ScanDesc* desc;      // [n_work] what a workgroup needs to start on work[i] (scan_desc_kernel)
+    // binned clusters (bin_kernel): the windows of the cluster's view as (key, ordinal, presence bit) entries, sorted by
+    // key partition and chunk; an item of such a cluster reads ITS entries instead of walking the whole view
+    const uint32_t* item_binned;      // [item] nonzero: the item's windows come from the queue
+    uint64_t* q_key; uint32_t* q_ord; uint32_t* q_bit;    // entries; word j of entry e's key: q_key[j * q_stride + e]
+    uint64_t q_stride;
+    uint32_t* q_off;                  // [item][BIN_CHUNKS + 1] first entry of every chunk of the item; [nchunks]: the end
+    const uint32_t* bin_cluster; const uint32_t* bin_item0; const uint32_t* bin_nparts; const uint32_t* bin_base;   // [grid of bin_kernel]
     uint32_t n_work;
     uint32_t k;
     uint32_t W;
@@ -169,7 +176,8 @@ struct ScanParams {
 // four dependent ones (work -> item arrays -> cluster arrays); the scan kernel requests the next one while it
 // works on the current item.
 constexpr uint32_t VIEW_IN_POOL = 0x80000000u;   // view_off flag: the cluster's view is in the unit-view pool
-struct ScanDesc { uint32_t item, c, part, nparts, ns, slice, seg0, nseg, nstr, compact, pad[6]; };
+constexpr uint32_t BIN_CHUNKS = 32;              // chunks (32 view columns each) of a binned cluster's view at most
+struct ScanDesc { uint32_t item, c, part, nparts, ns, slice, seg0, nseg, nstr, compact, binned, pad[5]; };
 static_assert(sizeof(ScanDesc) == 64, "ScanDesc is read as 16 words");
 
 __global__ __launch_bounds__(256) void scan_desc_kernel(ScanParams p, ScanDesc* out) {
@@ -181,6 +189,7 @@ __global__ __launch_bounds__(256) void scan_desc_kernel(ScanParams p, ScanDesc* 
     d.part = p.item_part[d.item]; d.nparts = p.item_nparts[d.item];
     d.ns = p.item_nslots[d.item]; d.slice = p.item_scratch[d.item];
     d.compact = p.item_compact[d.item];
+    d.binned = p.item_binned ? p.item_binned[d.item] : 0u;
     d.seg0 = p.cluster_seg_off[d.c]; d.nseg = p.cluster_vnseg[d.c]; d.nstr = p.cluster_vnstr[d.c];
     out[i] = d;
 }
@@ -410,10 +419,11 @@ __device__ __forceinline__ bool queue_push(uint64_t* keys, uint32_t* ord, uint32
     if (pn + m > 64) over = queue_flush<KW>(keys, ord, bits, misc, NS, ns, limit, lane, pq, pn);
     const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
     if (mine) wq[r] = (uint8_t)lane;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // (the list is this wave's own: its LDS operations run in order)
     __builtin_amdgcn_wave_barrier();
     const bool take = lane >= pn && lane < pn + m;
     const uint32_t src = take ? (uint32_t)wq[lane - pn] : lane;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();                                 // the list is rewritten by the next push
 #pragma unroll
     for (int j = 0; j < KW; j++) {
@@ -534,6 +544,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
     const uint32_t* const a_bits = in_pool ? p.u_bits : p.seg_bits;
     const uint32_t nstr = misc[dcur + 8];
     const bool compact = misc[dcur + 9] != 0;  // view has <= 64 columns: at most chunks 0 and 1
+    const bool binned = misc[dcur + 10] != 0;  // the cluster's windows were sorted by key partition (bin_kernel)
     const uint32_t nchunks = (nstr + 31) >> 5;
     const uint32_t limit = insert_limit(ns);
     // request the next item's descriptor now; it is looked at after the scan loop
@@ -588,7 +599,52 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
         if (tid == (ch >> 5)) mask_word |= 1u << (ch & 31);
     };
 
-    for (uint32_t t0 = seg0; t0 < seg1 && !overflow; t0 += SEG_TILE) {
+    if (binned) {
+        // ---- the item's own windows, chunk after chunk, 64 entries a wave and trip.  (Walking the view, an item that
+        // is one of P key partitions works out the key of EVERY window to keep one in P: at ten partitions the scan of
+        // a cluster cost ten scans' worth of key arithmetic, 80 % of its time.)
+        __syncthreads();                           // misc[M_CHUNK ..] was written above
+        for (uint32_t i = tid; i <= nchunks; i += SCAN_THREADS) misc[M_CHUNK + i] = p.q_off[(size_t)item * (BIN_CHUNKS + 1) + i];
+        __syncthreads();
+        const uint32_t qbeg = misc[M_CHUNK];
+        const uint32_t nhome = KW == 1 ? ns / SCAN_BUCKET : ns;
+        for (uint32_t qc = 0; qc < nchunks && !overflow; qc++) {
+            const uint32_t e0 = misc[M_CHUNK + qc], e1 = misc[M_CHUNK + qc + 1];
+            if (e0 == e1) continue;                // (uniform)
+            if (qc != ch) {
+                if (chunk_dirty) { flush_chunk(); chunk_dirty = false; __syncthreads(); }
+                ch = qc;
+            }
+            auto load = [&](uint32_t at, Key<KW>& kk, uint32_t& oo, uint32_t& bb) {
+                const uint32_t i = min(at + lane, e1 - 1);
+#pragma unroll
+                for (int j = 0; j < KW; j++) kk.w[j] = p.q_key[(size_t)j * p.q_stride + i];
+                oo = p.q_ord[i]; bb = p.q_bit[i];
+            };
+            uint32_t e = e0 + wave * 64;
+            Key<KW> key{};
+            uint32_t eo = 0, eb = 0;
+            if (e < e1) load(e, key, eo, eb);
+            while (e < e1) {
+                const uint32_t en = e + SCAN_WAVES * 64;
+                Key<KW> nkey;
+                uint32_t no, nb;
+                load(en < e1 ? en : e, nkey, no, nb);      // unconditional: one request in flight across the table work
+                const uint32_t h = key_hash<KW>(key);
+                const bool over = table_update<KW>(keys, ord, bits, misc, NS, ns, limit, e + lane < e1, key, __umulhi(h, nhome), eo, eb);
+                if (__any(over)) {
+                    if (lane == 0) atomicMin(&misc[M_PROG], (e - qbeg) >> 6);
+                    break;
+                }
+                key = nkey; eo = no; eb = nb;
+                e = en;
+            }
+            chunk_dirty = true;
+            __syncthreads();
+            if (misc[M_OVERFLOW]) overflow = true;
+        }
+    }
+    for (uint32_t t0 = seg0; t0 < seg1 && !overflow && !binned; t0 += SEG_TILE) {
         const uint32_t nseg = min(SEG_TILE, seg1 - t0);
         // ---- stage this tile's segment metadata (coalesced; tile 0 is there already), then unit prefix by wave 0
         if (t0 != seg0 && tid < nseg) {
@@ -734,9 +790,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
         // the same keys arrive at about the same rate in every partition and all through the item (the first sequence
         // of a cluster brings more new keys than the later ones: the extrapolation errs on the safe side).
         uint32_t tot = 0;
-        for (uint32_t s = seg0 + tid; s < seg1; s += SCAN_THREADS) {
-            const uint32_t len = a_len[s];
-            tot += len >= k ? (len - k + 64) >> 6 : 0;
+        if (binned) {
+            if (tid == 0) tot = (misc[M_CHUNK + nchunks] - misc[M_CHUNK] + 63) >> 6;     // (its progress counts 64 entries)
+        } else {
+            for (uint32_t s = seg0 + tid; s < seg1; s += SCAN_THREADS) {
+                const uint32_t len = a_len[s];
+                tot += len >= k ? (len - k + 64) >> 6 : 0;
+            }
         }
         for (int d = 1; d < 64; d <<= 1) tot += __shfl_xor(tot, d);
         if (tid == 0) misc[M_TMP] = 0;
@@ -825,6 +885,122 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
     if (tid == 0) atomicAdd(&pf_prof[24], 1ull);
 #endif
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bin_kernel: the windows of a cluster that takes several key partitions, sorted by partition and chunk
+// ---------------------------------------------------------------------------------------------
+// One workgroup per cluster walks the cluster's view twice: it counts the windows of every (key partition, chunk) cell,
+// gives every cell its place in the cluster's stretch of the entry arrays (partition-major: an item's entries are
+// contiguous, chunk after chunk), then writes (key, ordinal, presence bit) of every window to its cell.  The key
+// arithmetic is done twice per window here instead of once per window and partition in the scan.  The order of the
+// entries inside a cell depends on the run; what the scan makes of them (smallest ordinal, OR of the bits) does not.
+constexpr uint32_t BIN_THREADS = 1024, BIN_CELLS = 8192;      // partitions x chunks of a binned cluster at most
+template <int KW, bool CANON>
+__global__ __launch_bounds__(BIN_THREADS) void bin_kernel(ScanParams p) {
+    __shared__ uint32_t cell[BIN_CELLS];           // windows per cell, then the cell's write position
+    __shared__ uint32_t wave_tot[BIN_THREADS / 64 + 1];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t b = blockIdx.x;
+    const uint32_t c = p.bin_cluster[b], item0 = p.bin_item0[b], P = p.bin_nparts[b], base = p.bin_base[b];
+    const uint32_t raw = p.cluster_seg_off[c];
+    const bool in_pool = (raw & VIEW_IN_POOL) != 0;
+    const uint32_t seg0 = raw & ~VIEW_IN_POOL, seg1 = seg0 + p.cluster_vnseg[c];
+    const uint64_t* const a_woff = in_pool ? p.u_word_off : p.seg_word_off;
+    const uint32_t* const a_len = in_pool ? p.u_len : p.seg_len;
+    const uint32_t* const a_sample = in_pool ? p.u_sample : p.seg_sample;
+    const uint32_t* const a_ordb = in_pool ? p.u_ord_base : p.seg_ord_base;
+    const uint32_t* const a_bits = in_pool ? p.u_bits : p.seg_bits;
+    const uint32_t nch = (p.cluster_vnstr[c] + 31) >> 5;          // <= BIN_CHUNKS (host)
+    const uint32_t cells = P * nch;                                // <= BIN_CELLS (host)
+    const uint32_t k = p.k;
+    for (uint32_t i = tid; i < BIN_CELLS; i += BIN_THREADS) cell[i] = 0;
+    __syncthreads();
+    // every window of the view, one segment per wave at a time: sink(valid, partition, chunk, key, ordinal, bit)
+    auto walk = [&](auto&& sink) {
+        for (uint32_t s = seg0 + wave; s < seg1; s += BIN_THREADS / 64) {
+            const uint32_t len = a_len[s];
+            if (len < k) continue;
+            const uint32_t ninst = len - k + 1, ordb = a_ordb[s], bit = a_bits[s], ch = a_sample[s] >> 5;
+            const uint64_t* q = p.packed + a_woff[s] + (lane >> 5);
+            uint64_t cw[KW + 1];
+#pragma unroll
+            for (int j = 0; j <= KW; j++) cw[j] = q[j];
+            for (uint32_t u = 0; (u << 6) < ninst; u++) {
+                const bool more = ((u + 1) << 6) < ninst;
+                const uint64_t* qn = more ? q + 2 : q;                 // (unconditional: the next unit's words in flight)
+                uint64_t nw[KW + 1];
+#pragma unroll
+                for (int j = 0; j <= KW; j++) nw[j] = qn[j];
+                const uint32_t pos = (u << 6) + lane;
+                const bool valid = pos < ninst;
+                Key<KW> fwd, rc;
+                const bool rc_smaller = window_keys<KW>(k, lane, cw, fwd, rc);
+                if (CANON) {
+                    const Key<KW> key = rc_smaller ? rc : fwd;
+                    const uint32_t h = key_hash<KW>(key);
+                    sink(valid, ((h & 0xFFFFu) * P) >> 16, ch, key, ordb + pos, bit);
+                } else {
+                    uint32_t h = key_hash<KW>(fwd);
+                    sink(valid, ((h & 0xFFFFu) * P) >> 16, ch, fwd, 2 * (ordb + pos), bit);
+                    h = key_hash<KW>(rc);
+                    sink(valid, ((h & 0xFFFFu) * P) >> 16, ch, rc, 2 * (ordb + pos) + 1, bit);
+                }
+#pragma unroll
+                for (int j = 0; j <= KW; j++) cw[j] = nw[j];
+                q = qn;
+            }
+        }
+    };
+    walk([&](bool valid, uint32_t part, uint32_t ch, const Key<KW>&, uint32_t, uint32_t) {
+        if (valid) atomicAdd(&cell[part * nch + ch], 1u);
+    });
+    __syncthreads();
+    {   // cells -> positions (exclusive prefix in partition-major order), the items' chunk tables
+        constexpr uint32_t PER = BIN_CELLS / BIN_THREADS;
+        uint32_t v[PER], sum = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < PER; j++) {
+            const uint32_t i = tid * PER + j;
+            v[j] = i < cells ? cell[i] : 0;
+            sum += v[j];
+        }
+        uint32_t x = sum;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d);
+            if ((int)lane >= d) x += y;
+        }
+        if (lane == 63) wave_tot[wave] = x;
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t run = 0;
+            for (uint32_t w = 0; w < BIN_THREADS / 64; w++) { const uint32_t t = wave_tot[w]; wave_tot[w] = run; run += t; }
+            wave_tot[BIN_THREADS / 64] = run;
+        }
+        __syncthreads();
+        uint32_t run = base + wave_tot[wave] + x - sum;
+#pragma unroll
+        for (uint32_t j = 0; j < PER; j++) {
+            const uint32_t i = tid * PER + j;
+            if (i < cells) {
+                const uint32_t part = i / nch, ch = i - part * nch;
+                cell[i] = run;
+                p.q_off[(size_t)(item0 + part) * (BIN_CHUNKS + 1) + ch] = run;
+                if (ch == 0 && part) p.q_off[(size_t)(item0 + part - 1) * (BIN_CHUNKS + 1) + nch] = run;
+                run += v[j];
+            }
+        }
+        if (tid == 0) p.q_off[(size_t)(item0 + P - 1) * (BIN_CHUNKS + 1) + nch] = base + wave_tot[BIN_THREADS / 64];
+    }
+    __syncthreads();
+    walk([&](bool valid, uint32_t part, uint32_t ch, const Key<KW>& key, uint32_t o, uint32_t bit) {
+        if (!valid) return;
+        const uint32_t e = atomicAdd(&cell[part * nch + ch], 1u);
+#pragma unroll
+        for (int j = 0; j < KW; j++) p.q_key[(size_t)j * p.q_stride + e] = key.w[j];
+        p.q_ord[e] = o;
+        p.q_bit[e] = bit;
+    });
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -33,11 +33,12 @@ for case in range(n_cases):
     stroi = set(rng.choice(names, size=min(len(names), int(rng.integers(0, 3))), replace=False).tolist())
     dedup = bool(rng.random() < 0.8)
     unit_dedup = bool(rng.random() < 0.85)
+    key_binning = bool(rng.random() < 0.8)
     max_items = int(rng.choice([64, 2048]))
     cut = int(rng.integers(0, ncl + 1))
     try:
         for attempt in range(2):
-            eng = Engine(max_strains=(S + 31) // 32 * 32, stroi=stroi, dedup=dedup, unit_dedup=unit_dedup, max_items=max_items, **kw)
+            eng = Engine(max_strains=(S + 31) // 32 * 32, stroi=stroi, dedup=dedup, unit_dedup=unit_dedup, key_binning=key_binning, max_items=max_items, **kw)
             try:
                 outs = [eng.run(recs[:cut])] if cut else []
                 if cut < ncl:
