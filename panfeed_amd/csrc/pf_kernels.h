@@ -918,6 +918,55 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(ScanParams p) {
     __syncthreads();
     // every window of the view, one segment per wave at a time: sink(valid, partition, chunk, key, ordinal, bit)
     auto walk = [&](auto&& sink) {
+        if (in_pool) {
+            // pieces of the unit view (one unit each, KW + 2 words at most): a wave takes 64 consecutive pieces, every lane
+            // asks for ONE piece's numbers and then its words, and the pieces are handed out lane to lane -- two trips to
+            // memory per 64 pieces.  (Piece by piece they were two per piece, with little else in flight: 70 % of the kernel.)
+            for (uint32_t sb = seg0 + wave * 64; sb < seg1; sb += BIN_THREADS) {
+                const uint32_t s = sb + lane;
+                const bool has = s < seg1;
+                const uint32_t m_len = has ? a_len[s] : 0u, m_ordb = has ? a_ordb[s] : 0u, m_bit = has ? a_bits[s] : 0u;
+                const uint32_t m_ch = has ? a_sample[s] >> 5 : 0u;
+                const uint64_t m_woff = has ? a_woff[s] : 0ull;
+                uint32_t pw_lo[KW + 2], pw_hi[KW + 2];
+#pragma unroll
+                for (int j = 0; j < KW + 2; j++) {
+                    const uint64_t v = has ? p.packed[m_woff + j] : 0ull;
+                    pw_lo[j] = (uint32_t)v; pw_hi[j] = (uint32_t)(v >> 32);
+                }
+                const uint32_t cntp = min(64u, seg1 - sb);
+                for (uint32_t i = 0; i < cntp; i++) {
+                    const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)m_len, (int)i);
+                    if (len < k) continue;
+                    const uint32_t ninst = len - k + 1;
+                    const uint32_t ordb = (uint32_t)__builtin_amdgcn_readlane((int)m_ordb, (int)i);
+                    const uint32_t bit = (uint32_t)__builtin_amdgcn_readlane((int)m_bit, (int)i);
+                    const uint32_t ch = (uint32_t)__builtin_amdgcn_readlane((int)m_ch, (int)i);
+                    uint64_t uw[KW + 2];
+#pragma unroll
+                    for (int j = 0; j < KW + 2; j++)
+                        uw[j] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)pw_hi[j], (int)i) << 32) |
+                                (uint32_t)__builtin_amdgcn_readlane((int)pw_lo[j], (int)i);
+                    uint64_t cw[KW + 1];
+#pragma unroll
+                    for (int j = 0; j <= KW; j++) cw[j] = (lane >> 5) ? uw[j + 1] : uw[j];
+                    const bool valid = lane < ninst;
+                    Key<KW> fwd, rc;
+                    const bool rc_smaller = window_keys<KW>(k, lane, cw, fwd, rc);
+                    if (CANON) {
+                        const Key<KW> key = rc_smaller ? rc : fwd;
+                        const uint32_t h = key_hash<KW>(key);
+                        sink(valid, ((h & 0xFFFFu) * P) >> 16, ch, key, ordb + lane, bit);
+                    } else {
+                        uint32_t h = key_hash<KW>(fwd);
+                        sink(valid, ((h & 0xFFFFu) * P) >> 16, ch, fwd, 2 * (ordb + lane), bit);
+                        h = key_hash<KW>(rc);
+                        sink(valid, ((h & 0xFFFFu) * P) >> 16, ch, rc, 2 * (ordb + lane) + 1, bit);
+                    }
+                }
+            }
+            return;
+        }
         for (uint32_t s = seg0 + wave; s < seg1; s += BIN_THREADS / 64) {
             const uint32_t len = a_len[s];
             if (len < k) continue;
