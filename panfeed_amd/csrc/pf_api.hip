@@ -1418,7 +1418,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             em.cluster_kmer_off = c->cl_kmer_off.as<uint64_t>();
             em.tab_key = c->tab_key.as<uint64_t>(); em.tab_ord = c->tab_ord.as<uint32_t>();
             em.slot_hash = c->slot_hash.as<uint4>();
-            em.sorted_pair = c->sorted_pair.as<uint64_t>(); em.kept_prefix = c->kept_prefix.as<uint32_t>();
+            em.sorted_pair = c->sorted_pair.as<uint64_t>(); em.kept_prefix = c->kept_prefix.as<uint32_t>(); em.kept_prefix_rw = c->kept_prefix.as<uint32_t>();
             em.bm_occ = c->bm_occ.as<uint32_t>(); em.bm_keep = c->bm_keep.as<uint32_t>();
             em.pre_occ = c->pre_occ.as<uint32_t>(); em.pre_keep = c->pre_keep.as<uint32_t>();
             em.slot_out = c->slot_out.as<uint32_t>();

@@ -2347,8 +2347,13 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
             atomicOr(&occ[o >> 5], 1u << (o & 31));
             if (keep) atomicOr(&keepbm[o >> 5], 1u << (o & 31));
         }
+        // the kept k-mers of the item, (ordinal, slot) in any order, for emit_kernel -- which otherwise looks at every slot
+        // of the table and finds out slot by slot, load after load, that most are empty or dropped
+        if (bitmaps && keep && (o >> 5) < dense_words)
+            p.sorted_pair[(size_t)slice * NS + atomicAdd(&sh_cnt, 1u)] = ((uint64_t)o << 32) | i;
     }
     __syncthreads();
+    if (bitmaps && tid == 0) p.kept_prefix[(size_t)slice * (NS + 1)] = sh_cnt;
     PF_PROF_STAMP(44);
 
     if (big) {
@@ -2688,7 +2693,8 @@ struct EmitParams {
     const uint64_t* cluster_ordinal;
     const uint64_t* cluster_kmer_off;
     const uint64_t* tab_key; const uint32_t* tab_ord; const uint4* slot_hash;
-    const uint64_t* sorted_pair; const uint32_t* kept_prefix;                                       // mode 0
+ const uint64_t* sorted_pair; const uint32_t* kept_prefix;                                       // mode 0
+    uint32_t* kept_prefix_rw;        // (the same array: with bitmaps its words 1.. take the kept k-mers' output indices)
     const uint32_t* bm_occ; const uint32_t* bm_keep; const uint32_t* pre_occ; const uint32_t* pre_keep;   // mode 1
     uint32_t* slot_out;              // [slice][NS] mode 1: index of the slot's k-mer inside the cluster's output
     uint64_t* out_key; uint32_t* out_pid; uint64_t* out_first;     // out_first: first_seen each k-mer offered
@@ -2728,6 +2734,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
     __shared__ uint32_t lt_pid[LT_SLOTS];
     __shared__ uint32_t lt_count;
 
+    PF_PROF_BEGIN();
     const uint32_t tid = threadIdx.x;
     const uint32_t item = p.work[blockIdx.x];
     const uint32_t c = p.item_cluster[item];
@@ -2762,17 +2769,21 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
     }
 
     const uint32_t ns = p.item_nslots[item];
-    const uint32_t dense_words = (p.v_dense[c] + 31) >> 5;
-    const uint32_t* ordp = p.tab_ord + (size_t)slice * NS;
     const size_t gb0 = (size_t)p.item_scratch[sib0] * DENSE_WORDS_BIG;
     const uint64_t* sp = p.sorted_pair + (size_t)slice * NS;
     const uint32_t* kp = p.kept_prefix + (size_t)slice * (NS + 1);
     uint32_t* sout = p.slot_out + (size_t)slice * NS;    // per entry (slot / sorted position): index of its k-mer in
                                                          // the cluster's output, NONE when it is not kept
-    const uint32_t n_entries = sorted ? U : ns;
+    // entries: the item's k-mers in ordinal order (sorted), or its KEPT k-mers in any order (bitmaps: rows_kernel left
+    // their (ordinal, slot) pairs in sorted_pair and their number in kept_prefix[0]; kept_prefix[1 + i] takes entry i's
+    // output index here)
+    const uint32_t n_entries = sorted ? U : min(kp[0], ns);
+    uint32_t* kres = p.kept_prefix_rw + (size_t)slice * (NS + 1) + 1;
     for (uint32_t i = tid; i < LT_SLOTS; i += EMIT_THREADS) { lt_lo[i] = EMPTY64; lt_hi[i] = EMPTY64; lt_first[i] = EMPTY64; }
     if (tid == 0) lt_count = 0;
+    if (!sorted) for (uint32_t i = tid; i < ns; i += EMIT_THREADS) sout[i] = 0xFFFFFFFFu;
     __syncthreads();
+    PF_PROF_STAMP(32);
     auto row_id = [&](uint32_t slot, uint64_t& lo, uint64_t& hi) {
         const uint4 h = p.slot_hash[(size_t)slice * NS + slot];
         lo = ((uint64_t)h.x << 32) | h.y; hi = ((uint64_t)h.z << 32) | h.w;
@@ -2783,7 +2794,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
     for (uint32_t i0 = 0; i0 < n_entries; i0 += EMIT_THREADS) {
         const uint32_t i = i0 + tid;
         uint32_t res = 0xFFFFFFFFu, slot = 0;
-        uint64_t fs = 0;
+        uint64_t fs = 0, lo = 0, hi = 0;
         if (i < n_entries) {
             if (sorted) {
                 const uint32_t kb = kp[i];
@@ -2803,34 +2814,31 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
                     res = kept_before;
                     fs = (ordinal << 32) | (uint64_t)(rank + 1);
                 }
+                sout[i] = res;
             } else {
-                const uint32_t o = ordp[i];
-                slot = i;
-                if (o != NO_ORD && (o >> 5) < dense_words) {
-                    const uint32_t w = o >> 5, below = (1u << (o & 31)) - 1;
-                    // the cluster's bitmaps: this item's own, or (several items) their union, which
-                    // bitmap_merge_kernel left in the first item's place
-                    const size_t g2 = gb0 + w;
-                    const uint32_t kw = p.bm_keep[g2];
-                    if ((kw >> (o & 31)) & 1) {
-                        const uint32_t rank = p.pre_occ[g2] + __popc(p.bm_occ[g2] & below);
-                        const uint32_t kept_before = p.pre_keep[g2] + __popc(kw & below);
-                        res = kept_before;
-                        fs = (ordinal << 32) | (uint64_t)(rank + 1);
-                    }
-                }
+                const uint64_t pr = sp[i];
+                const uint32_t o = (uint32_t)(pr >> 32);
+                slot = (uint32_t)pr;
+                const uint32_t below = (1u << (o & 31)) - 1;
+                // the cluster's bitmaps: this item's own, or (several items) their union, which
+                // bitmap_merge_kernel left in the first item's place -- four loads that go out together
+                const size_t g2 = gb0 + (o >> 5);
+                const uint32_t kw = p.bm_keep[g2], po = p.pre_occ[g2], bo = p.bm_occ[g2], pk = p.pre_keep[g2];
+                row_id(slot, lo, hi);                          // (and the row hash with them)
+                res = pk + __popc(kw & below);
+                fs = (ordinal << 32) | (uint64_t)(po + __popc(bo & below) + 1);
+                kres[i] = res;
+                sout[slot] = res;
             }
-            sout[i] = res;
         }
         // local table: find or claim; an entry whose second word is not published yet is looked at again in the next
         // round of a WAVE-UNIFORM loop (no lane ever spins inside divergent code)
         int st = res != 0xFFFFFFFFu ? 2 : 0;
-        uint64_t lo = 0, hi = 0;
         uint32_t ls = 0;
         if (st == 2) {
             const uint64_t o_idx = obase + res;
             if (o_idx < p.out_cap) p.out_first[o_idx] = fs;
-            row_id(slot, lo, hi);
+            if (sorted) row_id(slot, lo, hi);
             ls = (uint32_t)(lo ^ (hi >> 7)) & (LT_SLOTS - 1);
         }
         for (;;) {
@@ -2861,6 +2869,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
         if (st == 1) atomicMin((unsigned long long*)&lt_first[ls], (unsigned long long)fs);
     }
     __syncthreads();
+    PF_PROF_STAMP(33);
     // pass 2: one insert into the run-global table per distinct pattern of this item
     for (uint32_t t0 = 0; t0 < LT_SLOTS; t0 += EMIT_THREADS) {
         const uint32_t t = t0 + tid;
@@ -2868,13 +2877,14 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
         if (lo != EMPTY64) lt_pid[t] = pattern_insert(p.pt, lo, (uint32_t)(lt_hi[t] >> 32), lt_first[t]);
     }
     __syncthreads();
+    PF_PROF_STAMP(34);
     // pass 3: pattern id per kept k-mer, outputs
     for (uint32_t i = tid; i < n_entries; i += EMIT_THREADS) {
-        const uint32_t kb = sout[i];
+        const uint32_t kb = sorted ? sout[i] : kres[i];
         if (kb == 0xFFFFFFFFu) continue;
         const uint64_t o_idx = obase + kb;
         if (o_idx >= p.out_cap) { p.pt.counters[2] = 1; continue; }   // cannot happen: the arena holds every item's limit
-        const uint32_t slot = sorted ? (uint32_t)sp[i] : i;
+        const uint32_t slot = (uint32_t)sp[i];
         uint64_t lo, hi;
         row_id(slot, lo, hi);
         uint32_t ls = (uint32_t)(lo ^ (hi >> 7)) & (LT_SLOTS - 1);
@@ -2892,6 +2902,11 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
         for (uint32_t j = 1; j < KW; j++) p.out_key[o_idx * KW + j] = p.tab_key[((size_t)slice * KW + j) * NS + slot];
         p.out_pid[o_idx] = pid;
     }
+#ifdef PF_PROF
+    __syncthreads();
+    PF_PROF_STAMP(35);
+    if (threadIdx.x == 0) { atomicAdd(&pf_prof[36], 1ull); atomicAdd(&pf_prof[37], (unsigned long long)lt_count); }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -28,15 +28,19 @@ names = {0: "finish: init + M", 1: "finish: A masks", 2: "finish: B row eval", 3
          5: "finish: find/claim", 6: "finish: publish+rows", 7: "finish: outputs", 8: "finish: workgroups",
          16: "scan: clear + tile0", 17: "scan: unit prefix", 18: "scan: windows", 19: "scan: next desc/tile",
          20: "scan: table dump", 21: "scan: desc swap", 24: "scan: items",
+         32: "emit: init + cluster row", 33: "emit: pass 1 (rank, local table)", 34: "emit: pass 2 (global inserts)",
+         35: "emit: pass 3 (outputs)", 36: "emit: items",
          40: "rows(wide): segments", 41: "rows(wide): A mask table", 42: "rows(wide): C rows", 43: "rows(wide): C hashes + D",
          44: "rows: slots", 45: "rows: bitmaps out", 46: "rows: sort + out", 47: "rows(wide): items",
          48: "rows(wide): distinct masks", 49: "rows(wide): slots", 50: "rows(wide): rounds"}
-for lo, hi, cnt in ((0, 8, 8), (16, 24, 24), (40, 47, 47)):
+for lo, hi, cnt in ((0, 8, 8), (16, 24, 24), (32, 36, 36), (40, 47, 47)):
     tot = sum(v[lo:hi])
     for i in list(range(lo, hi)) + [cnt]:
         if v[i]:
             print(f"{i:2d} {names.get(i, ''):24s} {v[i]:14d} {100.0 * v[i] / tot if i < hi else 0:6.1f}%"
                   + (f"  {v[i] / v[cnt]:9.0f} cyc/item" if i < hi and v[cnt] else ""))
+if v[36]:
+    print(f"37 emit: distinct patterns in the local table {v[37] / v[36]:9.1f} per item")
 for i in (48, 49, 50):
     if v[47]:
         print(f"{i:2d} {names[i]:28s} {v[i] / v[47]:9.1f} per item")
