@@ -11,6 +11,7 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 big = len(sys.argv) > 3 and sys.argv[3] == "big"        # BASELINE-sized clusters: hundreds to 1 000 samples
 fails = 0
+seen = {"binned": 0, "wide": 0, "retried": 0, "partitioned": 0}      # cases that took the path at least once
 t0 = time.time()
 for case in range(n_cases):
     rng = np.random.default_rng(seed0 * 100003 + case)
@@ -40,9 +41,15 @@ for case in range(n_cases):
         for attempt in range(2):
             eng = Engine(max_strains=(S + 31) // 32 * 32, stroi=stroi, dedup=dedup, unit_dedup=unit_dedup, key_binning=key_binning, max_items=max_items, **kw)
             try:
-                outs = [eng.run(recs[:cut])] if cut else []
-                if cut < ncl:
-                    outs.append(eng.run(recs[cut:]))
+                outs, hit = [], set()
+                for part in ([recs[:cut]] if cut else []) + ([recs[cut:]] if cut < ncl else []):
+                    outs.append(eng.run(part))
+                    t = eng.timing()
+                    hit |= {n for n, f in (("binned", "n_binned_clusters"), ("wide", "n_wide_clusters"), ("retried", "n_retried")) if t[f]}
+                    if t["n_items"] > len(part):
+                        hit.add("partitioned")
+                for n in hit:
+                    seen[n] += 1
                 break
             except Exception as e:  # noqa: BLE001
                 # a cluster that needs more work items than this tiny setting allows is refused by design
@@ -62,8 +69,9 @@ for case in range(n_cases):
         print("EXC", repr(e)[:200])
     if not ok:
         fails += 1
-        print("FAIL case", case, kw, gen, "S", S, "ncl", ncl, "dedup", dedup, "stroi", len(stroi), "shuffle", shuffle, flush=True)
+        print("FAIL case", case, kw, gen, "S", S, "ncl", ncl, "dedup", dedup, "stroi", len(stroi), "shuffle", shuffle, "unit_dedup", unit_dedup, "key_binning", key_binning,
+              "max_items", max_items, "cut", cut, flush=True)
     if case % 20 == 19:
         print(f"{case + 1} cases, {fails} failures, {time.time() - t0:.0f} s", flush=True)
-print("DONE", n_cases, "cases", fails, "failures")
+print("DONE", n_cases, "cases", fails, "failures; cases by path:", seen)
 sys.exit(1 if fails else 0)
