@@ -1068,7 +1068,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         // A cluster of three or more key partitions (a dedup view, keys of up to two words) has its windows sorted by
         // partition first (bin_kernel): its items then read their own windows instead of each walking the whole view.
         // The entry arrays belong to a sub-batch; a sub-batch ends where they would pass BIN_MAX_ENTRIES.
-        constexpr uint32_t BIN_MIN_PARTS = 3;
+        constexpr uint32_t BIN_MIN_PARTS = 3;      // (at two, a cluster's own bin_kernel workgroup takes longer than the second walk it saves)
         constexpr uint64_t BIN_MAX_ENTRIES = 1ull << 28;
         std::vector<uint32_t>& v_binned = c->hs_binned;
         std::vector<uint32_t>&bin_cluster = c->hs_bin[0], &bin_item0 = c->hs_bin[1], &bin_nparts = c->hs_bin[2], &bin_base = c->hs_bin[3];
@@ -1341,7 +1341,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
                 }
                 if (n_fin3) {
                     fp.work = c->work_fin3.as<uint32_t>() + fin3_off[s];
-                    hipLaunchKernelGGL((pf::finish_kernel<pf::FinLarge, true>), dim3(n_fin3), dim3(pf::FinLarge::THREADS), 0, c->stream, fp);
+                    hipLaunchKernelGGL((pf::finish_kernel<pf::FinLargeM, true>), dim3(n_fin3), dim3(pf::FinLargeM::THREADS), 0, c->stream, fp);
                     HIPCHK(hipGetLastError());
                 }
                 if (n_fin2) {

@@ -2921,6 +2921,10 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
 // what hides the latency of the global atomics and dependent loads this kernel is made of.
 struct FinSmall { static constexpr uint32_t THREADS = 512, DW = 1024, MR = 1024, AT = 256, ATL = 192; typedef uint8_t tag_t; };
 struct FinLarge { static constexpr uint32_t THREADS = 1024, DW = 2048, MR = 2048, AT = 512, ATL = 384; typedef uint16_t tag_t; };
+// The large class in its MULTI form (several key partitions) has no per-slot tags: the LDS they would take holds a mask table
+// of twice the size -- 70 KiB, still two workgroups per CU.  (Alleles that each carry their own substitutions give a cluster
+// about as many distinct masks as the gene has windows; every mask past the table is evaluated slot by slot.)
+struct FinLargeM { static constexpr uint32_t THREADS = 1024, DW = 2048, MR = 2048, AT = 1024, ATL = 768; typedef uint16_t tag_t; };
 // A third class for clusters whose distinct sequences carry up to 131 071 windows (60 sequences of 1 100 bases + flanks, or
 // 30 of 2 500): always in the MULTI form (no per-slot tags), 75 KiB, two workgroups per CU.  The 16-bit prefix counts are
 // kept: those of the upper half of the bitmap are relative to its first word (sh_half_*).
@@ -3331,7 +3335,8 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
     uint32_t e_hi = 0, e_pid = 0xFFFFFFFFu, e_newidx = 0;
     int e_state = -1;                             // -1 no entry, 0 found, 1 claimed, 2 deferred
     uint64_t e_key = 0;
-    if (tid == T - 1 && !is_row_entry) {
+    static_assert(T >= AT, "one thread per mask-table entry");
+    if (tid == (AT == T ? T - 2 : T - 1)) {       // (not the row entry's thread, which has its hash to work out meanwhile)
         sh_base = atomicAdd((unsigned long long*)&p.cursor[0], (unsigned long long)tot_k);
         atomicAdd((unsigned long long*)&p.cursor[1], (unsigned long long)tot_o);
         atomicAdd((unsigned long long*)&p.cursor[2], (unsigned long long)tot_k);
