@@ -1857,7 +1857,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
     __shared__ uint32_t at_keep[AT_SLOTS];
     // mode 2 ("wide": up to 1024 distinct sequences, a k-mer's allele mask is up to 32 words)
     __shared__ uint16_t slot_tag[9600];        // per slot: table position of its mask in this round, or a WIDE_ state
-    __shared__ uint32_t mstage[ROWS_THREADS / 32][33];   // the mask being expanded, per half-wave; word 32 stays zero
+    __shared__ uint32_t mstage[ROWS_THREADS / 32][4][33];   // the four masks being expanded, per half-wave; word 32 stays zero
     __shared__ uint32_t wstart[MAX_CHUNKS + 1];          // first segment of every 32-sample word
 
     PF_PROF_BEGIN();
@@ -2050,41 +2050,54 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         constexpr uint32_t WIDE_SEGREG = 32;
         uint32_t sg[WIDE_SEGREG / 2];
         uint32_t my_q0 = 0, my_q1 = 0, sg_used = 0;
-        if (hl == 0) mstage[hw][32] = 0;
-        auto gather_row = [&](uint32_t my_mask_word, uint32_t* row) {     // lane hl < nmw brings word hl of the mask
-            if (hl < nmw) mstage[hw][hl] = my_mask_word;
+        if (hl < 4) mstage[hw][hl][32] = 0;
+        // FOUR masks a call (entries e, e + 32, e + 64, e + 96 of the round's table): a segment's place and bit numbers are
+        // worked out once and looked up in the four masks -- three instructions a mask and segment where one mask a
+        // call took seven, and the step is bound by exactly those.
+        constexpr uint32_t GM = 4;
+        auto gather_rows = [&](uint32_t e0, uint32_t n_ent) {
+#pragma unroll
+            for (uint32_t m = 0; m < GM; m++) {
+                const uint32_t e = e0 + 32 * m;
+                if (hl < nmw) mstage[hw][m][hl] = e < n_ent ? tabw[e * nmw + hl] : 0u;
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const uint32_t* ms = mstage[hw];
+            const uint32_t* ms = mstage[hw][0];
+            constexpr uint32_t MS = 33;                                // words from one mask's stage to the next
             for (uint32_t w0 = 0; w0 < RW; w0 += 32) {
                 const uint32_t w = w0 + hl;
-                uint32_t word = 0;
+                uint32_t word[GM];
+#pragma unroll
+                for (uint32_t m = 0; m < GM; m++) word[m] = 0;
+                auto take = [&](uint32_t e) {                              // e: distinct index << 5 | sample & 31
+                    const uint32_t at = e >> 10, sh = (e >> 5) & 31u;
+#pragma unroll
+                    for (uint32_t m = 0; m < GM; m++) word[m] |= ((ms[m * MS + at] >> sh) & 1u) << (e & 31u);
+                };
                 if (w0 == 0) {
 #pragma unroll
                     for (uint32_t jb = 0; jb < WIDE_SEGREG / 2; jb += 4) {
                         if (2 * jb >= sg_used) break;                         // wave-uniform; eight segments a step
 #pragma unroll
                         for (uint32_t j = jb; j < jb + 4; j++) {
-                            // (opaque copy: decoded here, every time -- the compiler would otherwise keep three decoded
-                            // values per segment alive across the loop over the masks, 96 registers and a spill)
+                            // (opaque copy: decoded here, every time -- the compiler would otherwise keep the decoded
+                            // values of every segment alive across the loop over the masks and spill)
                             uint32_t pr = sg[j];
                             asm volatile("" : "+v"(pr));
-                            const uint32_t e0 = pr & 0xFFFFu, e1 = pr >> 16;
-                            word |= ((ms[e0 >> 10] >> ((e0 >> 5) & 31u)) & 1u) << (e0 & 31u);
-                            word |= ((ms[e1 >> 10] >> ((e1 >> 5) & 31u)) & 1u) << (e1 & 31u);
+                            take(pr & 0xFFFFu);
+                            take(pr >> 16);
                         }
                     }
-                    for (uint32_t q = my_q0 + WIDE_SEGREG; q < my_q1; q++) {   // a word with more segments than that
-                        const uint32_t e = segd[q], d = e >> 5;
-                        word |= ((ms[d >> 5] >> (d & 31u)) & 1u) << (e & 31u);
-                    }
+                    for (uint32_t q = my_q0 + WIDE_SEGREG; q < my_q1; q++) take(segd[q]);   // a word with more segments than that
                 } else if (w < nchunks) {
-                    for (uint32_t q = wstart[w], qe = wstart[w + 1]; q < qe; q++) {
-                        const uint32_t e = segd[q], d = e >> 5;
-                        word |= ((ms[d >> 5] >> (d & 31u)) & 1u) << (e & 31u);
-                    }
+                    for (uint32_t q = wstart[w], qe = wstart[w + 1]; q < qe; q++) take(segd[q]);
                 }
-                if (w < RW) row[w] = word;                          // (words past nchunks: zero, as the row hash wants them)
+                if (w < RW) {                                        // (words past nchunks: zero, as the row hash wants them)
+#pragma unroll
+                    for (uint32_t m = 0; m < GM; m++)
+                        if (e0 + 32 * m < n_ent) row_of(e0 + 32 * m)[w] = word[m];
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();                    // mstage[hw] is rewritten by the next call
@@ -2243,8 +2256,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
             sg_used = min(my_q1 - my_q0, WIDE_SEGREG);          // the most any lane of the wave holds
             for (int dd = 1; dd < 64; dd <<= 1) sg_used = max(sg_used, (uint32_t)__shfl_xor(sg_used, dd));
             // C: the rows of the round's masks, one half-wave per mask, into the row stripes ...
-            for (uint32_t e = hw; e < n_ent; e += ROWS_THREADS / 32)
-                gather_row(hl < nmw ? tabw[e * nmw + hl] : 0u, row_of(e));
+            for (uint32_t e = hw; e < n_ent; e += GM * (ROWS_THREADS / 32)) gather_rows(e, n_ent);
             __syncthreads();
             PF_PROF_STAMP(42);
             // ... and their hashes and keep flags, one LANE per mask (half-waves that ran the hash in step, as rounds 2-3
