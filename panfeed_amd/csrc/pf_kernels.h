@@ -1995,6 +1995,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
             segd[s] = (uint16_t)((p.seg_distinct[s0 + s] << 5) | (smp & 31u));
             atomicAdd(&wstart[(smp >> 5) + 1], 1u);
         }
+#pragma unroll 5
         for (uint32_t i = tid; i < ns; i += ROWS_THREADS) slot_tag[i] = ordp[i] == NO_ORD ? WIDE_EMPTY : WIDE_PENDING;
         __syncthreads();
         if (tid < 64) {
@@ -2325,29 +2326,8 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         }
         __syncthreads();
     }
-    for (uint32_t i = tid; i < ns; i += ROWS_THREADS) {
-        const uint32_t o = ordp[i];
-        if (o == NO_ORD) continue;
-        uint4 h;
-        bool keep, have_hash = false;                          // have_hash: slot_hash[i] is written already
-        if (expand) {
-            const uint64_t amask = (f0 ? (uint64_t)cb[i] : 0) | (f1 ? (uint64_t)cb[(size_t)NS + i] << 32 : 0);
-            bool found = false;
-            uint32_t a = (uint32_t)mix64(amask) & (AT_SLOTS - 1);
-            for (uint32_t probes = 0; amask && probes < AT_SLOTS; probes++) {
-                const uint64_t cur = at_key[a];
-                if (cur == 0) break;
-                if (cur == amask) { found = true; break; }
-                a = (a + 1) & (AT_SLOTS - 1);
-            }
-            if (found) { h = at_hash[a]; keep = at_keep[a] != 0; }
-            else keep = row_eval(true, amask, i, h);          // table was full: evaluate this slot on its own
-        } else if (wide) {
-            keep = slot_tag[i] == WIDE_KEEP; have_hash = true;        // (hash and flag: round D above)
-        } else {
-            keep = row_eval(false, 0, i, h);
-        }
-        if (!have_hash) p.slot_hash[(size_t)slice * NS + i] = h;
+    // a k-mer's ordinal and keep flag into the item's bitmaps (or its list of pairs to sort)
+    auto place = [&](uint32_t i, uint32_t o, bool keep) {
         if (!bitmaps) {
             keepf[i] = keep ? 1 : 0;
             const uint32_t at = atomicAdd(&sh_cnt, 1u);
@@ -2363,6 +2343,45 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         // of the table and finds out slot by slot, load after load, that most are empty or dropped
         if (bitmaps && keep && (o >> 5) < dense_words)
             p.sorted_pair[(size_t)slice * NS + atomicAdd(&sh_cnt, 1u)] = ((uint64_t)o << 32) | i;
+    };
+    if (wide) {
+        // (hash and flag of every slot: round D above; here only the ordinals are read, five slots' at a time)
+        constexpr uint32_t SU = 5;
+        for (uint32_t i0 = tid; i0 < ns; i0 += SU * ROWS_THREADS) {
+            uint32_t o_[SU];
+#pragma unroll
+            for (uint32_t u = 0; u < SU; u++) o_[u] = ordp[min(i0 + u * ROWS_THREADS, ns - 1)];
+#pragma unroll
+            for (uint32_t u = 0; u < SU; u++) asm volatile("" : "+v"(o_[u]));
+#pragma unroll
+            for (uint32_t u = 0; u < SU; u++) {
+                const uint32_t i = i0 + u * ROWS_THREADS;
+                if (i < ns && o_[u] != NO_ORD) place(i, o_[u], slot_tag[i] == WIDE_KEEP);
+            }
+        }
+    }
+    for (uint32_t i = tid; i < ns && !wide; i += ROWS_THREADS) {
+        const uint32_t o = ordp[i];
+        if (o == NO_ORD) continue;
+        uint4 h;
+        bool keep;
+        if (expand) {
+            const uint64_t amask = (f0 ? (uint64_t)cb[i] : 0) | (f1 ? (uint64_t)cb[(size_t)NS + i] << 32 : 0);
+            bool found = false;
+            uint32_t a = (uint32_t)mix64(amask) & (AT_SLOTS - 1);
+            for (uint32_t probes = 0; amask && probes < AT_SLOTS; probes++) {
+                const uint64_t cur = at_key[a];
+                if (cur == 0) break;
+                if (cur == amask) { found = true; break; }
+                a = (a + 1) & (AT_SLOTS - 1);
+            }
+            if (found) { h = at_hash[a]; keep = at_keep[a] != 0; }
+            else keep = row_eval(true, amask, i, h);          // table was full: evaluate this slot on its own
+        } else {
+            keep = row_eval(false, 0, i, h);
+        }
+        p.slot_hash[(size_t)slice * NS + i] = h;
+        place(i, o, keep);
     }
     __syncthreads();
     if (bitmaps && tid == 0) p.kept_prefix[(size_t)slice * (NS + 1)] = sh_cnt;
