@@ -3662,8 +3662,11 @@ __global__ __launch_bounds__(PR_THREADS) void pattern_rows_kernel(PatRowsParams 
     }
     uint32_t sg_used = min(my_q1 - my_q0, PR_SEGREG);
     for (int dd = 1; dd < 64; dd <<= 1) sg_used = max(sg_used, (uint32_t)__shfl_xor(sg_used, dd));
-    const bool sorted = !ranks_by_bitmap(mode, p.v_dense[c]);      // entries = sorted positions, or slots (emit_kernel)
-    const uint32_t total = sorted ? U : ns;
+    // entries = sorted positions, or (ranks by bitmap) the item's kept k-mers: (ordinal, slot) pairs from rows_kernel,
+    // their output indices from emit_kernel
+    const bool sorted = !ranks_by_bitmap(mode, p.v_dense[c]);
+    const uint32_t* kres = p.kept_prefix + (size_t)slice * (NS + 1) + 1;
+    const uint32_t total = sorted ? U : min(kres[-1], ns);
     const uint32_t stride = blockDim.x;
     const uint32_t rounds_total = (total + stride - 1) / stride;
     uint32_t round = 0;
@@ -3676,8 +3679,8 @@ __global__ __launch_bounds__(PR_THREADS) void pattern_rows_kernel(PatRowsParams 
             uint32_t slot = 0xFFFFFFFFu, kept_before = 0;
             if (i < total) {
                 // emit_kernel left the output index of every kept entry (sorted position / slot)
-                const uint32_t kb = sout[i];
-                if (kb != 0xFFFFFFFFu) { slot = sorted ? (uint32_t)sp[i] : i; kept_before = kb; }
+                const uint32_t kb = sorted ? sout[i] : kres[i];
+                if (kb != 0xFFFFFFFFu) { slot = (uint32_t)sp[i]; kept_before = kb; }
             }
             if (slot != 0xFFFFFFFFu) {
                 const uint64_t o = obase + kept_before;
