@@ -643,6 +643,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
             __syncthreads();
             if (misc[M_OVERFLOW]) overflow = true;
         }
+        PF_PROF_STAMP(18);
     }
     for (uint32_t t0 = seg0; t0 < seg1 && !overflow && !binned; t0 += SEG_TILE) {
         const uint32_t nseg = min(SEG_TILE, seg1 - t0);
