@@ -1096,8 +1096,10 @@ constexpr uint32_t DEDUP_MAX_D = 64;          // distinct sequences of a mode-1 
 constexpr uint32_t DEDUP_MAX_D_WIDE = 1024;   // ... of a mode-2 cluster (up to 32 presence words per k-mer)
 constexpr uint32_t DEDUP_MROWS = 4096;        // words of the M matrix: D * ceil4(W) <= this
 constexpr uint32_t DENSE_WORDS = 8192;        // ordinal bitmap words held in LDS two at a time (262144 dense ordinals)
-constexpr uint32_t DENSE_WORDS_BIG = 16384;   // ... one at a time (wide clusters of up to 524288 windows over their distinct
-                                              // sequences), and the words an item's bitmaps take in the scratch arrays
+constexpr uint32_t DENSE_WIN = 16384;         // ... words of the ONE LDS bitmap a larger cluster's ordinal space is walked with,
+                                              // stretch by stretch
+constexpr uint32_t DENSE_WORDS_BIG = 32768;   // the words an item's bitmaps take in the scratch arrays: wide clusters of up to
+                                              // 1 048 576 windows over their distinct sequences rank by bitmap
 constexpr uint32_t MODE_RETRY_WIDE = 0x80u;   // v_mode flag: mode 0 only because the small class was too small
 // How a cluster's k-mers get their rank (position in dict insertion order): from bitmaps over the cluster's dense ordinal
 // space -- prefix popcounts, summed over the cluster's key partitions -- whenever that space fits (every mode-1 cluster, and
@@ -1887,9 +1889,9 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
     uint32_t* occ = rsh + DEDUP_MROWS;
     uint32_t* keepbm = occ + DENSE_WORDS;
     const uint32_t dense_words = bitmaps ? (p.v_dense[c] + 31) >> 5 : 0;
-    // more dense ordinals than two LDS bitmaps hold (a wide cluster of up to 524 288 windows over its distinct sequences):
-    // ONE bitmap of DENSE_WORDS_BIG words, used twice -- occupied ordinals, then kept ones -- with the slots' keep flags
-    // parked in slot_tag meanwhile.  (Such clusters sorted their (ordinal, slot) pairs per item and searched every
+    // more dense ordinals than two LDS bitmaps hold (a wide cluster of up to 1 048 576 windows over its distinct sequences):
+    // ONE bitmap of DENSE_WIN words, per stretch of the ordinal space used twice -- occupied ordinals, then kept ones -- with
+    // the slots' keep flags parked in slot_tag meanwhile.  (Such clusters sorted their (ordinal, slot) pairs per item and searched every
     // sibling item per k-mer before: 130 dependent global reads per kept k-mer at ten key partitions.)
     const bool big = bitmaps && dense_words > DENSE_WORDS;
     uint32_t* bigbm = rsh;
@@ -2289,7 +2291,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         if (tid == 0) { atomicAdd(&pf_prof[47], 1ull); atomicAdd(&pf_prof[49], (unsigned long long)ns); }
 #endif
         // segd is no longer needed: its place is the bitmaps' or the pairs'
-        if (big) { for (uint32_t i = tid; i < DENSE_WORDS_BIG; i += ROWS_THREADS) bigbm[i] = 0; }
+        if (big) { }
         else if (bitmaps) { for (uint32_t i = tid; i < 2 * DENSE_WORDS; i += ROWS_THREADS) occ[i] = 0; }
         else { for (uint32_t i = tid; i < SORT_MAX; i += ROWS_THREADS) pairs[i] = EMPTY64; }
         __syncthreads();
@@ -2334,8 +2336,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
             const uint32_t at = atomicAdd(&sh_cnt, 1u);
             if (at < SORT_MAX) pairs[at] = ((uint64_t)o << 32) | i;
         } else if (big) {
-            if ((o >> 5) < dense_words) atomicOr(&bigbm[o >> 5], 1u << (o & 31));
-            slot_tag[i] = keep ? 1 : 0;
+            slot_tag[i] = keep ? 1 : 0;                    // (the bits: stretch by stretch, below)
         } else if ((o >> 5) < dense_words) {
             atomicOr(&occ[o >> 5], 1u << (o & 31));
             if (keep) atomicOr(&keepbm[o >> 5], 1u << (o & 31));
@@ -2389,36 +2390,42 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
     PF_PROF_STAMP(44);
 
     if (big) {
-        constexpr uint32_t PWB = DENSE_WORDS_BIG / ROWS_THREADS;     // 16 words per thread
+        // stretches of DENSE_WIN words of the ordinal space, one after the other; in each the LDS bitmap is used twice --
+        // the occupied ordinals of the stretch, then the kept ones -- with the counts of the stretches before it carried on
+        constexpr uint32_t PWB = DENSE_WIN / ROWS_THREADS;           // 16 words per thread
         const size_t gb = (size_t)slice * DENSE_WORDS_BIG;
-        for (int round = 0; round < 2; round++) {
-            uint32_t sm = 0;
-#pragma unroll
-            for (uint32_t j = 0; j < PWB; j++) sm += __popc(bigbm[tid * PWB + j]);
-            uint32_t tot;
-            uint32_t run = block_exscan(sm, wave_tot, &tot);
-            uint32_t* bm = round ? p.bm_keep : p.bm_occ;
-            uint32_t* pre = round ? p.pre_keep : p.pre_occ;
-#pragma unroll
-            for (uint32_t j = 0; j < PWB; j++) {
-                const uint32_t w = tid * PWB + j;
-                if (w < dense_words) {
-                    const uint32_t a = bigbm[w];
-                    bm[gb + w] = a; pre[gb + w] = run;
-                    run += __popc(a);
+        uint32_t base_o = 0, base_k = 0;
+        for (uint32_t w0 = 0; w0 < dense_words; w0 += DENSE_WIN) {
+            for (int round = 0; round < 2; round++) {
+                __syncthreads();
+                for (uint32_t i = tid; i < DENSE_WIN; i += ROWS_THREADS) bigbm[i] = 0;
+                __syncthreads();
+                for (uint32_t i = tid; i < ns; i += ROWS_THREADS) {
+                    const uint32_t o = ordp[i];
+                    if (o == NO_ORD || (o >> 5) >= dense_words || (o >> 5) < w0 || (o >> 5) >= w0 + DENSE_WIN) continue;
+                    if (!round || slot_tag[i] == 1) atomicOr(&bigbm[(o >> 5) - w0], 1u << (o & 31));
                 }
+                __syncthreads();
+                uint32_t sm = 0;
+#pragma unroll
+                for (uint32_t j = 0; j < PWB; j++) sm += __popc(bigbm[tid * PWB + j]);
+                uint32_t tot;
+                uint32_t run = (round ? base_k : base_o) + block_exscan(sm, wave_tot, &tot);
+                uint32_t* bm = round ? p.bm_keep : p.bm_occ;
+                uint32_t* pre = round ? p.pre_keep : p.pre_occ;
+#pragma unroll
+                for (uint32_t j = 0; j < PWB; j++) {
+                    const uint32_t w = w0 + tid * PWB + j;
+                    if (w < dense_words) {
+                        const uint32_t a = bigbm[tid * PWB + j];
+                        bm[gb + w] = a; pre[gb + w] = run;
+                        run += __popc(a);
+                    }
+                }
+                if (round) base_k += tot; else base_o += tot;
             }
-            if (tid == 0) { if (round) p.item_kept[item] = tot; else p.item_unique[item] = tot; }
-            if (round) break;
-            __syncthreads();
-            for (uint32_t i = tid; i < DENSE_WORDS_BIG; i += ROWS_THREADS) bigbm[i] = 0;
-            __syncthreads();
-            for (uint32_t i = tid; i < ns; i += ROWS_THREADS) {
-                const uint32_t o = ordp[i];
-                if (o != NO_ORD && (o >> 5) < dense_words && slot_tag[i] == 1) atomicOr(&bigbm[o >> 5], 1u << (o & 31));
-            }
-            __syncthreads();
         }
+        if (tid == 0) { p.item_unique[item] = base_o; p.item_kept[item] = base_k; }
         PF_PROF_STAMP(45);
         return;
     }

@@ -121,11 +121,11 @@ def test_more_distinct_sequences_than_samples():
             eng.close()
 
 
-@pytest.mark.parametrize("D,L,S", [(260, 1250, 800), (500, 900, 1600), (600, 980, 1800)], ids=["dense_325k", "dense_450k", "dense_570k_sorted"])
+@pytest.mark.parametrize("D,L,S", [(260, 1250, 800), (500, 900, 1600), (600, 980, 1800), (640, 1700, 1920)], ids=["dense_325k", "dense_450k", "dense_570k_two_stretches", "dense_1070k_sorted"])
 def test_wide_cluster_beyond_two_lds_bitmaps(D, L, S):
     """a wide cluster whose distinct sequences carry more than 262 144 windows (two LDS ordinal bitmaps' worth) and at
-    most 524 288: ranks from ONE big bitmap used twice (round 3) instead of sorted pairs and a search in every sibling
-    item; several key partitions; against the oracle"""
+    most 1 048 576: ranks from ONE LDS bitmap walked over the ordinal space in stretches of 524 288, used twice per stretch
+    (round 3), instead of sorted pairs and a search in every sibling item; several key partitions; against the oracle"""
     rng = np.random.default_rng(D + L)
     alleles = [np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, L)].tobytes()]
     seen = set(alleles)
@@ -134,7 +134,7 @@ def test_wide_cluster_beyond_two_lds_bitmaps(D, L, S):
         if a not in seen:
             seen.add(a)
             alleles.append(a)
-    assert 262144 < D * (L - 30) and (D * (L - 30) <= 524288) == (D < 600)      # the last case: beyond the big bitmap too
+    assert 262144 < D * (L - 30) and (D * (L - 30) <= 1048576) == (D < 640)      # the last case: beyond the bitmaps, sorted pairs
     names = [f"b{i:04d}" for i in range(S)]
     tms = _run_all([_cluster("g_big", names, alleles)], 31, S)
     assert tms[0]["n_wide_clusters"] == 1 and tms[0]["n_dedup_clusters"] == 1
