@@ -202,7 +202,7 @@ def make_step(eng, dbs, world, dist, dev, method):
         sums = []
         tot = {"kept": 0, "new": 0, "scan_ms": 0.0, "rows_ms": 0.0, "emit_ms": 0.0, "total_ms": 0.0, "dedup_ms": 0.0,
                "patrows_ms": 0.0, "md5_ms": 0.0, "finish_ms": 0.0, "merge_ms": 0.0,
-               "launches": 0, "items": 0, "retried": 0, "unique": 0, "dedup_clusters": 0, "scan_bytes": 0}
+               "launches": 0, "items": 0, "retried": 0, "unique": 0, "dedup_clusters": 0, "scan_bytes": 0, "binned": 0}
         for d in dbs:
             res = d.submit(eng)
             tm = eng.timing()
@@ -216,6 +216,7 @@ def make_step(eng, dbs, world, dist, dev, method):
             tot["launches"] += tm["scan_launches"]
             tot["items"] += tm["n_items"]
             tot["retried"] += tm["n_retried"]
+            tot["binned"] += tm["n_binned_clusters"]
             if checksum:                 # untimed legs only: what the files of this batch would hold, row for row
                 sums.append(eng.result_checksum())
         tot["checksums"] = sums
@@ -310,7 +311,7 @@ def allele_sweep(args, local, allele_model="star"):
                      "clusters_mode0": n - tm["n_dedup_clusters"], "scan_ms": tm["scan_ms"], "dedup_ms": tm["dedup_ms"],
                      "finish_ms": tm["finish_ms"], "rows_ms": tm["rows_ms"], "emit_ms": tm["emit_ms"],
                      "patrows_ms": tm["patrows_ms"], "md5_ms": tm["md5_ms"], "kept": int(res.n_kept),
-                     "patterns": int(res.n_new_patterns), "repartitioned": tm["n_retried"]})
+                     "patterns": int(res.n_new_patterns), "repartitioned": tm["n_retried"], "clusters_key_binned": tm["n_binned_clusters"]})
         db.free()
         eng.close()
     return rows
@@ -676,7 +677,8 @@ def main():
                                  "committed rocprofv3 --pmc passes of this same command (traffic_source)."},
             "device_ms_per_step": dict(kern_ms, submit_total=last["total_ms"]),
             "work_items": last["items"], "clusters_repartitioned": last["retried"],
-            "clusters_deduplicated": last["dedup_clusters"], "scan_packed_bytes": last["scan_bytes"],
+            "clusters_deduplicated": last["dedup_clusters"], "clusters_key_binned": last["binned"],
+            "scan_packed_bytes": last["scan_bytes"],
             "scan_every_copy": every,
             "setup_s": {"generate_and_upload": t_gen},
         }
