@@ -999,9 +999,11 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             room = 0;
             for (uint32_t j = 0; j < nu; j++) { lb[j] = (uint32_t)room; room += rec[lc[j]].words / 2; }
             if (nu) {
-                const size_t R = (size_t)room + 1;
-                PFCHK(up.word_off.ensure(R * 8)); PFCHK(up.len.ensure(R * 4)); PFCHK(up.sample.ensure(R * 4));
-                PFCHK(up.ord.ensure(R * 4)); PFCHK(up.bits.ensure(R * 4)); PFCHK(up.list.ensure((size_t)nu * 8));
+                // (twice the room: the wide kernel parks a cluster's pieces in the second stretch before it orders them by chunk)
+                const size_t R = (size_t)room + 1, R2 = 2 * R;
+                if (R2 > 0xFFFFFFF0ull) return fail(PF_ERR_CAPACITY, "unit view of %zu pieces: submit fewer clusters at a time", R);
+                PFCHK(up.word_off.ensure(R2 * 8)); PFCHK(up.len.ensure(R2 * 4)); PFCHK(up.sample.ensure(R2 * 4));
+                PFCHK(up.ord.ensure(R2 * 4)); PFCHK(up.bits.ensure(R2 * 4)); PFCHK(up.list.ensure((size_t)nu * 8));
                 HIPCHK(hipMemcpyAsync(up.list.p, up.pin, (size_t)nu * 8, hipMemcpyHostToDevice, c->stream));
                 pf::UnitParams q{};
                 q.packed = d.packed; q.cluster_seg_off = d.cluster_seg_off; q.v_nstr = c->v_nstr.as<uint32_t>();
@@ -1009,7 +1011,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
                 q.v_word_off = c->v_word_off.as<uint64_t>(); q.v_len = c->v_len.as<uint32_t>(); q.v_ord = c->v_ord.as<uint32_t>();
                 q.u_word_off = up.word_off.as<uint64_t>(); q.u_len = up.len.as<uint32_t>(); q.u_sample = up.sample.as<uint32_t>();
                 q.u_ord = up.ord.as<uint32_t>(); q.u_bits = up.bits.as<uint32_t>();
-                q.v_nseg = c->v_nseg.as<uint32_t>(); q.view_off = c->view_off.as<uint32_t>(); q.k = c->o.klength;
+                q.v_nseg = c->v_nseg.as<uint32_t>(); q.view_off = c->view_off.as<uint32_t>(); q.k = c->o.klength; q.tmp_off = (uint32_t)R;
                 PFCHK(mark_begin(c, 3));
                 if (nsmall) {
                     const dim3 g((nsmall + 3) / 4), b(256);

@@ -1524,6 +1524,8 @@ struct UnitParams {
     uint64_t* u_word_off; uint32_t* u_len; uint32_t* u_sample; uint32_t* u_ord; uint32_t* u_bits;   // the pool
     uint32_t* v_nseg; uint32_t* view_off;  // [C] rewritten when the cluster takes the unit view
     uint32_t k;
+    uint32_t tmp_off;                      // unit_class_kernel: a second stretch of the pool arrays, this far behind the first,
+                                           // takes a cluster's pieces in the order they are found
 };
 constexpr uint32_t UNIT_THREADS = 256;
 constexpr uint32_t UNIT_TAB = 4096;            // class-table slots per batch of unit positions
@@ -1563,8 +1565,13 @@ __global__ __launch_bounds__(UNIT_THREADS) void unit_class_kernel(UnitParams p) 
     const uint32_t UB = max(1u, UNIT_PAIRS / Dp);                    // unit positions per batch (Dp <= 1024 <= UNIT_PAIRS)
     const uint32_t span = 63 + k;                                    // bases a full unit covers
 
-    // pass 0 counts the pieces per chunk, pass 1 writes them behind the chunk's base
-    for (int pass = 0; pass < 2; pass++) {
+    // ONE walk: the pieces go to the cluster's second stretch of the pool as they are found, counted per chunk; they are put
+    // in chunk order afterwards (a few thousand 24-byte records: the walk -- hashing every unit of every distinct sequence,
+    // the class table, the word-for-word checks -- is what the kernel's time is, and it used to be done twice).
+    __shared__ uint32_t sh_npieces;
+    if (tid == 0) sh_npieces = 0;
+    const uint32_t tb = base + p.tmp_off;
+    {
         for (uint32_t u0 = 0; u0 < nunits; u0 += UB) {
             const uint32_t ub_n = min(UB, nunits - u0), npairs = ub_n * Dp;
             for (uint32_t i = tid; i < UNIT_TAB; i += UNIT_THREADS) { t_hash[i] = EMPTY64; t_min[i] = 0xFFFFFFFFu; }
@@ -1604,7 +1611,7 @@ __global__ __launch_bounds__(UNIT_THREADS) void unit_class_kernel(UnitParams p) 
             // ---- exactness: every member against the class's first member, word for word
 #pragma unroll
             for (uint32_t r = 0; r < UNIT_PER_THREAD; r++) {
-                if (my_slot[r] == 0xFFFFFFFFu || pass) continue;
+                if (my_slot[r] == 0xFFFFFFFFu) continue;
                 const uint32_t pi = tid + r * UNIT_THREADS, fi = t_min[my_slot[r]];
                 if (fi == pi) continue;
                 const uint32_t ub = pi / Dp, d = pi - ub * Dp, u = u0 + ub, fd = fi - (fi / Dp) * Dp;
@@ -1639,17 +1646,14 @@ __global__ __launch_bounds__(UNIT_THREADS) void unit_class_kernel(UnitParams p) 
                     const bool same = todo && my_slot[r] == lslot;
                     const uint32_t members = (uint32_t)(__ballot(same) >> half);
                     if (todo && lane == leader) {
-                        if (pass == 0) {
-                            atomicAdd(&ch_cnt[chunk], 1u);
-                        } else {
-                            const uint32_t fi = t_min[my_slot[r]], fd = fi - (fi / Dp) * Dp;
-                            const uint32_t at = base + ch_base[chunk] + atomicAdd(&ch_cnt[chunk], 1u);
-                            p.u_word_off[at] = (((uint64_t)d_whi[fd] << 32) | d_wlo[fd]) + 2 * (uint64_t)u;
-                            p.u_len[at] = min(d_len[fd] - 64 * u, span);
-                            p.u_ord[at] = d_ord[fd] + 64 * u;
-                            p.u_sample[at] = chunk << 5;
-                            p.u_bits[at] = members;
-                        }
+                        const uint32_t fi = t_min[my_slot[r]], fd = fi - (fi / Dp) * Dp;
+                        atomicAdd(&ch_cnt[chunk], 1u);
+                        const uint32_t at = tb + atomicAdd(&sh_npieces, 1u);
+                        p.u_word_off[at] = (((uint64_t)d_whi[fd] << 32) | d_wlo[fd]) + 2 * (uint64_t)u;
+                        p.u_len[at] = min(d_len[fd] - 64 * u, span);
+                        p.u_ord[at] = d_ord[fd] + 64 * u;
+                        p.u_sample[at] = chunk << 5;
+                        p.u_bits[at] = members;
                     }
                     if (same) todo = false;
                 }
@@ -1657,14 +1661,19 @@ __global__ __launch_bounds__(UNIT_THREADS) void unit_class_kernel(UnitParams p) 
             __syncthreads();
         }
         if (sh_bad) return;                                          // (uniform) the cluster keeps its plain view
-        if (pass == 0) {
-            if (tid == 0) {
-                uint32_t run = 0;
-                for (uint32_t i = 0; i < nchunks; i++) { ch_base[i] = run; run += ch_cnt[i]; ch_cnt[i] = 0; }
-                ch_base[nchunks] = run;
-            }
-            __syncthreads();
+        if (tid == 0) {
+            uint32_t run = 0;
+            for (uint32_t i = 0; i < nchunks; i++) { ch_base[i] = run; run += ch_cnt[i]; ch_cnt[i] = 0; }
+            ch_base[nchunks] = run;
         }
+        __syncthreads();                                             // (the pieces written above: visible to the workgroup)
+        for (uint32_t i = tid, n = sh_npieces; i < n; i += UNIT_THREADS) {
+            const uint32_t smp = p.u_sample[tb + i], chunk = smp >> 5;
+            const uint32_t at = base + ch_base[chunk] + atomicAdd(&ch_cnt[chunk], 1u);
+            p.u_word_off[at] = p.u_word_off[tb + i]; p.u_len[at] = p.u_len[tb + i]; p.u_ord[at] = p.u_ord[tb + i];
+            p.u_sample[at] = smp; p.u_bits[at] = p.u_bits[tb + i];
+        }
+        __syncthreads();
     }
     if (tid == 0) { p.view_off[c] = base | VIEW_IN_POOL; p.v_nseg[c] = ch_base[nchunks]; }
 }
