@@ -1692,7 +1692,7 @@ __global__ __launch_bounds__(256) void unit_class_small_kernel(UnitParams p, uin
     // instruction issue (9 000 wave-instructions per cluster, 0.7 ms per 50 000 clusters).  Classes inside a group of G
     // lanes: the group's lowest remaining lane leads, everyone compares its unit with the leader's (ds_bpermute), the
     // members leave; a class gives one piece per chunk of 32 columns it has members in.  Chunk-1 pieces go behind all
-    // chunk-0 pieces, so a cluster of more than 32 distinct sequences is walked twice (the first walk only counts).
+    // chunk-0 pieces: they are parked in the cluster's second stretch of the pool and moved there at the end.
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (wi >= n) return;                                             // (whole waves)
@@ -1711,8 +1711,8 @@ __global__ __launch_bounds__(256) void unit_class_small_kernel(UnitParams p, uin
     const uint32_t nunits = (maxlen - k + 64) >> 6, span = 63 + k;
     const uint64_t* w = p.packed + wo;
     const uint64_t below = lane ? ~0ull >> (64 - lane) : 0ull;       // the lanes in front of this one
-    uint32_t n0 = 0;                                                 // pieces of chunk 0 (known after the counting walk)
-    for (int pass = D > 32 ? 0 : 1; pass < 2; pass++) {
+    const uint32_t tb = base + p.tmp_off;
+    {
         uint32_t i0 = 0, i1 = 0;
         for (uint32_t u0 = 0; u0 < nunits; u0 += UPR) {
             const uint32_t u = u0 + ug;
@@ -1739,14 +1739,14 @@ __global__ __launch_bounds__(256) void unit_class_small_kernel(UnitParams p, uin
                 const uint32_t m0 = (uint32_t)members, m1 = (uint32_t)(members >> 32);
                 const bool lead = todo && lane == leader;
                 const uint64_t b0 = __ballot(lead && m0 != 0), b1 = __ballot(lead && m1 != 0);
-                if (pass && lead) {
+                if (lead) {
                     if (m0) {
                         const uint32_t at = base + i0 + (uint32_t)__popcll(b0 & below);
                         p.u_word_off[at] = wo + 2 * (uint64_t)u; p.u_len[at] = nb; p.u_ord[at] = ordb + 64 * u;
                         p.u_sample[at] = 0; p.u_bits[at] = m0;
                     }
                     if (m1) {
-                        const uint32_t at = base + n0 + i1 + (uint32_t)__popcll(b1 & below);
+                        const uint32_t at = tb + i1 + (uint32_t)__popcll(b1 & below);
                         p.u_word_off[at] = wo + 2 * (uint64_t)u; p.u_len[at] = nb; p.u_ord[at] = ordb + 64 * u;
                         p.u_sample[at] = 32; p.u_bits[at] = m1;
                     }
@@ -1755,8 +1755,15 @@ __global__ __launch_bounds__(256) void unit_class_small_kernel(UnitParams p, uin
                 if (same) todo = false;
             }
         }
-        if (!pass) n0 = i0;
-        else if (lane == 0) { p.view_off[c] = base | VIEW_IN_POOL; p.v_nseg[c] = i0 + i1; }
+        if (i1) {                                                    // (uniform) chunk 1's pieces behind chunk 0's
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's stores above, before its loads below
+            for (uint32_t j = lane; j < i1; j += 64) {
+                const uint32_t at = base + i0 + j;
+                p.u_word_off[at] = p.u_word_off[tb + j]; p.u_len[at] = p.u_len[tb + j]; p.u_ord[at] = p.u_ord[tb + j];
+                p.u_sample[at] = 32; p.u_bits[at] = p.u_bits[tb + j];
+            }
+        }
+        if (lane == 0) { p.view_off[c] = base | VIEW_IN_POOL; p.v_nseg[c] = i0 + i1; }
     }
 }
 
