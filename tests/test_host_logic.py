@@ -23,6 +23,20 @@ def test_library_exports_every_header_symbol():
     assert b"gfx950" in L.pf_version()
 
 
+def test_python_mirror_of_the_header_constants_and_structs():
+    """the ctypes side states the header's flag values and the layout of pf_timing again: they have to agree"""
+    import ctypes as C
+    from panfeed_amd import _lib
+    hdr = open(os.path.join(REPO, "include", "panfeed_hip.h")).read()
+    flags = dict(re.findall(r"#define\s+(PF_FLAG_[A-Z_]+)\s+(\d+)u", hdr))
+    assert flags == {"PF_FLAG_NO_DEDUP": str(_lib.FLAG_NO_DEDUP), "PF_FLAG_NO_UNIT_DEDUP": str(_lib.FLAG_NO_UNIT_DEDUP),
+                     "PF_FLAG_NO_KEY_BINNING": str(_lib.FLAG_NO_KEY_BINNING)}
+    body = re.search(r"typedef struct \{([^}]*)\} pf_timing;", hdr).group(1)
+    fields = re.findall(r"\b(float|uint32_t|uint64_t)\s+([a-z_0-9]+);", body)
+    ctype = {"float": C.c_float, "uint32_t": C.c_uint32, "uint64_t": C.c_uint64}
+    assert [(n, ctype[t]) for t, n in fields] == list(_lib.Timing._fields_)
+
+
 def test_no_device_fails_loudly():
     """without a GPU the product path raises -- it never falls back to a CPU implementation"""
     import torch
