@@ -5,9 +5,12 @@
 #include "../../include/panfeed_hip.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <immintrin.h>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -63,6 +66,40 @@ struct CodeLut {
 const CodeLut g_lut;
 inline int code_of(unsigned char ch) { return g_lut.t[ch]; }   // table lookup: no data-dependent branches
 
+// The two per-base passes, 32 bases at a time where the host has AVX2 (a lookup per base through a serial shift-or chain
+// was ~3 cycles a base, and the packer's threads are what `Seqinfo` records -> files waits for).
+static const bool g_avx2 = __builtin_cpu_supports("avx2");
+// every base of seq[0, n) one of A/C/G/T and comp its complement?  (n a multiple of 32)
+__attribute__((target("avx2"))) static bool clean32_avx2(const char* seq, const char* comp, uint32_t n) {
+    const __m256i A = _mm256_set1_epi8('A'), C = _mm256_set1_epi8('C'), G = _mm256_set1_epi8('G'), T = _mm256_set1_epi8('T');
+    __m256i all = _mm256_set1_epi8((char)0xFF);
+    for (uint32_t i = 0; i < n; i += 32) {
+        const __m256i s = _mm256_loadu_si256((const __m256i*)(seq + i)), c = _mm256_loadu_si256((const __m256i*)(comp + i));
+        const __m256i ok = _mm256_or_si256(
+            _mm256_or_si256(_mm256_and_si256(_mm256_cmpeq_epi8(s, A), _mm256_cmpeq_epi8(c, T)),
+                            _mm256_and_si256(_mm256_cmpeq_epi8(s, C), _mm256_cmpeq_epi8(c, G))),
+            _mm256_or_si256(_mm256_and_si256(_mm256_cmpeq_epi8(s, G), _mm256_cmpeq_epi8(c, C)),
+                            _mm256_and_si256(_mm256_cmpeq_epi8(s, T), _mm256_cmpeq_epi8(c, A))));
+        all = _mm256_and_si256(all, ok);
+    }
+    return (uint32_t)_mm256_movemask_epi8(all) == 0xFFFFFFFFu;
+}
+// 32 bases (A/C/G/T only) -> one word, first base in bits 63:62, A0 C1 G2 T3
+__attribute__((target("avx2"))) static inline uint64_t pack32_avx2(const char* p) {
+    const __m256i c = _mm256_loadu_si256((const __m256i*)p);
+    const __m256i x = _mm256_and_si256(_mm256_srli_epi16(c, 1), _mm256_set1_epi8(3));             // A0 C1 T2 G3
+    const __m256i code = _mm256_xor_si256(x, _mm256_and_si256(_mm256_srli_epi16(x, 1), _mm256_set1_epi8(1)));   // G <-> T
+    const __m256i p16 = _mm256_maddubs_epi16(code, _mm256_set1_epi16(0x0104));     // two bases: first * 4 + second
+    const __m256i p32 = _mm256_madd_epi16(p16, _mm256_set1_epi32(0x00010010));     // four bases in the low byte of a dword
+    const __m256i w16 = _mm256_packus_epi32(p32, p32);
+    const __m256i w8 = _mm256_packus_epi16(w16, w16);                              // bytes 0-3 of each half: its four dwords
+    const uint32_t lo = (uint32_t)_mm256_extract_epi32(w8, 0), hi = (uint32_t)_mm256_extract_epi32(w8, 4);
+    return ((uint64_t)__builtin_bswap32(lo) << 32) | __builtin_bswap32(hi);
+}
+__attribute__((target("avx2"))) static void pack_words_avx2(const char* seq, uint32_t nwords, uint64_t* wp) {
+    for (uint32_t w = 0; w < nwords; w++) wp[w] = pack32_avx2(seq + 32 * (size_t)w);
+}
+
 void pack_cluster(const pf_pack_in* in, uint32_t ci, ClusterOut& o) {
     const uint32_t k = in->klength, W = in->W;
     const uint32_t s0 = in->cluster_seq_off[ci], s1 = in->cluster_seq_off[ci + 1];
@@ -99,7 +136,12 @@ void pack_cluster(const pf_pack_in* in, uint32_t ci, ClusterOut& o) {
             // nearly every sequence is pure A/C/G/T with the right complement: one branch-free pass says so; only the
             // others are looked at base by base (where the non-ACGT letters are, whether the complement is wrong)
             unsigned acc = 0;
-            for (uint32_t i = 0; i < L; i++) acc |= (unsigned)(g_lut.u[(unsigned char)seq[i]] ^ g_lut.v[(unsigned char)comp[i]]);
+            uint32_t i = 0;
+            if (g_avx2 && L >= 32) {
+                i = L & ~31u;
+                acc = clean32_avx2(seq, comp, i) ? 0u : 1u;
+            }
+            for (; i < L; i++) acc |= (unsigned)(g_lut.u[(unsigned char)seq[i]] ^ g_lut.v[(unsigned char)comp[i]]);
             if (acc) {
                 for (uint32_t i = 0; i < L; i++) {
                     const int cs = code_of((unsigned char)seq[i]);
@@ -201,6 +243,10 @@ void pack_cluster(const pf_pack_in* in, uint32_t ci, ClusterOut& o) {
         const char* seq = in->seq[g.seq] + g.a;
         uint64_t* wp = o.words.data() + w0;
         uint32_t i0 = 0;
+        if (g_avx2) {
+            i0 = g.len & ~31u;
+            pack_words_avx2(seq, i0 >> 5, wp);
+        }
         for (; i0 + 32 <= g.len; i0 += 32) {                 // whole words: 32 lookups, no bounds inside
             uint64_t w = 0;
 #pragma GCC unroll 8
@@ -244,6 +290,7 @@ int pf_pack_records(const pf_pack_in* in, pf_packed** out) {
     if (in->klength < 1) return pk_fail(PF_ERR_ARG, "pf_pack_records: klength must be >= 1");
     const uint32_t C = in->n_clusters;
     std::vector<ClusterOut> outs(C);
+    const auto T_0 = std::chrono::steady_clock::now();
     unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
     if (C < 8) nt = 1;
     {
@@ -252,6 +299,7 @@ int pf_pack_records(const pf_pack_in* in, pf_packed** out) {
             th.emplace_back([&, t] { for (uint32_t ci = t; ci < C; ci += nt) pack_cluster(in, ci, outs[ci]); });
         for (auto& x : th) x.join();
     }
+    const auto T_par = std::chrono::steady_clock::now();
 
     for (uint32_t ci = 0; ci < C; ci++)
         if (!outs[ci].error.empty()) return pk_fail(PF_ERR_ARG, "cluster %u: %s", ci, outs[ci].error.c_str());
@@ -260,6 +308,15 @@ int pf_pack_records(const pf_pack_in* in, pf_packed** out) {
     p->gather = in->seq_flags != nullptr;
     if (p->gather && (!in->seq_src_off || !in->seq_src_start)) { delete p; return pk_fail(PF_ERR_ARG, "pf_pack_records: seq_src arrays missing"); }
     uint64_t woff = 0, strand_words = 0, lit_off = 0;
+    {   // the merged arrays' sizes are known: no growth by doubling while they are filled
+        size_t nseg = 0, nword = 4, nex = 0;
+        for (uint32_t ci = 0; ci < C; ci++) { nseg += outs[ci].seg_len.size(); nword += outs[ci].words.size(); nex += outs[ci].extras.size(); }
+        p->seg_word_off.reserve(nseg); p->seg_len.reserve(nseg); p->seg_sample.reserve(nseg); p->seg_ord_base.reserve(nseg);
+        p->seg_strand_off.reserve(nseg); p->cluster_seg_off.reserve((size_t)C + 1); p->packed.reserve(nword);
+        p->cluster_ninst.reserve(C);
+        p->extra_cluster.reserve(nex); p->extra_ord.reserve(nex); p->extra_bits.reserve(nex * in->W);
+        if (p->gather) { p->g_src_off.reserve(nseg); p->g_src_start.reserve(nseg); p->g_src_flags.reserve(nseg); }
+    }
     for (uint32_t ci = 0; ci < C; ci++) {
         ClusterOut& o = outs[ci];
         const uint32_t seg_base = (uint32_t)p->seg_len.size();
@@ -318,6 +375,9 @@ int pf_pack_records(const pf_pack_in* in, pf_packed** out) {
                                                           // reaches up to four words past its own)
     p->n_words_dev = p->gather ? woff + 4 : 0;
     p->n_strand_words = strand_words;
+    if (getenv("PF_DEBUG_TIMING"))
+        fprintf(stderr, "[pf_pack_records] clusters on %u threads %.4f s, merge %.4f s\n", nt, (T_par - T_0).count() / 1e9,
+                (std::chrono::steady_clock::now() - T_par).count() / 1e9);
     *out = p;
     return PF_OK;
 }

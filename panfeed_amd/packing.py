@@ -12,6 +12,7 @@ packed, are rare, and are grouped here exactly as cluster_cutter does
 from dataclasses import dataclass, field
 
 import numpy as np
+from itertools import chain
 
 _LUT = np.full(256, 255, dtype=np.uint8)
 for _i, _c in enumerate(b"ACGT"):
@@ -221,7 +222,7 @@ def build_batch_native(records, klength, canon, W, stroi=(), first_ordinal=0, wa
         if n > W * 32:
             raise ValueError(f"cluster {idx}: {n} strains exceed the context's max_strains")
         sorted_names = sorted(names)
-        col = {x: i for i, x in enumerate(sorted_names)}          # panfeed.py:47-49
+        col = dict(zip(sorted_names, range(n)))                    # panfeed.py:47-49
         presab = np.asarray(presab)
         if len(presab) > W * 32:
             raise ValueError(f"cluster {idx}: clusterpresab longer than max_strains")
@@ -237,13 +238,26 @@ def build_batch_native(records, klength, canon, W, stroi=(), first_ordinal=0, wa
         cl_npres.append(len(presab))
         cl_presab.append(pb)
         cl_ord.append(first_ordinal + ci)
-        counts = np.fromiter((len(gs[x]) for x in names), dtype=np.int64, count=n)
-        flat_s += [s for x in names for s in gs[x]]               # panfeed.py:54-55
-        col_parts.append(np.repeat(np.fromiter((col[x] for x in names), dtype=np.uint32, count=n), counts))
-        tg = np.fromiter(((1 if (stroi and x in stroi) else 0) for x in names), dtype=np.uint8, count=n)   # panfeed.py:90
+        # (per strain: whole-container calls, no Python-level loop with a dict look-up per name -- four of those were a
+        # third of the packer's Python side)
+        counts = np.fromiter(map(len, gs.values()), dtype=np.int64, count=n)
+        flat_s.extend(chain.from_iterable(gs.values()))           # panfeed.py:54-55
+        if names == sorted_names:
+            colv = np.arange(n, dtype=np.uint32)
+        else:
+            colv = np.fromiter(map(col.__getitem__, names), dtype=np.uint32, count=n)
+        tg = np.zeros(n, dtype=np.uint8)                          # panfeed.py:90
+        if stroi:
+            for x in stroi:
+                if x in col:
+                    tg[names.index(x)] = 1
         any_target = any_target or bool(tg.any())
-        tgt_parts.append(np.repeat(tg, counts))
-        strain_parts.append(np.repeat(np.arange(n, dtype=np.uint32), counts))
+        if int(counts.min(initial=1)) == 1 and int(counts.max(initial=1)) == 1:
+            col_parts.append(colv); tgt_parts.append(tg); strain_parts.append(np.arange(n, dtype=np.uint32))
+        else:
+            col_parts.append(np.repeat(colv, counts))
+            tgt_parts.append(np.repeat(tg, counts))
+            strain_parts.append(np.repeat(np.arange(n, dtype=np.uint32), counts))
         cl_names.append(names)
         cl_off.append(len(flat_s))
     nseq = len(flat_s)
