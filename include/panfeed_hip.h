@@ -305,6 +305,22 @@ int pf_pack_records(const pf_pack_in* in, pf_packed** out);
  * as_utf8 is the interpreter's PyUnicode_AsUTF8 -- one C loop instead of one FFI call per string, no assumption about the
  * object layout.  Call it with the GIL held (ctypes.PyDLL).  out[i] == 0: the API refused that object. */
 int pf_py_str_addresses(void* const* objs, uint64_t n, const char* (*as_utf8)(void*), uint64_t* out);
+/* The same for the two str attributes of every object of a Python list in one pass (Seqinfo.sequence / .compsequence,
+ * classes.py:11-18; what pattern_hasher's records carry, panfeed.py:54-67): addresses of their UTF-8 bytes, their length,
+ * flags[i] bit 0 = both str, equal length, all ASCII.  The interpreter's API comes as function pointers (PyList_GetItem,
+ * PyObject_GetAttr, PyUnicode_AsUTF8AndSize, PyUnicode_GetLength, Py_DecRef, PyErr_Clear); the attribute objects stay
+ * referenced in held[2 n] until pf_py_release.  Call both with the GIL held. */
+typedef struct pf_py_api {
+    void* (*list_get_item)(void*, long long);                 /* PyList_GetItem (borrowed reference) */
+    void* (*get_attr)(void*, void*);                          /* PyObject_GetAttr (new reference) */
+    const char* (*as_utf8_and_size)(void*, long long*);       /* PyUnicode_AsUTF8AndSize */
+    long long (*get_length)(void*);                           /* PyUnicode_GetLength */
+    void (*dec_ref)(void*);                                   /* Py_DecRef */
+    void (*err_clear)(void);                                  /* PyErr_Clear */
+} pf_py_api;
+int pf_py_seqinfo_columns(void* list, uint64_t n, void* attr_seq, void* attr_comp, const pf_py_api* api,
+                          uint64_t* a_seq, uint64_t* a_comp, uint32_t* len, uint8_t* flags, void** held);
+int pf_py_release(void** held, uint64_t n, const pf_py_api* api);
 int pf_packed_view(const pf_packed* p, pf_packed_view_t* view);
 void pf_packed_free(pf_packed* p);
 

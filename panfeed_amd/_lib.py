@@ -141,7 +141,7 @@ EXPORTS = ["pf_last_error", "pf_version", "pf_device_count", "pf_create", "pf_de
            "pf_pangenome_set_store", "pf_genomes_upload", "pf_genomes_clear", "pf_submit_gather", "pf_gzip_members", "pf_render_device",
            "pf_render_device_ex", "pf_render_pattern_rows", "pf_pangenome_weights", "pf_pangenome_set_range",
            "pf_rowfilter_create", "pf_rowfilter_scan", "pf_rowfilter_stats", "pf_rowfilter_destroy",
-           "pf_py_str_addresses", "pf_pangenome_close_async"]
+           "pf_py_str_addresses", "pf_pangenome_close_async", "pf_py_seqinfo_columns", "pf_py_release"]
 
 RENDER_NO_PATTERN_ROWS = 1
 ERR_ARG, ERR_OOM, ERR_HIP, ERR_CAPACITY, ERR_STATE = -1, -2, -3, -4, -5
@@ -257,6 +257,10 @@ def load_pydll():
         P = C.PyDLL(LIB_PATH)
         P.pf_py_str_addresses.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
         P.pf_py_str_addresses.restype = C.c_int
+        P.pf_py_seqinfo_columns.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_void_p] * 5
+        P.pf_py_seqinfo_columns.restype = C.c_int
+        P.pf_py_release.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+        P.pf_py_release.restype = C.c_int
         _pydll = P
     return _pydll
 

@@ -430,4 +430,41 @@ int pf_py_str_addresses(void* const* objs, uint64_t n, const char* (*as_utf8)(vo
     return PF_OK;
 }
 
+// Binding helper for CPython callers: two str attributes of every object of a Python list (Seqinfo.sequence and
+// .compsequence, classes.py:11-18) -> the address of their UTF-8 bytes and their length, in one C loop through the
+// interpreter's own API (function pointers: this library does not link against libpython; the caller holds the GIL).
+// The attribute objects are kept referenced in `held` (2 per object) until pf_py_release gives them back: an attribute that
+// is computed on access stays alive as long as its bytes are used.  flags[i]: bit 0 set = both are str of equal length, all
+// ASCII (their UTF-8 bytes are their characters); anything else leaves the object to the caller's general path.
+int pf_py_seqinfo_columns(void* list, uint64_t n, void* attr_seq, void* attr_comp, const pf_py_api* api,
+                          uint64_t* a_seq, uint64_t* a_comp, uint32_t* len, uint8_t* flags, void** held) {
+    if (!list || !attr_seq || !attr_comp || !api || (n && (!a_seq || !a_comp || !len || !flags || !held)))
+        return pk_fail(PF_ERR_ARG, "pf_py_seqinfo_columns: null argument");
+    for (uint64_t i = 0; i < n; i++) {
+        a_seq[i] = a_comp[i] = 0; len[i] = 0; flags[i] = 0; held[2 * i] = held[2 * i + 1] = nullptr;
+        void* o = api->list_get_item(list, (long long)i);
+        if (!o) { api->err_clear(); continue; }
+        void* s = api->get_attr(o, attr_seq);
+        void* c = s ? api->get_attr(o, attr_comp) : nullptr;
+        held[2 * i] = s; held[2 * i + 1] = c;
+        if (!s || !c) { api->err_clear(); continue; }
+        long long ns = 0, nc = 0;
+        const char* ps = api->as_utf8_and_size(s, &ns);
+        const char* pc = ps ? api->as_utf8_and_size(c, &nc) : nullptr;
+        if (!ps || !pc) { api->err_clear(); continue; }
+        const long long ls = api->get_length(s), lc = api->get_length(c);
+        if (ls < 0 || lc < 0) { api->err_clear(); continue; }
+        len[i] = (uint32_t)ls;
+        if (ls == lc && ls == ns && lc == nc && ls <= 0xFFFFFFFFll) {
+            a_seq[i] = (uint64_t)(uintptr_t)ps; a_comp[i] = (uint64_t)(uintptr_t)pc; flags[i] = 1;
+        }
+    }
+    return PF_OK;
+}
+int pf_py_release(void** held, uint64_t n, const pf_py_api* api) {
+    if (!api || (n && !held)) return pk_fail(PF_ERR_ARG, "pf_py_release: null argument");
+    for (uint64_t i = 0; i < n; i++) if (held[i]) { api->dec_ref(held[i]); held[i] = nullptr; }
+    return PF_OK;
+}
+
 }  // extern "C"

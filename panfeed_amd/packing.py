@@ -13,6 +13,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 from itertools import chain
+from sys import intern as sys_intern
 
 _LUT = np.full(256, 255, dtype=np.uint8)
 for _i, _c in enumerate(b"ACGT"):
@@ -198,6 +199,56 @@ def _ascii_addresses(strings):
     return out
 
 
+_PY_API = None
+
+
+def _py_api():
+    """the six interpreter functions pf_py_seqinfo_columns calls, as the library's pf_py_api struct"""
+    global _PY_API
+    if _PY_API is None:
+        import ctypes as C
+        fn = [C.pythonapi.PyList_GetItem, C.pythonapi.PyObject_GetAttr, C.pythonapi.PyUnicode_AsUTF8AndSize,
+              C.pythonapi.PyUnicode_GetLength, C.pythonapi.Py_DecRef, C.pythonapi.PyErr_Clear]
+        _PY_API = (C.c_void_p * 6)(*[C.cast(f, C.c_void_p).value for f in fn])
+    return _PY_API
+
+
+def _seqinfo_columns(flat_s):
+    """(addresses of .sequence bytes, of .compsequence bytes, lengths, held references) for a list of Seqinfo-like objects
+    whose two attributes are plain ASCII str of equal length -- or None when any of them is not (the caller's general path
+    then looks at them one by one and says what is wrong)"""
+    import ctypes as C
+    import sys
+
+    from . import _lib
+    n = len(flat_s)
+    if n == 0 or sys.implementation.name != "cpython" or type(flat_s) is not list:
+        return None
+    a_seq = np.empty(n, dtype=np.uint64); a_comp = np.empty(n, dtype=np.uint64)
+    a_len = np.empty(n, dtype=np.uint32); flags = np.empty(n, dtype=np.uint8)
+    held = np.zeros(2 * n, dtype=np.uint64)
+    api = _py_api()
+    _lib.check(_lib.load_pydll().pf_py_seqinfo_columns(
+        C.c_void_p(id(flat_s)), n, C.c_void_p(id(_ATTR_SEQ)), C.c_void_p(id(_ATTR_COMP)), C.cast(api, C.c_void_p),
+        C.c_void_p(a_seq.ctypes.data), C.c_void_p(a_comp.ctypes.data), C.c_void_p(a_len.ctypes.data),
+        C.c_void_p(flags.ctypes.data), C.c_void_p(held.ctypes.data)))
+    if not flags.all():
+        _release_held(held)
+        return None
+    return a_seq, a_comp, a_len.astype(np.int64), held
+
+
+def _release_held(held):
+    import ctypes as C
+
+    from . import _lib
+    _lib.check(_lib.load_pydll().pf_py_release(C.c_void_p(held.ctypes.data), len(held), C.cast(_py_api(), C.c_void_p)))
+
+
+_ATTR_SEQ = sys_intern("sequence")
+_ATTR_COMP = sys_intern("compsequence")
+
+
 def build_batch_native(records, klength, canon, W, stroi=(), first_ordinal=0, want_strand=True):
     """Same result as build_batch, with the per-base work (packing, non-ACGT splitting, slow-path grouping)
     done by the library's host threads (pf_pack_records, csrc/pf_pack.cpp)."""
@@ -261,14 +312,24 @@ def build_batch_native(records, klength, canon, W, stroi=(), first_ordinal=0, wa
         cl_names.append(names)
         cl_off.append(len(flat_s))
     nseq = len(flat_s)
-    seq_strs = [s.sequence for s in flat_s]
-    comp_strs = [s.compsequence for s in flat_s]
-    a_len = np.fromiter(map(len, seq_strs), dtype=np.int64, count=nseq)
-    if not np.array_equal(a_len, np.fromiter(map(len, comp_strs), dtype=np.int64, count=nseq)):
-        q = int(np.flatnonzero(a_len != np.fromiter(map(len, comp_strs), dtype=np.int64, count=nseq))[0])
-        ci = int(np.searchsorted(np.asarray(cl_off), q, side="right") - 1)
-        raise ValueError(f"{hb.idx[ci]}: sequence and compsequence differ in length")
-    if all(map(str.isascii, seq_strs)) and all(map(str.isascii, comp_strs)):
+    # the two attributes of every Seqinfo: one pass inside the library (addresses of the strings' own bytes, lengths, "plain
+    # ASCII of equal length" flags) instead of two list comprehensions, four maps and two address passes up here
+    fast = _seqinfo_columns(flat_s)
+    if fast is not None:
+        a_seq, a_comp, a_len, held = fast
+    else:
+        held = None
+    if fast is None:
+        seq_strs = [s.sequence for s in flat_s]
+        comp_strs = [s.compsequence for s in flat_s]
+        a_len = np.fromiter(map(len, seq_strs), dtype=np.int64, count=nseq)
+        if not np.array_equal(a_len, np.fromiter(map(len, comp_strs), dtype=np.int64, count=nseq)):
+            q = int(np.flatnonzero(a_len != np.fromiter(map(len, comp_strs), dtype=np.int64, count=nseq))[0])
+            ci = int(np.searchsorted(np.asarray(cl_off), q, side="right") - 1)
+            raise ValueError(f"{hb.idx[ci]}: sequence and compsequence differ in length")
+    if fast is not None:
+        pass
+    elif all(map(str.isascii, seq_strs)) and all(map(str.isascii, comp_strs)):
         # an ASCII str keeps its bytes in the object itself: their address is all the packer needs (the strings stay alive
         # in flat_s for the duration of the call) -- no copy of the batch's 300 MB of text at all
         a_seq = _ascii_addresses(seq_strs)
@@ -299,11 +360,15 @@ def build_batch_native(records, klength, canon, W, stroi=(), first_ordinal=0, wa
                       a_tgt.ctypes.data if any_target else None, a_off.ctypes.data, k, int(bool(canon)), W,
                       int(bool(want_strand)))
     handle = C.c_void_p()
-    _lib.check(L.pf_pack_records(C.byref(pin), C.byref(handle)))
     try:
-        _fill_from_packed(L, hb, handle, len(cl_nstr), seq_ref)
+        _lib.check(L.pf_pack_records(C.byref(pin), C.byref(handle)))
+        try:
+            _fill_from_packed(L, hb, handle, len(cl_nstr), seq_ref)
+        finally:
+            L.pf_packed_free(handle)
     finally:
-        L.pf_packed_free(handle)
+        if held is not None:
+            _release_held(held)
     hb.cluster_nstrains = np.asarray(cl_nstr, dtype=np.uint32)
     hb.cluster_npresab = np.asarray(cl_npres, dtype=np.uint32)
     hb.cluster_presab = (np.stack(cl_presab) if cl_presab else np.zeros((0, W), dtype=np.uint32)).astype(np.uint32)

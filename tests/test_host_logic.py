@@ -160,6 +160,55 @@ def test_native_packer_equals_numpy_packer():
         _same_batch(build_batch(recs, 31, canon, 3, stroi=st), packing.build_batch_native(recs, 31, canon, 3, stroi=st))
 
 
+def test_native_packer_takes_any_object_with_the_two_attributes():
+    """the one-pass attribute reader (pf_py_seqinfo_columns) against the general path: attributes computed on access (their
+    str objects live only while the library holds them), str subclasses, lower-case and non-ASCII text (falls back), a
+    missing attribute and a non-str attribute (errors of the general path)"""
+    from panfeed_amd.classes import Seqinfo
+    comp = str.maketrans("ACGTN", "TGCAN")
+
+    class Lazy:                                        # builds its strings anew on every access
+        def __init__(self, s):
+            self._s = s
+            self.id, self.chromosome, self.start, self.end, self.strand, self.offset = "g", "c", 1, len(s), 1, 0
+
+        @property
+        def sequence(self):
+            return "".join(self._s)
+
+        @property
+        def compsequence(self):
+            return "".join(self._s).translate(comp)
+
+    class MyStr(str):
+        pass
+
+    rng = np.random.default_rng(5)
+    seqs = ["".join(rng.choice(list("ACGT"), 70 + i)) for i in range(40)]
+    seqs[7] = seqs[7][:30] + "N" + seqs[7][31:]
+    plain = ({f"s{i:02d}": [Seqinfo(q, q.translate(comp), "g", "c", 1, len(q), 1, 0)] for i, q in enumerate(seqs)}, "x", np.ones(40, dtype=np.int64))
+    lazy = ({f"s{i:02d}": [Lazy(q)] for i, q in enumerate(seqs)}, "x", np.ones(40, dtype=np.int64))
+    sub = ({f"s{i:02d}": [Seqinfo(MyStr(q), MyStr(q.translate(comp)), "g", "c", 1, len(q), 1, 0)] for i, q in enumerate(seqs)}, "x",
+           np.ones(40, dtype=np.int64))
+    ref = packing.build_batch_native([plain], 11, True, 2)
+    for other in (lazy, sub):
+        _same_batch(ref, packing.build_batch_native([other], 11, True, 2))
+    _same_batch(build_batch([plain], 11, True, 2), ref)
+    # non-ASCII (latin-1) text: not handed over by address, same result as the reference-shaped packer
+    odd = ({"a": [Seqinfo("ACGTACGTAC\u00e9ACGTACGTTT", "TGCATGCATG\u00e9TGCATGCAAA", "g", "c", 1, 21, 1, 0)],
+            "b": [Seqinfo("ACGTACGTACGACGTACGTTT", "TGCATGCATGCTGCATGCAAA", "g", "c", 1, 21, 1, 0)]}, "y", np.ones(2, dtype=np.int64))
+    _same_batch(build_batch([odd], 5, True, 1), packing.build_batch_native([odd], 5, True, 1))
+    # what cannot be a record still fails the way it did
+    class NoComp:
+        sequence = "ACGTACGT"
+    with pytest.raises(AttributeError):
+        packing.build_batch_native([({"a": [NoComp()]}, "z", np.ones(1, dtype=np.int64))], 5, True, 1)
+    class Bytes:
+        sequence, compsequence = b"ACGTACGT", b"TGCATGCA"
+    with pytest.raises((TypeError, AttributeError, ValueError)):
+        packing.build_batch_native([({"a": [Bytes()]}, "z", np.ones(1, dtype=np.int64))], 5, True, 1)
+
+
 def test_native_packer_rejects_bad_complement():
     from panfeed_amd._lib import PanfeedHipError
     from panfeed_amd.classes import Seqinfo
