@@ -3615,9 +3615,14 @@ __global__ __launch_bounds__(PR_THREADS) void pattern_rows_kernel(PatRowsParams 
     __shared__ uint32_t l_count;
     // mode 2: the cluster's (distinct index << 5 | sample & 31) list, the first segment of every 32-sample word, and
     // the mask a wave is expanding
-    __shared__ uint16_t segd[DEDUP_MAX_SEGS];
+    __shared__ __align__(16) uint16_t segd[DEDUP_MAX_SEGS];
     __shared__ uint32_t wstart[MAX_CHUNKS + 1];
     __shared__ uint32_t mstage[PR_THREADS / 64][33];          // word 32 stays zero (the place unused segment registers point at)
+    // mode 1: the item's sample-set matrix M (rows_kernel left it in global memory), which a pattern's row is the OR of up
+    // to 64 rows of -- read from LDS, not through the cache, once per pattern word and member (it shares the place of the
+    // mode-2 segment list: an item is one or the other)
+    uint32_t* const Ml = reinterpret_cast<uint32_t*>(segd);
+    static_assert(sizeof(uint16_t) * DEDUP_MAX_SEGS >= sizeof(uint32_t) * DEDUP_MROWS, "M does not fit the segment list's place");
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const uint32_t item = p.work[blockIdx.x];
@@ -3663,6 +3668,11 @@ __global__ __launch_bounds__(PR_THREADS) void pattern_rows_kernel(PatRowsParams 
         }
         return nn;
     };
+    if (expand) {
+        const uint32_t mw = min(p.v_nstr[c] * Wp, DEDUP_MROWS);
+        for (uint32_t i = tid; i < mw; i += blockDim.x) Ml[i] = M[i];
+        __syncthreads();
+    }
     if (wide) {
         const uint32_t s0 = p.cluster_seg_off[c], s1 = p.cluster_seg_off[c + 1];
         for (uint32_t s = tid; s < s1 - s0; s += blockDim.x)
@@ -3761,7 +3771,7 @@ __global__ __launch_bounds__(PR_THREADS) void pattern_rows_kernel(PatRowsParams 
                         while (t) {
                             const uint32_t d = __ffsll((unsigned long long)t) - 1;
                             t &= t - 1;
-                            v |= M[d * Wp + w];
+                            v |= Ml[d * Wp + w];
                         }
                     } else if ((cm[w >> 5] >> (w & 31)) & 1) {
                         v = cb[(size_t)w * NS + slot];
