@@ -1939,6 +1939,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         __syncthreads();
         const uint32_t mw = p.v_nstr[c] * Wp;
         for (uint32_t i = tid; i < mw; i += ROWS_THREADS) p.mrows[(size_t)slice * DEDUP_MROWS + i] = M[i];
+        PF_PROF_STAMP(57);
     }
     const uint32_t npresent = sh_npres;
     // denominators of panfeed.py:191 / :196
@@ -2312,15 +2313,32 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         else { for (uint32_t i = tid; i < SORT_MAX; i += ROWS_THREADS) pairs[i] = EMPTY64; }
         __syncthreads();
     }
+    // mode 1: ordinal and the two mask words of XS slots of a thread, loaded together
+    constexpr uint32_t XS = 5;
+    uint32_t xo_[XS], xl_[XS], xh_[XS];
+    auto load_slots = [&](uint32_t i0) {
+#pragma unroll
+        for (uint32_t u = 0; u < XS; u++) {
+            const uint32_t i = min(i0 + u * ROWS_THREADS, ns - 1);
+            xo_[u] = ordp[i]; xl_[u] = cb[i]; xh_[u] = cb[(W > 1 ? NS : 0u) + i];     // (one plane only when W == 1; f1 is off then)
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < XS; u++) { asm volatile("" : "+v"(xo_[u])); asm volatile("" : "+v"(xl_[u])); asm volatile("" : "+v"(xh_[u])); }
+    };
     if (expand) {
         // Few distinct sequences -> few distinct masks: evaluate each distinct mask once (LDS table), then
         // hand the result to every slot that carries it.
         for (uint32_t t = tid; t < AT_SLOTS; t += ROWS_THREADS) at_key[t] = 0;
         if (tid == 0) at_count = 0;
         __syncthreads();
-        for (uint32_t i = tid; i < ns; i += ROWS_THREADS) {
-            if (ordp[i] == NO_ORD) continue;
-            const uint64_t amask = (f0 ? (uint64_t)cb[i] : 0) | (f1 ? (uint64_t)cb[(size_t)NS + i] << 32 : 0);
+        // (five slots a trip: their ordinals and mask words are asked for together -- slot by slot, ordinal then words, this
+        // loop and the one further down were 70 % of the kernel on clusters of 30-64 distinct sequences)
+        for (uint32_t i0 = tid; i0 < ns; i0 += XS * ROWS_THREADS)
+        for (uint32_t u = 0, first = 1; u < XS; u++, first = 0) {
+            if (first) load_slots(i0);
+            const uint32_t i = i0 + u * ROWS_THREADS;
+            if (i >= ns || xo_[u] == NO_ORD) continue;
+            const uint64_t amask = (f0 ? (uint64_t)xl_[u] : 0) | (f1 ? (uint64_t)xh_[u] << 32 : 0);
             if (!amask) continue;
             uint32_t a = (uint32_t)mix64(amask) & (AT_SLOTS - 1);
             for (uint32_t probes = 0; probes < AT_SLOTS; probes++) {
@@ -2335,15 +2353,20 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
             }
         }
         __syncthreads();
+        PF_PROF_STAMP(58);
         for (uint32_t t = tid; t < AT_SLOTS; t += ROWS_THREADS) {
             const uint64_t key = at_key[t];
             if (!key) continue;
             uint4 h;
-            const bool keep = row_eval(true, key, 0, h);
-            at_hash[t] = h;
+            const bool keep = row_eval(true, key, 0, h);         // (eight lanes per mask, as finish_kernel has it, measured
+            at_hash[t] = h;                                      // slower here: 1.94 -> 2.13 ms at ~60 distinct sequences)
             at_keep[t] = keep ? 1u : 0u;
         }
         __syncthreads();
+        PF_PROF_STAMP(59);
+#ifdef PF_PROF
+        if (tid == 0) { atomicAdd(&pf_prof[60], 1ull); atomicAdd(&pf_prof[61], (unsigned long long)at_count); }
+#endif
     }
     // a k-mer's ordinal and keep flag into the item's bitmaps (or its list of pairs to sort)
     auto place = [&](uint32_t i, uint32_t o, bool keep) {
@@ -2378,7 +2401,31 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
             }
         }
     }
-    for (uint32_t i = tid; i < ns && !wide; i += ROWS_THREADS) {
+    if (expand) {
+        for (uint32_t i0 = tid; i0 < ns; i0 += XS * ROWS_THREADS)
+        for (uint32_t u = 0, first = 1; u < XS; u++, first = 0) {
+            if (first) load_slots(i0);
+            const uint32_t i = i0 + u * ROWS_THREADS;
+            const uint32_t o = xo_[u];
+            if (i >= ns || o == NO_ORD) continue;
+            uint4 h;
+            bool keep;
+            const uint64_t amask = (f0 ? (uint64_t)xl_[u] : 0) | (f1 ? (uint64_t)xh_[u] << 32 : 0);
+            bool found = false;
+            uint32_t a = (uint32_t)mix64(amask) & (AT_SLOTS - 1);
+            for (uint32_t probes = 0; amask && probes < AT_SLOTS; probes++) {
+                const uint64_t cur = at_key[a];
+                if (cur == 0) break;
+                if (cur == amask) { found = true; break; }
+                a = (a + 1) & (AT_SLOTS - 1);
+            }
+            if (found) { h = at_hash[a]; keep = at_keep[a] != 0; }
+            else keep = row_eval(true, amask, i, h);          // table was full: evaluate this slot on its own
+            p.slot_hash[(size_t)slice * NS + i] = h;
+            place(i, o, keep);
+        }
+    }
+    for (uint32_t i = tid; i < ns && !wide && !expand; i += ROWS_THREADS) {
         const uint32_t o = ordp[i];
         if (o == NO_ORD) continue;
         uint4 h;
