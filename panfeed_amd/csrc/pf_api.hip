@@ -114,7 +114,7 @@ struct pf_ctx {
     DevBuf cl_rec, cl_overflow, cl_kmer_off, cl_kmer_cnt, cl_unique, cl_pattern, cl_first, cursor;
     // scan view built by cluster_dedup_kernel
     DevBuf v_word_off, v_len, v_sample, v_ord, seg_distinct, v_nseg, v_nstr, v_mode, v_dense, extra_off, extra_dense;
-    DevBuf bm_occ, bm_keep, pre_occ, pre_keep, mrows, slot_out, it_is_extra, cmask_lo, cmask_hi, it_compact;
+    DevBuf bm4, bm2, mrows, slot_out, it_is_extra, cmask_lo, cmask_hi, it_compact;
     DevBuf strand_bits, scan_desc, md5_list, wide_list;
     DevBuf v_bits, view_off;
     // unit view (unit_class_kernel): one pool of view entries per part of a batch's first pass, and the list
@@ -466,7 +466,7 @@ void pf_destroy(pf_ctx* c) {
                       &c->b_seg_sample, &c->b_seg_ord, &c->b_cl_seg_off, &c->b_cl_nstr, &c->b_cl_npres, &c->b_cl_presab,
                       &c->b_cl_ordinal, &c->b_extra_ord, &c->b_extra_bits, &c->b_seg_strand_off, &c->cl_rec, &c->v_word_off, &c->v_len, &c->v_sample, &c->v_ord,
                       &c->seg_distinct, &c->v_nseg, &c->v_nstr, &c->v_mode, &c->v_dense, &c->extra_off, &c->extra_dense,
-                      &c->bm_occ, &c->bm_keep, &c->pre_occ, &c->pre_keep, &c->mrows, &c->slot_out, &c->it_is_extra,
+                      &c->bm4, &c->bm2, &c->mrows, &c->slot_out, &c->it_is_extra,
                       &c->cmask_lo, &c->cmask_hi, &c->it_compact, &c->cl_overflow, &c->cl_kmer_off, &c->cl_kmer_cnt, &c->cl_unique, &c->cl_pattern,
                       &c->cl_first, &c->cursor, &c->strand_bits, &c->it_cluster, &c->it_part, &c->it_nparts,
                       &c->it_nslots, &c->it_slice, &c->it_sib0, &c->it_nsib, &c->it_extra_first, &c->it_count,
@@ -527,7 +527,7 @@ int pf_create(pf_ctx** out, int device, const pf_opts* o) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b) {
             const uint64_t slice_bytes = (uint64_t)c->NS * (8ull * c->KW + 4 + 4ull * c->W + 16 + 8 + 4 + 4 + 4 + 4) +
-                                         (uint64_t)pf::DENSE_WORDS_BIG * 16 + (uint64_t)pf::DEDUP_MROWS * 4 + 64;
+                                         (uint64_t)pf::DENSE_WORDS_BIG * 24 + (uint64_t)pf::DEDUP_MROWS * 4 + 64;
             const uint64_t fit = (free_b / 2) / slice_bytes;
             if (c->max_items > fit) c->max_items = (uint32_t)std::max<uint64_t>(fit, 64);
         }
@@ -563,8 +563,7 @@ int pf_create(pf_ctx** out, int device, const pf_opts* o) {
             !guard(c->chunkbits.ensure(S * NS * W * 4)) || !guard(c->chunkmask.ensure(S * 8 * 4)) ||
             !guard(c->slot_hash.ensure(S * NS * 16)) || !guard(c->sorted_pair.ensure(S * NS * 8)) ||
             !guard(c->kept_prefix.ensure(S * (NS + 1) * 4)) || !guard(c->cursor.ensure(64)) ||
-            !guard(c->bm_occ.ensure(S * pf::DENSE_WORDS_BIG * 4)) || !guard(c->bm_keep.ensure(S * pf::DENSE_WORDS_BIG * 4)) ||
-            !guard(c->pre_occ.ensure(S * pf::DENSE_WORDS_BIG * 4)) || !guard(c->pre_keep.ensure(S * pf::DENSE_WORDS_BIG * 4)) ||
+            !guard(c->bm4.ensure(S * pf::DENSE_WORDS_BIG * 16)) || !guard(c->bm2.ensure(S * pf::DENSE_WORDS_BIG * 8)) ||
             !guard(c->mrows.ensure(S * pf::DEDUP_MROWS * 4)) || !guard(c->slot_out.ensure(S * NS * 4)) ||
             !guard(c->cmask_lo.ensure(S * NS * 4)) || !guard(c->cmask_hi.ensure(S * NS * 4)))
             break;
@@ -1374,8 +1373,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             rp.chunkmask = c->chunkmask.as<uint32_t>();
             rp.slot_hash = c->slot_hash.as<uint4>(); rp.sorted_pair = c->sorted_pair.as<uint64_t>();
             rp.kept_prefix = c->kept_prefix.as<uint32_t>();
-            rp.bm_occ = c->bm_occ.as<uint32_t>(); rp.bm_keep = c->bm_keep.as<uint32_t>();
-            rp.pre_occ = c->pre_occ.as<uint32_t>(); rp.pre_keep = c->pre_keep.as<uint32_t>();
+            rp.bm4 = c->bm4.as<uint4>(); rp.bm2 = c->bm2.as<uint2>(); rp.item_nsib = c->it_nsib.as<uint32_t>();
             rp.mrows = c->mrows.as<uint32_t>();
             rp.item_unique = c->it_unique.as<uint32_t>(); rp.item_kept = c->it_kept.as<uint32_t>();
             rp.work = c->work_rows.as<uint32_t>() + rows_off[s]; rp.W = W; rp.NS = NS;
@@ -1403,8 +1401,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
                 bm.item_scratch = c->it_slice.as<uint32_t>(); bm.cluster_overflow = bp.cluster_overflow;
                 bm.v_mode = c->v_mode.as<uint32_t>(); bm.v_dense = c->v_dense.as<uint32_t>();
                 bm.item_fused = c->it_compact.as<uint32_t>();
-                bm.bm_occ = c->bm_occ.as<uint32_t>(); bm.bm_keep = c->bm_keep.as<uint32_t>();
-                bm.pre_occ = c->pre_occ.as<uint32_t>(); bm.pre_keep = c->pre_keep.as<uint32_t>();
+                bm.bm4 = c->bm4.as<uint4>(); bm.bm2 = c->bm2.as<uint2>();
                 hipLaunchKernelGGL(pf::bitmap_merge_kernel, dim3(sb.ncl), dim3(256), 0, c->stream, bm);
                 HIPCHK(hipGetLastError());
             }
@@ -1421,8 +1418,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             em.tab_key = c->tab_key.as<uint64_t>(); em.tab_ord = c->tab_ord.as<uint32_t>();
             em.slot_hash = c->slot_hash.as<uint4>();
             em.sorted_pair = c->sorted_pair.as<uint64_t>(); em.kept_prefix = c->kept_prefix.as<uint32_t>(); em.kept_prefix_rw = c->kept_prefix.as<uint32_t>();
-            em.bm_occ = c->bm_occ.as<uint32_t>(); em.bm_keep = c->bm_keep.as<uint32_t>();
-            em.pre_occ = c->pre_occ.as<uint32_t>(); em.pre_keep = c->pre_keep.as<uint32_t>();
+            em.bm4 = c->bm4.as<uint4>();
             em.slot_out = c->slot_out.as<uint32_t>();
             em.out_key = ar->key.as<uint64_t>(); em.out_pid = ar->pid.as<uint32_t>(); em.out_first = ar->first.as<uint64_t>();
             em.cluster_pattern = c->cl_pattern.as<uint32_t>(); em.cluster_first = c->cl_first.as<uint64_t>();

@@ -1830,7 +1830,11 @@ struct RowsParams {
     uint64_t* sorted_pair;   // [slice][NS]  ord << 32 | slot, ascending
     uint32_t* kept_prefix;   // [slice][NS+1] exclusive prefix of keep flags in sorted order
     // mode 1 (ordinal bitmaps)
-    uint32_t* bm_occ; uint32_t* bm_keep; uint32_t* pre_occ; uint32_t* pre_keep;   // [slice][DENSE_WORDS]
+    uint4* bm4;              // [slice][DENSE_WORDS_BIG] per ordinal word {occupied, kept, ordinals before it, kept ones before it}:
+                             // one 16-byte record, because emit_kernel asks for all four at a random word per kept k-mer
+    uint2* bm2;              // [slice][DENSE_WORDS_BIG] {occupied, kept} of an item that is one of several of its cluster: what
+                             // bitmap_merge_kernel reads (it writes the cluster's records into the first item's bm4)
+    const uint32_t* item_nsib;   // [item] items of the item's cluster
     uint32_t* mrows;         // [slice][DEDUP_MROWS]  M[d][Wp]: samples that carry distinct sequence d
     uint32_t* item_unique;   // [item]
     uint32_t* item_kept;     // [item]
@@ -2055,8 +2059,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         const uint32_t RW = (nchunks + 3) & ~3u;
         const uint32_t cap = min(min(AT_LIMIT, (20480u - ((nsegs + 1) >> 1)) / nmw), 4u * (DENSE_WORDS_BIG / RW));
         auto row_of = [&](uint32_t e) -> uint32_t* {
-            uint32_t* arr = (e & 2u) ? ((e & 1u) ? p.pre_keep : p.pre_occ) : ((e & 1u) ? p.bm_keep : p.bm_occ);
-            return arr + (size_t)slice * DENSE_WORDS_BIG + (size_t)(e >> 2) * RW;
+            return reinterpret_cast<uint32_t*>(p.bm4 + (size_t)slice * DENSE_WORDS_BIG) + (size_t)e * RW;
         };
         // one half-wave per mask: lane j gathers row word 32 r + j in round r, the 32 words of a round then go through
         // the row hash in order (eight blocks), every lane running it on the words read back from LDS (one broadcast
@@ -2457,6 +2460,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         // the occupied ordinals of the stretch, then the kept ones -- with the counts of the stretches before it carried on
         constexpr uint32_t PWB = DENSE_WIN / ROWS_THREADS;           // 16 words per thread
         const size_t gb = (size_t)slice * DENSE_WORDS_BIG;
+        const bool alone = p.item_nsib[item] == 1;
         uint32_t base_o = 0, base_k = 0;
         for (uint32_t w0 = 0; w0 < dense_words; w0 += DENSE_WIN) {
             for (int round = 0; round < 2; round++) {
@@ -2474,14 +2478,15 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
                 for (uint32_t j = 0; j < PWB; j++) sm += __popc(bigbm[tid * PWB + j]);
                 uint32_t tot;
                 uint32_t run = (round ? base_k : base_o) + block_exscan(sm, wave_tot, &tot);
-                uint32_t* bm = round ? p.bm_keep : p.bm_occ;
-                uint32_t* pre = round ? p.pre_keep : p.pre_occ;
+                uint32_t* rec = reinterpret_cast<uint32_t*>(p.bm4 + gb) + (round ? 1 : 0);      // .x / .y, and .z / .w two further on
+                uint32_t* rec2 = reinterpret_cast<uint32_t*>(p.bm2 + gb) + (round ? 1 : 0);
 #pragma unroll
                 for (uint32_t j = 0; j < PWB; j++) {
                     const uint32_t w = w0 + tid * PWB + j;
                     if (w < dense_words) {
                         const uint32_t a = bigbm[tid * PWB + j];
-                        bm[gb + w] = a; pre[gb + w] = run;
+                        if (alone) { rec[4 * (size_t)w] = a; rec[4 * (size_t)w + 2] = run; }
+                        else rec2[2 * (size_t)w] = a;
                         run += __popc(a);
                     }
                 }
@@ -2507,13 +2512,14 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         uint32_t bo = block_exscan(so, wave_tot, &tot_o);
         uint32_t bk = block_exscan(sk, wave_tot, &tot_k);
         const size_t gb = (size_t)slice * DENSE_WORDS_BIG;
+        const bool alone = p.item_nsib[item] == 1;
 #pragma unroll
         for (uint32_t j = 0; j < PW; j++) {
             const uint32_t w = tid * PW + j;
             if (w < dense_words) {
                 const uint32_t a = occ[w], b = keepbm[w];
-                p.bm_occ[gb + w] = a; p.bm_keep[gb + w] = b;
-                p.pre_occ[gb + w] = bo; p.pre_keep[gb + w] = bk;
+                if (alone) p.bm4[gb + w] = make_uint4(a, b, bo, bk);
+                else p.bm2[gb + w] = make_uint2(a, b);
                 bo += __popc(a); bk += __popc(b);
             }
         }
@@ -2579,7 +2585,8 @@ struct BitmapMergeParams {
     const uint32_t* sub_cluster; const uint32_t* cluster_item0; const uint32_t* cluster_nitems;   // as BaseParams
     const uint32_t* item_scratch; const uint32_t* cluster_overflow; const uint32_t* v_mode; const uint32_t* v_dense;
     const uint32_t* item_fused;        // [item] nonzero: finished by finish_kernel, which keeps its bitmaps in LDS
-    uint32_t* bm_occ; uint32_t* bm_keep; uint32_t* pre_occ; uint32_t* pre_keep;                   // [slice][DENSE_WORDS]
+    uint4* bm4;                        // [slice][DENSE_WORDS_BIG] {occupied, kept, ordinals before, kept before} per ordinal word
+    const uint2* bm2;                  // [slice][DENSE_WORDS_BIG] the items' own {occupied, kept}
 };
 __global__ __launch_bounds__(256) void bitmap_merge_kernel(BitmapMergeParams p) {
     __shared__ uint32_t wt_o[5], wt_k[5];
@@ -2596,7 +2603,8 @@ __global__ __launch_bounds__(256) void bitmap_merge_kernel(BitmapMergeParams p) 
         if (w < dense_words)
             for (uint32_t q = 0; q < ni; q++) {
                 const size_t g = (size_t)p.item_scratch[i0 + q] * DENSE_WORDS_BIG + w;
-                o |= p.bm_occ[g]; k |= p.bm_keep[g];
+                const uint2 ok = p.bm2[g];
+                o |= ok.x; k |= ok.y;
             }
         uint32_t xo = __popc(o), xk = __popc(k);
         const uint32_t so = xo, sk = xk;
@@ -2612,8 +2620,7 @@ __global__ __launch_bounds__(256) void bitmap_merge_kernel(BitmapMergeParams p) 
             to += wt_o[v]; tk += wt_k[v];
         }
         if (w < dense_words) {
-            p.bm_occ[g0 + w] = o; p.bm_keep[g0 + w] = k;
-            p.pre_occ[g0 + w] = bo + xo - so; p.pre_keep[g0 + w] = bk + xk - sk;
+            p.bm4[g0 + w] = make_uint4(o, k, bo + xo - so, bk + xk - sk);
         }
         run_o += to; run_k += tk;
         __syncthreads();
@@ -2797,7 +2804,7 @@ struct EmitParams {
     const uint64_t* tab_key; const uint32_t* tab_ord; const uint4* slot_hash;
  const uint64_t* sorted_pair; const uint32_t* kept_prefix;                                       // mode 0
     uint32_t* kept_prefix_rw;        // (the same array: with bitmaps its words 1.. take the kept k-mers' output indices)
-    const uint32_t* bm_occ; const uint32_t* bm_keep; const uint32_t* pre_occ; const uint32_t* pre_keep;   // mode 1
+    const uint4* bm4;                // ranks by bitmap: {occupied, kept, ordinals before, kept before} per ordinal word
     uint32_t* slot_out;              // [slice][NS] mode 1: index of the slot's k-mer inside the cluster's output
     uint64_t* out_key; uint32_t* out_pid; uint64_t* out_first;     // out_first: first_seen each k-mer offered
     uint32_t* cluster_pattern; uint64_t* cluster_first;
@@ -2897,6 +2904,9 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
         const uint32_t i = i0 + tid;
         uint32_t res = 0xFFFFFFFFu, slot = 0;
         uint64_t fs = 0, lo = 0, hi = 0;
+#ifdef PF_PROF
+        const uint64_t tp0 = __builtin_readcyclecounter();
+#endif
         if (i < n_entries) {
             if (sorted) {
                 const uint32_t kb = kp[i];
@@ -2925,7 +2935,8 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
                 // the cluster's bitmaps: this item's own, or (several items) their union, which
                 // bitmap_merge_kernel left in the first item's place -- four loads that go out together
                 const size_t g2 = gb0 + (o >> 5);
-                const uint32_t kw = p.bm_keep[g2], po = p.pre_occ[g2], bo = p.bm_occ[g2], pk = p.pre_keep[g2];
+                const uint4 rec = p.bm4[g2];
+                const uint32_t bo = rec.x, kw = rec.y, po = rec.z, pk = rec.w;
                 row_id(slot, lo, hi);                          // (and the row hash with them)
                 res = pk + __popc(kw & below);
                 fs = (ordinal << 32) | (uint64_t)(po + __popc(bo & below) + 1);
@@ -2935,6 +2946,11 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
         }
         // local table: find or claim; an entry whose second word is not published yet is looked at again in the next
         // round of a WAVE-UNIFORM loop (no lane ever spins inside divergent code)
+#ifdef PF_PROF
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint64_t tp1 = __builtin_readcyclecounter();
+        if (tid == 0) atomicAdd(&pf_prof[62], (unsigned long long)(tp1 - tp0));
+#endif
         int st = res != 0xFFFFFFFFu ? 2 : 0;
         uint32_t ls = 0;
         if (st == 2) {
@@ -2969,6 +2985,9 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
             if (!__any(st == 2)) break;
         }
         if (st == 1) atomicMin((unsigned long long*)&lt_first[ls], (unsigned long long)fs);
+#ifdef PF_PROF
+        if (tid == 0) { atomicAdd(&pf_prof[63], (unsigned long long)(__builtin_readcyclecounter() - tp1)); atomicAdd(&pf_prof[38], 1ull); }
+#endif
     }
     __syncthreads();
     PF_PROF_STAMP(33);

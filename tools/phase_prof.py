@@ -46,6 +46,8 @@ for i in (48, 49, 50):
         print(f"{i:2d} {names[i]:28s} {v[i] / v[47]:9.1f} per item")
 if v[47]:
     print(f"step A (wave 0): clear {v[55] / v[47]:.0f}, own slots {v[56] / v[47]:.0f}, waiting for the others {v[41] / v[47]:.0f} cycles per item")
+if v[38]:
+    print(f"emit pass 1, wave 0: {v[38] / v[36]:.1f} trips per item; per trip {v[62] / v[38]:.0f} cycles until the loads are in, {v[63] / v[38]:.0f} in the local table")
 if v[60]:
     print(f"rows, mode-1 items ({v[60]}): M {v[57] / v[60]:.0f}, mask table {v[58] / v[60]:.0f}, rows of {v[61] / v[60]:.0f} masks {v[59] / v[60]:.0f}, "
           f"slot loop {(v[44] - (v[44] if not v[47] else 0)) / max(v[60], 1):.0f} (with the wide items' share) cycles per item")
