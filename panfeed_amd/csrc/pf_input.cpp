@@ -654,6 +654,16 @@ int pf_pangenome_next(pf_pangenome* P, uint32_t max_clusters, pf_records** out, 
     size_t nlit = 0;
     for (auto& r : ro) nlit += r.seq.size();
     R->seq_store.reserve(nlit); R->comp_store.reserve(nlit);
+    {   // the merged columns' sizes are known: no growth by doubling while they are filled
+        size_t nseq = 0, nstr = 0, npres = 0;
+        for (auto& r : ro) { nseq += r.seq_len.size(); nstr += r.dict.size(); npres += r.presab.size(); }
+        R->ids.reserve(nseq); R->chroms.reserve(nseq); R->seq_len.reserve(nseq); R->seq_col.reserve(nseq);
+        R->seq_strain.reserve(nseq); R->seq_target.reserve(nseq); R->seq_strand.reserve(nseq); R->seq_start.reserve(nseq);
+        R->seq_end.reserve(nseq); R->seq_offset.reserve(nseq); R->seq_src_off.reserve(nseq); R->seq_src_start.reserve(nseq);
+        R->seq_flags.reserve(nseq); R->cluster_seq_off.reserve((size_t)made + 1); R->cluster_strain_off.reserve((size_t)made + 1);
+        R->cluster_nstrains.reserve(made); R->cluster_npresab.reserve(made); R->cluster_row.reserve(made);
+        R->cluster_presab.reserve(npres); R->strain_index.reserve(nstr);
+    }
     auto app = [](auto& dst, const auto& src) { dst.insert(dst.end(), src.begin(), src.end()); };
     for (uint32_t i = 0; i < made; i++) {
         RowOut& r = ro[i];
