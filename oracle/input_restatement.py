@@ -4,12 +4,13 @@
     iter_gene_clusters   /root/reference/panfeed/input.py:335-468
     panaroo table load   /root/reference/panfeed/input.py:188-191
 
-PARITY UNPINNED: the reference reads sequences through pyfaidx, which is neither in /root/reference nor
-installed here, and its own test data is absent.  What pyfaidx returns is restated from its documented
-behaviour (record key = header up to the first whitespace; sequence without line breaks;
-sequence_always_upper=True; Python-slice clipping; `-seq` = reverse complement with the table below).  This file
-checks the native reader (panfeed_amd/csrc/pf_input.cpp) -- two independent implementations of the same reading
-of input.py -- not the reference itself.
+PINNED by tests/golden/n1.json.gz (tools/gen_golden_n1.py: the reference's own `parse_gff`, `prep_data_n_fasta`,
+`set_input_output` and `iter_gene_clusters` run in the build container; tests/test_native_input.py::
+test_restatement_equals_reference_goldens) -- EXCEPT for pyfaidx, which is neither in /root/reference nor installed:
+the goldens were made with a declared double of `pyfaidx.Fasta` (record key = header up to the first whitespace;
+sequence without line breaks; sequence_always_upper=True; Python-slice clipping; `-seq` = reverse complement with the
+table below; `[::-1]`; `str`).  PARITY UNPINNED for those five operations, pinned for everything around them.
+This file checks the native reader (panfeed_amd/csrc/pf_input.cpp) on inputs the goldens do not cover.
 """
 import csv
 
@@ -62,7 +63,7 @@ def parse_gff(file_name):
                     continue
                 features[ID] = Feature(ID, chrom, start, end, strand)
             except Exception as e:
-                warnings.append(str(e))
+                warnings.append(f'{e}, skipping line "{line.rstrip()}" from {file_name}')
                 continue
     return features, warnings
 
@@ -82,10 +83,13 @@ def load_table(path):
     return strains, table
 
 
-def load_genomes(names, gff_paths, fasta_paths=None):
+def load_genomes(names, gff_paths, fasta_paths=None, log=None):
+    """prep_data_n_fasta, input.py:67-138 (log: parse_gff's warnings, `{e}, skipping line "..." from {file}`, :326-329)"""
     data = {}
     for i, nm in enumerate(names):
         feats, _w = parse_gff(gff_paths[i])
+        if log is not None:
+            log.extend(_w)
         if fasta_paths and fasta_paths[i]:
             contigs = read_fasta(open(fasta_paths[i]).read())
         else:
@@ -94,10 +98,14 @@ def load_genomes(names, gff_paths, fasta_paths=None):
     return data
 
 
-def iter_gene_clusters(strains, table, genome_data, up, down, down_start_codon, gene_list=None, log=None):
+def iter_gene_clusters(strains, table, genome_data, up, down, down_start_codon, gene_list=None, log=None,
+                       raise_missing=False):
     missing = set(strains).difference(genome_data.keys())
-    if missing and log is not None:
-        log.append(f"There are {len(missing)} strains present in the pangenome table but not in the GFF directory")
+    if missing:
+        if log is not None:
+            log.append(f"There are {len(missing)} strains present in the pangenome table but not in the GFF directory")
+        if raise_missing:
+            raise KeyError(f"Missing {len(missing)} from the GFF directory")
     sorted_strains = sorted(strains)
     sortstrain = {x: i for i, x in enumerate(sorted_strains)}
     for idx, cells in table:
@@ -118,11 +126,15 @@ def iter_gene_clusters(strains, table, genome_data, up, down, down_start_codon, 
                 if feat is None:
                     if log is not None:
                         log.append(f"Could not find gene {gene} from {idx} in {strain}")
+                    if raise_missing:
+                        raise KeyError(f"Could not find gene {gene} from {idx} in {strain}")
                     continue
                 ctg = contigs.get(feat.chromosome)
                 if ctg is None:
                     if log is not None:
                         log.append(f"Could not find chromosome {feat.chromosome} in {strain}")
+                    if raise_missing:
+                        raise KeyError(f"Could not find chromosome {feat.chromosome} in {strain}")
                     continue
                 offset = feat.start - 1 if (feat.strand > 0 and feat.start - 1 - up < 0) else up
                 offset_d = feat.start - 1 if (feat.strand < 0 and feat.start - 1 - down < 0) else down
@@ -142,6 +154,9 @@ def iter_gene_clusters(strains, table, genome_data, up, down, down_start_codon, 
                         seq_start, seq_end = feat.end - offset_d, feat.end + offset
                 gene_sequences[strain].append(Seqinfo(seq, seq.translate(_COMP), feat.id, feat.chromosome,
                                                       seq_start, seq_end, feat.strand, offset))
-        for strain in sorted(s for s, g in zip(strains, cells) if g is None):
+        # input.py:373 `absent = strains.difference(present)`: pandas sorts the difference -- except when `present` is
+        # empty (a row with no gene at all), where Index.difference returns the index as it is: table order
+        absent = [s for s, g in zip(strains, cells) if g is None]
+        for strain in (sorted(absent) if len(absent) < len(strains) else absent):
             gene_sequences[strain] = []
         yield gene_sequences, idx, clusterpresab

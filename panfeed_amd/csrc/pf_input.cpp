@@ -125,7 +125,8 @@ void parse_fasta(const char* p, const char* end, Genome& g) {
     }
 }
 
-// Python int(): optional surrounding whitespace, sign, digits (underscores and other bases not handled -> error)
+// Python int(str): optional surrounding whitespace, a sign, decimal digits with single underscores between them
+// ("1_0" is 10; "_1", "1_", "1__0" are errors); other bases and non-ASCII digits are not handled -> error
 bool py_int(const std::string& s, long long* out) {
     size_t a = 0, b = s.size();
     while (a < b && is_space(s[a])) a++;
@@ -135,12 +136,37 @@ bool py_int(const std::string& s, long long* out) {
     if (s[a] == '+' || s[a] == '-') { neg = s[a] == '-'; a++; }
     if (a == b) return false;
     long long v = 0;
+    bool prev_digit = false;
     for (size_t i = a; i < b; i++) {
+        if (s[i] == '_') {
+            if (!prev_digit || i + 1 == b) return false;
+            prev_digit = false;
+            continue;
+        }
         if (s[i] < '0' || s[i] > '9') return false;
         v = v * 10 + (s[i] - '0');
+        prev_digit = true;
     }
     *out = neg ? -v : v;
     return true;
+}
+
+// repr() of a str, as it appears in int()'s ValueError text: single quotes (double when the text holds ' and no "),
+// backslash escapes for \ \t \n \r and the quote, \xNN for other control bytes
+std::string py_repr(const std::string& s) {
+    const bool dq = s.find('\'') != std::string::npos && s.find('"') == std::string::npos;
+    const char q = dq ? '"' : '\'';
+    std::string r(1, q);
+    for (unsigned char c : s) {
+        if (c == (unsigned char)q || c == '\\') { r += '\\'; r += (char)c; }
+        else if (c == '\t') r += "\\t";
+        else if (c == '\n') r += "\\n";
+        else if (c == '\r') r += "\\r";
+        else if (c < 0x20 || c == 0x7f) { char b[8]; snprintf(b, sizeof b, "\\x%02x", c); r += b; }
+        else r += (char)c;
+    }
+    r += q;
+    return r;
 }
 
 // input.py:274-332 (feature_types = {'CDS'}).  Fields are looked at where they lie in the file's text: a line becomes
@@ -181,8 +207,12 @@ void parse_gff(const std::string& text, const std::string& file_name, Genome& g)
         if (!(fe[2] - fb[2] == 3 && memcmp(fb[2], "CDS", 3) == 0)) continue;      // input.py:300-301
         if (nf < 9) { warn("list index out of range"); continue; }
         long long st, en;
-        if (!py_int(std::string(fb[3], fe[3]), &st) || !py_int(std::string(fb[4], fe[4]), &en)) {
-            warn("invalid literal for int() with base 10"); continue;
+        {
+            const std::string f3(fb[3], fe[3]), f4(fb[4], fe[4]);
+            const bool ok3 = py_int(f3, &st);
+            if (!ok3 || !py_int(f4, &en)) {           // ValueError text of int(entries[3]) / int(entries[4]), input.py:304-305
+                warn(("invalid literal for int() with base 10: " + py_repr(ok3 ? f4 : f3)).c_str()); continue;
+            }
         }
         const int strand = (fe[6] - fb[6] == 1 && *fb[6] == '+') ? 1 : -1;       // input.py:309-312
         bool have = false;
@@ -310,7 +340,10 @@ void build_row(const pf_pangenome* P, size_t row, RowOut& R) {
     {
         std::vector<uint32_t> absent;
         for (size_t s = 0; s < S; s++) if (cells[s].empty()) absent.push_back((uint32_t)s);
-        std::sort(absent.begin(), absent.end(), [&](uint32_t a, uint32_t b) { return P->sorted_pos[a] < P->sorted_pos[b]; });
+        // input.py:373 `strains.difference(present)`: sorted by pandas -- unless `present` is empty (a row without any
+        // gene), where Index.difference hands the index back as it is, in table order (tests/golden/n1: grp_none)
+        if (absent.size() < S)
+            std::sort(absent.begin(), absent.end(), [&](uint32_t a, uint32_t b) { return P->sorted_pos[a] < P->sorted_pos[b]; });
         dict.insert(dict.end(), absent.begin(), absent.end());      // input.py:465-466
     }
     // column of each dict strain in sorted(cluster.keys())  (panfeed.py:47-49)

@@ -59,7 +59,7 @@ class Pangenome:
 
     def __init__(self, presence_absence, gffdir, fastadir=None, upstream=0, downstream=0,
                  downstream_start_codon=False, targets=(), genes=None, genome_names=None, gff_paths=None,
-                 fasta_paths=None):
+                 fasta_paths=None, raise_missing=False):
         self.L = _lib.load()
         if genome_names is None:
             names, _with_fa, gffs, fastas = what_are_my_inputfiles(gffdir, fastadir)
@@ -78,6 +78,7 @@ class Pangenome:
         o.fasta_paths = self._keep[2] if any(p is not None for p in fasta_paths) else None
         o.upstream, o.downstream = int(upstream), int(downstream)
         o.downstream_start_codon = int(bool(downstream_start_codon))
+        o.raise_missing = int(bool(raise_missing))      # input.py:345, 399, 409: a KeyError instead of a warning
         o.target_strains, o.n_targets = self._keep[3], len(self.targets)
         if genes is not None:
             o.gene_list, o.n_genes = self._keep[4], len(genes)

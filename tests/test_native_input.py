@@ -1,6 +1,11 @@
-"""Row N1: the native reader (csrc/pf_input.cpp) against the Python restatement of
-/root/reference/panfeed/input.py:274-468 (oracle/input_restatement.py) on a synthetic on-disk pangenome.
-PARITY UNPINNED at the pyfaidx boundary -- both sides restate the same reading of input.py."""
+"""Row N1: the native reader (csrc/pf_input.cpp) and the Python restatement of
+/root/reference/panfeed/input.py:274-468 (oracle/input_restatement.py), (1) both against tests/golden/n1.json.gz --
+what the reference's OWN parse_gff / prep_data_n_fasta / set_input_output / iter_gene_clusters yielded in the build
+container with a declared double of pyfaidx.Fasta (tools/gen_golden_n1.py) -- and (2) against each other on synthetic
+on-disk pangenomes the goldens do not cover.  PARITY UNPINNED only for the double's five operations (contig lookup,
+slice, reverse complement, reversal, str): see DESIGN.md."""
+import gzip
+import json
 import os
 
 import numpy as np
@@ -222,3 +227,82 @@ def test_reader_fuzz_against_restatement(tmp_path, seed):
         for s in g:
             assert g[s] == e[s], (gi, s)
     assert [x for x in nlog.strip().split("\n") if x] == log
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the reference's own reader code, run in the build container (tools/gen_golden_n1.py)
+_N1 = json.load(gzip.open(os.path.join(os.path.dirname(__file__), "golden", "n1.json.gz"), "rt"))
+_N1_CASES = {c["name"]: c for c in _N1["cases"]}
+
+
+def _n1_setup(case, tmp_path):
+    root = str(tmp_path)
+    for rel, text in _N1["pangenomes"][case["pangenome"]].items():
+        p = os.path.join(root, rel)
+        os.makedirs(os.path.dirname(p), exist_ok=True)
+        with open(p, "w", newline="") as fh:
+            fh.write(text)
+    e = case["expect"]
+    # (set_input_output's "No target strains provided" belongs to the CLI surface, not to the reader)
+    warnings = [w.replace("{DIR}", root) for w in e["warnings"] if w != "No target strains provided"]
+    gffdir = os.path.join(root, "gffs")
+    return root, gffdir, (gffdir if case["opts"]["fasta_dir"] else None), warnings
+
+
+def _as_json(records):
+    return [{"idx": idx, "presab": [int(x) for x in presab],
+             "strains": [[nm, [[s.sequence, s.compsequence, s.id, s.chromosome, int(s.start), int(s.end), int(s.strand),
+                                int(s.offset)] for s in seqs]] for nm, seqs in gs.items()]}
+            for gs, idx, presab in records]
+
+
+@pytest.mark.parametrize("name", sorted(_N1_CASES))
+def test_restatement_equals_reference_goldens(name, tmp_path):
+    case = _N1_CASES[name]
+    o, e = case["opts"], case["expect"]
+    root, gffdir, fastadir, warnings = _n1_setup(case, tmp_path)
+    names, with_fa, gffs, fastas = ni.what_are_my_inputfiles(gffdir, fastadir)
+    assert names == e["filelist"] and with_fa == e["fastalist"]
+    strains, table = ir.load_table(os.path.join(root, "gene_presence_absence.csv"))
+    assert strains == e["strains"]
+    log = []
+    data = ir.load_genomes(names, [gffs[n] for n in names], [fastas.get(n) for n in names], log=log)
+    feats = {g: {k: [f.id, f.chromosome, f.start, f.end, f.strand] for k, f in data[g][1].items()} for g in names}
+    assert feats == e["features"]                       # parse_gff, input.py:274-332 (the last field keeps its newline)
+    got, raised = [], None
+    try:
+        for rec in ir.iter_gene_clusters(strains, table, data, o["up"], o["down"], o["dsc"],
+                                         gene_list=set(o["genes"]) if o["genes"] is not None else None, log=log,
+                                         raise_missing=o["raise_missing"]):
+            got.append(rec)
+    except KeyError as ex:
+        raised = ex.args[0]
+    assert raised == e["raises"]
+    assert _as_json(got) == e["records"]
+    assert log == warnings
+
+
+@pytest.mark.parametrize("name", sorted(_N1_CASES))
+def test_native_reader_equals_reference_goldens(name, tmp_path):
+    from panfeed_amd._lib import PanfeedHipError
+    case = _N1_CASES[name]
+    o, e = case["opts"], case["expect"]
+    root, gffdir, fastadir, warnings = _n1_setup(case, tmp_path)
+    got, raised, nlog = [], None, ""
+    try:
+        with ni.Pangenome(os.path.join(root, "gene_presence_absence.csv"), gffdir, fastadir, o["up"], o["down"], o["dsc"],
+                          targets=o["targets"] or (), genes=o["genes"], raise_missing=o["raise_missing"]) as pg:
+            assert pg.strains == e["strains"] and pg.sorted_strains == sorted(e["strains"])
+            try:
+                for rec in pg.records(1):               # one row per call: rows before a raising one are yielded, as the generator does
+                    got.append(rec)
+            finally:
+                nlog = pg.take_log()
+    except PanfeedHipError as ex:
+        raised = str(ex)
+    if e["raises"] is None:
+        assert raised is None
+        assert [x for x in nlog.split("\n") if x] == [x for w in warnings for x in w.split("\n") if x]
+    else:
+        assert raised is not None and e["raises"] in raised
+    assert _as_json(got) == e["records"]
