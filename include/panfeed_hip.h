@@ -164,6 +164,8 @@ typedef struct {
     float finish_ms;   /* finish_kernel (fused rows+emit of single-item deduplicated clusters) */
     uint32_t n_wide_clusters;  /* clusters that went through the wide dedup class (more than 64 distinct sequences, ...) */
     uint32_t n_binned_clusters;/* clusters whose windows were sorted by key partition before the scan, retries included */
+    uint32_t n_scratch_grown;  /* times the context re-made its scratch for a cluster of more work items than max_items (since pf_create) */
+    uint32_t n_device_planned; /* clusters whose work items were laid out on the device (no host round trip before their scan) */
 } pf_timing;
 
 const char* pf_last_error(void);
@@ -233,6 +235,10 @@ int pf_merge_patterns_padded(pf_ctx* ctx, const void* d_gathered, uint64_t world
 int pf_result_checksum(pf_ctx* ctx, uint64_t out[3]);
 /* Number of patterns in the run-global set after the last pf_submit. */
 int pf_pattern_count(pf_ctx* ctx, uint64_t* n);
+/* Test hook: pattern tables of more than max_slots slots are refused as if the device were out of memory (0: no
+ * limit) -- the growth paths of the reference's unbounded `patterns` set (panfeed.py:146-150) have failure branches
+ * that a 288 GB device never takes on its own. */
+int pf_debug_limit_pattern_slots(pf_ctx* ctx, uint64_t max_slots);
 
 /* Device buffers for callers that keep batches resident (bench.py, tests): plain hipMalloc /
  * hipMemcpy / hipFree on the context's device. */

@@ -122,7 +122,8 @@ class Timing(C.Structure):
                 ("scan_launches", C.c_uint32), ("n_items", C.c_uint32), ("n_retried", C.c_uint32),
                 ("n_dedup_clusters", C.c_uint32), ("scan_packed_bytes", C.c_uint64),
                 ("dedup_ms", C.c_float), ("patrows_ms", C.c_float), ("md5_ms", C.c_float), ("finish_ms", C.c_float),
-                ("n_wide_clusters", C.c_uint32), ("n_binned_clusters", C.c_uint32)]
+                ("n_wide_clusters", C.c_uint32), ("n_binned_clusters", C.c_uint32),
+                ("n_scratch_grown", C.c_uint32), ("n_device_planned", C.c_uint32)]
 
 FLAG_NO_DEDUP = 1
 FLAG_NO_UNIT_DEDUP = 2
@@ -132,7 +133,7 @@ FLAG_NO_KEY_BINNING = 4
 # every symbol include/panfeed_hip.h declares
 EXPORTS = ["pf_last_error", "pf_version", "pf_device_count", "pf_create", "pf_destroy", "pf_reset_patterns",
            "pf_submit", "pf_fetch", "pf_get_timing", "pf_export_patterns", "pf_export_patterns_dev",
-           "pf_merge_patterns", "pf_merge_patterns_padded", "pf_pattern_count", "pf_result_checksum", "pf_dev_alloc", "pf_dev_free",
+           "pf_merge_patterns", "pf_merge_patterns_padded", "pf_pattern_count", "pf_debug_limit_pattern_slots", "pf_result_checksum", "pf_dev_alloc", "pf_dev_free",
            "pf_dev_upload", "pf_dev_download", "pf_synth_expand", "pf_pack_acgt", "pf_b64_digest",
            "pf_render_kmers_to_hashes", "pf_render_hashes_to_patterns", "pf_render_kmers_tsv", "pf_free_text",
            "pf_pack_records", "pf_packed_view", "pf_packed_free",
@@ -181,6 +182,7 @@ def load():
                                      C.POINTER(C.POINTER(C.c_uint64))]
     L.pf_export_patterns_dev.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
     L.pf_pattern_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.pf_debug_limit_pattern_slots.argtypes = [C.c_void_p, C.c_uint64]
     L.pf_result_checksum.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.pf_merge_patterns_padded.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64,
                                            C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)]

@@ -141,6 +141,9 @@ struct pf_ctx {
     uint32_t n_passes = 0;                 // arenas the last pf_submit used (arenas[] itself only ever grows)
     DevBuf rp_order, rp_rlen, rp_rowoff;   // pf_render_pattern_rows: the id list, row lengths, row offsets
     uint32_t n_grown = 0;                  // times the pattern table / pool were enlarged
+    uint32_t n_scratch_grown = 0;          // times the scratch slices were re-made for a cluster of more items than max_items
+    uint64_t pt_slot_limit = 0;            // test hook (pf_debug_limit_pattern_slots): allocations above it fail as if out of memory
+    uint32_t pregrow_failed_pool = 0;      // pool size at which growing ahead of need failed: not tried again at this size
     bool pt_stale = false;                 // a batch failed and its patterns could not be dropped (growth failed): reset first
     DevBuf mg_lo, mg_cnt;   // pf_merge_patterns scratch table ([cap][4] words) and its counter
     // the small per-pass arrays: one device block + its pinned host mirror, two of each because the two halves of a
@@ -274,6 +277,9 @@ struct PatternBufs {
     void release() { lo.release(); val.release(); first.release(); bits.release(); nan.release(); n.release(); md5.release(); b64.release(); }
 };
 int alloc_pattern_bufs(pf_ctx* c, uint64_t slots, bool with_b64, PatternBufs& pb) {
+    if (c->pt_slot_limit && slots > c->pt_slot_limit)
+        return fail(PF_ERR_OOM, "pattern table of %llu slots refused (limit %llu set by pf_debug_limit_pattern_slots)",
+                    (unsigned long long)slots, (unsigned long long)c->pt_slot_limit);
     pb.cap = slots;
     pb.pool = (uint32_t)std::min<uint64_t>(slots / 2, 0x7FFFFFF0ull);
     const size_t W = c->W, pool = pb.pool;
@@ -357,6 +363,52 @@ int grow_patterns(pf_ctx* c, uint64_t min_pool) {
     HIPCHK(hipMemcpy(c->pt_counters.p, cnt, 16, hipMemcpyHostToDevice));
     c->b64_done = std::min(c->b64_done, keep);
     c->n_grown++;
+    return PF_OK;
+}
+
+// bytes of scratch one work item (cluster x key partition) keeps while its sub-batch is in flight
+uint64_t slice_bytes(const pf_ctx* c) {
+    return (uint64_t)c->NS * (8ull * c->KW + 4 + 4ull * c->W + 16 + 8 + 4 + 4 + 4 + 4) + (uint64_t)pf::DENSE_WORDS_BIG * 24 +
+           (uint64_t)pf::DEDUP_MROWS * 4 + 64;
+}
+// the scratch slices of `items` work items (DevBuf::ensure: buffers that are large enough stay)
+int alloc_scratch(pf_ctx* c, uint32_t items) {
+    const size_t NS = c->NS, S = items, W = c->W;
+    PFCHK(c->tab_key.ensure(S * NS * 8 * c->KW)); PFCHK(c->tab_ord.ensure(S * NS * 4));
+    PFCHK(c->chunkbits.ensure(S * NS * W * 4)); PFCHK(c->chunkmask.ensure(S * 8 * 4));
+    PFCHK(c->slot_hash.ensure(S * NS * 16)); PFCHK(c->sorted_pair.ensure(S * NS * 8));
+    PFCHK(c->kept_prefix.ensure(S * (NS + 1) * 4));
+    PFCHK(c->bm4.ensure(S * pf::DENSE_WORDS_BIG * 16)); PFCHK(c->bm2.ensure(S * pf::DENSE_WORDS_BIG * 8));
+    PFCHK(c->mrows.ensure(S * pf::DEDUP_MROWS * 4)); PFCHK(c->slot_out.ensure(S * NS * 4));
+    PFCHK(c->cmask_lo.ensure(S * NS * 4)); PFCHK(c->cmask_hi.ensure(S * NS * 4));
+    return PF_OK;
+}
+// A cluster asks for more work items than a sub-batch holds (a very divergent or very wide cluster; an overflow retry
+// multiplies its key partitions): the scratch is re-made for `need` items -- when that fits half of the device memory
+// that is free once the old scratch is gone -- instead of failing the run.  Nothing may be in flight: the caller's
+// earlier passes keep their results in the arenas, not in the scratch.
+int grow_scratch(pf_ctx* c, uint32_t need) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    const uint64_t sb = slice_bytes(c);
+    const uint64_t have = (uint64_t)c->max_items * sb;
+    uint64_t want = std::max<uint64_t>(need, std::min<uint64_t>(2ull * c->max_items, 65536));
+    if (want * sb > (free_b + have) / 2) want = need;
+    if (want * sb > (free_b + have) / 2)
+        return fail(PF_ERR_CAPACITY, "a cluster needs %u work items (%.1f GB of scratch); %.1f GB of device memory are free",
+                    need, (double)need * sb / 1e9, (double)(free_b + have) / 1e9);
+    DevBuf* bufs[] = {&c->tab_key, &c->tab_ord, &c->chunkbits, &c->chunkmask, &c->slot_hash, &c->sorted_pair, &c->kept_prefix,
+                      &c->bm4, &c->bm2, &c->mrows, &c->slot_out, &c->cmask_lo, &c->cmask_hi};
+    for (DevBuf* b : bufs) b->release();          // (freed first: old and new need not fit side by side)
+    const int rc = alloc_scratch(c, (uint32_t)want);
+    if (rc != PF_OK) {                            // back to what it was; if even that fails the context is unusable
+        for (DevBuf* b : bufs) b->release();
+        if (alloc_scratch(c, c->max_items) != PF_OK) c->max_items = 0;
+        return rc;
+    }
+    c->max_items = (uint32_t)want;
+    c->n_scratch_grown++;
     return PF_OK;
 }
 
@@ -526,9 +578,7 @@ int pf_create(pf_ctx** out, int device, const pf_opts* o) {
         // work items of one launch = scratch slices resident at once; keep them within half of the free HBM
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b) {
-            const uint64_t slice_bytes = (uint64_t)c->NS * (8ull * c->KW + 4 + 4ull * c->W + 16 + 8 + 4 + 4 + 4 + 4) +
-                                         (uint64_t)pf::DENSE_WORDS_BIG * 24 + (uint64_t)pf::DEDUP_MROWS * 4 + 64;
-            const uint64_t fit = (free_b / 2) / slice_bytes;
+            const uint64_t fit = (free_b / 2) / slice_bytes(c);
             if (c->max_items > fit) c->max_items = (uint32_t)std::max<uint64_t>(fit, 64);
         }
     }
@@ -557,16 +607,7 @@ int pf_create(pf_ctx** out, int device, const pf_opts* o) {
         while (p2 < cap) p2 <<= 1;
         if (!guard(alloc_patterns(c, p2))) break;
         if (!guard(reset_patterns(c))) break;
-        // scratch slices
-        const size_t NS = c->NS, S = c->max_items, W = c->W;
-        if (!guard(c->tab_key.ensure(S * NS * 8 * c->KW)) || !guard(c->tab_ord.ensure(S * NS * 4)) ||
-            !guard(c->chunkbits.ensure(S * NS * W * 4)) || !guard(c->chunkmask.ensure(S * 8 * 4)) ||
-            !guard(c->slot_hash.ensure(S * NS * 16)) || !guard(c->sorted_pair.ensure(S * NS * 8)) ||
-            !guard(c->kept_prefix.ensure(S * (NS + 1) * 4)) || !guard(c->cursor.ensure(64)) ||
-            !guard(c->bm4.ensure(S * pf::DENSE_WORDS_BIG * 16)) || !guard(c->bm2.ensure(S * pf::DENSE_WORDS_BIG * 8)) ||
-            !guard(c->mrows.ensure(S * pf::DEDUP_MROWS * 4)) || !guard(c->slot_out.ensure(S * NS * 4)) ||
-            !guard(c->cmask_lo.ensure(S * NS * 4)) || !guard(c->cmask_hi.ensure(S * NS * 4)))
-            break;
+        if (!guard(c->cursor.ensure(64)) || !guard(alloc_scratch(c, c->max_items))) break;
         e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { rc = fail(PF_ERR_HIP, "pf_create sync: %s", hipGetErrorString(e)); break; }
     } while (0);
@@ -1102,8 +1143,11 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             }
             const uint32_t nex_items = fused ? 0 : (nex + lim_full - 1) / lim_full;
             const uint32_t nit = np + nex_items;
-            if (nit > c->max_items)
-                return fail(PF_ERR_CAPACITY, "cluster %u needs %u work items; raise max_items (%u)", ci, nit, c->max_items);
+            if (nit > c->max_items) {
+                if (c->max_items == 0) return fail(PF_ERR_STATE, "the context lost its scratch in a failed enlargement");
+                // (sub-batches already built for this pass hold at most the old max_items items each: still valid)
+                PFCHK(grow_scratch(c, nit));
+            }
             const uint64_t qn = rec[ci].vinst * mult;          // entries of the cluster's queue at most (its view's windows)
             const uint32_t vch = (rec[ci].vnstr + 31) / 32;
             const bool binned = !(c->o.flags & PF_FLAG_NO_KEY_BINNING) && np >= BIN_MIN_PARTS && KW <= 2 && rec[ci].mode != 0 &&
@@ -1628,25 +1672,43 @@ int pf_submit(pf_ctx* c, const pf_batch* b, pf_result* counters) {
     } else if (c->pt_stale) {
         return fail(PF_ERR_STATE, "the pattern table holds entries of a batch that failed while it was being enlarged; "
                                   "pf_reset_patterns (a new run) first");
-    } else if ((uint64_t)c->n_patterns * 2 > c->pt.pool) {
+    } else if ((uint64_t)c->n_patterns * 2 > c->pt.pool && c->pregrow_failed_pool != c->pt.pool) {
         // ahead of need: a re-run costs a whole batch.  No batch has failed here, so a growth that does not succeed
-        // (out of memory with both tables resident) leaves a table that is whole: carry on with it.
+        // (out of memory with both tables resident) leaves a table that is whole: carry on with it -- and do not try
+        // again at this pool size (every try is an allocation, a fill and a free of the larger table): the next
+        // growth is the one a batch that really runs out of ids asks for.
         const int rc = grow_patterns(c, (uint64_t)c->n_patterns * 2);
-        if (rc != PF_OK && rc != PF_ERR_OOM) return rc;
+        if (rc == PF_ERR_OOM) { c->pregrow_failed_pool = c->pt.pool; g_err.clear(); }
+        else if (rc != PF_OK) return rc;
     }
+    const uint64_t submits0 = c->n_submits;
     for (int attempt = 0;; attempt++) {
         uint64_t need = 0;
         const int rc = submit_once(c, b, gth, counters, &need, attempt > 0);
         if (rc != PF_RETRY_PATTERNS) return rc;
         int rg = attempt >= 8 ? fail(PF_ERR_CAPACITY, "pattern table still too small after %d enlargements", attempt)
                               : grow_patterns(c, std::max<uint64_t>(need, (uint64_t)c->pt.pool + 1));
-        if (rg != PF_OK) { c->pt_stale = true; return rg; }     // the failed batch's patterns are still in the table
+        if (rg != PF_OK) {
+            // the failed batch's patterns are still in the table; the batch itself does not count as submitted
+            c->pt_stale = true;
+            c->n_submits = submits0;
+            c->timing = pf_timing{};
+            return rg;
+        }
     }
+}
+
+int pf_debug_limit_pattern_slots(pf_ctx* c, uint64_t max_slots) {
+    if (!c) return fail(PF_ERR_ARG, "null context");
+    c->pt_slot_limit = max_slots;
+    c->pregrow_failed_pool = 0;
+    return PF_OK;
 }
 
 int pf_get_timing(pf_ctx* c, pf_timing* t) {
     if (!c || !t) return fail(PF_ERR_ARG, "null argument");
     *t = c->timing;
+    t->n_scratch_grown = c->n_scratch_grown;
     return PF_OK;
 }
 

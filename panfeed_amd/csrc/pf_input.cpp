@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <mutex>
 #include <sstream>
 #include <string>
 #include <thread>
@@ -437,11 +438,29 @@ void build_row(const pf_pangenome* P, size_t row, RowOut& R) {
 }
 }  // namespace
 
+// The closing threads stay joinable: the next asynchronous close, the next pf_pangenome_open and the process's exit join
+// what is still running (a detached thread could be freeing memory while the interpreter goes away, and nobody could
+// wait for it).  A thread that cannot be started (EAGAIN) makes this the synchronous close: nothing crosses the C ABI.
+namespace {
+struct Closers {
+    std::mutex mu;
+    std::vector<std::thread> th;
+    void join_all() {
+        std::vector<std::thread> mine;
+        { std::lock_guard<std::mutex> g(mu); mine.swap(th); }
+        for (auto& t : mine) if (t.joinable()) t.join();
+    }
+    ~Closers() { join_all(); }
+};
+Closers& closers() { static Closers c; return c; }
+}  // namespace
+
 extern "C" {
 
 int pf_pangenome_open(const pf_pangenome_opts* o, pf_pangenome** out) {
     if (!o || !out || !o->presence_absence_csv) return in_fail(PF_ERR_ARG, "pf_pangenome_open: null argument");
     *out = nullptr;
+    closers().join_all();              // a reader still being torn down in the background: its memory first
     std::string csv;
     if (!read_file(o->presence_absence_csv, csv)) return in_fail(PF_ERR_ARG, std::string("cannot read ") + o->presence_absence_csv);
     pf_pangenome* P = new pf_pangenome();
@@ -618,7 +637,14 @@ void pf_pangenome_close(pf_pangenome* P) {
 // that are done with the run; pf_pangenome_close is the one that has returned everything when it returns.
 void pf_pangenome_close_async(pf_pangenome* P) {
     if (!P) return;
-    std::thread([P] { pf_pangenome_close(P); }).detach();
+    closers().join_all();
+    try {
+        std::thread t([P] { pf_pangenome_close(P); });
+        std::lock_guard<std::mutex> g(closers().mu);
+        closers().th.push_back(std::move(t));
+    } catch (...) {
+        pf_pangenome_close(P);
+    }
 }
 
 int pf_pangenome_info(pf_pangenome* P, pf_pangenome_info_t* info) {

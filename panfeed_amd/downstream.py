@@ -132,8 +132,15 @@ def _associations(args, index_name=None):
     return a, [str(x) for x in a.index.unique()]
 
 
+_NAN_KEY = float("nan")      # ONE object for every NaN a column holds (tolist() makes a new one per cell, and nan != nan)
+
+
+def _key(v):
+    return _NAN_KEY if isinstance(v, float) and v != v else v
+
+
 def _ordered_unique(series):
-    return list(dict.fromkeys(series.tolist()))
+    return list(dict.fromkeys(_key(v) for v in series.tolist()))
 
 
 def _first_fields(rows):
@@ -173,14 +180,15 @@ def get_kmers(argv=None, out=None):
     # (get_kmers.py:131-134): a cluster named '007' or '1e3' parses as a number whose str() is not the file's bytes.  The
     # keys given to the filter are therefore the literal fields of the kept kmers_to_hashes rows, grouped by the value
     # pandas made of them (row i of `h` is line i of `rows`).
+    # (a value pandas read as NaN -- numeric cluster ids plus an 'NA' -- is a different object at every look: _key)
     literal = {}
     for val, lit in zip(h["cluster"].tolist(), _first_fields(rows)):
-        literal.setdefault(val, {})[lit] = None
+        literal.setdefault(_key(val), {})[lit] = None
     first = True
     b = a.join(h, how="inner") if clusters else None                       # get_kmers.py:136
     for idx in range(0, len(clusters), args.clusters_per_iteration):
         bunch = clusters[idx: idx + args.clusters_per_iteration]
-        fk = RowFilter([lit for c in bunch for lit in literal[c]], first_field=True, device=args.device)
+        fk = RowFilter([lit for c in bunch for lit in literal[_key(c)]], first_field=True, device=args.device)
         try:
             kheader, krows = fk.filter_file(args.kmers)
         finally:

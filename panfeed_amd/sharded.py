@@ -234,7 +234,9 @@ def run_files_sharded(presence_absence, gffdir, output, rank, world, dist=None, 
         pg.set_range(start, stop - start)
         eng = Engine(klength=klength, canon=canon, consider_missing=consider_missing, patfilt=patfilt, maf=maf,
                      multiple_files=multiple_files, max_strains=max(32, (pg.n_strains + 31) // 32 * 32),
-                     stroi=set(targets), device=gpu, max_items=max_items, pattern_capacity=pattern_capacity)
+                     stroi=set(targets), device=gpu,
+                     # the same rule as pipeline.run_files (a cluster that needs more makes the library re-make its scratch)
+                     max_items=max_items or max(512, 2 * int(batch_clusters)), pattern_capacity=pattern_capacity)
         if resident:
             pg.make_resident(eng)
         eng.next_ordinal = start

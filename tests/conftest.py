@@ -34,7 +34,7 @@ def case_records(case):
 
 
 def all_cases():
-    return load_cases("handmade.json.gz") + load_cases("seeded.json.gz")
+    return load_cases("handmade.json.gz") + load_cases("seeded.json.gz") + load_cases("wide.json.gz")
 
 
 def case_ids(cases):

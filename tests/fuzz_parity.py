@@ -52,7 +52,8 @@ for case in range(n_cases):
                     seen[n] += 1
                 break
             except Exception as e:  # noqa: BLE001
-                # a cluster that needs more work items than this tiny setting allows is refused by design
+                # (a cluster that needs more work items than this tiny setting allows makes the context re-make its scratch
+                # since round 4; the retry stays for libraries older than that)
                 if attempt == 0 and "raise max_items" in repr(e):
                     max_items = 8192
                     continue

@@ -53,3 +53,20 @@ def test_binned_clusters_in_several_sub_batches_and_batches():
     assert "".join(o.hashes_to_patterns for o in outs) == ehp
     assert "".join(o.kmers_tsv for o in outs) == ek
     eng.close()
+
+
+def test_scratch_grows_for_a_cluster_of_more_items_than_max_items():
+    """a cluster that needs more work items than the context was created for used to end the run (PF_ERR_CAPACITY "raise
+    max_items"); the scratch is re-made instead, once, and the results are the oracle's"""
+    from panfeed_amd.engine import Engine
+    S, k = 200, 31
+    recs = _records(5, S, first=777, flank=30, mean_len=900, min_len=600, max_len=1200, n_rate=0.0, paralog_rate=0.02,
+                    sub_rate=0.03, mean_alleles=60.0, allele_decay=1.0, allele_model="star")
+    (ek, ekh, ehp), _ = _oracle_texts(recs, klength=k, canon=True)
+    eng = Engine(klength=k, max_strains=S + 24, max_items=3)
+    outs = [eng.run(recs[:2]), eng.run(recs[2:])]
+    t = eng.timing()
+    assert t["n_scratch_grown"] >= 1 and max(o.timing["n_items"] for o in outs) > 3
+    assert "".join(o.kmers_to_hashes for o in outs) == ekh
+    assert "".join(o.hashes_to_patterns for o in outs) == ehp
+    eng.close()

@@ -110,3 +110,23 @@ def test_rowfilter_exact_keys(tmp_path):
     f = RowFilter([], first_field=True)
     assert f.filter_file(str(p))[1] == b""
     f.close()
+
+
+def test_numeric_cluster_ids_with_an_na(tmp_path):
+    """a cluster column pandas reads as float with an NA-like name in it: every NaN cell is a new float object
+    (`tolist()`), so a dict keyed by them missed its own keys (KeyError: nan); the reference's `isin` (get_kmers.py:131-134)
+    neither fails nor drops the rows"""
+    kh = "cluster\tk-mer\thashed_pattern\n" + "".join(f"{c}\t{k}\t{h}\n" for c, k, h in [
+        ("7", "", "H0"), ("7", "ACGTA", "H1"), ("NA", "", "H2"), ("NA", "CCGTA", "H1"), ("12", "GGGTA", "H3"), ("NA", "TTGTA", "H1")])
+    ks = ("cluster\tstrain\tfeature_id\tcontig\tfeature_strand\tcontig_start\tcontig_end\tgene_start\tgene_end\tstrand\tk-mer\n"
+          "7\ts1\tg\tc\t1\t1\t6\t0\t5\t1\tACGTA\nNA\ts1\tg\tc\t1\t9\t14\t0\t5\t1\tCCGTA\n12\ts1\tg\tc\t1\t1\t6\t0\t5\t1\tGGGTA\n")
+    assoc = "variant\tlrt-pvalue\nH1\t0.001\nH3\t0.5\n"
+    (tmp_path / "kh.tsv").write_text(kh)
+    (tmp_path / "ks.tsv").write_text(ks)
+    (tmp_path / "a.tsv").write_text(assoc)
+    got, rc = _run("get_kmers", ["-a", str(tmp_path / "a.tsv"), "-p", str(tmp_path / "kh.tsv"), "-k", str(tmp_path / "ks.tsv"), "-t", "0.01"])
+    assert rc == 0
+    lines = got.splitlines()
+    assert len(lines) == 1 + 3 and sum("ACGTA" in ln for ln in lines) == 1          # H1's three k-mers, the NA rows among them
+    got, rc = _run("get_clusters", ["-a", str(tmp_path / "a.tsv"), "-p", str(tmp_path / "kh.tsv"), "-t", "0.01"])
+    assert rc == 0 and sorted(got.split()) == ["7.0", "nan"]

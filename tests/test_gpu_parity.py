@@ -875,3 +875,40 @@ def test_device_rendered_text_equals_host_rendered(kw):
         if cm:
             assert b"\t\t" in hp or b"\t\n" in hp
     eng.close()
+
+
+def test_pattern_table_growth_that_fails():
+    """the failure branches of the growing pattern table (pf_debug_limit_pattern_slots stands in for a full device):
+    growing AHEAD of need fails -> the run carries on with the table it has and does not try again at that size; a batch
+    that really runs out of ids and cannot grow fails with PF_ERR_OOM, the context then refuses further batches until
+    pf_reset_patterns; with the limit lifted the same context gives the oracle's files again"""
+    from panfeed_amd import _lib, synth
+    from panfeed_amd.engine import Engine
+    cl = synth.generate(150, 40, first=5, mean_len=200, min_len=60, max_len=500, n_rate=0.0)
+    recs = [c.record() for c in cl]
+    (ek, ekh, ehp), st = _oracle_texts(recs, klength=21)
+    assert st["patterns"] > 1024
+    eng = Engine(klength=21, max_strains=64, pattern_capacity=1024)      # pool of 512 patterns
+    _lib.check(eng.L.pf_debug_limit_pattern_slots(eng.ctx, 1024))
+    parts = (recs[:6], recs[6:12], recs[12:18], recs[18:])
+    kh = hp = ""
+    failed_at = None
+    for i, part in enumerate(parts):
+        try:
+            o = eng.run(part)
+        except _lib.PanfeedHipError as e:
+            assert e.status == _lib.ERR_OOM and "limit" in str(e)
+            failed_at = i
+            break
+        kh += o.kmers_to_hashes
+        hp += o.hashes_to_patterns
+    assert failed_at is not None and failed_at >= 1       # the first batches fit; growth ahead of need failed silently
+    assert ekh.startswith(kh) and ehp.startswith(hp)      # what was written before the failure is the oracle's
+    with pytest.raises(_lib.PanfeedHipError, match="pf_reset_patterns"):
+        eng.run(parts[failed_at])
+    _lib.check(eng.L.pf_debug_limit_pattern_slots(eng.ctx, 0))
+    _lib.check(eng.L.pf_reset_patterns(eng.ctx))
+    eng.next_ordinal = 0
+    outs = [eng.run(part) for part in parts]
+    assert "".join(o.kmers_to_hashes for o in outs) == ekh and "".join(o.hashes_to_patterns for o in outs) == ehp
+    eng.close()

@@ -192,10 +192,50 @@ def seeded():
     return cases
 
 
+def wide():
+    """round 4: the reference itself on the shapes that were pinned only through the oracle before -- 130 and 260 samples
+    (5 and 9 column chunks of 32), keys of three and four 63-bit words (k = 65, 95, 126), and clusters of more than 32 /
+    more than 64 distinct sequences (the two-word and the wide allele-mask paths, several key partitions at the
+    library's table size)"""
+    cases = []
+
+    def recs(n_clusters, n_samples, first=0, shuffle=None, **kw):
+        cl = synth.generate(n_clusters, n_samples, first=first, shuffle_columns=shuffle, **kw)
+        return [c.record() for c in cl], cl[0].names
+
+    mid = dict(mean_len=260, min_len=140, max_len=500, n_rate=0.01, paralog_rate=0.03)
+    r, names = recs(3, 130, first=500, shuffle=13, **mid)
+    tg = [names[2], names[77]]
+    for nm, kw in [("wide130_k31", dict(stroi=tg)),
+                   ("wide130_k65", dict(stroi=tg, klength=65)),
+                   ("wide130_k95_noncanon", dict(stroi=None, klength=95, canon=False)),
+                   ("wide130_k126", dict(stroi=tg, klength=126)),
+                   ("wide130_k126_missing_nofilter", dict(stroi=None, klength=126, consider_missing=True, patfilt=False, maf=0.0))]:
+        cases.append(make_case(nm, r, names, **kw))
+    r, names = recs(2, 260, first=600, shuffle=17, **mid)
+    for nm, kw in [("wide260_k31", dict(stroi=[names[200]])),
+                   ("wide260_k65_maf005", dict(stroi=None, klength=65, maf=0.05)),
+                   ("wide260_k95", dict(stroi=None, klength=95)),
+                   ("wide260_k126_noncanon", dict(stroi=None, klength=126, canon=False))]:
+        cases.append(make_case(nm, r, names, **kw))
+    # many distinct sequences per cluster: ~45 (two mask words) and ~90 (the wide class), related and SURVEY's alleles
+    many = dict(mean_len=420, min_len=300, max_len=600, n_rate=0.0, paralog_rate=0.02, allele_decay=1.0)
+    r, names = recs(2, 130, first=700, flank=20, mean_alleles=45.0, allele_model="tree", **many)
+    cases.append(make_case("alleles45_tree_k31", r, names, stroi=[names[5]]))
+    cases.append(make_case("alleles45_tree_k65", r, names, stroi=None, klength=65))
+    r, names = recs(2, 260, first=800, flank=20, mean_alleles=90.0, allele_model="star", sub_rate=0.02, **many)
+    cases.append(make_case("alleles90_star_k31", r, names, stroi=None))
+    cases.append(make_case("alleles90_star_k31_missing", r, names, stroi=None, consider_missing=True))
+    r, names = recs(2, 260, first=900, flank=20, mean_alleles=90.0, allele_model="tree", **many)
+    cases.append(make_case("alleles90_tree_k31", r, names, stroi=[names[100]]))
+    cases.append(make_case("alleles90_tree_k95", r, names, stroi=None, klength=95))
+    return cases
+
+
 def main():
     outdir = os.path.join(REPO, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
-    for fname, cases in [("handmade.json.gz", handmade()), ("seeded.json.gz", seeded())]:
+    for fname, cases in [("handmade.json.gz", handmade()), ("seeded.json.gz", seeded()), ("wide.json.gz", wide())]:
         path = os.path.join(outdir, fname)
         with gzip.GzipFile(path, "wb", mtime=0) as fh:
             fh.write(json.dumps({"generator": "tools/gen_golden.py", "cases": cases},
