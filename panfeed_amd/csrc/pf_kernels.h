@@ -2588,8 +2588,15 @@ struct BitmapMergeParams {
     uint4* bm4;                        // [slice][DENSE_WORDS_BIG] {occupied, kept, ordinals before, kept before} per ordinal word
     const uint2* bm2;                  // [slice][DENSE_WORDS_BIG] the items' own {occupied, kept}
 };
-__global__ __launch_bounds__(256) void bitmap_merge_kernel(BitmapMergeParams p) {
-    __shared__ uint32_t wt_o[5], wt_k[5];
+constexpr uint32_t BM_THREADS = 256, BM_WPT = 4, BM_SIB = 64;   // words per thread and round; sibling slices staged at a time
+__global__ __launch_bounds__(BM_THREADS) void bitmap_merge_kernel(BitmapMergeParams p) {
+    // Round 3's form took one word per thread and round and walked the siblings in a loop whose every trip was two
+    // dependent loads (the sibling's slice number, then its word): 2 ni latencies in a row per 256 words, 92 % of the wave
+    // cycles waiting -- 2.6 ms per 2 000 clusters of ten key partitions for 0.75 GB of traffic.  Now the slice numbers are
+    // staged in LDS once, a thread takes BM_WPT words a round and asks for eight siblings' words of all of them before it
+    // looks at any.
+    __shared__ uint32_t wt_o[BM_THREADS / 64 + 1], wt_k[BM_THREADS / 64 + 1];
+    __shared__ uint32_t sib_slice[BM_SIB];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t c = p.sub_cluster[blockIdx.x];
     const uint32_t i0 = p.cluster_item0[blockIdx.x], ni = p.cluster_nitems[blockIdx.x];
@@ -2597,33 +2604,56 @@ __global__ __launch_bounds__(256) void bitmap_merge_kernel(BitmapMergeParams p) 
     const uint32_t dense_words = (p.v_dense[c] + 31) >> 5;
     const size_t g0 = (size_t)p.item_scratch[i0] * DENSE_WORDS_BIG;
     uint32_t run_o = 0, run_k = 0;                       // ordinals / kept ordinals in the words before this round's
-    for (uint32_t w0 = 0; w0 < dense_words; w0 += 256) {
-        const uint32_t w = w0 + tid;
-        uint32_t o = 0, k = 0;
-        if (w < dense_words)
-            for (uint32_t q = 0; q < ni; q++) {
-                const size_t g = (size_t)p.item_scratch[i0 + q] * DENSE_WORDS_BIG + w;
-                const uint2 ok = p.bm2[g];
-                o |= ok.x; k |= ok.y;
+    constexpr uint32_t RW = BM_THREADS * BM_WPT;
+    for (uint32_t w0 = 0; w0 < dense_words; w0 += RW) {
+        // thread t owns words w0 + t * BM_WPT .. + BM_WPT - 1 (consecutive: one 32-byte piece of every sibling's array)
+        const uint32_t wb = w0 + tid * BM_WPT;
+        uint32_t o[BM_WPT], k[BM_WPT];
+#pragma unroll
+        for (uint32_t j = 0; j < BM_WPT; j++) { o[j] = 0; k[j] = 0; }
+        for (uint32_t q0 = 0; q0 < ni; q0 += BM_SIB) {
+            const uint32_t nq = min(ni - q0, BM_SIB);
+            __syncthreads();
+            if (tid < nq) sib_slice[tid] = p.item_scratch[i0 + q0 + tid];
+            __syncthreads();
+            for (uint32_t q = 0; q < nq; q += 8) {
+                uint2 v[8][BM_WPT];
+#pragma unroll
+                for (uint32_t u = 0; u < 8; u++) {
+                    const size_t g = (size_t)sib_slice[min(q + u, nq - 1)] * DENSE_WORDS_BIG;
+#pragma unroll
+                    for (uint32_t j = 0; j < BM_WPT; j++) v[u][j] = p.bm2[g + min(wb + j, dense_words - 1)];
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 8; u++) {
+#pragma unroll
+                    for (uint32_t j = 0; j < BM_WPT; j++)
+                        if (q + u < nq && wb + j < dense_words) { o[j] |= v[u][j].x; k[j] |= v[u][j].y; }
+                }
             }
-        uint32_t xo = __popc(o), xk = __popc(k);
-        const uint32_t so = xo, sk = xk;
+        }
+        uint32_t so = 0, sk = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < BM_WPT; j++) { so += __popc(o[j]); sk += __popc(k[j]); }
+        uint32_t xo = so, xk = sk;
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t yo = __shfl_up(xo, d), yk = __shfl_up(xk, d);
             if ((int)lane >= d) { xo += yo; xk += yk; }
         }
+        __syncthreads();
         if (lane == 63) { wt_o[wave] = xo; wt_k[wave] = xk; }
         __syncthreads();
-        uint32_t bo = run_o, bk = run_k, to = 0, tk = 0;
-        for (uint32_t v = 0; v < 4; v++) {
+        uint32_t bo = run_o + xo - so, bk = run_k + xk - sk, to = 0, tk = 0;
+        for (uint32_t v = 0; v < BM_THREADS / 64; v++) {
             if (v < wave) { bo += wt_o[v]; bk += wt_k[v]; }
             to += wt_o[v]; tk += wt_k[v];
         }
-        if (w < dense_words) {
-            p.bm4[g0 + w] = make_uint4(o, k, bo + xo - so, bk + xk - sk);
+#pragma unroll
+        for (uint32_t j = 0; j < BM_WPT; j++) {
+            if (wb + j < dense_words) p.bm4[g0 + wb + j] = make_uint4(o[j], k[j], bo, bk);
+            bo += __popc(o[j]); bk += __popc(k[j]);
         }
         run_o += to; run_k += tk;
-        __syncthreads();
     }
 }
 

@@ -188,7 +188,9 @@ def get_kmers(argv=None, out=None):
     b = a.join(h, how="inner") if clusters else None                       # get_kmers.py:136
     for idx in range(0, len(clusters), args.clusters_per_iteration):
         bunch = clusters[idx: idx + args.clusters_per_iteration]
-        fk = RowFilter([lit for c in bunch for lit in literal[_key(c)]], first_field=True, device=args.device)
+        # (a NaN among the bunch selects nothing: the reference's `x['cluster'].isin(bunch)`, get_kmers.py:131-134, is False
+        # for a NaN cell when the bunch is a list of the column's unique() values -- such rows are dropped, not matched)
+        fk = RowFilter([lit for c in bunch if c is not _NAN_KEY for lit in literal[_key(c)]], first_field=True, device=args.device)
         try:
             kheader, krows = fk.filter_file(args.kmers)
         finally:
