@@ -102,7 +102,7 @@ struct pf_ctx {
     // SURVEY 8d's: flanks + a share of L) -- see the key-partition estimate
     double reg_n = 0, reg_x = 0, reg_y = 0, reg_xx = 0, reg_xy = 0, reg_yy = 0;
     uint64_t n_submits = 0;
-    std::vector<uint32_t> hs_count;
+    std::vector<uint32_t> hs_count, hs_plan;
     uint32_t n_patterns = 0;       // patterns allocated after the last submit
     uint32_t pid0 = 0;             // first pattern id of the last submit
     // scratch slices
@@ -156,8 +156,14 @@ struct pf_ctx {
     size_t pin_dedup_cap = 0;
     uint64_t* pin_small = nullptr; // pinned scratch: cursor values going up, cursor read-backs of a deferred pass
     static constexpr int MAX_PARTS = 8;
-    UPool upool[MAX_PARTS];
+    UPool upool[2 * MAX_PARTS];            // [2 h]: the device-planned clusters of part h, [2 h + 1]: the host-planned rest
     hipEvent_t ev_part[MAX_PARTS] = {};    // a part's dedup results have arrived in pinned memory
+    // plan_kernel's output per part: item arrays, work lists, unit-view list (one device block), its 40-byte summary in
+    // pinned memory; and the constant item arrays (zeros | ones | 0, 1, 2, ...) every device-planned pass shares
+    struct DPlan { DevBuf block, it_count, out; pf::PlanOut* pin_out = nullptr; uint32_t n = 0; };
+    DPlan dplan[MAX_PARTS];
+    DevBuf dp_const;
+    uint32_t dp_const_n = 0;
     hipEvent_t ev_stage[2] = {nullptr, nullptr};   // a staging slot's upload has left the pinned block
 
     // last batch bookkeeping
@@ -531,6 +537,8 @@ void pf_destroy(pf_ctx* c) {
     for (int i = 0; i < 2; i++) { if (c->stage_pins[i]) (void)hipHostFree(c->stage_pins[i]); c->stage_devs[i].release(); if (c->ev_stage[i]) (void)hipEventDestroy(c->ev_stage[i]); }
     for (auto e : c->ev_part) if (e) (void)hipEventDestroy(e);
 
+    for (auto& d : c->dplan) { d.block.release(); d.it_count.release(); d.out.release(); if (d.pin_out) (void)hipHostFree(d.pin_out); }
+    c->dp_const.release();
     for (auto& u : c->upool) {
         u.word_off.release(); u.len.release(); u.sample.release(); u.ord.release(); u.bits.release(); u.list.release();
         if (u.pin) (void)hipHostFree(u.pin);
@@ -892,6 +900,62 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         dp.k = c->o.klength; dp.W = W; dp.canon = c->o.canon;
         dp.enable = (c->o.flags & PF_FLAG_NO_DEDUP) ? 0u : 1u;
     }
+    // ---- the device plan (plan_kernel): the simple clusters' work items laid out behind the part's dedup, a 40-byte
+    // summary on its way to pinned memory.  The estimate's learned line is what this context knew when the batch came in
+    // (the host's own estimate for the rest of the part reads the same sums: they change at the end of a submit only).
+    const bool use_plan = !(c->o.flags & PF_FLAG_NO_DEVICE_PLAN) && C > 0 && c->max_items < (1u << 22);
+    const double share = 1.0 - std::pow(0.99, (double)c->o.klength) + 0.06;
+    double reg_a = 0.0, reg_b = 0.0, reg_half_sd = 0.0;
+    const bool reg_ready = c->reg_n >= 16;
+    if (reg_ready) {
+        const double n = c->reg_n, den = n * c->reg_xx - c->reg_x * c->reg_x;
+        reg_a = c->reg_y / n;
+        if (den > 1e-6 * n * c->reg_xx) { reg_b = (n * c->reg_xy - c->reg_x * c->reg_y) / den; reg_a = (c->reg_y - reg_b * c->reg_x) / n; }
+        const double ss = std::max(0.0, c->reg_yy - reg_a * c->reg_y - reg_b * c->reg_xy);     // residual sum of squares
+        // (half a residual standard deviation on top: with `room` at 0.9 of the table's limit that left no
+        // cluster of the headline workload, with or without 'N's, to overflow; 0 left 6, 1 to 3 standard
+        // deviations cost 0.5 % to 5 % in surplus partitions -- profiles/r02/partition_margin_experiment.txt)
+        reg_half_sd = 0.5 * std::sqrt(ss / std::max(1.0, n - 2.0));
+    }
+    struct DPtrs { uint32_t *it_cluster, *it_nslots, *w_scan, *w_fin, *w_fin2, *w_fin5, *unit_cluster, *unit_base, *tmp; };
+    auto dplan_ptrs = [&](const pf_ctx::DPlan& dp) {
+        uint32_t* b = dp.block.as<uint32_t>();
+        const size_t n = dp.n;
+        return DPtrs{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n, b + 5 * n, b + 6 * n, b + 7 * n, b + 8 * n};
+    };
+    auto launch_plan = [&](uint32_t h, uint32_t c0, uint32_t c1) -> int {
+        pf_ctx::DPlan& dp = c->dplan[h];
+        dp.n = c1 - c0;
+        PFCHK(dp.block.ensure((size_t)dp.n * 9 * 4));
+        PFCHK(dp.it_count.ensure((size_t)dp.n * 4));
+        PFCHK(dp.out.ensure(sizeof(pf::PlanOut)));
+        if (!dp.pin_out) {
+            hipError_t e = hipHostMalloc((void**)&dp.pin_out, 64, hipHostMallocDefault);
+            if (e != hipSuccess) return fail(PF_ERR_OOM, "hipHostMalloc(64) failed: %s", hipGetErrorString(e));
+        }
+        const DPtrs q = dplan_ptrs(dp);
+        pf::PlanParams pp{};
+        pp.rec = c->cl_rec.as<pf::ClusterRec>(); pp.extra_off = c->extra_off.as<uint32_t>();
+        pp.c0 = c0; pp.c1 = c1; pp.mult = c->o.canon ? 1u : 2u;
+        pp.NS = NS; pp.W = W; pp.max_items = c->max_items; pp.unit_view = (c->o.flags & PF_FLAG_NO_UNIT_DEDUP) ? 0u : 1u;
+        pp.share = share; pp.reg_a = reg_a; pp.reg_b = reg_b; pp.reg_half_sd = reg_half_sd; pp.reg_ready = reg_ready ? 1u : 0u;
+        pp.it_cluster = q.it_cluster; pp.it_nslots = q.it_nslots; pp.w_scan = q.w_scan; pp.w_fin = q.w_fin; pp.w_fin2 = q.w_fin2;
+        pp.w_fin5 = q.w_fin5; pp.unit_cluster = q.unit_cluster; pp.unit_base = q.unit_base; pp.tmp = q.tmp;
+        pp.out = dp.out.as<pf::PlanOut>();
+        hipLaunchKernelGGL(pf::plan_kernel, dim3(1), dim3(pf::PLAN_THREADS), 0, c->stream, pp);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(dp.pin_out, dp.out.p, sizeof(pf::PlanOut), hipMemcpyDeviceToHost, c->stream));
+        return PF_OK;
+    };
+    if (use_plan && C > c->dp_const_n) {
+        // zeros | ones | 0, 1, 2, ...: item_part / extra_first / is_extra / binned, item_nparts / nsib / compact, slice / sib0
+        const uint32_t n = C + C / 4 + 64;
+        std::vector<uint32_t> h(3 * (size_t)n, 0u);
+        for (uint32_t i = 0; i < n; i++) { h[n + i] = 1u; h[2 * (size_t)n + i] = i; }
+        PFCHK(c->dp_const.ensure(h.size() * 4));
+        HIPCHK(hipMemcpy(c->dp_const.p, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+        c->dp_const_n = n;
+    }
     // the dedup of part h and its results on their way to pinned memory (ev_part[h]); all parts are queued up front
     auto launch_dedup_part = [&](uint32_t h) -> int {
         const uint32_t c0 = h ? part_end[h - 1] : 0, c1 = part_end[h], n = c1 - c0;
@@ -906,6 +970,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
                                (const uint32_t*)nullptr,
                                c->v_mode.as<uint32_t>(), c->v_dense.as<uint32_t>(), c->v_nstr.as<uint32_t>(), c->cl_rec.as<pf::ClusterRec>());
             HIPCHK(hipGetLastError());
+            if (use_plan) PFCHK(launch_plan(h, c0, c1));
             HIPCHK(hipMemcpyAsync(rec + c0, c->cl_rec.as<pf::ClusterRec>() + c0, (size_t)n * sizeof(pf::ClusterRec), hipMemcpyDeviceToHost, c->stream));
         }
         HIPCHK(hipEventRecord(c->ev_part[h], c->stream));
@@ -947,7 +1012,6 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
     // Estimate of the distinct windows of D near-identical sequences of average length L = vinst / D: the first
     // contributes all of its windows, every further one the share a 1 % divergence touches (1 - 0.99^k: 27 % of the
     // 31-mers, 40 % of the 51-mers) plus a margin.
-    const double share = 1.0 - std::pow(0.99, (double)c->o.klength) + 0.06;
     // what the host does with a part's dedup results once they have arrived (ev_part[h])
     std::vector<uint32_t> wide_list;
     auto prep_half = [&](int h) -> int {
@@ -981,6 +1045,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             if (rec[i].ninst * mult >= 0xFFFFFFF0ull) return fail(PF_ERR_ARG, "cluster %u has too many k-mer instances", i);
             total_inst += rec[i].ninst * mult;
             c->timing.n_dedup_clusters += rec[i].mode ? 1u : 0u;
+            if (rec[i].pad) continue;          // laid out by plan_kernel: one key partition
             if (rec[i].mode && rec[i].vnstr) {
                 const double D = (double)rec[i].vnstr, L = (double)(rec[i].vinst * mult) / D;
                 const double est = L * (1.0 + share * (D - 1.0));
@@ -993,15 +1058,8 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
                 // Once the context has scanned enough such clusters it knows what a further sequence brings in THIS
                 // pangenome (the line through what it observed, plus a margin) and the first
                 // attempt is sized by that.
-                if (D >= 2.0 && c->reg_n >= 16) {
-                    const double n = c->reg_n, den = n * c->reg_xx - c->reg_x * c->reg_x;
-                    double a = c->reg_y / n, b = 0.0;
-                    if (den > 1e-6 * n * c->reg_xx) { b = (n * c->reg_xy - c->reg_x * c->reg_y) / den; a = (c->reg_y - b * c->reg_x) / n; }
-                    const double ss = std::max(0.0, c->reg_yy - a * c->reg_y - b * c->reg_xy);     // residual sum of squares
-                    // (half a residual standard deviation on top: with `room` at 0.9 of the table's limit that left no
-                    // cluster of the headline workload, with or without 'N's, to overflow; 0 left 6, 1 to 3 standard
-                    // deviations cost 0.5 % to 5 % in surplus partitions -- profiles/r02/partition_margin_experiment.txt)
-                    const double g = std::max(0.0, a + b * L) + 0.5 * std::sqrt(ss / std::max(1.0, n - 2.0));
+                if (D >= 2.0 && reg_ready) {
+                    const double g = std::max(0.0, reg_a + reg_b * L) + reg_half_sd;      // (the line: see launch_plan)
                     const double est2 = L + g * (D - 1.0);
                     // (an estimate never asks for more items than a sub-batch holds: the cluster then starts with what
                     // fits and an overflowing scan says how many partitions it really needs)
@@ -1016,7 +1074,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         // (unit_class_kernel).  A cluster's pieces number at most the units of its plain view: that is its room in
         // this part's pool.
         if (!(c->o.flags & PF_FLAG_NO_UNIT_DEDUP)) {
-            pf_ctx::UPool& up = c->upool[h];
+            pf_ctx::UPool& up = c->upool[2 * h + 1];
             const size_t need_pin = (size_t)(c1 - c0) * 8 + 64;
             if (need_pin > up.pin_cap) {
                 if (up.pin) (void)hipHostFree(up.pin);
@@ -1029,7 +1087,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             uint32_t nu = 0, nsmall = 0;
             uint64_t room = 0;
             uint32_t* lc = up.pin;
-            auto takes = [&](uint32_t i) { return rec[i].mode && rec[i].vnstr >= 2 && rec[i].words && room + rec[i].words / 2 < 0x7FFFFFF0ull; };
+            auto takes = [&](uint32_t i) { return !rec[i].pad && rec[i].mode && rec[i].vnstr >= 2 && rec[i].words && room + rec[i].words / 2 < 0x7FFFFFF0ull; };
             for (uint32_t i = c0; i < c1; i++)
                 if (rec[i].vnstr <= pf::UNIT_SMALL_MAX_D && takes(i)) { lc[nu++] = i; room += rec[i].words / 2; }
             nsmall = nu;
@@ -1075,13 +1133,151 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         }
         return PF_OK;
     };
-    uint32_t pass = 0;
+    // ---- parameter blocks of the scan and the fused finish kernels, from a pass's item arrays (the host's staged
+    // upload, or plan_kernel's block with the constant arrays standing in for what is the same for every simple cluster)
+    struct ItemPtrs { const uint32_t *cluster, *part, *nparts, *nslots, *slice, *compact, *binned; uint32_t* count; };
+    auto host_items = [&]() {
+        return ItemPtrs{c->it_cluster.as<uint32_t>(), c->it_part.as<uint32_t>(), c->it_nparts.as<uint32_t>(), c->it_nslots.as<uint32_t>(),
+                        c->it_slice.as<uint32_t>(), c->it_compact.as<uint32_t>(), c->it_binned.as<uint32_t>(), c->it_count.as<uint32_t>()};
+    };
+    auto scan_params = [&](const ItemPtrs& ip, const pf_ctx::UPool& up, const uint32_t* work) {
+        pf::ScanParams sp{};
+        sp.packed = d.packed; sp.seg_word_off = c->v_word_off.as<uint64_t>(); sp.seg_len = c->v_len.as<uint32_t>();
+        sp.seg_sample = c->v_sample.as<uint32_t>(); sp.seg_ord_base = c->v_ord.as<uint32_t>();
+        sp.seg_bits = c->v_bits.as<uint32_t>();
+        sp.u_word_off = up.word_off.as<uint64_t>(); sp.u_len = up.len.as<uint32_t>(); sp.u_sample = up.sample.as<uint32_t>();
+        sp.u_ord_base = up.ord.as<uint32_t>(); sp.u_bits = up.bits.as<uint32_t>();
+        sp.cluster_seg_off = c->view_off.as<uint32_t>(); sp.cluster_vnseg = c->v_nseg.as<uint32_t>();
+        sp.cluster_vnstr = c->v_nstr.as<uint32_t>();
+        sp.item_cluster = ip.cluster; sp.item_part = ip.part; sp.item_nparts = ip.nparts; sp.item_nslots = ip.nslots;
+        sp.item_scratch = ip.slice; sp.item_compact = ip.compact;
+        sp.cmask_lo = c->cmask_lo.as<uint32_t>(); sp.cmask_hi = c->cmask_hi.as<uint32_t>();
+        sp.tab_key = c->tab_key.as<uint64_t>(); sp.tab_ord = c->tab_ord.as<uint32_t>();
+        sp.chunkbits = c->chunkbits.as<uint32_t>(); sp.chunkmask = c->chunkmask.as<uint32_t>();
+        sp.item_count = ip.count; sp.cluster_overflow = c->cl_overflow.as<uint32_t>();
+        sp.work = work;
+        sp.k = c->o.klength; sp.W = W; sp.NS = NS;
+        sp.item_binned = ip.binned;
+        return sp;
+    };
+    auto finish_params = [&](const ItemPtrs& ip, Arena* ar) {
+        pf::FinishParams fp{};
+        fp.item_cluster = ip.cluster; fp.item_nslots = ip.nslots;
+        fp.item_scratch = ip.slice; fp.cluster_overflow = c->cl_overflow.as<uint32_t>();
+        fp.item_nparts = ip.nparts;
+        fp.cluster_seg_off = d.cluster_seg_off; fp.seg_sample = d.seg_sample;
+        fp.seg_distinct = c->seg_distinct.as<uint32_t>();
+        fp.v_nstr = c->v_nstr.as<uint32_t>(); fp.v_dense = c->v_dense.as<uint32_t>();
+        fp.cluster_nstrains = d.cluster_nstrains; fp.cluster_npresab = d.cluster_npresab;
+        fp.cluster_presab = d.cluster_presab; fp.cluster_ordinal = d.cluster_ordinal;
+        fp.maf_lo = c->d_maf_lo.as<uint32_t>(); fp.maf_hi = c->d_maf_hi.as<uint32_t>();
+        fp.tab_key = c->tab_key.as<uint64_t>(); fp.tab_ord = c->tab_ord.as<uint32_t>();
+        fp.cmask_lo = c->cmask_lo.as<uint32_t>(); fp.cmask_hi = c->cmask_hi.as<uint32_t>();
+        fp.item_count = ip.count;
+        fp.extra_off = c->extra_off.as<uint32_t>(); fp.extra_dense = c->extra_dense.as<uint32_t>();
+        fp.extra_bits = d.extra_bits;
+        fp.out_key = ar->key.as<uint64_t>(); fp.out_pid = ar->pid.as<uint32_t>();
+        fp.cluster_kmer_off = c->cl_kmer_off.as<uint64_t>(); fp.cluster_kmer_cnt = c->cl_kmer_cnt.as<uint32_t>();
+        fp.cluster_unique = c->cl_unique.as<uint32_t>(); fp.cluster_pattern = c->cl_pattern.as<uint32_t>();
+        fp.cursor = c->cursor.as<uint64_t>(); fp.pt = c->pt;
+        fp.pat_bits = c->pat_bits.as<uint32_t>();
+        fp.pat_nan = c->o.consider_missing ? c->pat_nan.as<uint32_t>() : nullptr;
+        fp.pat_n = c->pat_n.as<uint32_t>();
+        fp.out_base = ar->base; fp.out_cap = ar->cap; fp.W = W; fp.NS = NS; fp.KW = KW;
+        fp.consider_missing = c->o.consider_missing; fp.patfilt = c->o.patfilt; fp.multiple_files = c->o.multiple_files;
+        return fp;
+    };
+    uint64_t arena_base = 0;
+    struct Deferred { Arena* ar; uint32_t pin; };
+    std::vector<Deferred> deferred;        // passes launched and not yet waited for (their cursor read-backs are queued)
+    uint32_t arena_i = 0;                  // arenas used so far: one per launched pass, the device-planned ones included
+    // ---- the device-planned clusters of part h: unit view, scan, fused finish -- launched from plan_kernel's 40-byte summary
+    auto launch_planned = [&](uint32_t h) -> int {
+        pf_ctx::DPlan& dp = c->dplan[h];
+        const pf::PlanOut po = *dp.pin_out;
+        const uint32_t n = po.n_items;
+        if (!n) return PF_OK;
+        if (n > c->max_items || n > dp.n || po.n_fin + po.n_fin2 + po.n_fin5 != n || po.n_unit > n)
+            return fail(PF_ERR_STATE, "plan_kernel summary out of range (%u items of %u clusters)", n, dp.n);
+        const DPtrs q = dplan_ptrs(dp);
+        const uint32_t* zeros = c->dp_const.as<uint32_t>();
+        const uint32_t* ones = zeros + c->dp_const_n;
+        const uint32_t* iota = zeros + 2 * (size_t)c->dp_const_n;
+        const ItemPtrs ip{q.it_cluster, zeros, ones, q.it_nslots, iota, ones, zeros, dp.it_count.as<uint32_t>()};
+        while (c->arenas.size() <= arena_i) c->arenas.push_back(new Arena());
+        Arena* ar = c->arenas[arena_i];
+        ar->cap = std::max<uint64_t>(po.arena_cap, 1);
+        ar->base = arena_base;
+        PFCHK(ar->key.ensure((size_t)ar->cap * 8 * KW));
+        PFCHK(ar->pid.ensure((size_t)ar->cap * 4));
+        PFCHK(ar->first.ensure((size_t)ar->cap * 8));
+        c->pin_small[arena_i & 15] = arena_base;
+        HIPCHK(hipMemcpyAsync(c->cursor.p, &c->pin_small[arena_i & 15], 8, hipMemcpyHostToDevice, c->stream));
+        pf_ctx::UPool& up = c->upool[2 * h];
+        if (po.n_unit) {
+            const size_t R = (size_t)po.unit_room + 1, R2 = 2 * R;
+            if (R2 > 0xFFFFFFF0ull) return fail(PF_ERR_CAPACITY, "unit view of %zu pieces: submit fewer clusters at a time", R);
+            PFCHK(up.word_off.ensure(R2 * 8)); PFCHK(up.len.ensure(R2 * 4)); PFCHK(up.sample.ensure(R2 * 4));
+            PFCHK(up.ord.ensure(R2 * 4)); PFCHK(up.bits.ensure(R2 * 4));
+            pf::UnitParams uq{};
+            uq.packed = d.packed; uq.cluster_seg_off = d.cluster_seg_off; uq.v_nstr = c->v_nstr.as<uint32_t>();
+            uq.list_cluster = q.unit_cluster; uq.list_base = q.unit_base;
+            uq.v_word_off = c->v_word_off.as<uint64_t>(); uq.v_len = c->v_len.as<uint32_t>(); uq.v_ord = c->v_ord.as<uint32_t>();
+            uq.u_word_off = up.word_off.as<uint64_t>(); uq.u_len = up.len.as<uint32_t>(); uq.u_sample = up.sample.as<uint32_t>();
+            uq.u_ord = up.ord.as<uint32_t>(); uq.u_bits = up.bits.as<uint32_t>();
+            uq.v_nseg = c->v_nseg.as<uint32_t>(); uq.view_off = c->view_off.as<uint32_t>(); uq.k = c->o.klength; uq.tmp_off = (uint32_t)R;
+            PFCHK(mark_begin(c, 3));
+            const dim3 g((po.n_unit + 3) / 4), b(256);
+            switch ((63 + c->o.klength + 31) / 32) {       // words a unit's 63 + k bases take
+                case 2: hipLaunchKernelGGL(pf::unit_class_small_kernel<2>, g, b, 0, c->stream, uq, po.n_unit); break;
+                case 3: hipLaunchKernelGGL(pf::unit_class_small_kernel<3>, g, b, 0, c->stream, uq, po.n_unit); break;
+                case 4: hipLaunchKernelGGL(pf::unit_class_small_kernel<4>, g, b, 0, c->stream, uq, po.n_unit); break;
+                case 5: hipLaunchKernelGGL(pf::unit_class_small_kernel<5>, g, b, 0, c->stream, uq, po.n_unit); break;
+                default: hipLaunchKernelGGL(pf::unit_class_small_kernel<6>, g, b, 0, c->stream, uq, po.n_unit); break;
+            }
+            HIPCHK(hipGetLastError());
+            PFCHK(mark_end(c));
+        }
+        {
+            const pf::ScanParams sp = scan_params(ip, up, q.w_scan);
+            PFCHK(mark_begin(c, 0));
+            PFCHK(launch_scan(c, sp, n));
+            PFCHK(mark_end(c));
+            c->timing.scan_launches++;
+        }
+        {
+            pf::FinishParams fp = finish_params(ip, ar);
+            PFCHK(mark_begin(c, 6));
+            if (po.n_fin5) {
+                fp.work = q.w_fin5;
+                hipLaunchKernelGGL((pf::finish_kernel<pf::FinHuge, true>), dim3(po.n_fin5), dim3(pf::FinHuge::THREADS), 0, c->stream, fp);
+                HIPCHK(hipGetLastError());
+            }
+            if (po.n_fin2) {
+                fp.work = q.w_fin2;
+                hipLaunchKernelGGL((pf::finish_kernel<pf::FinLarge, false>), dim3(po.n_fin2), dim3(pf::FinLarge::THREADS), 0, c->stream, fp);
+                HIPCHK(hipGetLastError());
+            }
+            if (po.n_fin) {
+                fp.work = q.w_fin;
+                hipLaunchKernelGGL((pf::finish_kernel<pf::FinSmall, false>), dim3(po.n_fin), dim3(pf::FinSmall::THREADS), 0, c->stream, fp);
+                HIPCHK(hipGetLastError());
+            }
+            PFCHK(mark_end(c));
+        }
+        c->timing.n_items += n;
+        c->timing.n_device_planned += n;
+        const uint32_t pin = 16 + (arena_i & 31);
+        HIPCHK(hipMemcpyAsync(&c->pin_small[pin], c->cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
+        deferred.push_back(Deferred{ar, pin});
+        arena_base += ar->cap;
+        arena_i++;
+        return PF_OK;
+    };
+    uint32_t pass = 0;                     // host-planned passes: the parts' (what plan_kernel left of them), then the re-runs
     uint32_t cnt2[3] = {0, 0, 0};          // pattern counters {ids handed out, pool overflow, arena overflow}
     c->counters = pf_result{};
     const uint32_t lim_full = pf::insert_limit(NS);
-    uint64_t arena_base = 0;
-    struct Deferred { Arena* ar; uint32_t pin; };
-    std::vector<Deferred> deferred;        // parts launched and not yet waited for (their cursor read-backs are queued)
     for (;;) {
         c->stage_slot = (int)(pass & 1);
         if (pass < P) {
@@ -1095,18 +1291,24 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
                 }
                 ex_first.assign(h_exfirst, h_exfirst + C + 1);
             }
+            // the clusters plan_kernel laid out go first: the GPU starts on them while the rest of the part is built here
+            const uint32_t planned_arena = arena_i;
+            if (use_plan) PFCHK(launch_planned(pass));
             PFCHK(prep_half((int)pass));
-            const uint32_t c0 = pass ? part_end[pass - 1] : 0;
-            todo.resize(part_end[pass] - c0);
-            std::iota(todo.begin(), todo.end(), c0);
+            todo.clear();
+            for (uint32_t ci = pass ? part_end[pass - 1] : 0; ci < part_end[pass]; ci++) {
+                if (!rec[ci].pad) { todo.push_back(ci); continue; }
+                c->timing.scan_packed_bytes += rec[ci].words * 8;
+                c->cluster_arena[ci] = planned_arena;
+            }
         }
-        if (todo.empty()) break;
+        if (todo.empty() && pass >= P) break;
         // ---- items of this pass
         std::vector<Item>& items = c->hs_items;
         std::vector<uint8_t>& item_fused = c->hs_fused;      // 0 unfused, 1 fused small class, 2 fused large class
         items.clear(); item_fused.clear();
         items.reserve(todo.size() + 64); item_fused.reserve(todo.size() + 64);
-        struct Sub { uint32_t item0, nitems, cl0, ncl, part, bin0, nbin; uint64_t q_total; };
+        struct Sub { uint32_t item0, nitems, cl0, ncl, pool, bin0, nbin; uint64_t q_total; };
         // A cluster of three or more key partitions (a dedup view, keys of up to two words) has its windows sorted by
         // partition first (bin_kernel): its items then read their own windows instead of each walking the whole view.
         // The entry arrays belong to a sub-batch; a sub-batch ends where they would pass BIN_MAX_ENTRIES.
@@ -1115,7 +1317,8 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         std::vector<uint32_t>& v_binned = c->hs_binned;
         std::vector<uint32_t>&bin_cluster = c->hs_bin[0], &bin_item0 = c->hs_bin[1], &bin_nparts = c->hs_bin[2], &bin_base = c->hs_bin[3];
         v_binned.clear(); bin_cluster.clear(); bin_item0.clear(); bin_nparts.clear(); bin_base.clear();
-        auto part_of = [&](uint32_t ci) { uint32_t q = 0; while (q + 1 < P && ci >= part_end[q]) q++; return q; };
+        // (which unit-view pool a cluster's view lies in: its part's device-planned one or the host-planned one)
+        auto part_of = [&](uint32_t ci) { uint32_t q = 0; while (q + 1 < P && ci >= part_end[q]) q++; return 2 * q + (rec[ci].pad ? 0u : 1u); };
         std::vector<Sub> subs;
         std::vector<uint32_t>&sub_cluster = c->hs_sub[0], &sub_item0 = c->hs_sub[1], &sub_nitems = c->hs_sub[2];
         sub_cluster.clear(); sub_item0.clear(); sub_nitems.clear();
@@ -1152,13 +1355,13 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             const uint32_t vch = (rec[ci].vnstr + 31) / 32;
             const bool binned = !(c->o.flags & PF_FLAG_NO_KEY_BINNING) && np >= BIN_MIN_PARTS && KW <= 2 && rec[ci].mode != 0 &&
                                 vch <= pf::BIN_CHUNKS && (uint64_t)np * vch <= pf::BIN_CELLS && qn && qn <= BIN_MAX_ENTRIES;
-            // (a launch reads one part's unit-view pool: a re-run pass does not mix the parts' clusters in a sub-batch)
-            if (cur.nitems + nit > c->max_items || (cur.nitems && part_of(ci) != cur.part) ||
+            // (a launch reads one unit-view pool: a re-run pass does not mix the pools' clusters in a sub-batch)
+            if (cur.nitems + nit > c->max_items || (cur.nitems && part_of(ci) != cur.pool) ||
                 (binned && cur.q_total + qn > BIN_MAX_ENTRIES)) {
                 subs.push_back(cur);
                 cur = Sub{(uint32_t)items.size(), 0, (uint32_t)sub_cluster.size(), 0, part_of(ci), (uint32_t)bin_cluster.size(), 0, 0};
             }
-            if (!cur.nitems) cur.part = part_of(ci);
+            if (!cur.nitems) cur.pool = part_of(ci);
             const uint32_t sib0 = (uint32_t)items.size();
             // table size: a cluster that cannot overflow a small table gets one (less flush traffic)
             uint32_t ns = NS;
@@ -1192,14 +1395,14 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
                 cur.ncl++;
             }
             cur.nitems += nit;
-            c->cluster_arena[ci] = pass;
+            c->cluster_arena[ci] = arena_i;
         }
         if (cur.nitems) subs.push_back(cur);
 
         lap("build items");
         // ---- arena of this pass
-        while (c->arenas.size() <= pass) c->arenas.push_back(new Arena());
-        Arena* ar = c->arenas[pass];
+        while (c->arenas.size() <= arena_i) c->arenas.push_back(new Arena());
+        Arena* ar = c->arenas[arena_i];
         ar->cap = std::max<uint64_t>(arena_cap, 1);
         ar->base = arena_base;
         PFCHK(ar->key.ensure((size_t)ar->cap * 8 * KW));
@@ -1290,8 +1493,8 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         }
         // the cursor's next free index restarts at this arena's base
         {
-            c->pin_small[pass & 15] = arena_base;
-            HIPCHK(hipMemcpyAsync(c->cursor.p, &c->pin_small[pass & 15], 8, hipMemcpyHostToDevice, c->stream));
+            c->pin_small[arena_i & 15] = arena_base;
+            HIPCHK(hipMemcpyAsync(c->cursor.p, &c->pin_small[arena_i & 15], 8, hipMemcpyHostToDevice, c->stream));
         }
 
         lap("upload items");
@@ -1314,27 +1517,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
                 PFCHK(mark_end(c));
             }
             if (n_scan) {
-                pf::ScanParams sp{};
-                sp.packed = d.packed; sp.seg_word_off = c->v_word_off.as<uint64_t>(); sp.seg_len = c->v_len.as<uint32_t>();
-                sp.seg_sample = c->v_sample.as<uint32_t>(); sp.seg_ord_base = c->v_ord.as<uint32_t>();
-                sp.seg_bits = c->v_bits.as<uint32_t>();
-                {
-                    const pf_ctx::UPool& up = c->upool[sb.part];
-                    sp.u_word_off = up.word_off.as<uint64_t>(); sp.u_len = up.len.as<uint32_t>(); sp.u_sample = up.sample.as<uint32_t>();
-                    sp.u_ord_base = up.ord.as<uint32_t>(); sp.u_bits = up.bits.as<uint32_t>();
-                }
-                sp.cluster_seg_off = c->view_off.as<uint32_t>(); sp.cluster_vnseg = c->v_nseg.as<uint32_t>();
-                sp.cluster_vnstr = c->v_nstr.as<uint32_t>();
-                sp.item_cluster = c->it_cluster.as<uint32_t>(); sp.item_part = c->it_part.as<uint32_t>();
-                sp.item_nparts = c->it_nparts.as<uint32_t>(); sp.item_nslots = c->it_nslots.as<uint32_t>();
-                sp.item_scratch = c->it_slice.as<uint32_t>(); sp.item_compact = c->it_compact.as<uint32_t>();
-                sp.cmask_lo = c->cmask_lo.as<uint32_t>(); sp.cmask_hi = c->cmask_hi.as<uint32_t>();
-                sp.tab_key = c->tab_key.as<uint64_t>(); sp.tab_ord = c->tab_ord.as<uint32_t>();
-                sp.chunkbits = c->chunkbits.as<uint32_t>(); sp.chunkmask = c->chunkmask.as<uint32_t>();
-                sp.item_count = c->it_count.as<uint32_t>(); sp.cluster_overflow = c->cl_overflow.as<uint32_t>();
-                sp.work = c->work_scan.as<uint32_t>() + scan_off[s];
-                sp.k = c->o.klength; sp.W = W; sp.NS = NS;
-                sp.item_binned = c->it_binned.as<uint32_t>();
+                pf::ScanParams sp = scan_params(host_items(), c->upool[sb.pool], c->work_scan.as<uint32_t>() + scan_off[s]);
                 PFCHK(mark_begin(c, 0));
                 if (sb.nbin) {
                     const size_t qcap = (size_t)sb.q_total + 64;
@@ -1353,31 +1536,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
                            n_fin3 = fin3_off[s + 1] - fin3_off[s], n_fin5 = fin5_off[s + 1] - fin5_off[s],
                            n_rows = rows_off[s + 1] - rows_off[s];
             if (n_fin || n_fin2 || n_fin3 || n_fin5) {
-                pf::FinishParams fp{};
-                fp.work = c->work_fin.as<uint32_t>() + fin_off[s];
-                fp.item_cluster = c->it_cluster.as<uint32_t>(); fp.item_nslots = c->it_nslots.as<uint32_t>();
-                fp.item_scratch = c->it_slice.as<uint32_t>(); fp.cluster_overflow = c->cl_overflow.as<uint32_t>();
-                fp.item_nparts = c->it_nparts.as<uint32_t>();
-                fp.cluster_seg_off = d.cluster_seg_off; fp.seg_sample = d.seg_sample;
-                fp.seg_distinct = c->seg_distinct.as<uint32_t>();
-                fp.v_nstr = c->v_nstr.as<uint32_t>(); fp.v_dense = c->v_dense.as<uint32_t>();
-                fp.cluster_nstrains = d.cluster_nstrains; fp.cluster_npresab = d.cluster_npresab;
-                fp.cluster_presab = d.cluster_presab; fp.cluster_ordinal = d.cluster_ordinal;
-                fp.maf_lo = c->d_maf_lo.as<uint32_t>(); fp.maf_hi = c->d_maf_hi.as<uint32_t>();
-                fp.tab_key = c->tab_key.as<uint64_t>(); fp.tab_ord = c->tab_ord.as<uint32_t>();
-                fp.cmask_lo = c->cmask_lo.as<uint32_t>(); fp.cmask_hi = c->cmask_hi.as<uint32_t>();
-                fp.item_count = c->it_count.as<uint32_t>();
-                fp.extra_off = c->extra_off.as<uint32_t>(); fp.extra_dense = c->extra_dense.as<uint32_t>();
-                fp.extra_bits = d.extra_bits;
-                fp.out_key = ar->key.as<uint64_t>(); fp.out_pid = ar->pid.as<uint32_t>();
-                fp.cluster_kmer_off = c->cl_kmer_off.as<uint64_t>(); fp.cluster_kmer_cnt = c->cl_kmer_cnt.as<uint32_t>();
-                fp.cluster_unique = c->cl_unique.as<uint32_t>(); fp.cluster_pattern = c->cl_pattern.as<uint32_t>();
-                fp.cursor = c->cursor.as<uint64_t>(); fp.pt = c->pt;
-                fp.pat_bits = c->pat_bits.as<uint32_t>();
-                fp.pat_nan = c->o.consider_missing ? c->pat_nan.as<uint32_t>() : nullptr;
-                fp.pat_n = c->pat_n.as<uint32_t>();
-                fp.out_base = ar->base; fp.out_cap = ar->cap; fp.W = W; fp.NS = NS; fp.KW = KW;
-                fp.consider_missing = c->o.consider_missing; fp.patfilt = c->o.patfilt; fp.multiple_files = c->o.multiple_files;
+                pf::FinishParams fp = finish_params(host_items(), ar);
                 PFCHK(mark_begin(c, 6));
                 if (n_fin5) {   // the heaviest clusters first
                     fp.work = c->work_fin5.as<uint32_t>() + fin5_off[s];
@@ -1503,10 +1662,11 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         lap("launch pass");
         if (pass + 1 < P) {
             // no wait: the next part's pass is built now and goes in behind this one
-            const uint32_t pin = 16 + pass;
+            const uint32_t pin = 16 + (arena_i & 31);
             HIPCHK(hipMemcpyAsync(&c->pin_small[pin], c->cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
             deferred.push_back(Deferred{ar, pin});
             arena_base += ar->cap;
+            arena_i++;
             pass++;
             continue;
         }
@@ -1518,11 +1678,19 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         // (8 192 clusters settle the line; after that every 16th submit still looks, at half the old weight, so that a
         // pangenome whose later clusters differ from its first is followed -- the read-back is not free)
         // (not in the re-run of a batch after the pattern table grew: its clusters have been counted)
-        if (!rerun && (c->reg_n < 8192 || (c->n_submits & 15) == 0))
+        uint32_t learn_planned = 0;            // ... and plan_kernel's items of the last part (their clusters, their key counts)
+        if (!rerun && (c->reg_n < 8192 || (c->n_submits & 15) == 0)) {
             for (uint32_t ci : todo) if (rec[ci].mode && rec[ci].vnstr >= 2) { learn = true; break; }
+            if (use_plan && pass + 1 == P) learn_planned = std::min<uint32_t>(c->dplan[pass].pin_out->n_items, 4096u);
+        }
         if (learn) {
             c->hs_count.resize(NI);
             HIPCHK(hipMemcpyAsync(c->hs_count.data(), c->it_count.p, NI * 4, hipMemcpyDeviceToHost, c->stream));
+        }
+        if (learn_planned) {
+            c->hs_plan.resize(2 * (size_t)learn_planned);
+            HIPCHK(hipMemcpyAsync(c->hs_plan.data(), dplan_ptrs(c->dplan[pass]).it_cluster, (size_t)learn_planned * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(c->hs_plan.data() + learn_planned, c->dplan[pass].it_count.p, (size_t)learn_planned * 4, hipMemcpyDeviceToHost, c->stream));
         }
         HIPCHK(hipMemcpyAsync(ovf.data(), c->cl_overflow.p, (size_t)C * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(cur3, c->cursor.p, 24, hipMemcpyDeviceToHost, c->stream));
@@ -1535,7 +1703,8 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         if (ar->used > ar->cap) return fail(PF_ERR_CAPACITY, "output arena overflow (%llu > %llu)",
                                             (unsigned long long)ar->used, (unsigned long long)ar->cap);
         arena_base += ar->cap;
-        if (!deferred.empty()) {                   // the earlier parts' passes finished before this one
+        arena_i++;
+        if (!deferred.empty()) {                   // the earlier passes finished before this one
             for (const Deferred& df : deferred) {
                 df.ar->used = c->pin_small[df.pin] - df.ar->base;
                 if (df.ar->used > df.ar->cap)
@@ -1546,11 +1715,20 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             todo.resize(C);                        // every cluster has been through its first pass now
             std::iota(todo.begin(), todo.end(), 0u);
         }
-        if (learn) {
+        if (learn || learn_planned) {
             if (c->reg_n >= 8192) {
                 c->reg_n *= 0.5; c->reg_x *= 0.5; c->reg_y *= 0.5; c->reg_xx *= 0.5; c->reg_xy *= 0.5; c->reg_yy *= 0.5;
             }
             uint32_t looked = 0;               // (the GPU waits while this runs: a few thousand clusters say enough)
+            for (uint32_t i = 0; i < learn_planned && looked < 4096; i++) {
+                const uint32_t ci = c->hs_plan[i];
+                if (ci >= C || ovf[ci] || !rec[ci].mode || rec[ci].vnstr < 2 || !rec[ci].vinst) continue;
+                looked++;
+                const double D = (double)rec[ci].vnstr, L = (double)(rec[ci].vinst * mult) / D;
+                const double g = std::max(0.0, ((double)c->hs_plan[learn_planned + i] - L) / (D - 1.0));
+                c->reg_n += 1; c->reg_x += L; c->reg_y += g; c->reg_xx += L * L; c->reg_xy += L * g; c->reg_yy += g * g;
+            }
+            if (learn)
             for (size_t i = 0; i < NI && looked < 4096; i++) {
                 const Item& it = items[i];
                 if (it.is_extra || it.part != 0) continue;
@@ -1586,8 +1764,8 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         pass++;
         if (todo.empty()) break;
     }
-    for (size_t a = pass; a < c->arenas.size(); a++) c->arenas[a]->used = 0;   // arenas of an earlier, longer batch
-    c->n_passes = pass;
+    for (size_t a = arena_i; a < c->arenas.size(); a++) c->arenas[a]->used = 0;   // arenas of an earlier, longer batch
+    c->n_passes = arena_i;
 
     // ---- MD5 of the patterns this batch created (cnt2: read with the last pass's results)
     if (!C) {

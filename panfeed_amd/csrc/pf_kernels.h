@@ -4217,6 +4217,144 @@ __global__ __launch_bounds__(256) void cluster_ninst_kernel(const uint32_t* clus
 }
 
 // ---------------------------------------------------------------------------------------------
+// plan_kernel: the work items of a part's SIMPLE clusters, laid out on the device
+// ---------------------------------------------------------------------------------------------
+// The reference hands a cluster from `cluster_cutter` to `pattern_hasher` through a queue (__main__.py:39-52); here the
+// hand-off between the dedup pass and the scan was the host: it waited for the 40-byte records, walked them (key-partition
+// estimate, fused class, table size, unit-view room), built the item arrays and work lists and sent them up -- 0.15-0.25 ms
+// during which a small batch's GPU idled.  For the clusters that need nothing special -- a view of at most 64 distinct
+// sequences (mode 1), ONE key partition by the estimate, a fused finish class, few slow-path rows: 90-100 % of SURVEY 8d's
+// clusters -- this kernel does the same arithmetic on the device: item i of the pass = the i-th such cluster (its scratch
+// slice is i), work lists heaviest first (counting sort by log2 of the view's windows, as the host's), the unit-view list
+// with its pool offsets, and a 40-byte summary the host needs for the launches' grid sizes and the arena.  The host reads
+// the summary (one small copy), launches, and builds the REST of the part (several partitions, wide or every-copy views,
+// re-runs) the old way while the GPU is busy.
+struct PlanOut { uint32_t n_items, n_fin, n_fin2, n_fin5, n_unit, n_unit_small; uint64_t unit_room, arena_cap; };
+static_assert(sizeof(PlanOut) == 40, "PlanOut is copied to the host as one 40-byte record");
+struct PlanParams {
+    ClusterRec* rec;                 // [C]; pad <- 1 for the clusters laid out here
+    const uint32_t* extra_off;       // [C + 1] slow-path rows per cluster (CSR)
+    uint32_t c0, c1;                 // the part's clusters
+    uint32_t mult;                   // windows per position: 1 canonical, 2 not (panfeed.py:80-88)
+    uint32_t NS, W, max_items, unit_view;
+    // the key-partition estimate (pf_api.hip, prep_half): share = 1 - 0.99^k + 0.06; the learned line g = a + b L
+    double share, reg_a, reg_b, reg_half_sd;
+    uint32_t reg_ready, pad;
+    uint32_t* it_cluster; uint32_t* it_nslots;                        // [n] by item
+    uint32_t* w_scan; uint32_t* w_fin; uint32_t* w_fin2; uint32_t* w_fin5;    // [n] work lists (item numbers)
+    uint32_t* unit_cluster; uint32_t* unit_base;                      // [n] clusters that get a unit view, their pool offsets
+    uint32_t* tmp;                                                    // [n]
+    PlanOut* out;
+};
+constexpr uint32_t PLAN_THREADS = 1024;
+__global__ __launch_bounds__(PLAN_THREADS) void plan_kernel(PlanParams p) {
+    __shared__ uint32_t hist[3][66];
+    __shared__ uint32_t wave_tot[PLAN_THREADS / 64 + 1];
+    __shared__ uint32_t sh_fin5;
+    const uint32_t tid = threadIdx.x, n = p.c1 - p.c0;
+    for (uint32_t i = tid; i < 3 * 66; i += PLAN_THREADS) (&hist[0][0])[i] = 0;
+    if (tid == 0) sh_fin5 = 0;
+    __syncthreads();
+    const uint32_t lim_full = insert_limit(p.NS);
+    const double room = 0.9 * (double)lim_full;
+    const uint32_t Wp = (p.W + 3) & ~3u;
+    uint32_t base_items = 0, base_unit = 0;
+    uint64_t base_room = 0, arena = 0;
+    for (uint32_t start = 0; start < n; start += PLAN_THREADS) {
+        const uint32_t i = start + tid;
+        uint32_t cls = 0, ns = p.NS, wcls = 0, uroom = 0, nex = 0;
+        uint64_t inst = 0;
+        bool wants_unit = false;
+        if (i < n) {
+            const uint32_t c = p.c0 + i;
+            const ClusterRec r = p.rec[c];
+            nex = p.extra_off[c + 1] - p.extra_off[c];
+            inst = r.vinst * p.mult;
+            if (r.mode == 1 && nex <= FUSED_MAX_EXTRA && r.ninst * p.mult < 0xFFFFFFF0ull) {
+                bool one = true;                                  // one key partition by the estimate
+                if (r.vnstr) {
+                    const double D = (double)r.vnstr, L = (double)inst / D;
+                    if (D >= 2.0 && p.reg_ready) {
+                        const double g = fmax(0.0, p.reg_a + p.reg_b * L) + p.reg_half_sd;
+                        one = !(L + g * (D - 1.0) > room);
+                    } else {
+                        one = !(L * (1.0 + p.share * (D - 1.0)) > room) || D > 24.0;
+                    }
+                }
+                const uint32_t mwords = r.vnstr * Wp;
+                if (one) {
+                    if (r.dense < FinSmall::DW * 32 - 1 && mwords <= FinSmall::MR) cls = 1;
+                    else if (r.dense < FinLarge::DW * 32 - 1 && mwords <= FinLarge::MR) cls = 2;
+                    else if (r.dense < FinHuge::DW * 32 - 1 && mwords <= FinHuge::MR) cls = 5;
+                }
+                if (p.NS > 4096 + INSERT_SLACK && inst <= insert_limit(4096)) ns = 4096;
+                else if (p.NS > 6144 + INSERT_SLACK && inst <= insert_limit(6144)) ns = 6144;
+                wcls = r.vinst ? 63 - __clzll((long long)r.vinst) : 0;
+                wants_unit = p.unit_view && r.vnstr >= 2 && r.words;
+                uroom = (uint32_t)(r.words / 2);
+            }
+        }
+        uint32_t tot;
+        uint32_t idx = base_items + block_exscan(cls ? 1u : 0u, wave_tot, &tot);
+        if (idx >= p.max_items) cls = 0;                         // a sub-batch holds max_items items: the rest is the host's
+        const uint32_t n_new = min(tot, p.max_items - min(base_items, p.max_items));
+        if (!cls) wants_unit = false;
+        uint32_t rtot;
+        const uint64_t ubase = base_room + block_exscan(wants_unit ? uroom : 0u, wave_tot, &rtot);
+        if (wants_unit && ubase + uroom >= 0x7FFFFFF0ull) wants_unit = false;     // (never met: 2^31 pieces in one part)
+        uint32_t utot;
+        const uint32_t uidx = base_unit + block_exscan(wants_unit ? 1u : 0u, wave_tot, &utot);
+        uint32_t t = 0;
+        if (cls) {
+            const uint32_t c = p.c0 + i;
+            p.it_cluster[idx] = c;
+            p.it_nslots[idx] = ns;
+            p.rec[c].pad = 1;
+            const uint32_t list = cls == 1 ? 1u : cls == 2 ? 2u : 3u;
+            atomicAdd(&hist[0][64 - wcls], 1u);
+            if (list < 3) atomicAdd(&hist[list][64 - wcls], 1u);
+            t = (idx << 9) | (list << 7) | (64 - wcls);          // idx < 2^22 (the host keeps max_items below that)
+            arena += (inst < (uint64_t)insert_limit(ns) ? inst : (uint64_t)insert_limit(ns)) + nex;
+            if (wants_unit) { p.unit_cluster[uidx] = c; p.unit_base[uidx] = (uint32_t)ubase; }
+        }
+        if (i < n) p.tmp[i] = cls ? (t | 0x80000000u) : 0u;
+        base_items += n_new; base_room += rtot; base_unit += utot;
+    }
+    // (arena: every thread summed its own clusters)
+    for (int d = 32; d > 0; d >>= 1) arena += __shfl_down(arena, d);
+    __shared__ unsigned long long sh_arena;
+    if (tid == 0) sh_arena = 0;
+    __syncthreads();
+    if ((tid & 63) == 0 && arena) atomicAdd(&sh_arena, (unsigned long long)arena);
+    __syncthreads();
+    // heaviest class first: exclusive prefix over the 65 classes of each list
+    if (tid < 3) {
+        uint32_t run = 0;
+        for (uint32_t b = 0; b < 66; b++) { const uint32_t v = hist[tid][b]; hist[tid][b] = run; run += v; }
+    }
+    __syncthreads();
+    const uint32_t n_scan = hist[0][65], n_fin = hist[1][65], n_fin2 = hist[2][65];
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += PLAN_THREADS) {
+        const uint32_t t = p.tmp[i];
+        if (!(t & 0x80000000u)) continue;
+        const uint32_t idx = (t & 0x7FFFFFFFu) >> 9, list = (t >> 7) & 3u, b = t & 127u;
+        p.w_scan[atomicAdd(&hist[0][b], 1u)] = idx;
+        if (list == 1) p.w_fin[atomicAdd(&hist[1][b], 1u)] = idx;
+        else if (list == 2) p.w_fin2[atomicAdd(&hist[2][b], 1u)] = idx;
+        else p.w_fin5[atomicAdd(&sh_fin5, 1u)] = idx;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        PlanOut o;
+        o.n_items = n_scan; o.n_fin = n_fin; o.n_fin2 = n_fin2; o.n_fin5 = sh_fin5;
+        o.n_unit = base_unit; o.n_unit_small = base_unit;
+        o.unit_room = base_room; o.arena_cap = sh_arena;
+        *p.out = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Text of the output files, written on the device (row N2): the rows are assembled in LDS, one row per thread,
 // and leave the workgroup as coalesced 16-byte stores.
 // ---------------------------------------------------------------------------------------------

@@ -35,11 +35,12 @@ for case in range(n_cases):
     dedup = bool(rng.random() < 0.8)
     unit_dedup = bool(rng.random() < 0.85)
     key_binning = bool(rng.random() < 0.8)
+    device_plan = bool(rng.random() < 0.75)
     max_items = int(rng.choice([64, 2048]))
     cut = int(rng.integers(0, ncl + 1))
     try:
         for attempt in range(2):
-            eng = Engine(max_strains=(S + 31) // 32 * 32, stroi=stroi, dedup=dedup, unit_dedup=unit_dedup, key_binning=key_binning, max_items=max_items, **kw)
+            eng = Engine(max_strains=(S + 31) // 32 * 32, stroi=stroi, dedup=dedup, unit_dedup=unit_dedup, key_binning=key_binning, device_plan=device_plan, max_items=max_items, **kw)
             try:
                 outs, hit = [], set()
                 for part in ([recs[:cut]] if cut else []) + ([recs[cut:]] if cut < ncl else []):
@@ -70,7 +71,7 @@ for case in range(n_cases):
         print("EXC", repr(e)[:200])
     if not ok:
         fails += 1
-        print("FAIL case", case, kw, gen, "S", S, "ncl", ncl, "dedup", dedup, "stroi", len(stroi), "shuffle", shuffle, "unit_dedup", unit_dedup, "key_binning", key_binning,
+        print("FAIL case", case, kw, gen, "S", S, "ncl", ncl, "dedup", dedup, "stroi", len(stroi), "shuffle", shuffle, "unit_dedup", unit_dedup, "key_binning", key_binning, "device_plan", device_plan,
               "max_items", max_items, "cut", cut, flush=True)
     if case % 20 == 19:
         print(f"{case + 1} cases, {fails} failures, {time.time() - t0:.0f} s", flush=True)

@@ -200,14 +200,45 @@ def test_large_batch_two_part_first_pass():
     # two clusters whose tables overflow, one in each part
     for pos, seed in ((100, 1), (8000, 2)):
         recs[pos] = _diverse_records(24, 900, seed, n_clusters=1)[0][0]
-    eng = Engine(klength=21, max_strains=32, max_items=4096)          # several sub-batches per part as well
-    out = eng.run(recs)
-    assert out.timing["n_retried"] >= 2 and out.timing["n_dedup_clusters"] > 4000
     (ek, ekh, ehp), st = _oracle_texts(recs, klength=21)
-    assert out.kmers_to_hashes == ekh
-    assert out.hashes_to_patterns == ehp
-    assert out.stats["unique_kmers"] == st["unique_kmers"]
-    eng.close()
+    # max_items=4096: several sub-batches per part as well -- and plan_kernel (the simple clusters' work items laid out
+    # on the device) takes the first 4096 of a part, the host the rest; with it off the host builds every item
+    for device_plan in (True, False):
+        eng = Engine(klength=21, max_strains=32, max_items=4096, device_plan=device_plan)
+        out = eng.run(recs)
+        assert out.timing["n_retried"] >= 2 and out.timing["n_dedup_clusters"] > 4000
+        assert (out.timing["n_device_planned"] >= 4096) == device_plan
+        assert out.kmers_to_hashes == ekh
+        assert out.hashes_to_patterns == ehp
+        assert out.stats["unique_kmers"] == st["unique_kmers"]
+        eng.close()
+
+
+@pytest.mark.parametrize("k,canon,missing", [(31, True, False), (51, False, False), (21, True, True)])
+def test_device_planned_equals_host_planned(k, canon, missing):
+    """plan_kernel against the host's item builder on a batch that has a bit of everything -- simple clusters of all three
+    fused classes, clusters of several key partitions, slow-path rows ('N's), paralogs, a target strain: the same files as
+    the oracle either way, two submits on one context (the learned key-partition line comes into play in the second)"""
+    from panfeed_amd import synth
+    from panfeed_amd.engine import Engine
+    S = 70
+    cl = synth.generate(260, S, first=9100, flank=20, mean_len=500, min_len=60, max_len=2500, n_rate=0.01, paralog_rate=0.05)
+    cl += synth.generate(12, S, first=9500, flank=20, mean_len=900, min_len=600, max_len=1500, n_rate=0.0, paralog_rate=0.02,
+                         mean_alleles=30.0, allele_decay=1.0)
+    recs = [c.record() for c in cl]
+    names = sorted(recs[0][0].keys())
+    stroi = {names[4]}
+    (ek, ekh, ehp), st = _oracle_texts(recs, stroi=stroi, klength=k, canon=canon, consider_missing=missing)
+    planned = {}
+    for device_plan in (True, False):
+        eng = Engine(klength=k, canon=canon, consider_missing=missing, max_strains=96, stroi=stroi, device_plan=device_plan)
+        outs = [eng.run(recs[:120]), eng.run(recs[120:])]
+        planned[device_plan] = sum(o.timing["n_device_planned"] for o in outs)
+        assert "".join(o.kmers_to_hashes for o in outs) == ekh
+        assert "".join(o.hashes_to_patterns for o in outs) == ehp
+        assert "".join(o.kmers_tsv for o in outs) == ek
+        eng.close()
+    assert planned[False] == 0 and planned[True] > 200
 
 
 def _diverse_records(n_samples, length, seed, n_clusters=2):
