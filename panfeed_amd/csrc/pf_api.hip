@@ -154,7 +154,10 @@ struct pf_ctx {
     int stage_slot = 0;
     void* pin_dedup = nullptr;     // pinned host copies of the per-cluster arrays the dedup kernel leaves
     size_t pin_dedup_cap = 0;
-    uint64_t* pin_small = nullptr; // pinned scratch: cursor values going up, cursor read-backs of a deferred pass
+    uint64_t* pin_small = nullptr; // pinned scratch: cursor values going up [0..15], cursor read-backs of deferred passes [16..47],
+                                   // the last pass's cursor triple [48..50] and pattern counters [52..53]
+    uint32_t* pin_ovf = nullptr;   // pinned: the per-cluster overflow words of the last pass (a pageable destination makes
+    size_t pin_ovf_cap = 0;        // hipMemcpyAsync a staged, blocking copy)
     static constexpr int MAX_PARTS = 8;
     UPool upool[2 * MAX_PARTS];            // [2 h]: the device-planned clusters of part h, [2 h + 1]: the host-planned rest
     hipEvent_t ev_part[MAX_PARTS] = {};    // a part's dedup results have arrived in pinned memory
@@ -546,6 +549,7 @@ void pf_destroy(pf_ctx* c) {
     c->v_bits.release(); c->view_off.release();
     if (c->pin_dedup) (void)hipHostFree(c->pin_dedup);
     if (c->pin_small) (void)hipHostFree(c->pin_small);
+    if (c->pin_ovf) (void)hipHostFree(c->pin_ovf);
     c->scan_desc.release(); c->pat_b64.release(); c->txt_dev.release(); c->txt_meta.release();
     c->rp_order.release(); c->rp_rlen.release(); c->rp_rowoff.release(); c->wide_list.release();
     for (int i = 0; i < 2; i++) if (c->txt_pins[i]) (void)hipHostFree(c->txt_pins[i]); c->md5_list.release();
@@ -1671,8 +1675,17 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             continue;
         }
         // ---- who overflowed?
-        std::vector<uint32_t> ovf(C);
-        uint64_t cur3[3];
+        if ((size_t)C * 4 + 64 > c->pin_ovf_cap) {
+            if (c->pin_ovf) (void)hipHostFree(c->pin_ovf);
+            c->pin_ovf = nullptr; c->pin_ovf_cap = 0;
+            const size_t want = ((size_t)C * 4 + 64) * 5 / 4;
+            hipError_t e = hipHostMalloc((void**)&c->pin_ovf, want, hipHostMallocDefault);
+            if (e != hipSuccess) return fail(PF_ERR_OOM, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+            c->pin_ovf_cap = want;
+        }
+        uint32_t* const ovf = c->pin_ovf;
+        uint64_t* const cur3 = &c->pin_small[48];
+        uint32_t* const cnt_pin = reinterpret_cast<uint32_t*>(&c->pin_small[52]);
         // clusters of this pass the key-partition estimate can learn from: their items' key counts come along
         bool learn = false;
         // (8 192 clusters settle the line; after that every 16th submit still looks, at half the old weight, so that a
@@ -1692,11 +1705,12 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             HIPCHK(hipMemcpyAsync(c->hs_plan.data(), dplan_ptrs(c->dplan[pass]).it_cluster, (size_t)learn_planned * 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipMemcpyAsync(c->hs_plan.data() + learn_planned, c->dplan[pass].it_count.p, (size_t)learn_planned * 4, hipMemcpyDeviceToHost, c->stream));
         }
-        HIPCHK(hipMemcpyAsync(ovf.data(), c->cl_overflow.p, (size_t)C * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(ovf, c->cl_overflow.p, (size_t)C * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(cur3, c->cursor.p, 24, hipMemcpyDeviceToHost, c->stream));
         // (the pattern counters come along: when this was the last pass the MD5 launch needs no round trip of its own)
-        HIPCHK(hipMemcpyAsync(cnt2, c->pt_counters.p, 12, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(cnt_pin, c->pt_counters.p, 12, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
+        cnt2[0] = cnt_pin[0]; cnt2[1] = cnt_pin[1]; cnt2[2] = cnt_pin[2];
         c->counters.n_unique = cur3[1]; c->counters.n_kept = cur3[2];
         lap("sync pass");
         ar->used = cur3[0] - ar->base;

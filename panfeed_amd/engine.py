@@ -200,22 +200,25 @@ class Engine:
                 ordinal += len(chunk)
         return self.run_batches(host_batches(), prefetch, device_text, defer_patterns=defer_patterns)
 
-    def run_pangenome(self, pangenome, batch_clusters=256, prefetch=2, device_text=False, defer_patterns=False):
+    def run_pangenome(self, pangenome, batch_clusters=256, prefetch=2, device_text=False, defer_patterns=False,
+                      before_first_submit=None):
         """run_stream fed by the native reader (native_input.Pangenome): table rows -> records -> packed batches
         without leaving the library, then the GPU; yields BatchOutput in table order."""
         if tuple(sorted(pangenome.targets)) != tuple(sorted(self.stroi or ())):
             raise ValueError("the pangenome reader and the engine were given different target strains")
         return self.run_batches(pangenome.batches(self.k, self.canon, self.W, max_clusters=batch_clusters,
                                                   first_ordinal=self.next_ordinal), prefetch, device_text,
-                                defer_patterns=defer_patterns)
+                                defer_patterns=defer_patterns, before_first_submit=before_first_submit)
 
-    def run_batches(self, host_batches, prefetch=2, device_text=False, defer_patterns=False):
+    def run_batches(self, host_batches, prefetch=2, device_text=False, defer_patterns=False, before_first_submit=None):
         """GPU over an iterator of HostBatch, the next ones being prepared on one host thread meanwhile.
         device_text: kmers_to_hashes / hashes_to_patterns of a batch without target-strain rows come back as
         memoryviews of text the GPU wrote (render_device; valid until the batch after the next one has been rendered)
         instead of str; batches with kmers.tsv rows and --multiple-files runs keep the host renderers.
         defer_patterns: leave hashes_to_patterns empty -- a rank of a sharded run renders its pattern rows after the
-        run-global merge (`render_pattern_rows`)."""
+        run-global merge (`render_pattern_rows`).
+        before_first_submit: called once, right before the first pf_submit (pipeline.run_files joins the thread that
+        uploads the genomes there: the packer has been at work on the first batches meanwhile)."""
         from concurrent.futures import ThreadPoolExecutor
         import time as _time
         it = iter(host_batches)
@@ -241,6 +244,11 @@ class Engine:
                     break
                 pending.append(pool.submit(pack_next))
                 self.next_ordinal = int(hb.cluster_ordinal[-1]) + 1 if hb.n_clusters else self.next_ordinal
+                if before_first_submit is not None:
+                    t0 = _time.perf_counter()
+                    before_first_submit()
+                    before_first_submit = None
+                    st["first_submit_wait_s"] = _time.perf_counter() - t0
                 t0 = _time.perf_counter()
                 res = self.submit_host_batch(hb)
                 t1 = _time.perf_counter()

@@ -108,6 +108,39 @@ class Pangenome:
         self.genome_bases = int(sum(lens[i] for i in range(n.value)))
         return self
 
+    def contig_layout(self):
+        """(n, ptrs, lens, off): the contigs and the word offsets pf_genomes_upload gives them in the genome store --
+        2 * ceil(len / 64) + 4 words each, one after the other (csrc/pf_api.hip: pf_genomes_upload)"""
+        n = C.c_uint32()
+        ptrs = C.POINTER(C.c_char_p)()
+        lens = C.POINTER(C.c_uint64)()
+        _lib.check(self.L.pf_pangenome_contigs(self.h, C.byref(n), C.byref(ptrs), C.byref(lens)))
+        ln = np.ctypeslib.as_array(lens, shape=(n.value,)).astype(np.uint64) if n.value else np.zeros(0, np.uint64)
+        words = 2 * ((ln + np.uint64(63)) // np.uint64(64)) + np.uint64(4)
+        off = np.zeros(max(n.value, 1), dtype=np.uint64)
+        off[1:n.value] = np.cumsum(words)[:-1] if n.value > 1 else off[1:n.value]
+        return n, ptrs, lens, off
+
+    def assign_store(self):
+        """Switch the reader to by-reference records BEFORE the genomes are in HBM: the store's layout follows from the
+        contig lengths alone, so the packer thread can go ahead while `upload_store` runs on another thread."""
+        n, _ptrs, _lens, off = self.contig_layout()
+        self._store_off = off
+        _lib.check(self.L.pf_pangenome_set_store(self.h, off.ctypes.data_as(C.POINTER(C.c_uint64)), n.value))
+        self.resident = True
+        self.n_contigs = int(n.value)
+        return self
+
+    def upload_store(self, engine):
+        """the upload that belongs to `assign_store` (blocking; the library packs 2 bits per base on the device)"""
+        n, ptrs, lens, off = self.contig_layout()
+        got = (C.c_uint64 * max(n.value, 1))()
+        _lib.check(self.L.pf_genomes_upload(engine.ctx, n.value, ptrs, lens, got))
+        if n.value and not np.array_equal(np.ctypeslib.as_array(got)[:n.value], off[:n.value]):
+            raise RuntimeError("pf_genomes_upload laid the contigs out differently from Pangenome.contig_layout")
+        self.genome_bases = int(sum(lens[i] for i in range(n.value)))
+        return self
+
     def weights(self):
         """per processed cluster (table rows that pass --genes, table order): its number of gene entries, paralogs
         counted -- what a sharded run balances its contiguous ranges by (`distributed.shard_range`)"""

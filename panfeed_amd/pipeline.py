@@ -21,6 +21,18 @@ class _Columns:
         self.columns = list(columns)
 
 
+def _peek_n_strains(presence_absence):
+    """strain columns of the panaroo table, from its header record alone (input.py:188-191: index_col=0, the columns
+    'Non-unique Gene name' and 'Annotation' dropped); 0 when the file cannot be read that way"""
+    import csv
+    try:
+        with open(presence_absence, newline="") as fh:
+            header = next(csv.reader(fh))
+        return sum(1 for h in header[1:] if h not in ("Non-unique Gene name", "Annotation"))
+    except Exception:       # noqa: BLE001
+        return 0
+
+
 def run_files(presence_absence, gffdir, output, fastadir=None, klength=31, canon=True, consider_missing=False,
               patfilt=True, maf=0.01, upstream=0, downstream=0, downstream_start_codon=False, targets=(), genes=None,
               compress=False, multiple_files=False, batch_clusters=256, resident=True, device_text=True, device=0,
@@ -36,25 +48,81 @@ def run_files(presence_absence, gffdir, output, fastadir=None, klength=31, canon
         raise FileExistsError(f"Output directory {output} already exists; remove it or change the output path")
     os.makedirs(output)
     targets = tuple(targets or ())
-    pg = Pangenome(presence_absence, gffdir, fastadir, upstream, downstream, downstream_start_codon, targets=targets,
-                   genes=genes)
+
+    def make_engine(n_strains):
+        return Engine(klength=klength, canon=canon, consider_missing=consider_missing, patfilt=patfilt, maf=maf,
+                      multiple_files=multiple_files, max_strains=max(32, (n_strains + 31) // 32 * 32),
+                      stroi=set(targets), device=device,
+                      # work items in flight = scratch slices (1.9 MB each at 1 000 strains): sized for the batches of this
+                      # run, not the library's default of 2 048 -- creating and freeing 4 GB of scratch was a third of a
+                      # one-second run's time
+                      max_items=max_items or max(512, 2 * int(batch_clusters)), pattern_capacity=pattern_capacity)
+
+    # the context (stream, tables, ~1 GB of scratch: 7 ms) is made on a thread of its own while the reader opens the
+    # pangenome; it needs the number of strains, which the table's header line says
+    early = {}
+    n_peek = _peek_n_strains(presence_absence)
+
+    def early_engine():
+        t0 = _time.perf_counter()
+        try:
+            early["eng"] = make_engine(n_peek)
+        except Exception as e:       # noqa: BLE001  (made again below, where the error belongs)
+            early["err"] = e
+        early["s"] = _time.perf_counter() - t0
+    et = None
+    if n_peek:
+        et = threading.Thread(target=early_engine, name="panfeed-context")
+        et.start()
+    try:
+        pg = Pangenome(presence_absence, gffdir, fastadir, upstream, downstream, downstream_start_codon, targets=targets,
+                       genes=genes)
+    except BaseException:
+        if et is not None:
+            et.join()
+            if "eng" in early:
+                early["eng"].close()
+        raise
     eng = None
+    uploader = None
     stats = {"clusters": 0, "instances": 0, "kept_kmers": 0, "patterns": 0, "device_ms": 0.0, "bytes": 0}
     stages = {"open_parse_s": _time.perf_counter() - t_start, "write_busy_s": 0.0}
     try:
         t0 = _time.perf_counter()
-        eng = Engine(klength=klength, canon=canon, consider_missing=consider_missing, patfilt=patfilt, maf=maf,
-                     multiple_files=multiple_files, max_strains=max(32, (pg.n_strains + 31) // 32 * 32),
-                     stroi=set(targets), device=device,
-                     # work items in flight = scratch slices (1.9 MB each at 1 000 strains): sized for the batches of this
-                     # run, not the library's default of 2 048 -- creating and freeing 4 GB of scratch was a third of a
-                     # one-second run's time
-                     max_items=max_items or max(512, 2 * int(batch_clusters)), pattern_capacity=pattern_capacity)
-        stages["context_s"] = _time.perf_counter() - t0
+        if et is not None:
+            et.join()
+            eng = early.get("eng")
+            if eng is not None and eng.max_strains < pg.n_strains:        # (the header was not what the reader made of it)
+                eng.close()
+                eng = None
+        if eng is None:
+            eng = make_engine(pg.n_strains)
+        stages["context_s"] = early.get("s", 0.0) if "eng" in early and eng is early["eng"] else _time.perf_counter() - t0
+        stages["context_wait_s"] = _time.perf_counter() - t0
         t0 = _time.perf_counter()
+        upload_err = []
+        stages["genome_upload_s"] = 0.0
         if resident:
-            pg.make_resident(eng)
-        stages["genome_upload_s"] = _time.perf_counter() - t0
+            # The genome store's layout follows from the contig lengths: the reader switches to by-reference records at
+            # once and the packer thread starts on the first batches while the contigs go up on a thread of their own
+            # (the library packs them to 2 bits per base on the device); the first pf_submit waits for that thread.
+            pg.assign_store()
+
+            def upload():
+                t1 = _time.perf_counter()
+                try:
+                    pg.upload_store(eng)
+                except Exception as e:       # noqa: BLE001
+                    upload_err.append(e)
+                stages["genome_upload_s"] = _time.perf_counter() - t1
+            uploader = threading.Thread(target=upload, name="panfeed-genomes")
+            uploader.start()
+
+        def wait_for_genomes():
+            if uploader is not None:
+                uploader.join()
+            if upload_err:
+                raise upload_err[0]
         cols = _Columns(pg.strains)
         if multiple_files:
             kmer_stroi = hash_pat = kmer_hash = None
@@ -122,7 +190,8 @@ def run_files(presence_absence, gffdir, output, fastadir=None, klength=31, canon
         wt = threading.Thread(target=writer, name="panfeed-writer")
         wt.start()
         try:
-            batches = eng.run_pangenome(pg, batch_clusters=batch_clusters, device_text=device_text)
+            batches = eng.run_pangenome(pg, batch_clusters=batch_clusters, device_text=device_text,
+                                        before_first_submit=wait_for_genomes)
             while True:
                 slots.acquire()
                 o = next(batches, None)
@@ -152,6 +221,8 @@ def run_files(presence_absence, gffdir, output, fastadir=None, klength=31, canon
         stats["stages"] = stages
         return stats
     finally:
+        if uploader is not None:
+            uploader.join()                  # (an error on the way: the upload reads the reader's contigs)
         t0 = _time.perf_counter()
         pg.close(wait=False)                 # the run is over: the reader's memory goes back in the background
         t1 = _time.perf_counter()
