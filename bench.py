@@ -84,6 +84,7 @@ def parse(argv=None):
     ap.add_argument("--no-e2e-leg", action="store_true", help="skip the end-to-end (files -> files) leg")
     ap.add_argument("--no-weak-leg", action="store_true", help="N > 1, strong scaling: skip the weak-scaling sub-leg")
     ap.add_argument("--e2e-clusters", type=int, default=1000, help="clusters of the end-to-end leg's on-disk pangenome")
+    ap.add_argument("--e2e-long-clusters", type=int, default=8000, help="clusters of the long files -> files run (0: skip)")
     ap.add_argument("--e2e-records-clusters", type=int, default=400, help="clusters of the records -> files figure")
     ap.add_argument("--targets-clusters", type=int, default=0, help="clusters of the --targets second pass leg")
     ap.add_argument("--sweep-alleles", action="store_true", help="extra leg: throughput vs distinct sequences per cluster")
@@ -407,6 +408,52 @@ def end_to_end(args, local):
         shutil.rmtree(scratch, ignore_errors=True)
     out["records_note"] = ("Seqinfo records (Python strings, one target strain: kmers.tsv rows included) -> pf_pack_records -> "
                            "H2D -> kernels -> text -> three files; the records are made before the clock starts")
+    # ---- the same files -> files run, long enough for the start-up (opening 1 000 GFFs, the context, the genomes' upload) to be
+    # a small share: what a whole pangenome runs at.  Fewer clusters when the scratch space does not hold the inputs.
+    n_long = args.e2e_long_clusters
+    while n_long >= 1000:
+        scratch = tempfile.mkdtemp(prefix="pf_bench_e2e_long_")
+        try:
+            free = shutil.disk_usage(scratch).free
+            if free < n_long * 1.3e6 * 1.6:        # 1.21 MB of GFF3 + FASTA per cluster in, 0.34 MB of TSV out, and room to spare
+                out.setdefault("long_leg_fallbacks", []).append(f"{n_long} clusters need {n_long * 1.3e6 * 1.6 / 1e9:.1f} GB of scratch, "
+                                                                f"{free / 1e9:.1f} GB free")
+                n_long //= 2
+                continue
+            t0 = time.time()
+            cl = synth.generate(n_long, S, first=0, flank=up, n_rate=0.001, mean_alleles=args.mean_alleles,
+                                allele_decay=args.allele_decay, allele_model=args.allele_model)
+            ninst = sum(c.n_instances(k) for c in cl)
+            csvp, gffs, _fas = synth.write_pangenome(scratch, cl, missing_gene_rate=0.0, workers=min(16, os.cpu_count() or 1))
+            in_bytes = sum(os.path.getsize(p) for p in gffs.values()) + os.path.getsize(csvp)
+            setup = time.time() - t0
+            del cl
+            od = os.path.join(scratch, "out")
+            t0 = time.time()
+            st = run_files(csvp, os.path.join(scratch, "gffs"), od, klength=k, upstream=up, downstream=up, batch_clusters=256,
+                           device_text=True, device=local)
+            dt = time.time() - t0
+            assert st["instances"] == ninst, (st["instances"], ninst)
+            fbytes = sum(os.path.getsize(os.path.join(od, f)) for f in os.listdir(od))
+            stg = st["stages"]
+            waits = {"the reader + packer thread (pack_wait_s)": stg.get("pack_wait_s", 0.0),
+                     "the genomes' upload (first_submit_wait_s)": stg.get("first_submit_wait_s", 0.0),
+                     "pf_submit itself (submit_s: coordinates up, gather, kernels)": stg.get("submit_s", 0.0),
+                     "the text stage (text_s: device text + its copy to the host)": stg.get("text_s", 0.0)}
+            out["files_to_files_device_text_long"] = {
+                "clusters": n_long, "setup_write_inputs_s": setup, "input_bytes": in_bytes, "seconds": dt, "inst_per_s": ninst / dt,
+                "output_bytes": fbytes, "output_GBps": fbytes / dt / 1e9, "input_GBps": in_bytes / dt / 1e9, "instances": ninst,
+                "kept_kmers": st["kept_kmers"], "patterns": st["patterns"],
+                "gpu_busy_share": stg.get("device_ms", 0.0) / 1e3 / dt,
+                "gpu_thread_waits_longest_on": max(waits, key=waits.get),
+                "start_up_share": (stg.get("open_parse_s", 0.0) + stg.get("context_wait_s", 0.0) + stg.get("first_submit_wait_s", 0.0)) / dt,
+                "stages_s": {a: round(b, 4) for a, b in stg.items()}}
+            break
+        except OSError as e:                       # no room after all: half the clusters
+            out.setdefault("long_leg_fallbacks", []).append(f"{n_long} clusters: {e}")
+            n_long //= 2
+        finally:
+            shutil.rmtree(scratch, ignore_errors=True)
     return out
 
 

@@ -36,7 +36,7 @@ def _peek_n_strains(presence_absence):
 def run_files(presence_absence, gffdir, output, fastadir=None, klength=31, canon=True, consider_missing=False,
               patfilt=True, maf=0.01, upstream=0, downstream=0, downstream_start_codon=False, targets=(), genes=None,
               compress=False, multiple_files=False, batch_clusters=256, resident=True, device_text=True, device=0,
-              max_items=0, pattern_capacity=0):
+              max_items=0, pattern_capacity=0, overlap=True):
     """One directory of outputs (`kmers.tsv`, `kmers_to_hashes.tsv`, `hashes_to_patterns.tsv`, `.gz` under
     `compress`; under `multiple_files` one such directory per gene cluster, `<output>/<cluster>/`, the pattern set
     starting empty in each: `panfeed.py:35-43,153-167`) from a panaroo table and a directory (or file of files) of GFFs.  Option names and meaning follow
@@ -61,7 +61,7 @@ def run_files(presence_absence, gffdir, output, fastadir=None, klength=31, canon
     # the context (stream, tables, ~1 GB of scratch: 7 ms) is made on a thread of its own while the reader opens the
     # pangenome; it needs the number of strains, which the table's header line says
     early = {}
-    n_peek = _peek_n_strains(presence_absence)
+    n_peek = _peek_n_strains(presence_absence) if overlap else 0
 
     def early_engine():
         t0 = _time.perf_counter()
@@ -106,6 +106,10 @@ def run_files(presence_absence, gffdir, output, fastadir=None, klength=31, canon
             # The genome store's layout follows from the contig lengths: the reader switches to by-reference records at
             # once and the packer thread starts on the first batches while the contigs go up on a thread of their own
             # (the library packs them to 2 bits per base on the device); the first pf_submit waits for that thread.
+            if not overlap:
+                pg.make_resident(eng)
+                stages["genome_upload_s"] = _time.perf_counter() - t0
+        if resident and overlap:
             pg.assign_store()
 
             def upload():

@@ -156,77 +156,123 @@ def generate(n_clusters, n_samples, first=0, shuffle_columns=None, **kw):
     return [generate_cluster(first + i, names, **kw) for i in range(n_clusters)]
 
 
+def _sample_files(outdir, nm, genes, rng, wrap, missing_gene_rate, lower_rate, drop, separate):
+    """one sample's GFF3 (+ FASTA): (gff path or None, fasta path or None)"""
+    import os
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    ncontig = int(rng.integers(1, 4))
+    contigs = [[] for _ in range(ncontig)]
+    for g in genes:
+        contigs[int(rng.integers(0, ncontig))].append(g)
+    gff_lines = ["##gff-version 3"]
+    fasta_lines = []
+    for c, glist in enumerate(contigs):
+        cname = f"{nm}_contig{c + 1}"
+        seq = bytearray()
+        first = True
+        for gid, s, strand, inset in glist:
+            spacer = 0 if (first and rng.random() < 0.3) else int(rng.integers(3, 180))
+            first = False
+            seq += np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, spacer)].tobytes()
+            start = len(seq) + 1 + inset          # clusters made with flank=F: the CDS is the inner part, so
+            seq += s if strand > 0 else s[::-1].translate(comp)
+            end = len(seq) - inset                # reading with upstream=downstream=F returns the whole allele
+            if rng.random() >= missing_gene_rate:
+                gff_lines.append(f"{cname}\tProdigal\tCDS\t{start}\t{end}\t.\t{'+' if strand > 0 else '-'}\t0\t"
+                                 f"ID={gid};Parent={gid}_gene;product=hypothetical protein")
+                gff_lines.append(f"{cname}\tProdigal\tgene\t{start}\t{end}\t.\t{'+' if strand > 0 else '-'}\t.\tID={gid}_gene")
+        if rng.random() < 0.7:
+            seq += np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(rng.integers(1, 150)))].tobytes()
+        seq = bytes(seq)
+        if lower_rate:
+            arr = np.frombuffer(seq, np.uint8).copy()
+            low = rng.random(len(arr)) < lower_rate
+            arr[low] |= 0x20
+            seq = arr.tobytes()
+        fasta_lines.append(f">{cname} len={len(seq)}")
+        fasta_lines += [seq[i:i + wrap].decode() for i in range(0, len(seq), wrap)]
+        gff_lines.insert(1 + c, f"##sequence-region {cname} 1 {len(seq)}")
+    if drop:
+        return None, None
+    path = os.path.join(outdir, "gffs", f"{nm}.gff")
+    fa = None
+    with open(path, "w") as fh:
+        fh.write("\n".join(gff_lines) + "\n")
+        if separate:
+            fa = os.path.join(outdir, "gffs", f"{nm}.fasta")
+            with open(fa, "w") as f2:
+                f2.write("\n".join(fasta_lines) + "\n")
+        else:
+            fh.write("##FASTA\n" + "\n".join(fasta_lines) + "\n")
+    return path, fa
+
+
+_POOL_ARGS = None      # (clusters, outdir, seed, wrap, ...) of a parallel write_pangenome, inherited by its forked workers
+
+
+def _pool_sample(si):
+    clusters, outdir, seed, wrap, missing_gene_rate, lower_rate, drop_gff_for, separate_fasta_for = _POOL_ARGS
+    nm = clusters[0].names[si]
+    genes = []
+    for cl in clusters:
+        k = 0
+        for q in np.flatnonzero(cl.seq_sample == si):
+            genes.append((f"{nm}_{cl.index:05d}_{k}", cl.seq_string(int(q)).encode(), int(cl.seq_strand[q]), int(cl.up)))
+            k += 1
+    rng = np.random.Generator(np.random.PCG64([seed, si]))
+    return nm, _sample_files(outdir, nm, genes, rng, wrap, missing_gene_rate, lower_rate, nm in drop_gff_for, nm in separate_fasta_for)
+
+
 def write_pangenome(outdir, clusters, seed=1, wrap=60, drop_gff_for=(), missing_gene_rate=0.01, lower_rate=0.02,
-                    separate_fasta_for=()):
+                    separate_fasta_for=(), workers=0):
     """Write `clusters` as an on-disk pangenome the way panfeed reads it: one Prokka-style GFF3 per sample
     (CDS features, ##FASTA section) and a panaroo gene_presence_absence.csv.  Genes sit on 1-3 contigs per sample with
     random spacers, some flush against a contig edge (offset clipping), - strand genes stored reverse-complemented.
+    workers > 0: the samples' files are written by that many forked processes, each sample from a random stream of its
+    own (another layout than workers=0 gives for the same seed -- both are valid pangenomes of the same clusters).
     Returns (csv_path, {sample: gff_path}, {sample: fasta_path or None})."""
     import os
-    rng = np.random.Generator(np.random.PCG64(seed))
-    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
     names = clusters[0].names
-    per_sample = {nm: [] for nm in names}          # (cluster index, copy, seq bytes, strand)
     cells = [dict() for _ in clusters]
-    for ci, cl in enumerate(clusters):
-        copies = {}
-        for q in range(cl.n_seqs):
-            nm = names[int(cl.seq_sample[q])]
-            k = copies.get(nm, 0)
-            copies[nm] = k + 1
-            gid = f"{nm}_{cl.index:05d}_{k}"
-            per_sample[nm].append((gid, cl.seq_string(q).encode(), int(cl.seq_strand[q]), int(cl.up)))
-            cells[ci].setdefault(nm, []).append(gid)
     os.makedirs(os.path.join(outdir, "gffs"), exist_ok=True)
     gffs, fastas = {}, {}
-    for nm in names:
-        genes = per_sample[nm]
-        ncontig = int(rng.integers(1, 4))
-        contigs = [[] for _ in range(ncontig)]
-        for g in genes:
-            contigs[int(rng.integers(0, ncontig))].append(g)
-        gff_lines = ["##gff-version 3"]
-        fasta_lines = []
-        for c, glist in enumerate(contigs):
-            cname = f"{nm}_contig{c + 1}"
-            seq = bytearray()
-            first = True
-            for gid, s, strand, inset in glist:
-                spacer = 0 if (first and rng.random() < 0.3) else int(rng.integers(3, 180))
-                first = False
-                seq += np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, spacer)].tobytes()
-                start = len(seq) + 1 + inset          # clusters made with flank=F: the CDS is the inner part, so
-                seq += s if strand > 0 else s[::-1].translate(comp)
-                end = len(seq) - inset                # reading with upstream=downstream=F returns the whole allele
-                if rng.random() >= missing_gene_rate:
-                    gff_lines.append(f"{cname}\tProdigal\tCDS\t{start}\t{end}\t.\t{'+' if strand > 0 else '-'}\t0\t"
-                                     f"ID={gid};Parent={gid}_gene;product=hypothetical protein")
-                    gff_lines.append(f"{cname}\tProdigal\tgene\t{start}\t{end}\t.\t{'+' if strand > 0 else '-'}\t.\tID={gid}_gene")
-            if rng.random() < 0.7:
-                seq += np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(rng.integers(1, 150)))].tobytes()
-            seq = bytes(seq)
-            if lower_rate:
-                arr = np.frombuffer(seq, np.uint8).copy()
-                low = rng.random(len(arr)) < lower_rate
-                arr[low] |= 0x20
-                seq = arr.tobytes()
-            fasta_lines.append(f">{cname} len={len(seq)}")
-            fasta_lines += [seq[i:i + wrap].decode() for i in range(0, len(seq), wrap)]
-            gff_lines.insert(1 + c, f"##sequence-region {cname} 1 {len(seq)}")
-        if nm in drop_gff_for:
-            continue
-        path = os.path.join(outdir, "gffs", f"{nm}.gff")
-        with open(path, "w") as fh:
-            fh.write("\n".join(gff_lines) + "\n")
-            if nm in separate_fasta_for:
-                fa = os.path.join(outdir, "gffs", f"{nm}.fasta")
-                with open(fa, "w") as f2:
-                    f2.write("\n".join(fasta_lines) + "\n")
+    if workers > 0:
+        import multiprocessing as mp
+        global _POOL_ARGS
+        for ci, cl in enumerate(clusters):
+            copies = {}
+            for q in range(cl.n_seqs):
+                nm = names[int(cl.seq_sample[q])]
+                k = copies.get(nm, 0)
+                copies[nm] = k + 1
+                cells[ci].setdefault(nm, []).append(f"{nm}_{cl.index:05d}_{k}")
+        _POOL_ARGS = (clusters, outdir, seed, wrap, missing_gene_rate, lower_rate, set(drop_gff_for), set(separate_fasta_for))
+        try:
+            with mp.get_context("fork").Pool(workers) as pool:
+                for nm, (path, fa) in pool.imap_unordered(_pool_sample, range(len(names)), chunksize=4):
+                    if path is not None:
+                        gffs[nm] = path
+                        fastas[nm] = fa
+        finally:
+            _POOL_ARGS = None
+    else:
+        rng = np.random.Generator(np.random.PCG64(seed))
+        per_sample = {nm: [] for nm in names}          # (gene id, seq bytes, strand, inset)
+        for ci, cl in enumerate(clusters):
+            copies = {}
+            for q in range(cl.n_seqs):
+                nm = names[int(cl.seq_sample[q])]
+                k = copies.get(nm, 0)
+                copies[nm] = k + 1
+                gid = f"{nm}_{cl.index:05d}_{k}"
+                per_sample[nm].append((gid, cl.seq_string(q).encode(), int(cl.seq_strand[q]), int(cl.up)))
+                cells[ci].setdefault(nm, []).append(gid)
+        for nm in names:
+            path, fa = _sample_files(outdir, nm, per_sample[nm], rng, wrap, missing_gene_rate, lower_rate,
+                                     nm in drop_gff_for, nm in separate_fasta_for)
+            if path is not None:
+                gffs[nm] = path
                 fastas[nm] = fa
-            else:
-                fh.write("##FASTA\n" + "\n".join(fasta_lines) + "\n")
-                fastas[nm] = None
-        gffs[nm] = path
     csv_path = os.path.join(outdir, "gene_presence_absence.csv")
     with open(csv_path, "w") as fh:
         fh.write(",".join(["Gene", "Non-unique Gene name", "Annotation"] + names) + "\n")

@@ -194,6 +194,23 @@ def test_by_reference_batches_describe_the_same_input(pangenome):
     assert n_ref > 150 and n_rev > 50 and n_lit > 10          # text stays for the target strain and the N-carrying ones
 
 
+def test_parallel_writer_makes_a_valid_pangenome(tmp_path):
+    """synth.write_pangenome(workers=N) (bench.py's long end-to-end leg): every sample from its own random stream, written
+    by forked processes; the reader and the restatement agree on it and every cluster's sequences are the generator's"""
+    cl = synth.generate(9, 14, first=77, flank=10, mean_len=150, min_len=30, max_len=400, n_rate=0.05, paralog_rate=0.1)
+    csvp, gffs, fas = synth.write_pangenome(str(tmp_path), cl, seed=5, workers=3, missing_gene_rate=0.0, lower_rate=0.0)
+    gn = sorted(gffs)
+    p = dict(csv=csvp, genomes=gn, gff=[gffs[n] for n in gn], fasta=[fas[n] for n in gn])
+    _s, exp = _expected(p, 10, 10, False)
+    with _open(p, 10, 10) as pg:
+        got = list(pg.records(4))
+    assert len(got) == len(exp) == len(cl)
+    for (g, gi, gp), (e, ei, ep), c in zip(got, exp, cl):
+        assert gi == ei == c.idx and (gp == ep).all() and g == e
+        want = sorted(c.seq_string(q) for q in range(c.n_seqs))
+        assert sorted(s.sequence for seqs in g.values() for s in seqs) == want
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_reader_fuzz_against_restatement(tmp_path, seed):
     """random small pangenomes and options: native reader == Python restatement, record for record"""
