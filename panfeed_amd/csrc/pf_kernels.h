@@ -1882,6 +1882,13 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
     __shared__ uint16_t slot_tag[9600];        // per slot: table position of its mask in this round, or a WIDE_ state
     __shared__ uint32_t mstage[ROWS_THREADS / 32][4][33];   // the four masks being expanded, per half-wave; word 32 stays zero
     __shared__ uint32_t wstart[MAX_CHUNKS + 1];          // first segment of every 32-sample word
+    // mode 2, masks of ONE distinct sequence (a k-mer private to an allele: 98 % of the slots of a cluster of 150 alleles
+    // that each carry their own substitutions, 40 % where the alleles descend from one another): row, hash and keep flag
+    // per distinct sequence, once, from the sample sets M -- such slots never see the mask table
+    constexpr uint32_t SINGLE_MAX = 512;
+    constexpr uint16_t SINGLE_TAG = 0x8000u;             // slot_tag: SINGLE_TAG | distinct index
+    __shared__ uint4 single_hash[SINGLE_MAX];
+    __shared__ uint32_t single_keep[SINGLE_MAX / 32];
 
     PF_PROF_BEGIN();
     const uint32_t tid = threadIdx.x;
@@ -2155,6 +2162,31 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
             hout = make_uint4(st.h1, st.h2, st.h3, st.h4);
             return keep;
         };
+        // ---- singleton masks: M[d] = the samples that carry distinct sequence d, in the place the round's table will
+        // take afterwards; one lane per d hashes its row
+        const uint32_t m_base = (((nsegs + 1) >> 1) + 3u) & ~3u;
+        const bool singles = D <= SINGLE_MAX && m_base + D * RW <= 20480u;
+        if (singles) {
+            uint32_t* Ms = rsh + m_base;
+            for (uint32_t i = tid; i < D * RW; i += ROWS_THREADS) Ms[i] = 0;
+            if (tid < SINGLE_MAX / 32) single_keep[tid] = 0;
+            __syncthreads();
+            for (uint32_t s = tid; s < nsegs; s += ROWS_THREADS) {
+                const uint32_t e = segd[s];                                   // distinct index << 5 | sample & 31
+                // (the sample's word: the segments are sorted by sample, wstart[w] = segments of the words before w)
+                uint32_t lo_w = 0, hi_w = nchunks;
+                while (lo_w + 1 < hi_w) { const uint32_t mid = (lo_w + hi_w) >> 1; if (wstart[mid] <= s) lo_w = mid; else hi_w = mid; }
+                atomicOr(&Ms[(e >> 5) * RW + lo_w], 1u << (e & 31u));
+            }
+            __syncthreads();
+            if (tid < D) {
+                uint4 h;
+                const bool keep = row_hash(Ms + tid * RW, h);
+                single_hash[tid] = h;
+                if (keep) atomicOr(&single_keep[tid >> 5], 1u << (tid & 31u));
+            }
+            __syncthreads();
+        }
         for (;;) {
             for (uint32_t t = tid; t < AT_SLOTS; t += ROWS_THREADS) at_key[t] = 0;
             if (tid == 0) { at_count = 0; sh_more = 0; }
@@ -2201,6 +2233,12 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
                         if (!pend[u]) continue;
                         const uint32_t i = i0 + u * ROWS_THREADS;
                         const uint32_t (&w)[NWA] = wu[u];
+                        if (singles) {
+                            uint32_t pc = 0, at = 0;
+#pragma unroll
+                            for (uint32_t j = 0; j < NWA; j++) { pc += __popc(w[j]); if (w[j]) at = 32u * j + (uint32_t)__ffs((int)w[j]) - 1u; }
+                            if (pc == 1) { slot_tag[i] = (uint16_t)(SINGLE_TAG | at); continue; }
+                        }
                         uint64_t a1 = 0x9E3779B97F4A7C15ull, a2 = 0xC2B2AE3D27D4EB4Full;
 #pragma unroll
                         for (uint32_t j = 0; j < NWA; j++) {              // sums of word x odd constant of its place
@@ -2294,8 +2332,15 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
             // D: every slot of the round takes its mask's result
             for (uint32_t i = tid; i < ns; i += ROWS_THREADS) {
                 const uint32_t tag = slot_tag[i];
+                if (tag >= SINGLE_TAG && tag < SINGLE_TAG + SINGLE_MAX) {
+                    const uint32_t dd = tag - SINGLE_TAG;
+                    const bool kp = (single_keep[dd >> 5] >> (dd & 31u)) & 1u;
+                    if (kp) p.slot_hash[(size_t)slice * NS + i] = single_hash[dd];
+                    slot_tag[i] = kp ? WIDE_KEEP : WIDE_DROP;
+                    continue;
+                }
                 if (tag >= AT_SLOTS) continue;
-                p.slot_hash[(size_t)slice * NS + i] = at_hash[tag];
+                if (at_keep[tag]) p.slot_hash[(size_t)slice * NS + i] = at_hash[tag];    // (emit_kernel reads kept k-mers' only)
                 slot_tag[i] = at_keep[tag] ? WIDE_KEEP : WIDE_DROP;
             }
             __syncthreads();
@@ -2424,7 +2469,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
             }
             if (found) { h = at_hash[a]; keep = at_keep[a] != 0; }
             else keep = row_eval(true, amask, i, h);          // table was full: evaluate this slot on its own
-            p.slot_hash[(size_t)slice * NS + i] = h;
+            if (keep) p.slot_hash[(size_t)slice * NS + i] = h;
             place(i, o, keep);
         }
     }
@@ -2448,7 +2493,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         } else {
             keep = row_eval(false, 0, i, h);
         }
-        p.slot_hash[(size_t)slice * NS + i] = h;
+        if (keep) p.slot_hash[(size_t)slice * NS + i] = h;
         place(i, o, keep);
     }
     __syncthreads();

@@ -8,6 +8,8 @@ BENCH_DEFAULT="python bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-ever
 case "$1" in
 build)
   mkdir -p ab
+  cp panfeed_amd/libpanfeed_hip.so ab/.shipped.so 2>/dev/null || true
+  trap 'if [ -f ab/.shipped.so ]; then mv ab/.shipped.so panfeed_amd/libpanfeed_hip.so; fi' EXIT
   PF_CXXFLAGS="$3" python -c 'import __graft_entry__ as g; g.build(force=True)'
   cp panfeed_amd/libpanfeed_hip.so "ab/$2.so"
   ;;
@@ -16,6 +18,8 @@ run)
   CMD=${*:-$BENCH_DEFAULT}
   mkdir -p gpurun_out/ab
   cp panfeed_amd/libpanfeed_hip.so gpurun_out/ab/.orig.so
+  # whatever way this ends (a failed or timed-out step under set -e included), the shipped library is back in its place
+  trap 'cp gpurun_out/ab/.orig.so panfeed_amd/libpanfeed_hip.so' EXIT
   for r in $(seq 1 $R); do
     for v in "$A" "$B"; do
       cp "$v" panfeed_amd/libpanfeed_hip.so
@@ -27,7 +31,6 @@ print(sys.argv[1], "%.3e" % d["value"], round(d["ms_per_step"], 3), {k: round(v,
 PY
     done
   done
-  cp gpurun_out/ab/.orig.so panfeed_amd/libpanfeed_hip.so
   ;;
 *) echo "usage: ab_bench.sh build NAME [FLAGS] | run A.so B.so [ROUNDS] [CMD...]"; exit 2;;
 esac

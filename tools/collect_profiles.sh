@@ -2,7 +2,7 @@
 # to be copied into profiles/ROUND/.  (The headline's bench line, kernel stats and PMC passes: tools/profile_round.sh.)
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-R=${1:-r03}; OUT=gpurun_out/${R}_extra
+R=${1:-r04}; OUT=gpurun_out/${R}_extra
 rm -rf $OUT && mkdir -p $OUT
 F="--no-every-copy-leg --no-n-leg --no-e2e-leg"
 # BASELINE configs[1]: 5 000 clusters x 200 samples, no flanks
@@ -27,9 +27,11 @@ find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collectio
 # randomised differential runs against the oracle (tests/fuzz_parity.py): small and BASELINE-sized clusters
 (timeout -k 10 400 python tests/fuzz_parity.py 1000 301 | tail -1; timeout -k 10 400 python tests/fuzz_parity.py 200 302 big | tail -1) > $OUT/fuzz_parity_runs.txt 2>&1
 # cycles per phase inside rows / emit / scan / finish at ~140 distinct sequences per cluster (a -DPF_PROF build, then the shipped one again)
+cp panfeed_amd/libpanfeed_hip.so $OUT/.shipped.so
+trap 'cp '"$OUT"'/.shipped.so panfeed_amd/libpanfeed_hip.so' EXIT     # the shipped library back, whatever fails below (set -e)
 PF_PROF=1 python -c "import __graft_entry__ as g; g.build(force=True)" > /dev/null 2>&1
 for M in tree star; do (echo "== 2000 clusters, mean 150 alleles, $M"; timeout -k 10 200 python tools/phase_prof.py 2000 150 $M 2>/dev/null) >> $OUT/phase_profile_150_alleles.txt; done
-python -c "import __graft_entry__ as g; g.build(force=True)" > /dev/null 2>&1
+cp $OUT/.shipped.so panfeed_amd/libpanfeed_hip.so
 # BASELINE configs[4] shape: 5 000 samples, k = 21 and 51, --targets second pass
 timeout -k 10 400 python bench.py --samples 5000 --k 21 --clusters 6000 --steps 5 --warmup 2 --no-n-leg --no-e2e-leg --targets-clusters 4 > $OUT/bench_cfg4_6000x5000_k21_targets.json 2> $OUT/cfg4a.err
 timeout -k 10 400 python bench.py --samples 5000 --k 51 --clusters 6000 --steps 5 --warmup 2 --no-n-leg --no-e2e-leg > $OUT/bench_cfg4_6000x5000_k51.json 2> $OUT/cfg4b.err
