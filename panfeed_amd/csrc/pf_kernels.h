@@ -2165,7 +2165,10 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         // ---- singleton masks: M[d] = the samples that carry distinct sequence d, in the place the round's table will
         // take afterwards; one lane per d hashes its row
         const uint32_t m_base = (((nsegs + 1) >> 1) + 3u) & ~3u;
-        const bool singles = D <= SINGLE_MAX && m_base + D * RW <= 20480u;
+        // (for clusters of three or more work items: there an allele's private k-mers are nearly all there is and its mask
+        // comes back in every item -- 2 000 clusters of ~150 SURVEY alleles, ten items each: rows_kernel 6.2 -> 5.7 ms; with
+        // related alleles, two items a cluster, the set-up cost what it saved: 1.40 -> 1.54 ms)
+        const bool singles = D <= SINGLE_MAX && m_base + D * RW <= 20480u && p.item_nsib[item] >= 3;
         if (singles) {
             uint32_t* Ms = rsh + m_base;
             for (uint32_t i = tid; i < D * RW; i += ROWS_THREADS) Ms[i] = 0;

@@ -74,9 +74,21 @@ def _first_per_digest(rows, engine=None):
     return keep, n_distinct
 
 
+def _check_collective_device(dist, *tensors):
+    """RCCL moves device memory: under the nccl backend every tensor handed to a collective has to live on THIS rank's
+    GPU (a host tensor, or one on another rank's device, fails deep inside the collective -- or hangs the group)."""
+    if dist is None or not dist.is_initialized() or dist.get_backend() != "nccl":
+        return
+    cur = torch.cuda.current_device()
+    for t in tensors:
+        if not t.is_cuda or t.device.index != cur:
+            raise ValueError(f"tensor on {t.device} handed to an RCCL collective of the rank whose device is cuda:{cur}")
+
+
 def _merge_owner(md5, first_seen, dist, engine):
     world = dist.get_world_size()
     dev = md5.device
+    _check_collective_device(dist, md5, first_seen)
     n = md5.shape[0]
     pay = _pack_rows(md5, first_seen)
     owner = (((pay[:, 0] >> 17) & 0x7FFFFFFF) % world).to(torch.int16)    # any fixed function of the digest
@@ -115,6 +127,7 @@ def merge_pattern_tensors(md5, first_seen, dist=None, engine=None, method="owner
         return _merge_owner(md5, first_seen, dist, engine)
     if multi:
         world, rank = dist.get_world_size(), dist.get_rank()
+        _check_collective_device(dist, md5, first_seen)
         counts = torch.zeros(world, dtype=torch.int64, device=dev)
         mine = torch.tensor([n], dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(counts, mine)

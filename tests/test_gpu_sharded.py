@@ -89,3 +89,37 @@ def test_single_rank_with_device_tensors(tmp_path):
     for f in FILES:
         assert read_out(out, f, False) == case["expect"][f], f
     assert stats["patterns"] == case["expect"]["n_patterns"] == stats["pattern_rows"]
+
+
+def test_rccl_calls_through_a_real_nccl_group():
+    """tools/nccl_selftest.py as its own process: a `torch.distributed` group of the nccl backend (= RCCL) on the one GPU
+    of this box -- the owner form's all-to-alls and all-reduce with their split sizes and dtypes, the ordinal-range
+    all-gather and the id selection of `sharded.finish_shard`, on device tensors of the rank's own GPU.  (World 2 over
+    nccl needs two devices; the multi-rank control flow is covered over gloo above.  No scaling curve exists.)"""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(repo, "tools", "nccl_selftest.py")], cwd=repo, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "owner: n_global 3000 (expected 3000), keep marks ok" in r.stdout
+    assert "finish_shard path on cuda:0" in r.stdout and "WRONG" not in r.stdout
+
+
+def test_collective_refuses_a_tensor_of_another_device():
+    """under nccl a host tensor must not reach a collective (it would fail inside RCCL, or hang the group)"""
+    import torch
+    from panfeed_amd import distributed
+
+    class FakeDist:
+        @staticmethod
+        def is_initialized():
+            return True
+
+        @staticmethod
+        def get_backend():
+            return "nccl"
+    with pytest.raises(ValueError, match="RCCL collective"):
+        distributed._check_collective_device(FakeDist, torch.zeros(4, 16, dtype=torch.uint8))
+    distributed._check_collective_device(FakeDist, torch.zeros(4, device="cuda:0"))
