@@ -176,9 +176,20 @@ def oracle_sample(args, local, threads, n, n_rate, timed):
     return base, par
 
 
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) of the kernel sources the library is built from: what a committed counter summary
+    is compared with (the GPU box has no .git; tools/pmc_summary.py stamps the same hash into the summary)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("pf_kernels.h", "pf_api.hip"):
+        with open(os.path.join(REPO, "panfeed_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def load_pmc():
     """committed rocprofv3 --pmc summary of the default command (tools/profile_round.sh): HBM bytes and SQ counters"""
-    for rel in ("profiles/r03/final_pmc_summary.json", "profiles/r02/final_pmc_summary.json"):
+    for rel in ("profiles/r04/final_pmc_summary.json", "profiles/r03/final_pmc_summary.json", "profiles/r02/final_pmc_summary.json"):
         path = os.path.join(REPO, rel)
         if os.path.exists(path):
             with open(path) as fh:
@@ -704,7 +715,12 @@ def main():
                            if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": "pf_submit kernel chain (dedup+scan+finish+md5)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": traffic_src, "algorithmic_bytes_per_step": alg,
+                         "traffic_source": traffic_src,
+                         # the counters are a committed pass, not this run's: which commit's kernels it profiled, and whether
+                         # the kernel sources of THIS build are those (false: re-collect with tools/profile_round.sh)
+                         "traffic_commit": (pmc or {}).get("commit"),
+                         "traffic_matches_this_build": (pmc or {}).get("kernel_source_sha16") == kernel_source_hash() if pmc else None,
+                         "algorithmic_bytes_per_step": alg,
                          "must_move_bytes_per_step": alg_must,
                          "must_move_GBps": alg_must / chain_s / 1e9 if chain_s > 0 else 0.0,
                          "must_move_frac": alg_must / chain_s / 1e9 / HBM_PEAK_GBS if chain_s > 0 else 0.0,

@@ -1,10 +1,11 @@
 # bench line + rocprofv3 kernel stats + PMC passes (HBM bytes, SQ counters) of the default bench command.
-# usage (on a GPU box): bash tools/profile_round.sh [--prof-only] [ROUND] ; results under gpurun_out/ROUND/ (default r03), to be
+# usage (on a GPU box): PF_COMMIT=<git rev-parse --short HEAD, taken where .git is> bash tools/profile_round.sh [--prof-only] [ROUND] ;
+# results under gpurun_out/ROUND/ (default r04), to be
 # copied into profiles/ROUND/
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 PROF_ONLY=0; if [ "$1" = "--prof-only" ]; then PROF_ONLY=1; shift; fi
-OUT=gpurun_out/${1:-r03}
+OUT=gpurun_out/${1:-r04}
 rm -rf $OUT && mkdir -p $OUT
 if [ "$PROF_ONLY" = 0 ]; then
 timeout -k 10 500 python bench.py --steps 5 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
