@@ -78,7 +78,7 @@ def parse(argv=None):
     ap.add_argument("--no-dedup", action="store_true", help="scan every copy of identical sequences (PF_FLAG_NO_DEDUP)")
     ap.add_argument("--no-unit-dedup", action="store_true", help="scan every unit of every distinct sequence (PF_FLAG_NO_UNIT_DEDUP)")
     ap.add_argument("--no-key-binning", action="store_true", help="key partitions walk the whole cluster (PF_FLAG_NO_KEY_BINNING)")
-    ap.add_argument("--no-device-plan", action="store_true", help="the host builds every work item (PF_FLAG_NO_DEVICE_PLAN)")
+    ap.add_argument("--device-plan", action="store_true", help="the simple clusters' work items laid out on the device (PF_FLAG_DEVICE_PLAN)")
     ap.add_argument("--no-every-copy-leg", action="store_true", help="skip the extra scan-every-copy step")
     ap.add_argument("--no-n-leg", action="store_true", help="skip the leg with SURVEY 8d's share of 'N's")
     ap.add_argument("--no-e2e-leg", action="store_true", help="skip the end-to-end (files -> files) leg")
@@ -303,7 +303,7 @@ def allele_sweep(args, local, allele_model="star"):
     for mean_alleles in (7, 30, 60, 70, 150, 500):
         eng = Engine(klength=k, max_strains=(S + 31) // 32 * 32, device=local, max_items=32768, pattern_capacity=1 << 24,
                      unit_dedup=not args.no_unit_dedup, key_binning=not args.no_key_binning,
-                     device_plan=not args.no_device_plan)
+                     device_plan=args.device_plan)
         cl = synth.generate(n, S, first=0, flank=args.flank, n_rate=0.0, mean_alleles=mean_alleles, allele_decay=1.0,
                             allele_model=allele_model)
         distinct = float(np.mean([len(np.unique(c.seq_allele)) for c in cl]))
@@ -521,7 +521,7 @@ def main():
         args.pattern_capacity = 1 << 25 if n_mine * max(S, 1) >= 20_000_000 else 1 << 22
     eng = Engine(klength=k, max_strains=(S + 31) // 32 * 32, device=local, max_items=max_items,
                  pattern_capacity=args.pattern_capacity, dedup=not args.no_dedup, unit_dedup=not args.no_unit_dedup, key_binning=not args.no_key_binning,
-                 device_plan=not args.no_device_plan)
+                 device_plan=args.device_plan)
 
     def build(first, n_mine, n_rate=None):
         # generate + upload in slabs so the host never holds more than a slab of cluster objects

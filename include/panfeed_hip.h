@@ -69,12 +69,13 @@ typedef struct {
    by partition first, so that every pass reads its own windows only.  With this flag every pass walks the whole cluster
    and keeps its share (same output, slower on clusters of many alleles). */
 #define PF_FLAG_NO_KEY_BINNING 4u
-/* The work items of a batch's simple clusters (at most 64 distinct sequences, one key partition, a fused finish class)
-   are laid out by a kernel right behind the dedup pass, and the host only reads a 40-byte summary before it launches
-   their scan (the reference's hand-off is a queue, __main__.py:39-52).  With this flag the host builds every work item
-   from the per-cluster records, as rounds 1-3 did (same output; a host round trip and O(clusters) host work in front of
-   the scan). */
-#define PF_FLAG_NO_DEVICE_PLAN 8u
+/* Opt-in: the work items of a batch's simple clusters (at most 64 distinct sequences, one key partition, a fused finish
+   class) are laid out by three small kernels right behind the dedup pass, and the host reads a 40-byte summary before it
+   launches their scan (the reference's hand-off is a queue, __main__.py:39-52), building only the rest of the batch from
+   the per-cluster records.  Same output.  Off by default: measured on MI355X it saves a small batch 0.02-0.03 ms of 2.6
+   and costs a 50 000-cluster batch 0.2 ms of 15 (two scan launches per part instead of one heaviest-first launch; the
+   host's work was hidden behind the other part's kernels already) -- DESIGN.md section 6. */
+#define PF_FLAG_DEVICE_PLAN 8u
 
 /*
  * One batch of gene clusters = the records iter_gene_clusters yields

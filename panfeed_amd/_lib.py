@@ -128,7 +128,7 @@ class Timing(C.Structure):
 FLAG_NO_DEDUP = 1
 FLAG_NO_UNIT_DEDUP = 2
 FLAG_NO_KEY_BINNING = 4
-FLAG_NO_DEVICE_PLAN = 8
+FLAG_DEVICE_PLAN = 8
 
 
 # every symbol include/panfeed_hip.h declares

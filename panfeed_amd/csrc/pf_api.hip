@@ -165,7 +165,7 @@ struct pf_ctx {
     // pinned memory; and the constant item arrays (zeros | ones | 0, 1, 2, ...) every device-planned pass shares
     struct DPlan { DevBuf block, it_count, out; pf::PlanOut* pin_out = nullptr; uint32_t n = 0; };
     DPlan dplan[MAX_PARTS];
-    DevBuf dp_const;
+    DevBuf dp_const, plan_room, plan_arena;
     uint32_t dp_const_n = 0;
     hipEvent_t ev_stage[2] = {nullptr, nullptr};   // a staging slot's upload has left the pinned block
 
@@ -541,7 +541,7 @@ void pf_destroy(pf_ctx* c) {
     for (auto e : c->ev_part) if (e) (void)hipEventDestroy(e);
 
     for (auto& d : c->dplan) { d.block.release(); d.it_count.release(); d.out.release(); if (d.pin_out) (void)hipHostFree(d.pin_out); }
-    c->dp_const.release();
+    c->dp_const.release(); c->plan_room.release(); c->plan_arena.release();
     for (auto& u : c->upool) {
         u.word_off.release(); u.len.release(); u.sample.release(); u.ord.release(); u.bits.release(); u.list.release();
         if (u.pin) (void)hipHostFree(u.pin);
@@ -907,7 +907,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
     // ---- the device plan (plan_kernel): the simple clusters' work items laid out behind the part's dedup, a 40-byte
     // summary on its way to pinned memory.  The estimate's learned line is what this context knew when the batch came in
     // (the host's own estimate for the rest of the part reads the same sums: they change at the end of a submit only).
-    const bool use_plan = !(c->o.flags & PF_FLAG_NO_DEVICE_PLAN) && C > 0 && c->max_items < (1u << 22);
+    const bool use_plan = (c->o.flags & PF_FLAG_DEVICE_PLAN) && C > 0 && c->max_items < (1u << 22);
     const double share = 1.0 - std::pow(0.99, (double)c->o.klength) + 0.06;
     double reg_a = 0.0, reg_b = 0.0, reg_half_sd = 0.0;
     const bool reg_ready = c->reg_n >= 16;
@@ -921,7 +921,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         // deviations cost 0.5 % to 5 % in surplus partitions -- profiles/r02/partition_margin_experiment.txt)
         reg_half_sd = 0.5 * std::sqrt(ss / std::max(1.0, n - 2.0));
     }
-    struct DPtrs { uint32_t *it_cluster, *it_nslots, *w_scan, *w_fin, *w_fin2, *w_fin5, *unit_cluster, *unit_base, *tmp; };
+    struct DPtrs { uint32_t *it_cluster, *it_nslots, *w_scan, *w_fin, *w_fin2, *w_fin5, *unit_cluster, *unit_base, *blk; };
     auto dplan_ptrs = [&](const pf_ctx::DPlan& dp) {
         uint32_t* b = dp.block.as<uint32_t>();
         const size_t n = dp.n;
@@ -930,7 +930,8 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
     auto launch_plan = [&](uint32_t h, uint32_t c0, uint32_t c1) -> int {
         pf_ctx::DPlan& dp = c->dplan[h];
         dp.n = c1 - c0;
-        PFCHK(dp.block.ensure((size_t)dp.n * 9 * 4));
+        const uint32_t nblk = (dp.n + pf::PLAN_THREADS - 1) / pf::PLAN_THREADS;
+        PFCHK(dp.block.ensure(((size_t)dp.n * 8 + (size_t)nblk * pf::PLAN_BLK_WORDS) * 4));
         PFCHK(dp.it_count.ensure((size_t)dp.n * 4));
         PFCHK(dp.out.ensure(sizeof(pf::PlanOut)));
         if (!dp.pin_out) {
@@ -939,14 +940,15 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         }
         const DPtrs q = dplan_ptrs(dp);
         pf::PlanParams pp{};
-        pp.rec = c->cl_rec.as<pf::ClusterRec>(); pp.extra_off = c->extra_off.as<uint32_t>();
-        pp.c0 = c0; pp.c1 = c1; pp.mult = c->o.canon ? 1u : 2u;
-        pp.NS = NS; pp.W = W; pp.max_items = c->max_items; pp.unit_view = (c->o.flags & PF_FLAG_NO_UNIT_DEDUP) ? 0u : 1u;
-        pp.share = share; pp.reg_a = reg_a; pp.reg_b = reg_b; pp.reg_half_sd = reg_half_sd; pp.reg_ready = reg_ready ? 1u : 0u;
+        pp.rec = c->cl_rec.as<pf::ClusterRec>(); pp.plan_room = c->plan_room.as<uint32_t>(); pp.plan_arena = c->plan_arena.as<uint32_t>();
+        pp.c0 = c0; pp.c1 = c1;
+        pp.NS = NS; pp.max_items = c->max_items;
         pp.it_cluster = q.it_cluster; pp.it_nslots = q.it_nslots; pp.w_scan = q.w_scan; pp.w_fin = q.w_fin; pp.w_fin2 = q.w_fin2;
-        pp.w_fin5 = q.w_fin5; pp.unit_cluster = q.unit_cluster; pp.unit_base = q.unit_base; pp.tmp = q.tmp;
+        pp.w_fin5 = q.w_fin5; pp.unit_cluster = q.unit_cluster; pp.unit_base = q.unit_base; pp.blk = q.blk;
         pp.out = dp.out.as<pf::PlanOut>();
-        hipLaunchKernelGGL(pf::plan_kernel, dim3(1), dim3(pf::PLAN_THREADS), 0, c->stream, pp);
+        hipLaunchKernelGGL(pf::plan_count_kernel, dim3(nblk), dim3(pf::PLAN_THREADS), 0, c->stream, pp);
+        hipLaunchKernelGGL(pf::plan_scan_kernel, dim3(1), dim3(256), 0, c->stream, pp, nblk);
+        hipLaunchKernelGGL(pf::plan_scatter_kernel, dim3(nblk), dim3(pf::PLAN_THREADS), 0, c->stream, pp);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(dp.pin_out, dp.out.p, sizeof(pf::PlanOut), hipMemcpyDeviceToHost, c->stream));
         return PF_OK;
@@ -960,6 +962,15 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         HIPCHK(hipMemcpy(c->dp_const.p, h.data(), h.size() * 4, hipMemcpyHostToDevice));
         c->dp_const_n = n;
     }
+    // what cluster_ninst_kernel works out per cluster for plan_kernel (nothing when the host builds every item)
+    pf::PlanClassify pcls{};
+    if (use_plan) {
+        PFCHK(c->plan_room.ensure((size_t)C * 4));
+        PFCHK(c->plan_arena.ensure((size_t)C * 4));
+        pcls.extra_off = c->extra_off.as<uint32_t>(); pcls.plan_room = c->plan_room.as<uint32_t>(); pcls.plan_arena = c->plan_arena.as<uint32_t>();
+        pcls.mult = c->o.canon ? 1u : 2u; pcls.NS = NS; pcls.W = W; pcls.unit_view = (c->o.flags & PF_FLAG_NO_UNIT_DEDUP) ? 0u : 1u;
+        pcls.reg_ready = reg_ready ? 1u : 0u; pcls.share = share; pcls.reg_a = reg_a; pcls.reg_b = reg_b; pcls.reg_half_sd = reg_half_sd;
+    }
     // the dedup of part h and its results on their way to pinned memory (ev_part[h]); all parts are queued up front
     auto launch_dedup_part = [&](uint32_t h) -> int {
         const uint32_t c0 = h ? part_end[h - 1] : 0, c1 = part_end[h], n = c1 - c0;
@@ -972,7 +983,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             hipLaunchKernelGGL(pf::cluster_ninst_kernel, dim3((n + 3) / 4), dim3(256), 0, c->stream, d.cluster_seg_off,
                                d.seg_len, c->v_len.as<uint32_t>(), c->v_nseg.as<uint32_t>(), c->o.klength, c0, c1,
                                (const uint32_t*)nullptr,
-                               c->v_mode.as<uint32_t>(), c->v_dense.as<uint32_t>(), c->v_nstr.as<uint32_t>(), c->cl_rec.as<pf::ClusterRec>());
+                               c->v_mode.as<uint32_t>(), c->v_dense.as<uint32_t>(), c->v_nstr.as<uint32_t>(), c->cl_rec.as<pf::ClusterRec>(), pcls);
             HIPCHK(hipGetLastError());
             if (use_plan) PFCHK(launch_plan(h, c0, c1));
             HIPCHK(hipMemcpyAsync(rec + c0, c->cl_rec.as<pf::ClusterRec>() + c0, (size_t)n * sizeof(pf::ClusterRec), hipMemcpyDeviceToHost, c->stream));
@@ -1037,7 +1048,8 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             hipLaunchKernelGGL(pf::cluster_ninst_kernel, dim3((nw + 3) / 4), dim3(256), 0, c->stream, d.cluster_seg_off,
                                d.seg_len, c->v_len.as<uint32_t>(), c->v_nseg.as<uint32_t>(), c->o.klength, 0u, nw,
                                c->wide_list.as<uint32_t>(),
-                               c->v_mode.as<uint32_t>(), c->v_dense.as<uint32_t>(), c->v_nstr.as<uint32_t>(), c->cl_rec.as<pf::ClusterRec>());
+                               c->v_mode.as<uint32_t>(), c->v_dense.as<uint32_t>(), c->v_nstr.as<uint32_t>(), c->cl_rec.as<pf::ClusterRec>(),
+                               pf::PlanClassify{});        // (the wide class's clusters are the host's: no plan bits)
             HIPCHK(hipGetLastError());
             const size_t n = c1 - c0;
             HIPCHK(hipMemcpyAsync(rec + c0, c->cl_rec.as<pf::ClusterRec>() + c0, n * sizeof(pf::ClusterRec), hipMemcpyDeviceToHost, c->stream));
@@ -1049,7 +1061,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             if (rec[i].ninst * mult >= 0xFFFFFFF0ull) return fail(PF_ERR_ARG, "cluster %u has too many k-mer instances", i);
             total_inst += rec[i].ninst * mult;
             c->timing.n_dedup_clusters += rec[i].mode ? 1u : 0u;
-            if (rec[i].pad) continue;          // laid out by plan_kernel: one key partition
+            if (rec[i].pad & pf::PLAN_PLANNED) continue;          // laid out by plan_kernel: one key partition
             if (rec[i].mode && rec[i].vnstr) {
                 const double D = (double)rec[i].vnstr, L = (double)(rec[i].vinst * mult) / D;
                 const double est = L * (1.0 + share * (D - 1.0));
@@ -1091,7 +1103,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             uint32_t nu = 0, nsmall = 0;
             uint64_t room = 0;
             uint32_t* lc = up.pin;
-            auto takes = [&](uint32_t i) { return !rec[i].pad && rec[i].mode && rec[i].vnstr >= 2 && rec[i].words && room + rec[i].words / 2 < 0x7FFFFFF0ull; };
+            auto takes = [&](uint32_t i) { return !(rec[i].pad & pf::PLAN_PLANNED) && rec[i].mode && rec[i].vnstr >= 2 && rec[i].words && room + rec[i].words / 2 < 0x7FFFFFF0ull; };
             for (uint32_t i = c0; i < c1; i++)
                 if (rec[i].vnstr <= pf::UNIT_SMALL_MAX_D && takes(i)) { lc[nu++] = i; room += rec[i].words / 2; }
             nsmall = nu;
@@ -1301,7 +1313,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             PFCHK(prep_half((int)pass));
             todo.clear();
             for (uint32_t ci = pass ? part_end[pass - 1] : 0; ci < part_end[pass]; ci++) {
-                if (!rec[ci].pad) { todo.push_back(ci); continue; }
+                if (!(rec[ci].pad & pf::PLAN_PLANNED)) { todo.push_back(ci); continue; }
                 c->timing.scan_packed_bytes += rec[ci].words * 8;
                 c->cluster_arena[ci] = planned_arena;
             }
@@ -1322,7 +1334,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         std::vector<uint32_t>&bin_cluster = c->hs_bin[0], &bin_item0 = c->hs_bin[1], &bin_nparts = c->hs_bin[2], &bin_base = c->hs_bin[3];
         v_binned.clear(); bin_cluster.clear(); bin_item0.clear(); bin_nparts.clear(); bin_base.clear();
         // (which unit-view pool a cluster's view lies in: its part's device-planned one or the host-planned one)
-        auto part_of = [&](uint32_t ci) { uint32_t q = 0; while (q + 1 < P && ci >= part_end[q]) q++; return 2 * q + (rec[ci].pad ? 0u : 1u); };
+        auto part_of = [&](uint32_t ci) { uint32_t q = 0; while (q + 1 < P && ci >= part_end[q]) q++; return 2 * q + ((rec[ci].pad & pf::PLAN_PLANNED) ? 0u : 1u); };
         std::vector<Sub> subs;
         std::vector<uint32_t>&sub_cluster = c->hs_sub[0], &sub_item0 = c->hs_sub[1], &sub_nitems = c->hs_sub[2];
         sub_cluster.clear(); sub_item0.clear(); sub_nitems.clear();

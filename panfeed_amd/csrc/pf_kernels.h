@@ -4233,11 +4233,24 @@ __global__ __launch_bounds__(256) void merge_lookup_kernel(MergeParams p) {
 // dense ordinal space and number of view columns they make the 40-byte record the host plans the batch's work from.
 struct ClusterRec { uint64_t ninst, vinst, words; uint32_t mode, dense, vnstr, pad; };
 static_assert(sizeof(ClusterRec) == 40, "ClusterRec is copied to the host as 40-byte records");
+// What plan_kernel needs to know of a cluster, worked out here where every cluster has a wave of its own (the first cut
+// did it inside plan_kernel's ONE workgroup: a float64 division and a dozen branches per cluster made a part of 37 500
+// clusters 0.18 ms of a single CU): ClusterRec.pad = PLAN_CLS bits | table size | weight class, plan_room[c] = room of the
+// cluster's unit view (0: none), plan_arena[c] = output entries to reserve.
+struct PlanClassify {
+    const uint32_t* extra_off;       // [C + 1] slow-path rows per cluster (CSR); nullptr: no classification (pad = 0)
+    uint32_t* plan_room; uint32_t* plan_arena;
+    uint32_t mult, NS, W, unit_view, reg_ready, pad;
+    double share, reg_a, reg_b, reg_half_sd;     // the key-partition estimate (pf_api.hip, prep_half)
+};
+constexpr uint32_t PLAN_PLANNED = 1u;            // ClusterRec.pad bit 0: laid out by plan_kernel
+constexpr uint32_t PLAN_CLS_SHIFT = 8, PLAN_NS_SHIFT = 12, PLAN_W_SHIFT = 16;   // class (1, 2, 5), table (0: NS, 1: 4096, 2: 6144), 64 - log2(windows)
+
 __global__ __launch_bounds__(256) void cluster_ninst_kernel(const uint32_t* cluster_seg_off, const uint32_t* seg_len,
                                                             const uint32_t* v_len, const uint32_t* v_nseg, uint32_t k,
                                                             uint32_t c_first, uint32_t c_end, const uint32_t* list,
                                                             const uint32_t* v_mode, const uint32_t* v_dense,
-                                                            const uint32_t* v_nstr, ClusterRec* rec) {
+                                                            const uint32_t* v_nstr, ClusterRec* rec, PlanClassify pc) {
     // clusters c_first .. c_end - 1, or (list) list[c_first .. c_end - 1]
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t idx = c_first + ((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -4260,6 +4273,40 @@ __global__ __launch_bounds__(256) void cluster_ninst_kernel(const uint32_t* clus
     if (lane == 0) {
         ClusterRec r;
         r.ninst = n; r.vinst = nv; r.words = wv; r.mode = v_mode[c]; r.dense = v_dense[c]; r.vnstr = v_nstr[c]; r.pad = 0;
+        if (pc.extra_off) {
+            const uint32_t nex = pc.extra_off[c + 1] - pc.extra_off[c];
+            const uint64_t inst = r.vinst * pc.mult;
+            uint32_t cls = 0, nsi = 0, room_u = 0, arena = 0;
+            if (r.mode == 1 && nex <= FUSED_MAX_EXTRA && r.ninst * pc.mult < 0xFFFFFFF0ull) {
+                const double room = 0.9 * (double)insert_limit(pc.NS);
+                bool one = true;                                  // one key partition by the estimate
+                if (r.vnstr) {
+                    const double D = (double)r.vnstr, L = (double)inst / D;
+                    if (D >= 2.0 && pc.reg_ready) {
+                        const double g = fmax(0.0, pc.reg_a + pc.reg_b * L) + pc.reg_half_sd;
+                        one = !(L + g * (D - 1.0) > room);
+                    } else {
+                        one = !(L * (1.0 + pc.share * (D - 1.0)) > room) || D > 24.0;
+                    }
+                }
+                const uint32_t mwords = r.vnstr * ((pc.W + 3) & ~3u);
+                if (one) {
+                    if (r.dense < FinSmall::DW * 32 - 1 && mwords <= FinSmall::MR) cls = 1;
+                    else if (r.dense < FinLarge::DW * 32 - 1 && mwords <= FinLarge::MR) cls = 2;
+                    else if (r.dense < FinHuge::DW * 32 - 1 && mwords <= FinHuge::MR) cls = 5;
+                }
+                uint32_t ns = pc.NS;
+                if (pc.NS > 4096 + INSERT_SLACK && inst <= insert_limit(4096)) { ns = 4096; nsi = 1; }
+                else if (pc.NS > 6144 + INSERT_SLACK && inst <= insert_limit(6144)) { ns = 6144; nsi = 2; }
+                if (cls) {
+                    const uint32_t wcls = r.vinst ? 63 - __clzll((long long)r.vinst) : 0;
+                    r.pad = (cls << PLAN_CLS_SHIFT) | (nsi << PLAN_NS_SHIFT) | ((64 - wcls) << PLAN_W_SHIFT);
+                    arena = (uint32_t)(inst < (uint64_t)insert_limit(ns) ? inst : (uint64_t)insert_limit(ns)) + nex;
+                    if (pc.unit_view && r.vnstr >= 2 && r.words) room_u = (uint32_t)min(r.words / 2, (uint64_t)0x7FFFFFFFu);
+                }
+            }
+            pc.plan_room[c] = room_u; pc.plan_arena[c] = arena;
+        }
         rec[c] = r;
     }
 }
@@ -4280,127 +4327,159 @@ __global__ __launch_bounds__(256) void cluster_ninst_kernel(const uint32_t* clus
 struct PlanOut { uint32_t n_items, n_fin, n_fin2, n_fin5, n_unit, n_unit_small; uint64_t unit_room, arena_cap; };
 static_assert(sizeof(PlanOut) == 40, "PlanOut is copied to the host as one 40-byte record");
 struct PlanParams {
-    ClusterRec* rec;                 // [C]; pad <- 1 for the clusters laid out here
-    const uint32_t* extra_off;       // [C + 1] slow-path rows per cluster (CSR)
+    ClusterRec* rec;                 // [C]; pad: class bits from cluster_ninst_kernel, PLAN_PLANNED set here
+    const uint32_t* plan_room; const uint32_t* plan_arena;            // [C] from cluster_ninst_kernel
     uint32_t c0, c1;                 // the part's clusters
-    uint32_t mult;                   // windows per position: 1 canonical, 2 not (panfeed.py:80-88)
-    uint32_t NS, W, max_items, unit_view;
-    // the key-partition estimate (pf_api.hip, prep_half): share = 1 - 0.99^k + 0.06; the learned line g = a + b L
-    double share, reg_a, reg_b, reg_half_sd;
-    uint32_t reg_ready, pad;
+    uint32_t NS, max_items;
     uint32_t* it_cluster; uint32_t* it_nslots;                        // [n] by item
     uint32_t* w_scan; uint32_t* w_fin; uint32_t* w_fin2; uint32_t* w_fin5;    // [n] work lists (item numbers)
     uint32_t* unit_cluster; uint32_t* unit_base;                      // [n] clusters that get a unit view, their pool offsets
-    uint32_t* tmp;                                                    // [n]
+    uint32_t* blk;                   // [PLAN_BLK_WORDS per workgroup] counts of a workgroup, then (plan_scan_kernel) its bases
     PlanOut* out;
 };
+// Three small launches, every workgroup 1 024 clusters: count -> scan over the workgroups (one workgroup) -> scatter.
+// (The first cuts did all of it in ONE workgroup with the item numbers as a running count: 0.12-0.28 ms for a part of
+// 37 500 clusters on a single CU, the rest of the GPU idle -- more than the host round trip it replaced.)
 constexpr uint32_t PLAN_THREADS = 1024;
-__global__ __launch_bounds__(PLAN_THREADS) void plan_kernel(PlanParams p) {
-    __shared__ uint32_t hist[3][66];
-    __shared__ uint32_t wave_tot[PLAN_THREADS / 64 + 1];
-    __shared__ uint32_t sh_fin5;
-    const uint32_t tid = threadIdx.x, n = p.c1 - p.c0;
-    for (uint32_t i = tid; i < 3 * 66; i += PLAN_THREADS) (&hist[0][0])[i] = 0;
-    if (tid == 0) sh_fin5 = 0;
-    __syncthreads();
-    const uint32_t lim_full = insert_limit(p.NS);
-    const double room = 0.9 * (double)lim_full;
-    const uint32_t Wp = (p.W + 3) & ~3u;
-    uint32_t base_items = 0, base_unit = 0;
-    uint64_t base_room = 0, arena = 0;
-    for (uint32_t start = 0; start < n; start += PLAN_THREADS) {
-        const uint32_t i = start + tid;
-        uint32_t cls = 0, ns = p.NS, wcls = 0, uroom = 0, nex = 0;
-        uint64_t inst = 0;
-        bool wants_unit = false;
-        if (i < n) {
-            const uint32_t c = p.c0 + i;
-            const ClusterRec r = p.rec[c];
-            nex = p.extra_off[c + 1] - p.extra_off[c];
-            inst = r.vinst * p.mult;
-            if (r.mode == 1 && nex <= FUSED_MAX_EXTRA && r.ninst * p.mult < 0xFFFFFFF0ull) {
-                bool one = true;                                  // one key partition by the estimate
-                if (r.vnstr) {
-                    const double D = (double)r.vnstr, L = (double)inst / D;
-                    if (D >= 2.0 && p.reg_ready) {
-                        const double g = fmax(0.0, p.reg_a + p.reg_b * L) + p.reg_half_sd;
-                        one = !(L + g * (D - 1.0) > room);
-                    } else {
-                        one = !(L * (1.0 + p.share * (D - 1.0)) > room) || D > 24.0;
-                    }
-                }
-                const uint32_t mwords = r.vnstr * Wp;
-                if (one) {
-                    if (r.dense < FinSmall::DW * 32 - 1 && mwords <= FinSmall::MR) cls = 1;
-                    else if (r.dense < FinLarge::DW * 32 - 1 && mwords <= FinLarge::MR) cls = 2;
-                    else if (r.dense < FinHuge::DW * 32 - 1 && mwords <= FinHuge::MR) cls = 5;
-                }
-                if (p.NS > 4096 + INSERT_SLACK && inst <= insert_limit(4096)) ns = 4096;
-                else if (p.NS > 6144 + INSERT_SLACK && inst <= insert_limit(6144)) ns = 6144;
-                wcls = r.vinst ? 63 - __clzll((long long)r.vinst) : 0;
-                wants_unit = p.unit_view && r.vnstr >= 2 && r.words;
-                uroom = (uint32_t)(r.words / 2);
-            }
-        }
-        uint32_t tot;
-        uint32_t idx = base_items + block_exscan(cls ? 1u : 0u, wave_tot, &tot);
-        if (idx >= p.max_items) cls = 0;                         // a sub-batch holds max_items items: the rest is the host's
-        const uint32_t n_new = min(tot, p.max_items - min(base_items, p.max_items));
-        if (!cls) wants_unit = false;
-        uint32_t rtot;
-        const uint64_t ubase = base_room + block_exscan(wants_unit ? uroom : 0u, wave_tot, &rtot);
-        if (wants_unit && ubase + uroom >= 0x7FFFFFF0ull) wants_unit = false;     // (never met: 2^31 pieces in one part)
-        uint32_t utot;
-        const uint32_t uidx = base_unit + block_exscan(wants_unit ? 1u : 0u, wave_tot, &utot);
-        uint32_t t = 0;
-        if (cls) {
-            const uint32_t c = p.c0 + i;
-            p.it_cluster[idx] = c;
-            p.it_nslots[idx] = ns;
-            p.rec[c].pad = 1;
-            const uint32_t list = cls == 1 ? 1u : cls == 2 ? 2u : 3u;
-            atomicAdd(&hist[0][64 - wcls], 1u);
-            if (list < 3) atomicAdd(&hist[list][64 - wcls], 1u);
-            t = (idx << 9) | (list << 7) | (64 - wcls);          // idx < 2^22 (the host keeps max_items below that)
-            arena += (inst < (uint64_t)insert_limit(ns) ? inst : (uint64_t)insert_limit(ns)) + nex;
-            if (wants_unit) { p.unit_cluster[uidx] = c; p.unit_base[uidx] = (uint32_t)ubase; }
-        }
-        if (i < n) p.tmp[i] = cls ? (t | 0x80000000u) : 0u;
-        base_items += n_new; base_room += rtot; base_unit += utot;
+constexpr uint32_t PLAN_BINS = 66;               // weight classes 64 - log2(windows): 0 .. 64, and one spare
+// per workgroup: [0] items [1] unit views [2,3] unit room (u64) [4,5] arena (u64) [6] fin5 items [7] accepted; then the weight
+// histograms of the scan / fin / fin2 lists
+constexpr uint32_t PLAN_BLK_HIST = 8, PLAN_BLK_WORDS = PLAN_BLK_HIST + 3 * PLAN_BINS;
+// `active` lanes count themselves into LDS counter h[bin]; returns the lane's place among the counter's takers (the
+// counter's old value + the lane's rank among the lanes of its wave that asked for the same bin).  Wave-aggregated: the
+// clusters of a batch have two or three weight classes between them, and 64 lanes' atomics on ONE LDS address run one
+// after the other.
+__device__ __forceinline__ uint32_t wave_bin_take(uint32_t* h, bool active, uint32_t bin) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint64_t todo = __ballot(active);
+    uint32_t place = 0;
+    while (todo) {
+        const int leader = __ffsll((unsigned long long)todo) - 1;
+        const uint32_t b = __shfl(bin, leader);
+        const uint64_t same = __ballot(active && bin == b);
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(&h[b], (uint32_t)__popcll(same));
+        base = __shfl(base, leader);
+        if (active && bin == b) place = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
     }
-    // (arena: every thread summed its own clusters)
-    for (int d = 32; d > 0; d >>= 1) arena += __shfl_down(arena, d);
-    __shared__ unsigned long long sh_arena;
-    if (tid == 0) sh_arena = 0;
+    return place;
+}
+__device__ __forceinline__ void plan_info(const PlanParams& p, uint32_t i, uint32_t n, uint32_t& info, uint32_t& uroom) {
+    info = i < n ? p.rec[p.c0 + i].pad >> PLAN_CLS_SHIFT : 0u;             // nonzero: a simple cluster
+    uroom = info ? p.plan_room[p.c0 + i] : 0u;
+}
+__global__ __launch_bounds__(PLAN_THREADS) void plan_count_kernel(PlanParams p) {
+    __shared__ uint32_t cnt[PLAN_BLK_WORDS];
+    __shared__ unsigned long long s64[2];
+    const uint32_t tid = threadIdx.x, n = p.c1 - p.c0, i = blockIdx.x * PLAN_THREADS + tid;
+    for (uint32_t k = tid; k < PLAN_BLK_WORDS; k += PLAN_THREADS) cnt[k] = 0;
+    if (tid < 2) s64[tid] = 0;
     __syncthreads();
-    if ((tid & 63) == 0 && arena) atomicAdd(&sh_arena, (unsigned long long)arena);
-    __syncthreads();
-    // heaviest class first: exclusive prefix over the 65 classes of each list
-    if (tid < 3) {
-        uint32_t run = 0;
-        for (uint32_t b = 0; b < 66; b++) { const uint32_t v = hist[tid][b]; hist[tid][b] = run; run += v; }
+    uint32_t info, uroom;
+    plan_info(p, i, n, info, uroom);
+    const uint32_t cls = info & 15u, b = (info >> (PLAN_W_SHIFT - PLAN_CLS_SHIFT)) & 127u;
+    (void)wave_bin_take(cnt + PLAN_BLK_HIST, info != 0, b);
+    (void)wave_bin_take(cnt + PLAN_BLK_HIST + PLAN_BINS, cls == 1, b);
+    (void)wave_bin_take(cnt + PLAN_BLK_HIST + 2 * PLAN_BINS, cls == 2, b);
+    (void)wave_bin_take(cnt, info != 0, 0);
+    (void)wave_bin_take(cnt, uroom != 0, 1);
+    (void)wave_bin_take(cnt, cls == 5, 6);
+    uint64_t room = uroom, arena = info ? p.plan_arena[p.c0 + i] : 0u;
+    for (int d = 32; d > 0; d >>= 1) { room += __shfl_down(room, d); arena += __shfl_down(arena, d); }
+    if ((tid & 63) == 0) {
+        if (room) atomicAdd(&s64[0], (unsigned long long)room);
+        if (arena) atomicAdd(&s64[1], (unsigned long long)arena);
     }
     __syncthreads();
-    const uint32_t n_scan = hist[0][65], n_fin = hist[1][65], n_fin2 = hist[2][65];
-    __syncthreads();
-    for (uint32_t i = tid; i < n; i += PLAN_THREADS) {
-        const uint32_t t = p.tmp[i];
-        if (!(t & 0x80000000u)) continue;
-        const uint32_t idx = (t & 0x7FFFFFFFu) >> 9, list = (t >> 7) & 3u, b = t & 127u;
-        p.w_scan[atomicAdd(&hist[0][b], 1u)] = idx;
-        if (list == 1) p.w_fin[atomicAdd(&hist[1][b], 1u)] = idx;
-        else if (list == 2) p.w_fin2[atomicAdd(&hist[2][b], 1u)] = idx;
-        else p.w_fin5[atomicAdd(&sh_fin5, 1u)] = idx;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        PlanOut o;
-        o.n_items = n_scan; o.n_fin = n_fin; o.n_fin2 = n_fin2; o.n_fin5 = sh_fin5;
-        o.n_unit = base_unit; o.n_unit_small = base_unit;
-        o.unit_room = base_room; o.arena_cap = sh_arena;
-        *p.out = o;
+    uint32_t* o = p.blk + (size_t)blockIdx.x * PLAN_BLK_WORDS;
+    for (uint32_t k = tid; k < PLAN_BLK_WORDS; k += PLAN_THREADS) {
+        uint32_t v = cnt[k];
+        if (k == 2) v = (uint32_t)s64[0]; else if (k == 3) v = (uint32_t)(s64[0] >> 32);
+        else if (k == 4) v = (uint32_t)s64[1]; else if (k == 5) v = (uint32_t)(s64[1] >> 32);
+        o[k] = v;
     }
 }
+// counts -> bases, in place.  A sub-batch holds max_items items: workgroups are taken while their items fit, the clusters
+// of the others are the host's (whole workgroups, so that the histograms stay those of the accepted clusters).
+__global__ __launch_bounds__(256) void plan_scan_kernel(PlanParams p, uint32_t nblk) {
+    __shared__ uint32_t sh_acc;                  // accepted workgroups
+    __shared__ uint32_t list_tot[3], bin_base[3][PLAN_BINS];
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) {
+        uint32_t items = 0, units = 0, fin5 = 0, acc = 0;
+        uint64_t room = 0, arena = 0;
+        for (uint32_t b = 0; b < nblk; b++) {
+            uint32_t* o = p.blk + (size_t)b * PLAN_BLK_WORDS;
+            const uint32_t ni = o[0], nu = o[1], n5 = o[6];
+            const uint64_t r = o[2] | ((uint64_t)o[3] << 32), a = o[4] | ((uint64_t)o[5] << 32);
+            const bool ok = acc == b && items + ni <= p.max_items;
+            o[7] = ok ? 1u : 0u;
+            if (!ok) continue;
+            o[0] = items; o[1] = units; o[2] = (uint32_t)room; o[3] = (uint32_t)(room >> 32); o[6] = fin5;
+            items += ni; units += nu; room += r; arena += a; fin5 += n5; acc = b + 1;
+        }
+        sh_acc = acc;
+        PlanOut out;
+        out.n_items = items; out.n_fin = 0; out.n_fin2 = 0; out.n_fin5 = fin5; out.n_unit = units; out.n_unit_small = units;
+        out.unit_room = room; out.arena_cap = arena;
+        *p.out = out;
+    }
+    __syncthreads();
+    const uint32_t acc = sh_acc;
+    // every (list, weight class): its count over the accepted workgroups, then the workgroups' bases inside it
+    for (uint32_t e = tid; e < 3 * PLAN_BINS; e += 256) {
+        uint32_t run = 0;
+        for (uint32_t b = 0; b < acc; b++) {
+            uint32_t* o = p.blk + (size_t)b * PLAN_BLK_WORDS + PLAN_BLK_HIST + e;
+            const uint32_t v = *o; *o = run; run += v;
+        }
+        bin_base[e / PLAN_BINS][e % PLAN_BINS] = run;           // (for now: the class's total)
+    }
+    __syncthreads();
+    if (tid < 3) {                                               // heaviest class first
+        uint32_t run = 0;
+        for (uint32_t b = 0; b < PLAN_BINS; b++) { const uint32_t v = bin_base[tid][b]; bin_base[tid][b] = run; run += v; }
+        list_tot[tid] = run;
+    }
+    __syncthreads();
+    for (uint32_t e = tid; e < 3 * PLAN_BINS; e += 256) {
+        const uint32_t add = bin_base[e / PLAN_BINS][e % PLAN_BINS];
+        for (uint32_t b = 0; b < acc; b++) p.blk[(size_t)b * PLAN_BLK_WORDS + PLAN_BLK_HIST + e] += add;
+    }
+    if (tid == 0) { p.out->n_fin = list_tot[1]; p.out->n_fin2 = list_tot[2]; }
+}
+__global__ __launch_bounds__(PLAN_THREADS) void plan_scatter_kernel(PlanParams p) {
+    __shared__ uint32_t base[PLAN_BLK_WORDS];
+    __shared__ uint32_t wave_tot[PLAN_THREADS / 64 + 1];
+    const uint32_t tid = threadIdx.x, n = p.c1 - p.c0, i = blockIdx.x * PLAN_THREADS + tid;
+    const uint32_t* o = p.blk + (size_t)blockIdx.x * PLAN_BLK_WORDS;
+    if (!o[7]) return;                                           // past max_items: the host's clusters (pad keeps no PLAN_PLANNED)
+    for (uint32_t k = tid; k < PLAN_BLK_WORDS; k += PLAN_THREADS) base[k] = o[k];
+    __syncthreads();
+    uint32_t info, uroom;
+    plan_info(p, i, n, info, uroom);
+    uint32_t tot;
+    const uint32_t idx = base[0] + block_exscan(info ? 1u : 0u, wave_tot, &tot);
+    const uint32_t uidx = base[1] + block_exscan(uroom ? 1u : 0u, wave_tot, &tot);
+    const uint64_t ubase = (base[2] | ((uint64_t)base[3] << 32)) + block_exscan(uroom, wave_tot, &tot);
+    const uint32_t cls = info & 15u, nsi = (info >> (PLAN_NS_SHIFT - PLAN_CLS_SHIFT)) & 3u;
+    const uint32_t b = (info >> (PLAN_W_SHIFT - PLAN_CLS_SHIFT)) & 127u;
+    const uint32_t at0 = wave_bin_take(base + PLAN_BLK_HIST, info != 0, b);
+    const uint32_t at1 = wave_bin_take(base + PLAN_BLK_HIST + PLAN_BINS, cls == 1, b);
+    const uint32_t at2 = wave_bin_take(base + PLAN_BLK_HIST + 2 * PLAN_BINS, cls == 2, b);
+    const uint32_t at5 = wave_bin_take(base, cls == 5, 6);
+    if (!info) return;
+    const uint32_t c = p.c0 + i;
+    p.it_cluster[idx] = c;
+    p.it_nslots[idx] = nsi == 1 ? 4096u : nsi == 2 ? 6144u : p.NS;
+    p.rec[c].pad = (info << PLAN_CLS_SHIFT) | PLAN_PLANNED;
+    p.w_scan[at0] = idx;
+    if (cls == 1) p.w_fin[at1] = idx;
+    else if (cls == 2) p.w_fin2[at2] = idx;
+    else p.w_fin5[at5] = idx;
+    if (uroom) { p.unit_cluster[uidx] = c; p.unit_base[uidx] = (uint32_t)ubase; }   // (a part whose pieces pass 2^31 is refused by
+}                                                                                   // the host from the summary's unit_room)
 
 // ---------------------------------------------------------------------------------------------
 // Text of the output files, written on the device (row N2): the rows are assembled in LDS, one row per thread,

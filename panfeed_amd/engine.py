@@ -81,7 +81,7 @@ class BatchOutput:
 class Engine:
     def __init__(self, klength=31, canon=True, consider_missing=False, patfilt=True, maf=0.01,
                  multiple_files=False, max_strains=1024, stroi=(), device=0, pattern_capacity=0,
-                 max_items=0, dedup=True, unit_dedup=True, key_binning=True, device_plan=True):
+                 max_items=0, dedup=True, unit_dedup=True, key_binning=True, device_plan=False):
         self.L = _lib.load()
         self.k = int(klength)
         self.canon = bool(canon)
@@ -98,7 +98,7 @@ class Engine:
                       self._lo.ctypes.data_as(C.POINTER(C.c_uint32)), self._hi.ctypes.data_as(C.POINTER(C.c_uint32)),
                       int(pattern_capacity), int(max_items),
                       (0 if dedup else _lib.FLAG_NO_DEDUP) | (0 if unit_dedup else _lib.FLAG_NO_UNIT_DEDUP) |
-                      (0 if key_binning else _lib.FLAG_NO_KEY_BINNING) | (0 if device_plan else _lib.FLAG_NO_DEVICE_PLAN))
+                      (0 if key_binning else _lib.FLAG_NO_KEY_BINNING) | (_lib.FLAG_DEVICE_PLAN if device_plan else 0))
         self.ctx = C.c_void_p()
         _lib.check(self.L.pf_create(C.byref(self.ctx), int(device), C.byref(o)))
         self.next_ordinal = 0

@@ -35,7 +35,7 @@ for case in range(n_cases):
     dedup = bool(rng.random() < 0.8)
     unit_dedup = bool(rng.random() < 0.85)
     key_binning = bool(rng.random() < 0.8)
-    device_plan = bool(rng.random() < 0.75)
+    device_plan = bool(rng.random() < 0.5)
     max_items = int(rng.choice([64, 2048]))
     cut = int(rng.integers(0, ncl + 1))
     try:

@@ -31,7 +31,7 @@ def test_python_mirror_of_the_header_constants_and_structs():
     flags = dict(re.findall(r"#define\s+(PF_FLAG_[A-Z_]+)\s+(\d+)u", hdr))
     assert flags == {"PF_FLAG_NO_DEDUP": str(_lib.FLAG_NO_DEDUP), "PF_FLAG_NO_UNIT_DEDUP": str(_lib.FLAG_NO_UNIT_DEDUP),
                      "PF_FLAG_NO_KEY_BINNING": str(_lib.FLAG_NO_KEY_BINNING),
-                     "PF_FLAG_NO_DEVICE_PLAN": str(_lib.FLAG_NO_DEVICE_PLAN)}
+                     "PF_FLAG_DEVICE_PLAN": str(_lib.FLAG_DEVICE_PLAN)}
     body = re.search(r"typedef struct \{([^}]*)\} pf_timing;", hdr).group(1)
     fields = re.findall(r"\b(float|uint32_t|uint64_t)\s+([a-z_0-9]+);", body)
     ctype = {"float": C.c_float, "uint32_t": C.c_uint32, "uint64_t": C.c_uint64}
