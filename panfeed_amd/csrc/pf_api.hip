@@ -1311,6 +1311,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             const uint32_t planned_arena = arena_i;
             if (use_plan) PFCHK(launch_planned(pass));
             PFCHK(prep_half((int)pass));
+            lap("  prep (records, unit view)");
             todo.clear();
             for (uint32_t ci = pass ? part_end[pass - 1] : 0; ci < part_end[pass]; ci++) {
                 if (!(rec[ci].pad & pf::PLAN_PLANNED)) { todo.push_back(ci); continue; }
@@ -1415,7 +1416,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         }
         if (cur.nitems) subs.push_back(cur);
 
-        lap("build items");
+        lap("  items");
         // ---- arena of this pass
         while (c->arenas.size() <= arena_i) c->arenas.push_back(new Arena());
         Arena* ar = c->arenas[arena_i];
@@ -1440,6 +1441,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             v_nsib[i] = items[i].nsib; v_exfirst[i] = items[i].extra_first; v_isex[i] = items[i].is_extra;
             v_compact[i] = item_fused[i] ? 1 : 0;
         }
+        lap("  arena + item columns");
         PFCHK(c->it_count.ensure(std::max<size_t>(NI, 1) * 4));
         PFCHK(c->it_unique.ensure(std::max<size_t>(NI, 1) * 4));
         PFCHK(c->it_kept.ensure(std::max<size_t>(NI, 1) * 4));
@@ -1505,6 +1507,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
                 {&c->sub_cluster, &sub_cluster},
                 {&c->sub_item0, &sub_item0}, {&c->sub_nitems, &sub_nitems}, {&c->work_scan, &w_scan},
                 {&c->work_extra, &w_extra}, {&c->work_fin, &w_fin}, {&c->work_fin2, &w_fin2}, {&c->work_fin3, &w_fin3}, {&c->work_fin5, &w_fin5}, {&c->work_rows, &w_rows}};
+            lap("  work lists");
             PFCHK(staged_upload(c, arrs));
         }
         // the cursor's next free index restarts at this arena's base
