@@ -2818,11 +2818,22 @@ __device__ __forceinline__ uint32_t pattern_insert_lower(const PatternTable& t, 
     for (;;) {
         uint64_t slot = 0;
         if (st == 2) st = pattern_find_or_claim(t, lo, hi32, &slot, &pid);
-        if (st == 1) {
-            const uint32_t id = atomicAdd(&t.counters[0], 1u);
-            if (id >= t.pool) { t.counters[1] = 1; pid = PID_NONE; } else pid = id;
-            pattern_publish(t, slot, hi32, pid);            // published even on failure: nobody waits for ever
-            st = 0;
+        // ids for the lanes that claimed a slot: ONE add on the run-global counter per wave and trip (every new pattern of a
+        // batch used to make its own atomic on that one address -- 5 M of them per 2 000 clusters of 150 alleles, which L2
+        // serves one after the other)
+        const uint64_t claimed = __ballot(st == 1);
+        if (claimed) {
+            const int leader = __ffsll((unsigned long long)claimed) - 1;
+            const uint32_t lane = threadIdx.x & 63;
+            uint32_t base = 0;
+            if ((int)lane == leader) base = atomicAdd(&t.counters[0], (uint32_t)__popcll(claimed));
+            base = __shfl(base, leader);
+            if (st == 1) {
+                const uint32_t id = base + (uint32_t)__popcll(claimed & ((1ull << lane) - 1ull));
+                if (id >= t.pool) { t.counters[1] = 1; pid = PID_NONE; } else pid = id;
+                pattern_publish(t, slot, hi32, pid);        // published even on failure: nobody waits for ever
+                st = 0;
+            }
         }
         if (!__any(st == 2)) break;
         __builtin_amdgcn_s_sleep(1);
@@ -2968,7 +2979,11 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
     uint32_t* kres = p.kept_prefix_rw + (size_t)slice * (NS + 1) + 1;
     for (uint32_t i = tid; i < LT_SLOTS; i += EMIT_THREADS) { lt_lo[i] = EMPTY64; lt_hi[i] = EMPTY64; lt_first[i] = EMPTY64; }
     if (tid == 0) lt_count = 0;
-    if (!sorted) for (uint32_t i = tid; i < ns; i += EMIT_THREADS) sout[i] = 0xFFFFFFFFu;
+    // (ranks by bitmap: nobody reads a slot's output index -- pattern_rows_kernel and pass 3 go by entry, kres[] -- so the
+    // array is not initialised slot by slot (38 KB of stores per item) nor written per kept k-mer; its first n_entries words
+    // take, per entry, where pass 1 found the k-mer's pattern in the local table, so that pass 3 need not read the row hash
+    // and probe again)
+    constexpr uint32_t LS_NONE = 0xFFFFFFFFu;
     __syncthreads();
     PF_PROF_STAMP(32);
     auto row_id = [&](uint32_t slot, uint64_t& lo, uint64_t& hi) {
@@ -3019,7 +3034,6 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
                 res = pk + __popc(kw & below);
                 fs = (ordinal << 32) | (uint64_t)(po + __popc(bo & below) + 1);
                 kres[i] = res;
-                sout[slot] = res;
             }
         }
         // local table: find or claim; an entry whose second word is not published yet is looked at again in the next
@@ -3063,6 +3077,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
             if (!__any(st == 2)) break;
         }
         if (st == 1) atomicMin((unsigned long long*)&lt_first[ls], (unsigned long long)fs);
+        if (!sorted && i < n_entries) sout[i] = st == 1 ? ls : LS_NONE;
 #ifdef PF_PROF
         if (tid == 0) { atomicAdd(&pf_prof[63], (unsigned long long)(__builtin_readcyclecounter() - tp1)); atomicAdd(&pf_prof[38], 1ull); }
 #endif
@@ -3084,16 +3099,22 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
         const uint64_t o_idx = obase + kb;
         if (o_idx >= p.out_cap) { p.pt.counters[2] = 1; continue; }   // cannot happen: the arena holds every item's limit
         const uint32_t slot = (uint32_t)sp[i];
-        uint64_t lo, hi;
-        row_id(slot, lo, hi);
-        uint32_t ls = (uint32_t)(lo ^ (hi >> 7)) & (LT_SLOTS - 1);
         uint32_t pid = 0xFFFFFFFFu;
         bool found = false;
-        for (uint32_t probes = 0; probes < LT_SLOTS; probes++) {
-            const uint64_t cur = lt_lo[ls];
-            if (cur == EMPTY64) break;
-            if (cur == lo && lt_hi[ls] == hi) { pid = lt_pid[ls]; found = true; break; }
-            ls = (ls + 1) & (LT_SLOTS - 1);
+        uint64_t lo = 0, hi = 0;
+        if (!sorted) {
+            const uint32_t lsv = sout[i];                      // pass 1's place in the local table
+            if (lsv != LS_NONE) { pid = lt_pid[lsv]; found = true; }
+            else row_id(slot, lo, hi);
+        } else {
+            row_id(slot, lo, hi);
+            uint32_t ls = (uint32_t)(lo ^ (hi >> 7)) & (LT_SLOTS - 1);
+            for (uint32_t probes = 0; probes < LT_SLOTS; probes++) {
+                const uint64_t cur = lt_lo[ls];
+                if (cur == EMPTY64) break;
+                if (cur == lo && lt_hi[ls] == hi) { pid = lt_pid[ls]; found = true; break; }
+                ls = (ls + 1) & (LT_SLOTS - 1);
+            }
         }
         // not in the local table (it was full): straight to the run-global table
         if (!found) pid = pattern_insert(p.pt, lo, (uint32_t)(hi >> 32), p.out_first[o_idx]);
