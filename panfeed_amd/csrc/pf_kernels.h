@@ -2026,8 +2026,9 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
             segd[s] = (uint16_t)((p.seg_distinct[s0 + s] << 5) | (smp & 31u));
             atomicAdd(&wstart[(smp >> 5) + 1], 1u);
         }
-#pragma unroll 5
-        for (uint32_t i = tid; i < ns; i += ROWS_THREADS) slot_tag[i] = ordp[i] == NO_ORD ? WIDE_EMPTY : WIDE_PENDING;
+        // (every slot starts as waiting; step A, which asks for a slot's mask words anyway, asks for its ordinal with them and
+        // finds the empty ones -- a pass of its own over the table's ordinals was 9 600 more loads per item)
+        for (uint32_t i = tid; i < ns; i += ROWS_THREADS) slot_tag[i] = WIDE_PENDING;
         __syncthreads();
         if (tid < 64) {
             constexpr uint32_t PL = (MAX_CHUNKS + 1 + 63) / 64;          // entries per lane
@@ -2203,7 +2204,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
             auto step_a = [&](auto nbc) {
                 constexpr uint32_t NWA = decltype(nbc)::value * MWB, U = NWA == MWB ? 4 : NWA == 2 * MWB ? 2 : 1;
                 for (uint32_t i0 = tid; i0 < ns; i0 += U * ROWS_THREADS) {
-                    uint32_t wu[U][NWA];
+                    uint32_t wu[U][NWA], ou[U];
                     bool pend[U], any = false;
 #pragma unroll
                     for (uint32_t u = 0; u < U; u++) {
@@ -2219,11 +2220,13 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
                         const uint32_t i = min(i0 + u * ROWS_THREADS, ns - 1);
 #pragma unroll
                         for (uint32_t j = 0; j < NWA; j++) wu[u][j] = cb[min(j, nmw - 1) * NS + i];   // (32-bit index: a slice is W * NS words)
+                        ou[u] = ordp[i];
                     }
 #pragma unroll
                     for (uint32_t u = 0; u < U; u++) {
 #pragma unroll
                         for (uint32_t j = 0; j < NWA; j++) asm volatile("" : "+v"(wu[u][j]));
+                        asm volatile("" : "+v"(ou[u]));
                     }
 #pragma unroll
                     for (uint32_t u = 0; u < U; u++) {
@@ -2235,6 +2238,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
                     for (uint32_t u = 0; u < U; u++) {
                         if (!pend[u]) continue;
                         const uint32_t i = i0 + u * ROWS_THREADS;
+                        if (ou[u] == NO_ORD) { slot_tag[i] = WIDE_EMPTY; continue; }
                         const uint32_t (&w)[NWA] = wu[u];
                         if (singles) {
                             uint32_t pc = 0, at = 0;
