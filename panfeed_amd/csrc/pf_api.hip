@@ -58,7 +58,9 @@ struct DevBuf {
         if (view) { p = nullptr; cap = 0; view = false; }
         if (bytes <= cap) return PF_OK;
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        size_t want = bytes + bytes / 8 + 256;
+        // (a quarter of slack: re-making a multi-gigabyte buffer -- hipFree, hipMalloc -- was seen to take 0.25 s in the middle
+        // of a submit when a batch's key-partition queues came out a little larger than the batch before's)
+        size_t want = bytes + bytes / 4 + 256;
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) {
             p = nullptr;
