@@ -173,6 +173,8 @@ typedef struct {
     uint32_t n_binned_clusters;/* clusters whose windows were sorted by key partition before the scan, retries included */
     uint32_t n_scratch_grown;  /* times the context re-made its scratch for a cluster of more work items than max_items (since pf_create) */
     uint32_t n_device_planned; /* clusters whose work items were laid out on the device (no host round trip before their scan) */
+    uint32_t n_side_launches;  /* launches whose fused finish kernels ran on the context's second stream, beside the general path's */
+    uint32_t reserved;
 } pf_timing;
 
 const char* pf_last_error(void);

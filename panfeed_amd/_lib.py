@@ -123,7 +123,8 @@ class Timing(C.Structure):
                 ("n_dedup_clusters", C.c_uint32), ("scan_packed_bytes", C.c_uint64),
                 ("dedup_ms", C.c_float), ("patrows_ms", C.c_float), ("md5_ms", C.c_float), ("finish_ms", C.c_float),
                 ("n_wide_clusters", C.c_uint32), ("n_binned_clusters", C.c_uint32),
-                ("n_scratch_grown", C.c_uint32), ("n_device_planned", C.c_uint32)]
+                ("n_scratch_grown", C.c_uint32), ("n_device_planned", C.c_uint32),
+                ("n_side_launches", C.c_uint32), ("reserved", C.c_uint32)]
 
 FLAG_NO_DEDUP = 1
 FLAG_NO_UNIT_DEDUP = 2

@@ -91,6 +91,8 @@ struct EvPair { hipEvent_t a, b; int cat; };
 struct pf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;            // the fused finish kernels of a SMALL launch run here, beside the general path's kernels
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     pf_opts o{};
     int KW = 1;
     uint32_t NS = 0, W = 0, max_items = 0;
@@ -559,6 +561,9 @@ void pf_destroy(pf_ctx* c) {
     c->mg_lo.release(); c->mg_cnt.release();
     if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
     if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -605,6 +610,8 @@ int pf_create(pf_ctx** out, int device, const pf_opts* o) {
     do {
         hipError_t e = hipStreamCreate(&c->stream);
         if (e != hipSuccess) { rc = fail(PF_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); break; }
+        if (hipStreamCreate(&c->side) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { rc = fail(PF_ERR_HIP, "hipStreamCreate (side) failed"); break; }
         bool ev_ok = true;
         for (auto& ev : c->ev_part) ev_ok = ev_ok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
         for (auto& ev : c->ev_stage) ev_ok = ev_ok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
@@ -712,7 +719,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
     c->have_batch = false;
     // whatever way this call ends, nothing it queued is still reading the caller's arrays or the pinned staging
     // blocks afterwards (the successful path has waited already; an error return may come with work in flight)
-    struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{c->stream};
+    struct Drain { hipStream_t s, s2; ~Drain() { (void)hipStreamSynchronize(s2); (void)hipStreamSynchronize(s); } } drain{c->stream, c->side};
     const uint32_t C = b->n_clusters, NSEG = b->n_segs, W = c->W, NS = c->NS, KW = (uint32_t)c->KW;
     if (b->n_segs && (!b->packed || !b->seg_word_off || !b->seg_len || !b->seg_sample || !b->seg_ord_base))
         return fail(PF_ERR_ARG, "segment arrays missing");
@@ -1556,30 +1563,47 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             const uint32_t n_fin = fin_off[s + 1] - fin_off[s], n_fin2 = fin2_off[s + 1] - fin2_off[s],
                            n_fin3 = fin3_off[s + 1] - fin3_off[s], n_fin5 = fin5_off[s + 1] - fin5_off[s],
                            n_rows = rows_off[s + 1] - rows_off[s];
-            if (n_fin || n_fin2 || n_fin3 || n_fin5) {
+            // A launch whose fused-finish workgroups do not fill the GPU while general-path items wait behind them (a batch
+            // of many-allele clusters with a few dozen simple ones: two 1 024-thread workgroups took 0.4 ms each with the
+            // other 250 CUs idle; any batch of a few hundred clusters): the finish kernels go to the context's second
+            // stream and run BESIDE rows / emit / pattern rows -- they share nothing but atomically claimed output room
+            // and the run-global pattern table.  (Not for full launches: two latency-bound kernels that each fill the GPU
+            // take each other's wave slots -- five such pairings lost in rounds 2-3.)
+            const uint32_t n_fused_wg = n_fin + n_fin2 + n_fin3 + n_fin5;
+            const bool beside = n_fused_wg && n_rows && n_fused_wg <= 2u * (uint32_t)c->n_cu;
+            if (n_fused_wg) {
                 pf::FinishParams fp = finish_params(host_items(), ar);
-                PFCHK(mark_begin(c, 6));
+                hipStream_t fs = c->stream;
+                if (beside) {
+                    HIPCHK(hipEventRecord(c->ev_fork, c->stream));
+                    HIPCHK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+                    fs = c->side;
+                    c->timing.n_side_launches++;
+                } else {
+                    PFCHK(mark_begin(c, 6));
+                }
                 if (n_fin5) {   // the heaviest clusters first
                     fp.work = c->work_fin5.as<uint32_t>() + fin5_off[s];
-                    hipLaunchKernelGGL((pf::finish_kernel<pf::FinHuge, true>), dim3(n_fin5), dim3(pf::FinHuge::THREADS), 0, c->stream, fp);
+                    hipLaunchKernelGGL((pf::finish_kernel<pf::FinHuge, true>), dim3(n_fin5), dim3(pf::FinHuge::THREADS), 0, fs, fp);
                     HIPCHK(hipGetLastError());
                 }
                 if (n_fin3) {
                     fp.work = c->work_fin3.as<uint32_t>() + fin3_off[s];
-                    hipLaunchKernelGGL((pf::finish_kernel<pf::FinLargeM, true>), dim3(n_fin3), dim3(pf::FinLargeM::THREADS), 0, c->stream, fp);
+                    hipLaunchKernelGGL((pf::finish_kernel<pf::FinLargeM, true>), dim3(n_fin3), dim3(pf::FinLargeM::THREADS), 0, fs, fp);
                     HIPCHK(hipGetLastError());
                 }
                 if (n_fin2) {
                     fp.work = c->work_fin2.as<uint32_t>() + fin2_off[s];
-                    hipLaunchKernelGGL((pf::finish_kernel<pf::FinLarge, false>), dim3(n_fin2), dim3(pf::FinLarge::THREADS), 0, c->stream, fp);
+                    hipLaunchKernelGGL((pf::finish_kernel<pf::FinLarge, false>), dim3(n_fin2), dim3(pf::FinLarge::THREADS), 0, fs, fp);
                     HIPCHK(hipGetLastError());
                 }
                 if (n_fin) {
                     fp.work = c->work_fin.as<uint32_t>() + fin_off[s];
-                    hipLaunchKernelGGL((pf::finish_kernel<pf::FinSmall, false>), dim3(n_fin), dim3(pf::FinSmall::THREADS), 0, c->stream, fp);
+                    hipLaunchKernelGGL((pf::finish_kernel<pf::FinSmall, false>), dim3(n_fin), dim3(pf::FinSmall::THREADS), 0, fs, fp);
                     HIPCHK(hipGetLastError());
                 }
-                PFCHK(mark_end(c));
+                if (beside) HIPCHK(hipEventRecord(c->ev_join, c->side));
+                else PFCHK(mark_end(c));
             }
             if (!n_rows) continue;
             pf::RowsParams rp{};
@@ -1676,6 +1700,7 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
             hipLaunchKernelGGL(pf::pattern_rows_kernel, dim3(n_rows), dim3(pf::PR_THREADS), 0, c->stream, pr);
             HIPCHK(hipGetLastError());
             PFCHK(mark_end(c));
+            if (beside) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));   // the next sub-batch takes the scratch slices over
         }
         c->timing.n_items += (uint32_t)NI;
         for (uint32_t ci : todo) c->timing.scan_packed_bytes += rec[ci].words * 8 * nparts[ci];

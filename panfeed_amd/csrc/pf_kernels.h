@@ -2723,11 +2723,11 @@ struct BaseParams {
     uint32_t n;
 };
 __global__ __launch_bounds__(1024) void cluster_base_kernel(BaseParams p) {
+    // (output room is CLAIMED -- one atomic add per 1 024 clusters -- not read and written back: the fused finish kernels of
+    // the same sub-batch may be running beside this kernel on the context's second stream, and they claim theirs the same way)
     __shared__ uint32_t wave_tot[17];
     __shared__ uint64_t sh_base;
     const uint32_t tid = threadIdx.x;
-    if (tid == 0) sh_base = p.cursor[0];
-    __syncthreads();
     uint64_t uniq_sum = 0;
     for (uint32_t start = 0; start < p.n; start += 1024) {
         const uint32_t i = start + tid;
@@ -2743,6 +2743,11 @@ __global__ __launch_bounds__(1024) void cluster_base_kernel(BaseParams p) {
         }
         uint32_t total;
         const uint32_t ex = block_exscan(kept, wave_tot, &total);
+        if (tid == 0) {
+            sh_base = atomicAdd((unsigned long long*)&p.cursor[0], (unsigned long long)total);
+            if (total) atomicAdd((unsigned long long*)&p.cursor[2], (unsigned long long)total);
+        }
+        __syncthreads();
         if (i < p.n && live) {
             p.cluster_kmer_off[c] = sh_base + ex;
             p.cluster_kmer_cnt[c] = kept;
@@ -2750,17 +2755,10 @@ __global__ __launch_bounds__(1024) void cluster_base_kernel(BaseParams p) {
             uniq_sum += uniq;
         }
         __syncthreads();
-        if (tid == 0) sh_base += total;
-        __syncthreads();
     }
     // totals
     for (int d = 32; d > 0; d >>= 1) uniq_sum += __shfl_down(uniq_sum, d);
     if ((tid & 63) == 0 && uniq_sum) atomicAdd((unsigned long long*)&p.cursor[1], (unsigned long long)uniq_sum);
-    __syncthreads();
-    if (tid == 0) {
-        p.cursor[2] += sh_base - p.cursor[0];
-        p.cursor[0] = sh_base;
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
