@@ -70,3 +70,22 @@ def test_scratch_grows_for_a_cluster_of_more_items_than_max_items():
     assert "".join(o.kmers_to_hashes for o in outs) == ekh
     assert "".join(o.hashes_to_patterns for o in outs) == ehp
     eng.close()
+
+
+def test_fused_finish_beside_the_general_path():
+    """a launch with a few simple clusters (fused finish) and a few of many distinct sequences (general path): the finish
+    kernels run on the context's second stream beside rows / emit / pattern rows; output room is claimed atomically by both
+    sides -- the files are the oracle's, in cluster order, whatever order the two sides finish in"""
+    from panfeed_amd.engine import Engine
+    S, k = 200, 31
+    few = _records(20, S, first=31000, flank=30, mean_len=500, min_len=200, max_len=900, n_rate=0.01, paralog_rate=0.03)
+    many = _records(5, S, first=32000, flank=30, mean_len=700, min_len=500, max_len=900, n_rate=0.0, paralog_rate=0.02,
+                    mean_alleles=90.0, allele_decay=1.0, allele_model="tree")
+    recs = few[:10] + many[:3] + few[10:] + many[3:]
+    (ek, ekh, ehp), _ = _oracle_texts(recs, klength=k, canon=True)
+    eng = Engine(klength=k, max_strains=S + 24)
+    outs = [eng.run(recs[:14]), eng.run(recs[14:])]
+    assert sum(o.timing["n_side_launches"] for o in outs) >= 2
+    assert "".join(o.kmers_to_hashes for o in outs) == ekh
+    assert "".join(o.hashes_to_patterns for o in outs) == ehp
+    eng.close()
