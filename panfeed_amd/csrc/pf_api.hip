@@ -57,10 +57,12 @@ struct DevBuf {
     int ensure(size_t bytes) {
         if (view) { p = nullptr; cap = 0; view = false; }
         if (bytes <= cap) return PF_OK;
+        const bool regrow = p != nullptr;
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        // (a quarter of slack: re-making a multi-gigabyte buffer -- hipFree, hipMalloc -- was seen to take 0.25 s in the middle
-        // of a submit when a batch's key-partition queues came out a little larger than the batch before's)
-        size_t want = bytes + bytes / 4 + 256;
+        // (a buffer that has to be re-made gets a quarter of slack: hipFree + hipMalloc of a multi-gigabyte buffer was seen to
+        // take 0.25 s in the middle of a submit when a batch's key-partition queues came out a little larger than the batch
+        // before's; a first allocation -- the scratch slices are 123 GB in bench.py -- gets a sixteenth)
+        size_t want = bytes + (regrow ? bytes / 4 : bytes / 16) + 256;
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) {
             p = nullptr;
