@@ -140,6 +140,26 @@ def test_run_files_pipeline(tmp_path, compress, resident, device_text):
     assert rd("kmers.tsv") == KMERS_TSV_HEADER + ek
 
 
+def test_run_files_serial_start_up_writes_the_same_files(tmp_path):
+    """run_files' overlapped start-up (context made while the reader opens, genomes uploaded while the packer starts:
+    the store's layout comes from the contig lengths alone) against the serial one: the same three files"""
+    import os
+    from panfeed_amd import synth
+    from panfeed_amd.pipeline import run_files
+    cl = synth.generate(40, 30, first=900, flank=10, mean_len=250, min_len=50, max_len=700, n_rate=0.03, paralog_rate=0.05)
+    src = tmp_path / "in"
+    csvp, _gffs, _fas = synth.write_pangenome(str(src), cl, workers=2)
+    texts = {}
+    for overlap in (True, False):
+        out = str(tmp_path / f"out_{overlap}")
+        st = run_files(csvp, str(src / "gffs"), out, klength=21, upstream=10, downstream=10, batch_clusters=9, overlap=overlap)
+        assert st["clusters"] == 40
+        if overlap:
+            assert "first_submit_wait_s" in st["stages"] and st["stages"]["genome_upload_s"] > 0
+        texts[overlap] = {f: open(os.path.join(out, f)).read() for f in sorted(os.listdir(out))}
+    assert texts[True] == texts[False] and len(texts[True]) == 3
+
+
 def test_run_files_multiple_files(tmp_path):
     """--multiple-files through the pipeline: one directory per cluster, patterns start empty in each"""
     import os

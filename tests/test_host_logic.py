@@ -324,3 +324,15 @@ def test_bench_gpus_n_refuses_without_devices():
     r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2"], env=env2, capture_output=True, text=True,
                        timeout=300)
     assert r.returncode == 2 and "--gpus 2 but the launcher started 3" in r.stderr
+
+
+def test_strain_count_from_the_table_header(tmp_path):
+    """pipeline._peek_n_strains: the context is made while the reader opens and needs the number of strains first -- the
+    header record of the panaroo table, 'Non-unique Gene name' and 'Annotation' dropped (input.py:188-191)"""
+    from panfeed_amd.pipeline import _peek_n_strains
+    p = tmp_path / "t.csv"
+    p.write_text('Gene,Non-unique Gene name,Annotation,s1,"s,2",s3\ng1,,"x, y",a,b,c\n')
+    assert _peek_n_strains(str(p)) == 3
+    p.write_text("Gene,s1,s2\n")
+    assert _peek_n_strains(str(p)) == 2
+    assert _peek_n_strains(str(tmp_path / "absent.csv")) == 0
