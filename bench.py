@@ -188,13 +188,20 @@ def kernel_source_hash():
 
 
 def load_pmc():
-    """committed rocprofv3 --pmc summary of the default command (tools/profile_round.sh): HBM bytes and SQ counters"""
-    for rel in ("profiles/r04/final_pmc_summary.json", "profiles/r03/final_pmc_summary.json", "profiles/r02/final_pmc_summary.json"):
-        path = os.path.join(REPO, rel)
-        if os.path.exists(path):
-            with open(path) as fh:
-                return json.load(fh), rel
-    return None, None
+    """committed rocprofv3 --pmc summary of the default command (tools/profile_round.sh): HBM bytes and SQ counters.
+    Only a summary whose kernel sources are THIS build's is used (kernel_source_sha16, stamped by tools/pmc_summary.py):
+    counters of other kernels are not this run's traffic.  Returns (summary or None, its path, path of the newest
+    summary that was passed over as stale or None)."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9]*", "final_pmc_summary.json")), reverse=True)
+    want, stale = kernel_source_hash(), None
+    for path in paths:
+        with open(path) as fh:
+            pmc = json.load(fh)
+        if pmc.get("kernel_source_sha16") == want:
+            return pmc, os.path.relpath(path, REPO), stale
+        stale = stale or os.path.relpath(path, REPO)
+    return None, None, stale
 
 
 # which roof bounds which kernel, and why (DESIGN.md sections 4 and 6): the dedup pass streams the packed input (HBM);
@@ -657,7 +664,7 @@ def main():
             pk["algorithmic_GBps"] = packed_bytes / (pk["ms"] / 1e3) / 1e9     # it has to read the packed input once
             pk["frac_of_hbm_peak"] = pk["algorithmic_GBps"] / HBM_PEAK_GBS
         default_cmd = default_shape and world == 1 and not strong and args.n_rate == 0.0
-        pmc, pmc_rel = load_pmc() if default_cmd else (None, None)
+        pmc, pmc_rel, pmc_stale = load_pmc() if default_cmd else (None, None, None)
         if pmc:
             tot = 0.0
             for name, v in pmc["kernels"].items():
@@ -719,7 +726,10 @@ def main():
                          # the counters are a committed pass, not this run's: which commit's kernels it profiled, and whether
                          # the kernel sources of THIS build are those (false: re-collect with tools/profile_round.sh)
                          "traffic_commit": (pmc or {}).get("commit"),
-                         "traffic_matches_this_build": (pmc or {}).get("kernel_source_sha16") == kernel_source_hash() if pmc else None,
+                         "traffic_matches_this_build": True if pmc else None,
+                         # a committed summary of OTHER kernel sources is not used: traffic stays null until
+                         # tools/profile_round.sh has been run on this build
+                         "traffic_stale_summary_ignored": pmc_stale,
                          "algorithmic_bytes_per_step": alg,
                          "must_move_bytes_per_step": alg_must,
                          "must_move_GBps": alg_must / chain_s / 1e9 if chain_s > 0 else 0.0,

@@ -248,6 +248,12 @@ int pf_pattern_count(pf_ctx* ctx, uint64_t* n);
  * limit) -- the growth paths of the reference's unbounded `patterns` set (panfeed.py:146-150) have failure branches
  * that a 288 GB device never takes on its own. */
 int pf_debug_limit_pattern_slots(pf_ctx* ctx, uint64_t max_slots);
+/* Test hook, process-wide: a single device allocation of the library's growable buffers above max_bytes is refused as if
+ * the device were out of memory (0: no limit).  stats (may be NULL) receives, and resets, what was seen since the last
+ * call: stats[0] = the largest buffer size asked for, stats[1] = allocations whose size-plus-slack request failed and
+ * whose exact-size retry succeeded.  A buffer's slack is a convenience: a run must not fail while the bytes it needs
+ * exist (the reference's structures grow until the machine is full, panfeed.py:146-150). */
+int pf_debug_limit_alloc(uint64_t max_bytes, uint64_t stats[2]);
 
 /* Device buffers for callers that keep batches resident (bench.py, tests): plain hipMalloc /
  * hipMemcpy / hipFree on the context's device. */

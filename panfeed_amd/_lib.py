@@ -6,6 +6,7 @@ every entry point raises ``PanfeedHipError`` with the library's message on a non
 """
 import ctypes as C
 import os
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpanfeed_hip.so")
@@ -135,7 +136,7 @@ FLAG_DEVICE_PLAN = 8
 # every symbol include/panfeed_hip.h declares
 EXPORTS = ["pf_last_error", "pf_version", "pf_device_count", "pf_create", "pf_destroy", "pf_reset_patterns",
            "pf_submit", "pf_fetch", "pf_get_timing", "pf_export_patterns", "pf_export_patterns_dev",
-           "pf_merge_patterns", "pf_merge_patterns_padded", "pf_pattern_count", "pf_debug_limit_pattern_slots", "pf_result_checksum", "pf_dev_alloc", "pf_dev_free",
+           "pf_merge_patterns", "pf_merge_patterns_padded", "pf_pattern_count", "pf_debug_limit_pattern_slots", "pf_debug_limit_alloc", "pf_result_checksum", "pf_dev_alloc", "pf_dev_free",
            "pf_dev_upload", "pf_dev_download", "pf_synth_expand", "pf_pack_acgt", "pf_b64_digest",
            "pf_render_kmers_to_hashes", "pf_render_hashes_to_patterns", "pf_render_kmers_tsv", "pf_free_text",
            "pf_pack_records", "pf_packed_view", "pf_packed_free",
@@ -150,10 +151,19 @@ RENDER_NO_PATTERN_ROWS = 1
 ERR_ARG, ERR_OOM, ERR_HIP, ERR_CAPACITY, ERR_STATE = -1, -2, -3, -4, -5
 
 _lib = None
+_load_lock = threading.Lock()
 
 
 def load():
     """dlopen the HIP library; raises if it is not built -- never falls back to anything else."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _load_lock:
+        return _load_locked()
+
+
+def _load_locked():
     global _lib
     if _lib is not None:
         return _lib
@@ -185,6 +195,7 @@ def load():
     L.pf_export_patterns_dev.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
     L.pf_pattern_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.pf_debug_limit_pattern_slots.argtypes = [C.c_void_p, C.c_uint64]
+    L.pf_debug_limit_alloc.argtypes = [C.c_uint64, C.POINTER(C.c_uint64)]
     L.pf_result_checksum.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.pf_merge_patterns_padded.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64,
                                            C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)]

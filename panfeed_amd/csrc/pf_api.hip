@@ -50,6 +50,16 @@ int fail(int code, const char* fmt, ...) {
         if (r_ != PF_OK) return r_; \
     } while (0)
 
+// test hook (pf_debug_limit_alloc): single device allocations above the limit are refused as if the device were out of
+// memory; the largest request and the exact-size retries that succeeded are counted
+std::atomic<uint64_t> g_alloc_limit{0}, g_alloc_max_request{0}, g_alloc_exact_retries{0};
+
+hipError_t dev_malloc(void** p, size_t bytes) {
+    const uint64_t lim = g_alloc_limit.load(std::memory_order_relaxed);
+    if (lim && bytes > lim) { *p = nullptr; return hipErrorOutOfMemory; }
+    return hipMalloc(p, bytes);
+}
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -59,12 +69,22 @@ struct DevBuf {
         if (bytes <= cap) return PF_OK;
         const bool regrow = p != nullptr;
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        uint64_t seen = g_alloc_max_request.load(std::memory_order_relaxed);
+        while (bytes > seen && !g_alloc_max_request.compare_exchange_weak(seen, bytes)) {}
         // (a buffer that has to be re-made gets a quarter of slack: hipFree + hipMalloc of a multi-gigabyte buffer was seen to
         // take 0.25 s in the middle of a submit when a batch's key-partition queues came out a little larger than the batch
-        // before's; a first allocation -- the scratch slices are 123 GB in bench.py -- gets a sixteenth)
+        // before's; a first allocation -- the scratch slices are 123 GB in bench.py -- gets a sixteenth).  The slack is a
+        // convenience, never a requirement: when it does not fit, the exact size is asked for before giving up.
         size_t want = bytes + (regrow ? bytes / 4 : bytes / 16) + 256;
-        hipError_t e = hipMalloc(&p, want);
+        hipError_t e = dev_malloc(&p, want);
         if (e != hipSuccess) {
+            (void)hipGetLastError();
+            want = bytes;
+            e = dev_malloc(&p, want);
+            if (e == hipSuccess) g_alloc_exact_retries.fetch_add(1, std::memory_order_relaxed);
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
             p = nullptr;
             return fail(PF_ERR_OOM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
         }
@@ -200,16 +220,18 @@ int get_event(pf_ctx* c, hipEvent_t* ev) {
     HIPCHK(hipEventCreate(ev));
     return PF_OK;
 }
-int mark_begin(pf_ctx* c, int cat) {
+// a timed stretch of one category on `s` (the context's stream unless the launches go to the side stream); the pairs are
+// read after the batch's last synchronisation, when both streams have drained
+int mark_begin(pf_ctx* c, int cat, hipStream_t s = nullptr) {
     EvPair e; e.cat = cat;
     PFCHK(get_event(c, &e.a));
     PFCHK(get_event(c, &e.b));
-    HIPCHK(hipEventRecord(e.a, c->stream));
+    HIPCHK(hipEventRecord(e.a, s ? s : c->stream));
     c->events.push_back(e);
     return PF_OK;
 }
-int mark_end(pf_ctx* c) {
-    HIPCHK(hipEventRecord(c->events.back().b, c->stream));
+int mark_end(pf_ctx* c, hipStream_t s = nullptr) {
+    HIPCHK(hipEventRecord(c->events.back().b, s ? s : c->stream));
     return PF_OK;
 }
 
@@ -1581,9 +1603,8 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
                     HIPCHK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
                     fs = c->side;
                     c->timing.n_side_launches++;
-                } else {
-                    PFCHK(mark_begin(c, 6));
                 }
+                PFCHK(mark_begin(c, 6, fs));      // (on the side stream too: finish_ms must not leave these launches out)
                 if (n_fin5) {   // the heaviest clusters first
                     fp.work = c->work_fin5.as<uint32_t>() + fin5_off[s];
                     hipLaunchKernelGGL((pf::finish_kernel<pf::FinHuge, true>), dim3(n_fin5), dim3(pf::FinHuge::THREADS), 0, fs, fp);
@@ -1604,8 +1625,8 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
                     hipLaunchKernelGGL((pf::finish_kernel<pf::FinSmall, false>), dim3(n_fin), dim3(pf::FinSmall::THREADS), 0, fs, fp);
                     HIPCHK(hipGetLastError());
                 }
+                PFCHK(mark_end(c, fs));
                 if (beside) HIPCHK(hipEventRecord(c->ev_join, c->side));
-                else PFCHK(mark_end(c));
             }
             if (!n_rows) continue;
             pf::RowsParams rp{};
@@ -1938,6 +1959,15 @@ int pf_debug_limit_pattern_slots(pf_ctx* c, uint64_t max_slots) {
     if (!c) return fail(PF_ERR_ARG, "null context");
     c->pt_slot_limit = max_slots;
     c->pregrow_failed_pool = 0;
+    return PF_OK;
+}
+
+int pf_debug_limit_alloc(uint64_t max_bytes, uint64_t stats[2]) {
+    if (stats) {
+        stats[0] = g_alloc_max_request.exchange(0);
+        stats[1] = g_alloc_exact_retries.exchange(0);
+    }
+    g_alloc_limit.store(max_bytes);
     return PF_OK;
 }
 

@@ -206,15 +206,21 @@ void parse_gff(const std::string& text, const std::string& file_name, Genome& g)
         };
         if (nf < 3) { warn("list index out of range"); continue; }
         if (!(fe[2] - fb[2] == 3 && memcmp(fb[2], "CDS", 3) == 0)) continue;      // input.py:300-301
-        if (nf < 9) { warn("list index out of range"); continue; }
+        // the reference evaluates entries[3], int(), entries[4], int(), entries[6], entries[8] in that order
+        // (input.py:303-316): the first of them to fail names the warning
         long long st, en;
         {
-            const std::string f3(fb[3], fe[3]), f4(fb[4], fe[4]);
-            const bool ok3 = py_int(f3, &st);
-            if (!ok3 || !py_int(f4, &en)) {           // ValueError text of int(entries[3]) / int(entries[4]), input.py:304-305
-                warn(("invalid literal for int() with base 10: " + py_repr(ok3 ? f4 : f3)).c_str()); continue;
+            bool bad = false;
+            for (int f = 3; f <= 4 && !bad; f++) {
+                if (nf <= (size_t)f) { warn("list index out of range"); bad = true; break; }
+                const std::string fs(fb[f], fe[f]);
+                if (!py_int(fs, f == 3 ? &st : &en)) {    // ValueError text of int(entries[3]) / int(entries[4]), input.py:304-305
+                    warn(("invalid literal for int() with base 10: " + py_repr(fs)).c_str()); bad = true;
+                }
             }
+            if (bad) continue;
         }
+        if (nf < 9) { warn("list index out of range"); continue; }      // entries[6], entries[8]
         const int strand = (fe[6] - fb[6] == 1 && *fb[6] == '+') ? 1 : -1;       // input.py:309-312
         bool have = false;
         const char* idb = nullptr; const char* ide = nullptr;
@@ -638,11 +644,21 @@ void pf_pangenome_close(pf_pangenome* P) {
 void pf_pangenome_close_async(pf_pangenome* P) {
     if (!P) return;
     closers().join_all();
+    // the vector's slot is made BEFORE the thread exists: once the thread runs it owns P, and nothing after its start may
+    // throw (a joinable std::thread destroyed by unwinding is std::terminate; a second close would free P twice)
+    std::unique_lock<std::mutex> g(closers().mu);
     try {
-        std::thread t([P] { pf_pangenome_close(P); });
-        std::lock_guard<std::mutex> g(closers().mu);
-        closers().th.push_back(std::move(t));
+        closers().th.emplace_back();
     } catch (...) {
+        g.unlock();
+        pf_pangenome_close(P);
+        return;
+    }
+    try {
+        closers().th.back() = std::thread([P] { pf_pangenome_close(P); });
+    } catch (...) {                      // the thread's constructor itself threw: nothing runs, P is still ours
+        closers().th.pop_back();
+        g.unlock();
         pf_pangenome_close(P);
     }
 }

@@ -62,6 +62,8 @@ def run_files(presence_absence, gffdir, output, fastadir=None, klength=31, canon
     # pangenome; it needs the number of strains, which the table's header line says
     early = {}
     n_peek = _peek_n_strains(presence_absence) if overlap else 0
+    from . import _lib
+    _lib.load()        # once, on this thread, before two threads could both make the process's first call to it
 
     def early_engine():
         t0 = _time.perf_counter()
@@ -216,6 +218,7 @@ def run_files(presence_absence, gffdir, output, fastadir=None, klength=31, canon
                     fh.close()
         if failed:
             raise failed[0]
+        wait_for_genomes()      # a run that submitted nothing (empty table, --genes matching nothing) still reports a failed upload
         stats["log"] = pg.take_log()
         # where the wall time went: opening + parsing the inputs, creating the context, uploading the genomes, then the
         # overlapped stages of the batches (Engine.run_batches: read + pack on its thread, pf_submit = upload + kernels,

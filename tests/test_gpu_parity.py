@@ -943,3 +943,43 @@ def test_pattern_table_growth_that_fails():
     outs = [eng.run(part) for part in parts]
     assert "".join(o.kmers_to_hashes for o in outs) == ekh and "".join(o.hashes_to_patterns for o in outs) == ehp
     eng.close()
+
+
+def test_buffer_slack_is_not_required():
+    """a growable device buffer asks for its size plus slack; when that does not fit it must fall back to the exact size
+    instead of failing (round 4's allele sweep ran out of HBM on the slack of a 123 GB scratch).  pf_debug_limit_alloc
+    stands in for a nearly full device: the limit is the largest buffer a first run asked for, so that buffer's slack is
+    refused and its exact size is not."""
+    import ctypes as C
+    from panfeed_amd import _lib, synth
+    from panfeed_amd.engine import Engine
+    cl = synth.generate(40, 60, first=11, flank=20, mean_len=400, min_len=60, max_len=900, n_rate=0.01, paralog_rate=0.03)
+    recs = [c.record() for c in cl]
+    (ek, ekh, ehp), st = _oracle_texts(recs, klength=31)
+    L = _lib.load()
+    stats = (C.c_uint64 * 2)()
+    _lib.check(L.pf_debug_limit_alloc(0, stats))                  # clears the counters
+    eng = Engine(klength=31, max_strains=64)
+    o = eng.run(recs)
+    assert o.kmers_to_hashes == ekh and o.hashes_to_patterns == ehp
+    eng.close()
+    _lib.check(L.pf_debug_limit_alloc(0, stats))
+    largest = int(stats[0])
+    assert largest > 0 and int(stats[1]) == 0
+    try:
+        _lib.check(L.pf_debug_limit_alloc(largest, None))
+        eng = Engine(klength=31, max_strains=64)
+        o = eng.run(recs)
+        assert o.kmers_to_hashes == ekh and o.hashes_to_patterns == ehp
+        # a buffer that is re-made (a second, larger batch) takes the same way
+        o2 = eng.run(recs + recs)
+        eng.close()
+        _lib.check(L.pf_debug_limit_alloc(largest - 1, stats))
+        assert int(stats[1]) >= 1, "no allocation took the exact-size retry"
+        # below the largest buffer's own size the run has to fail as out of memory, loudly
+        with pytest.raises(_lib.PanfeedHipError) as ei:
+            eng = Engine(klength=31, max_strains=64)
+            eng.run(recs)
+        assert ei.value.status == _lib.ERR_OOM
+    finally:
+        _lib.check(L.pf_debug_limit_alloc(0, None))

@@ -205,6 +205,13 @@ def handmade_pangenome():
         "a_c1\tsrc\tCDS\t 12 \t+25\t.\t+\t0\tID=a_g5;note=int() takes blanks and a sign",
         "a_c1\tsrc\tCDS\t1_0\t2_5\t.\t+\t0\tID=a_g6;note=int() takes underscores",
         "a_c1\tsrc\tCDS\t3\t9",
+        # short rows: the FIRST failing expression names the warning (int(entries[3]), int(entries[4]) come before
+        # entries[6] and entries[8]); a row's last field keeps its newline, in the repr too
+        "a_c1\tsrc\tCDS\txyz\t9",
+        "a_c1\tsrc\tCDS\t3\tqq",
+        "a_c1\tsrc\tCDS\t3",
+        "a_c1\tsrc\tCDS\t3\t9\t.\t+",
+        "a_c1\tsrc\tCDS\t3\t9\t.\t+\t0",
         "a_c1\tsrc\tCDS\t3\t9\t.\t+\t0\tName=no id at all",
         "a_c1\tsrc\tCDS\t3\t19\t.\t+\t0\tParent=x;ID=a_g7=tail;IDx=a_g7b;y=2",
         "a_c1\tsrc\tCDS\t2\t18\t.\t+\t0\tIDENTITY;ID=a_g8;",
