@@ -270,28 +270,48 @@ def targets_pass(args, local):
     t0 = time.time()
     eng.submit_host_batch(hb)
     t_submit = time.time() - t0
+    # the rows: written by the GPU (kt_text_kernel), every block of the text through pinned host memory -- what a writer
+    # thread would hand to its file
     t0 = time.time()
-    text = eng._render_targets(hb, hb.targets, owned=True)       # the library's block, no copy into Python
+    dt = eng.render_targets_device(hb)
+    nbytes = 0
+    for blk in dt.chunks():
+        nbytes += len(blk)
     t_render = time.time() - t0
     split = dict(eng.render_targets_timing)
-    nbytes = len(text)
-    rows = 0
-    arr = np.frombuffer(text.view, dtype=np.uint8)
-    for a in range(0, nbytes, 1 << 28):
-        rows += int(np.count_nonzero(arr[a:a + (1 << 28)] == 10))
-    del arr
+    # untimed: the same text again for the row count and a CRC, against the host renderer's (pf_render_kmers_tsv)
+    import zlib
+    rows, crc_dev = 0, 0
+    for blk in dt.chunks():
+        arr = np.frombuffer(blk, dtype=np.uint8)
+        rows += int(np.count_nonzero(arr == 10))
+        crc_dev = zlib.crc32(blk, crc_dev)
+    t0 = time.time()
+    text = eng._render_targets(hb, hb.targets, owned=True)
+    t_host = time.time() - t0
+    host_split = dict(eng.render_targets_timing)
+    crc_host = 0
+    for a in range(0, len(text), 1 << 28):
+        crc_host = zlib.crc32(text.view[a:a + (1 << 28)], crc_host)
+    same = crc_host == crc_dev and len(text) == nbytes
     text.release()
     eng.close()
+    if not same:
+        raise SystemExit("targets pass: the device-written kmers.tsv differs from the host renderer's")
     return {"clusters": args.targets_clusters, "target_strains": S, "rows": rows, "bytes": nbytes,
-            "pack_s": t_pack, "submit_s": t_submit, "marshal_s": split["marshal_s"], "library_render_s": split["render_s"],
+            "pack_s": t_pack, "submit_s": t_submit, "marshal_s": split["marshal_s"],
+            "device_render_and_copy_out_s": t_render - split["marshal_s"],
             "render_s": t_render,
-            "rows_per_s_library": rows / split["render_s"] if split["render_s"] else None,
-            "GBps_library": nbytes / split["render_s"] / 1e9 if split["render_s"] else None,
             "rows_per_s_end_to_end": rows / (t_pack + t_submit + t_render),
-            "note": "kmers.tsv rows for every sample of the clusters (all strains are targets): strand bits on the "
-                    "device (strand_bits_kernel, inside submit; only they cross PCIe), text by pf_render_kmers_tsv on "
-                    "the host threads (library_render_s), handed to the writer without a copy; marshal_s = the Python "
-                    "side turning its per-sequence objects into the C structs"}
+            "GBps_text_out": nbytes / (t_render - split["marshal_s"]) / 1e9 if t_render > split["marshal_s"] else None,
+            "equals_host_renderer": same,
+            "host_renderer": {"render_s": t_host, "marshal_s": host_split["marshal_s"], "library_render_s": host_split["render_s"],
+                              "rows_per_s_end_to_end": rows / (t_pack + t_submit + t_host)},
+            "note": "kmers.tsv rows for every sample of the clusters (all strains are targets), host strings in, text out: "
+                    "pack_s = records -> packed batch (pf_pack_records), submit_s = pf_submit (strand bits stay on the "
+                    "device), render_s = marshalling of the per-sequence fields + kt_len / kt_text kernels + every block "
+                    "of the text copied to pinned host memory (pf_device_text_chunk); equals_host_renderer = same length "
+                    "and CRC-32 as pf_render_kmers_tsv's text (host_renderer: round 4's path, timed after)"}
 
 
 def allele_sweep(args, local, allele_model="star"):

@@ -447,6 +447,18 @@ typedef struct {
 int pf_render_kmers_tsv(pf_ctx* ctx, const pf_target_seq* seqs, uint32_t n, const uint32_t* seg_strand_off,
                         char** out, uint64_t* nbytes);
 void pf_free_text(char* p);
+/* The same rows (panfeed.py:90-107) written ON THE DEVICE: the used_strand bits and the packed bases of the last
+ * pf_submit are there already, so neither they nor the sequences' letters cross PCIe -- per sequence only its five
+ * constant fields, as text, and four numbers go up.  Sequences that are pure A/C/G/T (one segment covering every
+ * window) are written by the GPU; the others (an 'N' inside, an over-long name) by the host renderer above and copied
+ * to their places, so that the text is that of pf_render_kmers_tsv byte for byte, in the order of `seqs`.  The text
+ * stays in device memory; *nbytes is its size.  With every sample a target (BASELINE configs[4]'s second pass) it is
+ * the largest output of a run. */
+int pf_render_kmers_tsv_device(pf_ctx* ctx, const pf_target_seq* seqs, uint32_t n, uint64_t* nbytes);
+/* Bytes [offset, offset + *nbytes) of that text, *nbytes = min(max_bytes, what is left), in pinned host memory owned by
+ * the context: valid until the next call of this function (the block after it is already being copied when the call
+ * returns, so that the caller's write of one block overlaps the copy of the next). */
+int pf_device_text_chunk(pf_ctx* ctx, uint64_t offset, uint64_t max_bytes, const char** ptr, uint64_t* nbytes);
 
 /* The bodies of kmers_to_hashes.tsv and hashes_to_patterns.tsv of the last pf_submit written ON THE DEVICE
  * (panfeed.py:177,208 and :181-187,217-223): rows assembled in LDS, coalesced stores, one copy to pinned host memory.

@@ -138,7 +138,7 @@ EXPORTS = ["pf_last_error", "pf_version", "pf_device_count", "pf_create", "pf_de
            "pf_submit", "pf_fetch", "pf_get_timing", "pf_export_patterns", "pf_export_patterns_dev",
            "pf_merge_patterns", "pf_merge_patterns_padded", "pf_pattern_count", "pf_debug_limit_pattern_slots", "pf_debug_limit_alloc", "pf_result_checksum", "pf_dev_alloc", "pf_dev_free",
            "pf_dev_upload", "pf_dev_download", "pf_synth_expand", "pf_pack_acgt", "pf_b64_digest",
-           "pf_render_kmers_to_hashes", "pf_render_hashes_to_patterns", "pf_render_kmers_tsv", "pf_free_text",
+           "pf_render_kmers_to_hashes", "pf_render_hashes_to_patterns", "pf_render_kmers_tsv", "pf_render_kmers_tsv_device", "pf_device_text_chunk", "pf_free_text",
            "pf_pack_records", "pf_packed_view", "pf_packed_free",
            "pf_pangenome_open", "pf_pangenome_close", "pf_pangenome_info", "pf_pangenome_strain",
            "pf_pangenome_take_log", "pf_pangenome_next", "pf_records_free", "pf_pangenome_contigs",
@@ -213,6 +213,8 @@ def _load_locked():
     L.pf_render_kmers_to_hashes.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
                                             C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.pf_render_hashes_to_patterns.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.pf_render_kmers_tsv_device.argtypes = [C.c_void_p, C.POINTER(TargetSeq), C.c_uint32, C.POINTER(C.c_uint64)]
+    L.pf_device_text_chunk.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.pf_render_kmers_tsv.argtypes = [C.c_void_p, C.POINTER(TargetSeq), C.c_uint32, C.c_void_p,
                                       C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.pf_pack_records.argtypes = [C.POINTER(PackIn), C.POINTER(C.c_void_p)]

@@ -151,6 +151,17 @@ struct pf_ctx {
     char* txt_pins[2] = {nullptr, nullptr};   // pinned host copies of the rendered text, used alternately so that a
     size_t txt_pin_caps[2] = {0, 0};          // writer thread may still be on the previous batch's
     int txt_slot = 0;
+    // kmers.tsv written on the device (pf_render_kmers_tsv_device): descriptors, tiles, the text; pinned blocks for its way out
+    DevBuf kt_seqs, kt_tiles, kt_prefix, kt_tbytes, kt_toff, kt_text;
+    uint64_t kt_bytes = 0;
+    uint32_t kt_host_seqs = 0;
+    char* kt_pins[2] = {nullptr, nullptr};
+    size_t kt_pin_caps[2] = {0, 0};
+    bool kt_pref_valid = false;
+    uint64_t kt_pref_off = 0, kt_pref_n = 0;
+    int kt_pref_slot = 0;
+    pf_batch last{};                      // the last pf_submit's batch arrays as device pointers (valid until the next submit)
+    uint32_t last_nseg = 0;
     DevBuf g_store, b_literal, g_src_off, g_src_start, g_src_flags;   // genomes resident in HBM + per-batch gather lists
     uint64_t g_words = 0;
     const pf_gather* pending_gather = nullptr;
@@ -581,6 +592,8 @@ void pf_destroy(pf_ctx* c) {
     c->scan_desc.release(); c->pat_b64.release(); c->txt_dev.release(); c->txt_meta.release();
     c->rp_order.release(); c->rp_rlen.release(); c->rp_rowoff.release(); c->wide_list.release();
     for (int i = 0; i < 2; i++) if (c->txt_pins[i]) (void)hipHostFree(c->txt_pins[i]); c->md5_list.release();
+    for (int i = 0; i < 2; i++) if (c->kt_pins[i]) (void)hipHostFree(c->kt_pins[i]);
+    for (DevBuf* b : {&c->kt_seqs, &c->kt_tiles, &c->kt_prefix, &c->kt_tbytes, &c->kt_toff, &c->kt_text}) b->release();
     c->g_store.release(); c->b_literal.release(); c->g_src_off.release(); c->g_src_start.release(); c->g_src_flags.release();
     c->mg_lo.release(); c->mg_cnt.release();
     if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
@@ -1902,6 +1915,9 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
     }
 
     c->n_clusters = C;
+    c->last = d; c->last_nseg = NSEG;
+    if (!c->n_strand_words) c->last.seg_strand_off = nullptr;
+    c->kt_bytes = 0; c->kt_pref_valid = false;
     c->counters = pf_result{};
     c->counters.n_instances = total_inst;
     c->counters.n_unique = n_unique_total;
@@ -2200,8 +2216,9 @@ inline char* put_i64(char* w, long long v) {
 inline size_t len_i64(long long v) { char t[24]; return (size_t)(put_i64(t, v) - t); }
 }  // namespace
 
-int pf_render_kmers_tsv(pf_ctx* c, const pf_target_seq* seqs, uint32_t n, const uint32_t* seg_strand_off, char** out,
-                        uint64_t* nbytes) {
+namespace {
+int render_kmers_tsv_host(pf_ctx* c, const pf_target_seq* seqs, uint32_t n, const uint32_t* seg_strand_off, char** out,
+                          uint64_t* nbytes, std::vector<uint64_t>* sizes_out) {
     if (!c || !out || !nbytes || (n && !seqs)) return fail(PF_ERR_ARG, "null argument");
     if (!c->have_batch) return fail(PF_ERR_STATE, "pf_render_kmers_tsv without a successful pf_submit");
     HIPCHK(hipSetDevice(c->device));
@@ -2316,6 +2333,179 @@ int pf_render_kmers_tsv(pf_ctx* c, const pf_target_seq* seqs, uint32_t n, const 
     buf[off[n]] = 0;
     *out = buf;
     *nbytes = off[n];
+    if (sizes_out) sizes_out->swap(size);
+    return PF_OK;
+}
+}  // namespace
+
+int pf_render_kmers_tsv(pf_ctx* c, const pf_target_seq* seqs, uint32_t n, const uint32_t* seg_strand_off, char** out,
+                        uint64_t* nbytes) {
+    return render_kmers_tsv_host(c, seqs, n, seg_strand_off, out, nbytes, nullptr);
+}
+
+// The same rows written by the GPU (kt_len_kernel / kt_text_kernel) for the sequences that are pure A/C/G/T -- one
+// segment of the batch covering every window -- and by the host renderer above for the others (a target sequence with
+// an 'N', a row too long for the kernel's tile), which are copied to their places in the device text: the text of all
+// n sequences, in order, stays in device memory and is handed out block by block (pf_device_text_chunk).
+int pf_render_kmers_tsv_device(pf_ctx* c, const pf_target_seq* seqs, uint32_t n, uint64_t* nbytes) {
+    if (!c || !nbytes || (n && !seqs)) return fail(PF_ERR_ARG, "null argument");
+    if (!c->have_batch) return fail(PF_ERR_STATE, "pf_render_kmers_tsv_device without a successful pf_submit");
+    HIPCHK(hipSetDevice(c->device));
+    c->kt_bytes = 0; c->kt_pref_valid = false;
+    const uint32_t k = c->o.klength;
+    const bool canon = c->o.canon != 0;
+    const uint32_t reps = canon ? 1u : 2u;
+    if (canon && n && (!c->last.seg_strand_off || !c->n_strand_words))
+        for (uint32_t i = 0; i < n; i++) if ((long long)seqs[i].len - k + 1 > 0 && seqs[i].n_segs) return fail(PF_ERR_STATE, "the last pf_submit carried no strand bits for target segments");
+    // ---- which sequences the device writes; their descriptors, the prefix block, the tiles
+    std::vector<pf::KtSeq> ks;
+    std::vector<uint2> tiles;
+    std::vector<uint32_t> host_idx;              // sequences left to the host renderer
+    std::vector<uint8_t> on_dev(n, 0);
+    std::string prefix;
+    auto digits = [](long long v) { return len_i64(v); };
+    for (uint32_t i = 0; i < n; i++) {
+        const pf_target_seq& s = seqs[i];
+        const long long nk = (long long)s.len - k + 1;
+        if (nk <= 0) continue;                   // no window, no row (panfeed.py:59,64)
+        bool dev = s.n_segs == 1 && s.n_ambig == 0 && s.seg_start[0] == 0 && s.seg_nwin[0] == (uint64_t)nk &&
+                   s.seg_index[0] < c->last_nseg && (uint64_t)nk * reps < 0xFFFFFF00ull;
+        size_t plen = 0;
+        if (dev) {
+            plen = strlen(s.cluster) + strlen(s.strain) + strlen(s.id) + strlen(s.chromosome) + 5 + digits(s.strand);
+            // the longest row this sequence can have must fit the tile KT_ROWS times over
+            const long long far = s.strand > 0 ? s.start + nk + k : s.end - nk - k;
+            const size_t num = std::max(digits(s.strand > 0 ? s.start : s.end), digits(far));
+            const size_t gnum = std::max(digits(-s.offset), digits(nk + k - s.offset));
+            const size_t rowmax = plen + 2 * num + 2 * gnum + std::max(digits(s.strand), digits(-(long long)s.strand)) + 5 + k + 1;
+            if (rowmax * pf::KT_ROWS > pf::KT_TILE || prefix.size() + plen > 0x7FFFFFF0u) dev = false;
+        }
+        if (!dev) { host_idx.push_back(i); continue; }
+        on_dev[i] = 1;
+        pf::KtSeq q{};
+        q.base = s.strand > 0 ? s.start : s.end; q.offset = s.offset; q.strand = s.strand;
+        q.seg = s.seg_index[0]; q.nk = (uint32_t)nk; q.prefix_off = (uint32_t)prefix.size(); q.prefix_len = (uint32_t)plen;
+        prefix += s.cluster; prefix += '\t'; prefix += s.strain; prefix += '\t'; prefix += s.id; prefix += '\t';
+        prefix += s.chromosome; prefix += '\t';
+        { char t[24]; prefix.append(t, put_i64(t, s.strand) - t); }
+        prefix += '\t';
+        const uint32_t rows = (uint32_t)nk * reps, si = (uint32_t)ks.size();
+        for (uint32_t r0 = 0; r0 < rows; r0 += pf::KT_ROWS) tiles.push_back(make_uint2(si, r0));
+        ks.push_back(q);
+    }
+    // ---- the host's share, rendered in one go (its sequences' sizes come back with it)
+    char* htext = nullptr;
+    uint64_t hbytes = 0;
+    std::vector<uint64_t> hsizes;
+    struct FreeText { char*& p; ~FreeText() { free(p); } } free_htext{htext};
+    if (!host_idx.empty()) {
+        std::vector<pf_target_seq> hs(host_idx.size());
+        for (size_t j = 0; j < host_idx.size(); j++) hs[j] = seqs[host_idx[j]];
+        // (the batch's strand offsets, host side: the caller's array went to the device with the batch)
+        std::vector<uint32_t> sso;
+        if (canon && c->last.seg_strand_off && c->last_nseg) {
+            sso.resize(c->last_nseg);
+            HIPCHK(hipMemcpy(sso.data(), c->last.seg_strand_off, (size_t)c->last_nseg * 4, hipMemcpyDeviceToHost));
+        }
+        PFCHK(render_kmers_tsv_host(c, hs.data(), (uint32_t)hs.size(), sso.empty() ? nullptr : sso.data(), &htext, &hbytes, &hsizes));
+    }
+    // ---- tile sizes
+    const uint32_t NT = (uint32_t)tiles.size();
+    pf::KtParams kp{};
+    std::vector<uint32_t> tbytes(NT);
+    if (NT) {
+        PFCHK(c->kt_seqs.ensure(ks.size() * sizeof(pf::KtSeq)));
+        PFCHK(c->kt_tiles.ensure((size_t)NT * 8));
+        PFCHK(c->kt_prefix.ensure(prefix.size() + 16));
+        PFCHK(c->kt_tbytes.ensure((size_t)NT * 4));
+        PFCHK(c->kt_toff.ensure((size_t)NT * 8));
+        HIPCHK(hipMemcpyAsync(c->kt_seqs.p, ks.data(), ks.size() * sizeof(pf::KtSeq), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->kt_tiles.p, tiles.data(), (size_t)NT * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->kt_prefix.p, prefix.data(), prefix.size(), hipMemcpyHostToDevice, c->stream));
+        kp.seqs = c->kt_seqs.as<pf::KtSeq>(); kp.tiles = c->kt_tiles.as<uint2>(); kp.prefix = c->kt_prefix.as<char>();
+        kp.packed = c->last.packed; kp.seg_word_off = c->last.seg_word_off; kp.seg_strand_off = c->last.seg_strand_off;
+        kp.strand_bits = c->strand_bits.as<uint64_t>();
+        kp.tile_bytes = c->kt_tbytes.as<uint32_t>(); kp.tile_off = c->kt_toff.as<uint64_t>();
+        kp.k = k; kp.canon = canon ? 1u : 0u;
+        hipLaunchKernelGGL(pf::kt_len_kernel, dim3(NT), dim3(pf::KT_ROWS), 0, c->stream, kp);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(tbytes.data(), c->kt_tbytes.p, (size_t)NT * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    // ---- offsets, in the order of the sequences
+    std::vector<uint64_t> toff(NT), hoff(host_idx.size());
+    uint64_t total = 0;
+    {
+        size_t ti = 0, hi = 0;
+        uint32_t si = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            if (on_dev[i]) {
+                while (ti < NT && tiles[ti].x == si) { toff[ti] = total; total += tbytes[ti]; ti++; }
+                si++;
+            } else if (hi < host_idx.size() && host_idx[hi] == i) {
+                hoff[hi] = total; total += hsizes[hi]; hi++;
+            }
+        }
+    }
+    PFCHK(c->kt_text.ensure((size_t)total + 64));
+    if (NT) {
+        HIPCHK(hipMemcpyAsync(c->kt_toff.p, toff.data(), (size_t)NT * 8, hipMemcpyHostToDevice, c->stream));
+        kp.text = c->kt_text.as<char>();
+        hipLaunchKernelGGL(pf::kt_text_kernel, dim3(NT), dim3(pf::KT_ROWS), 0, c->stream, kp);
+        HIPCHK(hipGetLastError());
+    }
+    {
+        uint64_t at = 0;
+        for (size_t j = 0; j < host_idx.size(); j++) {
+            if (hsizes[j]) HIPCHK(hipMemcpyAsync(c->kt_text.as<char>() + hoff[j], htext + at, (size_t)hsizes[j], hipMemcpyHostToDevice, c->stream));
+            at += hsizes[j];
+        }
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->kt_bytes = total;
+    c->kt_host_seqs = (uint32_t)host_idx.size();
+    *nbytes = total;
+    return PF_OK;
+}
+
+// Bytes [offset, offset + n) of the text the last pf_render_kmers_tsv_device left on the device, n = min(max_bytes, what
+// remains), in pinned host memory; the block after it is already on its way when the call returns.
+int pf_device_text_chunk(pf_ctx* c, uint64_t offset, uint64_t max_bytes, const char** ptr, uint64_t* nbytes) {
+    if (!c || !ptr || !nbytes || !max_bytes) return fail(PF_ERR_ARG, "null argument");
+    if (offset > c->kt_bytes) return fail(PF_ERR_ARG, "offset beyond the text");
+    HIPCHK(hipSetDevice(c->device));
+    auto ensure_pin = [&](int slot) -> int {
+        if (c->kt_pin_caps[slot] >= max_bytes) return PF_OK;
+        if (c->kt_pins[slot]) (void)hipHostFree(c->kt_pins[slot]);
+        c->kt_pins[slot] = nullptr; c->kt_pin_caps[slot] = 0;
+        hipError_t e = hipHostMalloc((void**)&c->kt_pins[slot], max_bytes, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(PF_ERR_OOM, "hipHostMalloc(%llu) failed: %s", (unsigned long long)max_bytes, hipGetErrorString(e));
+        c->kt_pin_caps[slot] = max_bytes;
+        return PF_OK;
+    };
+    const uint64_t n = std::min<uint64_t>(max_bytes, c->kt_bytes - offset);
+    int slot;
+    if (c->kt_pref_valid && c->kt_pref_off == offset && c->kt_pref_n == n) {
+        slot = c->kt_pref_slot;                       // requested by the call before: wait for it
+        HIPCHK(hipStreamSynchronize(c->side));
+    } else {
+        HIPCHK(hipStreamSynchronize(c->side));        // (a block in flight that nobody asked for)
+        slot = 0;
+        PFCHK(ensure_pin(slot));
+        if (n) HIPCHK(hipMemcpyAsync(c->kt_pins[slot], c->kt_text.as<char>() + offset, n, hipMemcpyDeviceToHost, c->side));
+        HIPCHK(hipStreamSynchronize(c->side));
+    }
+    c->kt_pref_valid = false;
+    const uint64_t next = offset + n;
+    if (n && next < c->kt_bytes) {
+        const int ns = slot ^ 1;
+        PFCHK(ensure_pin(ns));
+        const uint64_t nn = std::min<uint64_t>(max_bytes, c->kt_bytes - next);
+        HIPCHK(hipMemcpyAsync(c->kt_pins[ns], c->kt_text.as<char>() + next, nn, hipMemcpyDeviceToHost, c->side));
+        c->kt_pref_valid = true; c->kt_pref_off = next; c->kt_pref_n = nn; c->kt_pref_slot = ns;
+    }
+    *ptr = c->kt_pins[slot];
+    *nbytes = n;
     return PF_OK;
 }
 

@@ -4606,6 +4606,138 @@ __global__ __launch_bounds__(256) void kh_text_kernel(KhTextParams p) {
     for (uint32_t i = lead + (mid << 4) + threadIdx.x; i < nbytes; i += blockDim.x) g[i] = tile[mis + i];
 }
 
+// ---------------------------------------------------------------------------------------------
+// kmers.tsv on the device: the positional rows of target strains (panfeed.py:90-107)
+// ---------------------------------------------------------------------------------------------
+// One row per window of a target strain's sequence (two in non-canonical mode):
+//   "<idx>\t<strain>\t<feature_id>\t<contig>\t<feature_strand>\t<contig_start>\t<contig_end>\t<gene_start>\t<gene_end>\t<strand>\t<k-mer>\n"
+// The first five fields are the same for every row of a sequence (the host sends them once per sequence, as text); the
+// four coordinates follow from the window's position (panfeed.py:91-102), the strand used from the strand bits
+// strand_bits_kernel left for the batch, the k-mer's letters from the packed bases.  A workgroup takes KT_ROWS
+// consecutive rows of one sequence: kt_len_kernel adds up their bytes (the rows' lengths vary with the digits of their
+// numbers), the host turns the tiles' sizes into offsets, kt_text_kernel writes the rows into an LDS tile -- every thread
+// its own row, at the place a block scan of the lengths gives it -- and the tile leaves as coalesced 16-byte stores.
+constexpr uint32_t KT_ROWS = 256;            // rows per workgroup (one per thread)
+constexpr uint32_t KT_TILE = 61440;          // bytes of LDS tile: a sequence whose rows may be longer than KT_TILE / KT_ROWS stays on the host
+struct KtSeq {
+    int64_t base;                            // seq.start (feature strand > 0) or seq.end: panfeed.py:91-99
+    int64_t offset;                          // panfeed.py:101-102
+    int64_t strand;                          // feature strand as the record holds it
+    uint32_t seg;                            // its segment in the batch (pure A/C/G/T: one segment, every window)
+    uint32_t nk;                             // windows
+    uint32_t prefix_off, prefix_len;         // "<idx>\t<strain>\t<feature_id>\t<contig>\t<feature_strand>\t"
+};
+struct KtParams {
+    const KtSeq* seqs; const uint2* tiles;   // tile = (sequence, first row)
+    const char* prefix;
+    const uint64_t* packed; const uint64_t* seg_word_off; const uint32_t* seg_strand_off; const uint64_t* strand_bits;
+    uint32_t* tile_bytes;                    // kt_len_kernel out
+    const uint64_t* tile_off; char* text;    // kt_text_kernel in / out
+    uint32_t k, canon;
+};
+__device__ __forceinline__ uint32_t kt_dec_len(int64_t v) {
+    uint64_t a = v < 0 ? 0ull - (uint64_t)v : (uint64_t)v;
+    uint32_t n = v < 0 ? 2u : 1u;
+    while (a > 0xFFFFFFFFull) { a /= 10; n++; }
+    uint32_t b = (uint32_t)a;
+    while (b >= 10) { b /= 10; n++; }
+    return n;
+}
+__device__ __forceinline__ char* kt_put_dec(char* w, int64_t v) {
+    uint64_t a = v < 0 ? 0ull - (uint64_t)v : (uint64_t)v;
+    if (v < 0) *w++ = '-';
+    char t[20];
+    int n = 0;
+    while (a > 0xFFFFFFFFull) { t[n++] = (char)('0' + a % 10); a /= 10; }
+    uint32_t b = (uint32_t)a;
+    do { t[n++] = (char)('0' + b % 10); b /= 10; } while (b);
+    while (n) *w++ = t[--n];
+    return w;
+}
+struct KtRow { int64_t ts, te, gs, ge, us; uint32_t pos; bool rc; };
+__device__ __forceinline__ bool kt_row(const KtParams& p, const KtSeq& s, uint32_t row, KtRow& r) {
+    const uint32_t reps = p.canon ? 1u : 2u;
+    if (row >= s.nk * reps) return false;
+    const uint32_t pos = row / reps;
+    const int64_t k = p.k;
+    r.pos = pos;
+    if (s.strand > 0) { r.ts = s.base + pos; r.te = s.base + pos + k; }          // panfeed.py:91-94
+    else { r.te = s.base - pos; r.ts = s.base - pos - k; }                        // panfeed.py:96-99
+    r.gs = (int64_t)pos - s.offset; r.ge = (int64_t)pos + k - s.offset;          // panfeed.py:101-102
+    if (p.canon) {
+        const uint64_t w = p.strand_bits[(size_t)p.seg_strand_off[s.seg] + (pos >> 6)];
+        r.rc = (w >> (pos & 63)) & 1;
+        r.us = r.rc ? -1 : 1;                                                     // panfeed.py:69-75
+    } else {
+        r.rc = (row & 1u) != 0;                                                   // panfeed.py:106-107
+        r.us = r.rc ? -s.strand : s.strand;
+    }
+    return true;
+}
+__device__ __forceinline__ uint32_t kt_row_len(const KtParams& p, const KtSeq& s, const KtRow& r) {
+    return s.prefix_len + kt_dec_len(r.ts) + kt_dec_len(r.te) + kt_dec_len(r.gs) + kt_dec_len(r.ge) + kt_dec_len(r.us) + 5 + p.k + 1;
+}
+__global__ __launch_bounds__(KT_ROWS) void kt_len_kernel(KtParams p) {
+    __shared__ uint32_t wsum[KT_ROWS / 64];
+    const uint2 t = p.tiles[blockIdx.x];
+    const KtSeq s = p.seqs[t.x];
+    KtRow r;
+    uint32_t len = kt_row(p, s, t.y + threadIdx.x, r) ? kt_row_len(p, s, r) : 0u;
+    for (int d = 32; d > 0; d >>= 1) len += __shfl_down(len, d);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = len;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t a = 0; for (uint32_t i = 0; i < KT_ROWS / 64; i++) a += wsum[i]; p.tile_bytes[blockIdx.x] = a; }
+}
+__global__ __launch_bounds__(KT_ROWS) void kt_text_kernel(KtParams p) {
+    __shared__ __align__(16) char tile[KT_TILE + 32];
+    __shared__ uint32_t wsum[KT_ROWS / 64 + 1];
+    const uint2 t = p.tiles[blockIdx.x];
+    const KtSeq s = p.seqs[t.x];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    KtRow r;
+    const bool have = kt_row(p, s, t.y + threadIdx.x, r);
+    const uint32_t len = have ? kt_row_len(p, s, r) : 0u;
+    uint32_t x = len;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d); if ((int)lane >= d) x += y; }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    uint32_t before = x - len, total = 0;
+    for (uint32_t i = 0; i < KT_ROWS / 64; i++) { if (i < wave) before += wsum[i]; total += wsum[i]; }
+    const uint64_t gbase = p.tile_off[blockIdx.x];
+    const uint32_t mis = (uint32_t)(gbase & 15);                             // tile[mis + i] <-> text[gbase + i]
+    if (have && before + len <= KT_TILE) {
+        char* w = tile + mis + before;
+        const char* pre = p.prefix + s.prefix_off;
+        for (uint32_t i = 0; i < s.prefix_len; i++) w[i] = pre[i];
+        w += s.prefix_len;
+        w = kt_put_dec(w, r.ts); *w++ = '\t';
+        w = kt_put_dec(w, r.te); *w++ = '\t';
+        w = kt_put_dec(w, r.gs); *w++ = '\t';
+        w = kt_put_dec(w, r.ge); *w++ = '\t';
+        w = kt_put_dec(w, r.us); *w++ = '\t';
+        // the window's letters (forward), or its reverse complement's: base i of the segment is bits 63-2(i%32)..62-2(i%32)
+        const uint64_t* words = p.packed + p.seg_word_off[s.seg];
+        const uint32_t k = p.k;
+        for (uint32_t q = 0; q < k; q++) {
+            const uint32_t i = r.rc ? r.pos + k - 1 - q : r.pos + q;
+            uint32_t code = (uint32_t)(words[i >> 5] >> (62 - 2 * (i & 31))) & 3u;
+            if (r.rc) code = 3u - code;
+            w[q] = (char)(0x54474341u >> (8 * code));                        // "ACGT"
+        }
+        w[k] = '\n';
+    }
+    __syncthreads();
+    const uint32_t nbytes = min(total, KT_TILE);
+    char* g = p.text + gbase;
+    const uint32_t lead = min(nbytes, (16 - mis) & 15);
+    for (uint32_t i = threadIdx.x; i < lead; i += blockDim.x) g[i] = tile[mis + i];
+    const uint32_t mid = (nbytes - lead) >> 4;
+    const uint4* src = reinterpret_cast<const uint4*>(tile + mis + lead);
+    uint4* dst = reinterpret_cast<uint4*>(g + lead);
+    for (uint32_t i = threadIdx.x; i < mid; i += blockDim.x) dst[i] = src[i];
+    for (uint32_t i = lead + (mid << 4) + threadIdx.x; i < nbytes; i += blockDim.x) g[i] = tile[mis + i];
+}
+
 struct HpTextParams {
     const uint32_t* order;           // [n] new pattern ids in first-seen order
     const uint64_t* row_off;         // [n+1] byte offsets of the rows

@@ -60,6 +60,35 @@ class OwnedText:
             pass
 
 
+class DeviceText:
+    """Text the GPU wrote and still holds (pf_render_kmers_tsv_device): handed out block by block through pinned memory
+    (`chunks`, each block valid until the next is asked for), or as one `bytes` (`bytes(x)`).  Belongs to the engine's
+    last submit: use it before the next one."""
+
+    def __init__(self, engine, nbytes):
+        self._eng, self._n = engine, int(nbytes)
+
+    def __len__(self):
+        return self._n
+
+    def chunks(self, max_bytes=64 << 20):
+        eng, off = self._eng, 0
+        ptr, nb = C.c_void_p(), C.c_uint64()
+        while off < self._n:
+            _lib.check(eng.L.pf_device_text_chunk(eng.ctx, off, int(max_bytes), C.byref(ptr), C.byref(nb)))
+            n = int(nb.value)
+            yield memoryview((C.c_char * n).from_address(ptr.value)).cast("B")
+            off += n
+
+    def __bytes__(self):
+        out = bytearray(self._n)
+        at = 0
+        for blk in self.chunks():
+            out[at:at + len(blk)] = blk
+            at += len(blk)
+        return bytes(out)
+
+
 def _view(ptr, n, dtype):
     if n == 0:
         return np.zeros(0, dtype=dtype)
@@ -266,8 +295,9 @@ class Engine:
                 if texts is not None:
                     out = BatchOutput()
                     out.kmers_to_hashes, out.hashes_to_patterns = texts
-                    # target strains: their rows by the library's host renderer (only the strand bits leave the device)
-                    out.kmers_tsv = self._render_targets(hb, hb.targets, owned=True) if hb.targets else b""
+                    # target strains: their rows written by the GPU too (the next submit reuses the device's text
+                    # block, so the rows come over now)
+                    out.kmers_tsv = bytes(self.render_targets_device(hb)) if hb.n_targets else b""
                     out.stats = {"clusters": int(hb.n_clusters), "instances": int(hb.n_instances),
                                  "device_instances": int(res.n_instances), "unique_kmers": int(res.n_unique),
                                  "kept_kmers": int(res.n_kept), "new_patterns": int(res.n_new_patterns),
@@ -356,7 +386,7 @@ class Engine:
             self.L.pf_free_text(buf)
         # kmers.tsv body (panfeed.py:90-107): one row per window of the target strains' sequences
         kt_by_cluster = [[] for _ in range(C_)]
-        if hb.targets:
+        if hb.n_targets:
             if self.multiple_files:
                 by_cl = {}
                 for meta in hb.targets:
@@ -419,19 +449,125 @@ class Engine:
                                                      C.byref(txt), C.byref(nb)))
             yield _take(txt, nb.value)
 
+    def render_targets_device(self, hb):
+        """kmers.tsv rows of every target sequence of `hb` (the last submit), written on the device
+        (pf_render_kmers_tsv_device): a DeviceText.  Same bytes as `_render_targets(hb, hb.targets)`."""
+        import time as _time
+        t0 = _time.time()
+        if hb.target_table is not None and hb.target_table.resolve is not None and hb._targets is None:
+            rec, n, keep, held = self._marshal_table(hb, hb.target_table)
+        else:
+            rec, n, keep = self._marshal_targets(hb, hb.targets)
+            held = None
+        try:
+            arr = C.cast(rec.ctypes.data, C.POINTER(_lib.TargetSeq))
+            nb = C.c_uint64()
+            t1 = _time.time()
+            _lib.check(self.L.pf_render_kmers_tsv_device(self.ctx, arr, n, C.byref(nb)))
+        finally:
+            if held is not None:
+                from .packing import _release_held
+                _release_held(held)
+        del keep
+        self.render_targets_timing = {"marshal_s": t1 - t0, "render_s": _time.time() - t1, "copy_s": 0.0}
+        return DeviceText(self, nb.value)
+
+    _TS = np.dtype([("cluster", "u8"), ("strain", "u8"), ("id", "u8"), ("chromosome", "u8"), ("sequence", "u8"),
+                    ("compsequence", "u8"), ("len", "u4"), ("strand", "i4"), ("start", "i8"), ("end", "i8"),
+                    ("offset", "i8"), ("n_segs", "u4"), ("n_ambig", "u4"), ("seg_index", "u8"), ("seg_start", "u8"),
+                    ("seg_nwin", "u8"), ("ambig_pos", "u8"), ("ambig_used", "u8"), ("ambig_key", "u8")])
+
+    def _marshal_table(self, hb, tt):
+        """pf_target_seq records straight from the packer's flat target arrays (packing.TargetTable): no per-sequence
+        Python objects, numpy columns only.  Returns (records, n, what must stay alive, held string references)."""
+        from .packing import _seqinfo_columns
+        TS = self._TS
+        assert TS.itemsize == C.sizeof(_lib.TargetSeq)
+        n = len(tt)
+        rec = np.zeros(max(n, 1), dtype=TS)
+        keep = [rec]
+        held = None
+        if not n:
+            return rec, 0, keep, None
+
+        def block(strings):
+            blob = ("\0".join(strings) + "\0").encode()
+            ends = np.flatnonzero(np.frombuffer(blob, dtype=np.uint8) == 0)
+            if len(ends) != len(strings):
+                raise ValueError("a NUL byte inside a name or sequence")
+            starts = np.concatenate(([0], ends[:-1] + 1)).astype(np.uint64)
+            keep.append(blob)
+            return starts + np.uint64(C.cast(C.c_char_p(blob), C.c_void_p).value), (ends - starts.astype(np.int64)).astype(np.uint32)
+
+        ci, strains, seqs = tt.resolve(tt.t_seq)
+        rec["cluster"][:n] = block(list(hb.idx))[0][ci]
+        for field, values in (("strain", [str(x) for x in strains]), ("id", [str(s.id) for s in seqs]),
+                              ("chromosome", [str(s.chromosome) for s in seqs])):
+            uniq = {}
+            idx = np.fromiter((uniq.setdefault(v, len(uniq)) for v in values), dtype=np.int64, count=n)
+            rec[field][:n] = block(list(uniq))[0][idx]
+        fast = _seqinfo_columns(seqs)
+        if fast is not None:
+            a_seq, a_comp, a_len, held = fast
+            rec["sequence"][:n], rec["compsequence"][:n], rec["len"][:n] = a_seq, a_comp, a_len
+        else:
+            addr, lens = block([s.sequence for s in seqs])
+            rec["sequence"][:n], rec["len"][:n] = addr, lens
+            addr, lens2 = block([s.compsequence for s in seqs])
+            rec["compsequence"][:n] = addr
+            if not np.array_equal(lens, lens2):
+                raise ValueError("sequence and compsequence of different lengths")
+        rec["strand"][:n] = np.fromiter((int(s.strand) for s in seqs), dtype=np.int32, count=n)
+        rec["start"][:n] = np.fromiter((int(s.start) for s in seqs), dtype=np.int64, count=n)
+        rec["end"][:n] = np.fromiter((int(s.end) for s in seqs), dtype=np.int64, count=n)
+        rec["offset"][:n] = np.fromiter((int(s.offset) for s in seqs), dtype=np.int64, count=n)
+        so, ao = tt.t_so.astype(np.uint64), tt.t_ao.astype(np.uint64)
+        cols = [np.ascontiguousarray(x, dtype=np.uint32) if len(x) else np.zeros(1, np.uint32) for x in (tt.t_si, tt.t_ss, tt.t_sn)]
+        keep += cols
+        rec["n_segs"][:n] = np.diff(tt.t_so.astype(np.int64))
+        for field, col in zip(("seg_index", "seg_start", "seg_nwin"), cols):
+            rec[field][:n] = np.uint64(col.ctypes.data) + so[:-1] * np.uint64(4)
+        rec["n_ambig"][:n] = np.diff(tt.t_ao.astype(np.int64))
+        ap = np.ascontiguousarray(tt.t_ap, dtype=np.uint32) if len(tt.t_ap) else np.zeros(1, np.uint32)
+        au = np.ascontiguousarray(tt.t_au, dtype=np.int8) if len(tt.t_au) else np.zeros(1, np.int8)
+        akeys = bytes(tt.akeys) + b"\0"
+        kaddr = np.uint64(C.cast(C.c_char_p(akeys), C.c_void_p).value) + np.arange(max(len(tt.t_ap), 1), dtype=np.uint64) * np.uint64(tt.k)
+        kaddr = np.ascontiguousarray(kaddr)
+        keep += [ap, au, akeys, kaddr]
+        rec["ambig_pos"][:n] = np.uint64(ap.ctypes.data) + ao[:-1] * np.uint64(4)
+        rec["ambig_used"][:n] = np.uint64(au.ctypes.data) + ao[:-1]
+        rec["ambig_key"][:n] = np.uint64(kaddr.ctypes.data) + ao[:-1] * np.uint64(8)
+        return rec, n, keep, held
+
     def _render_targets(self, hb, metas, as_bytes=False, owned=False):
         """kmers.tsv rows of `metas` (packing.SeqMeta, in order) through pf_render_kmers_tsv: str, `bytes` (as_bytes) or
         the library's own block without a copy (owned: an OwnedText)"""
         import time as _time
         t0 = _time.time()
+        rec, n, keep = self._marshal_targets(hb, metas)
+        arr = C.cast(rec.ctypes.data, C.POINTER(_lib.TargetSeq))
+        buf, nb = C.c_void_p(), C.c_uint64()
+        sso = hb.seg_strand_off.ctypes.data_as(C.c_void_p) if hb.n_strand_words else None
+        t1 = _time.time()
+        _lib.check(self.L.pf_render_kmers_tsv(self.ctx, arr, n, sso, C.byref(buf), C.byref(nb)))
+        t2 = _time.time()
+        del keep
+        if owned:
+            self.render_targets_timing = {"marshal_s": t1 - t0, "render_s": t2 - t1, "copy_s": 0.0}
+            return OwnedText(self.L, buf, nb.value)
+        text = _take(buf, nb.value)
+        self.L.pf_free_text(buf)
+        # where the time of the last call went: Python marshalling of the records, the library's renderer, the copy out
+        self.render_targets_timing = {"marshal_s": t1 - t0, "render_s": t2 - t1, "copy_s": _time.time() - t2}
+        return text if as_bytes else text.decode()
+
+    def _marshal_targets(self, hb, metas):
+        """pf_target_seq records of `metas` (packing.SeqMeta): (records, n, what must stay alive while they are used)"""
         n = len(metas)
         # The C structs are filled column by column (numpy) instead of sequence by sequence (ctypes): every kind of
         # string goes into ONE NUL-separated block whose pieces are addressed by offset, the few per-sequence lists
         # (ACGT runs, non-ACGT windows) into flat arrays.  23 -> ~4 us per target sequence.
-        TS = np.dtype([("cluster", "u8"), ("strain", "u8"), ("id", "u8"), ("chromosome", "u8"), ("sequence", "u8"),
-                       ("compsequence", "u8"), ("len", "u4"), ("strand", "i4"), ("start", "i8"), ("end", "i8"),
-                       ("offset", "i8"), ("n_segs", "u4"), ("n_ambig", "u4"), ("seg_index", "u8"), ("seg_start", "u8"),
-                       ("seg_nwin", "u8"), ("ambig_pos", "u8"), ("ambig_used", "u8"), ("ambig_key", "u8")])
+        TS = self._TS
         assert TS.itemsize == C.sizeof(_lib.TargetSeq)
         rec = np.zeros(max(n, 1), dtype=TS)
         keep = [rec]
@@ -496,18 +632,4 @@ class Engine:
             rec["ambig_pos"][:n] = np.uint64(ap.ctypes.data) + aoff * np.uint64(4)
             rec["ambig_used"][:n] = np.uint64(au.ctypes.data) + aoff
             rec["ambig_key"][:n] = np.uint64(kaddr.ctypes.data) + aoff * np.uint64(8)
-        arr = C.cast(rec.ctypes.data, C.POINTER(_lib.TargetSeq))
-        buf, nb = C.c_void_p(), C.c_uint64()
-        sso = hb.seg_strand_off.ctypes.data_as(C.c_void_p) if hb.n_strand_words else None
-        t1 = _time.time()
-        _lib.check(self.L.pf_render_kmers_tsv(self.ctx, arr, n, sso, C.byref(buf), C.byref(nb)))
-        t2 = _time.time()
-        del keep
-        if owned:
-            self.render_targets_timing = {"marshal_s": t1 - t0, "render_s": t2 - t1, "copy_s": 0.0}
-            return OwnedText(self.L, buf, nb.value)
-        text = _take(buf, nb.value)
-        self.L.pf_free_text(buf)
-        # where the time of the last call went: Python marshalling of the records, the library's renderer, the copy out
-        self.render_targets_timing = {"marshal_s": t1 - t0, "render_s": t2 - t1, "copy_s": _time.time() - t2}
-        return text if as_bytes else text.decode()
+        return rec, n, keep

@@ -69,6 +69,39 @@ class SeqMeta:
     ambig: dict            # pos -> (canonseq, used_strand) for slow-path windows (canonical mode)
 
 
+class TargetTable:
+    """The target-strain sequences of a batch as the packer's flat arrays (pf_packed's target_* arrays): which input
+    sequence each is, its A/C/G/T runs (segment index in the batch, first window, windows) and its windows with another
+    letter (position, strand used, canonical text).  `metas()` gives the per-sequence SeqMeta objects the host renderer's
+    marshalling and the tests read; the device renderer's marshalling (Engine._marshal_table) goes by the arrays, with
+    `resolve(t_seq) -> (cluster indices, strain names, Seqinfos)` for what only the records know."""
+
+    def __init__(self, k, t_seq, t_so, t_si, t_ss, t_sn, t_ao, t_ap, t_au, akeys, seq_ref, resolve=None):
+        self.k = k
+        self.t_seq, self.t_so, self.t_si, self.t_ss, self.t_sn = t_seq, t_so, t_si, t_ss, t_sn
+        self.t_ao, self.t_ap, self.t_au, self.akeys = t_ao, t_ap, t_au, akeys
+        self.seq_ref, self.resolve = seq_ref, resolve
+        self._metas = None
+
+    def __len__(self):
+        return len(self.t_seq)
+
+    def metas(self):
+        if self._metas is None:
+            k, out = self.k, []
+            t_so, t_ao, t_si, t_ss, t_sn, t_ap, t_au, akeys = (self.t_so, self.t_ao, self.t_si, self.t_ss, self.t_sn,
+                                                               self.t_ap, self.t_au, self.akeys)
+            for ti in range(len(self.t_seq)):
+                ci, strain, s = self.seq_ref(int(self.t_seq[ti]))
+                segs = [(int(t_si[j]), int(t_ss[j]), int(t_sn[j])) for j in range(t_so[ti], t_so[ti + 1])]
+                ambig = {int(t_ap[j]): (akeys[j * k:(j + 1) * k].decode("latin-1"), int(t_au[j]))
+                         for j in range(t_ao[ti], t_ao[ti + 1])}
+                out.append(SeqMeta(ci, strain, s, 0, max(len(s.sequence) - k + 1, 0), segs, ambig))
+            self._metas = out
+            self.seq_ref = None
+        return self._metas
+
+
 @dataclass
 class HostBatch:
     k: int
@@ -93,7 +126,8 @@ class HostBatch:
     extra_ord: np.ndarray = None
     extra_bits: np.ndarray = None
     extra_keys: list = field(default_factory=list)        # k-mer strings of the slow-path rows
-    targets: list = field(default_factory=list)           # SeqMeta of sequences in target strains
+    target_table: object = None                           # TargetTable: the target strains' sequences, flat
+    _targets: list = None                                 # their SeqMeta (made on first use)
     n_instances: int = 0                                  # trip count of panfeed.py:64 (x2 non-canonical)
     # with genomes resident in HBM (pf_submit_gather): `packed` holds only the host-packed ("literal") segments,
     # seg_word_off are offsets in the device buffer of n_words_dev words the gather fills
@@ -105,6 +139,19 @@ class HostBatch:
     @property
     def n_clusters(self):
         return len(self.idx)
+
+    @property
+    def targets(self):
+        """SeqMeta of the sequences in target strains (panfeed.py:90), in iteration order"""
+        if self._targets is None:
+            self._targets = self.target_table.metas() if self.target_table is not None else []
+        return self._targets
+
+    @property
+    def n_targets(self):
+        if self._targets is not None:
+            return len(self._targets)
+        return len(self.target_table) if self.target_table is not None else 0
 
 
 def decode_keys(keys, k, key_words):
@@ -125,8 +172,10 @@ def decode_keys(keys, k, key_words):
     return [row.tobytes().decode() for row in out]
 
 
-def _fill_from_packed(L, hb, handle, n_clusters, seq_ref):
-    """Copy a pf_packed result into `hb`; seq_ref(q) -> (cluster index, strain, Seqinfo) of input sequence q."""
+def _fill_from_packed(L, hb, handle, n_clusters, seq_ref, resolve=None):
+    """Copy a pf_packed result into `hb`; seq_ref(q) -> (cluster index, strain, Seqinfo) of input sequence q.  With
+    `resolve` (TargetTable) the records behind seq_ref outlive the call and the per-target objects are made on first use;
+    without it they are made here."""
     import ctypes as C
 
     from . import _lib
@@ -166,12 +215,10 @@ def _fill_from_packed(L, hb, handle, n_clusters, seq_ref):
     t_ap = arr(v.target_ambig_pos, nta, np.uint32)
     t_au = arr(v.target_ambig_used, nta, np.int8)
     akeys = C.string_at(v.target_ambig_keys, nta * k) if nta else b""
-    for ti in range(nt):
-        ci, strain, s = seq_ref(int(t_seq[ti]))
-        segs = [(int(t_si[j]), int(t_ss[j]), int(t_sn[j])) for j in range(t_so[ti], t_so[ti + 1])]
-        ambig = {int(t_ap[j]): (akeys[j * k:(j + 1) * k].decode("latin-1"), int(t_au[j]))
-                 for j in range(t_ao[ti], t_ao[ti + 1])}
-        hb.targets.append(SeqMeta(ci, strain, s, 0, max(len(s.sequence) - k + 1, 0), segs, ambig))
+    hb.target_table = TargetTable(k, t_seq, t_so, t_si, t_ss, t_sn, t_ao, t_ap, t_au, akeys, seq_ref, resolve)
+    hb._targets = None
+    if resolve is None:
+        hb.targets                     # (the caller's records go away with the call: the objects are made now)
 
 
 def _ascii_addresses(strings):
@@ -267,6 +314,7 @@ def build_batch_native(records, klength, canon, W, stroi=(), first_ordinal=0, wa
     cl_off = [0]
     cl_nstr, cl_npres, cl_presab, cl_ord = [], [], [], []
     any_target = False
+    stroi_set = stroi if isinstance(stroi, (set, frozenset, dict)) else frozenset(stroi or ())
     for ci, (gs, idx, presab) in enumerate(records):
         names = list(gs.keys())
         n = len(names)
@@ -297,11 +345,10 @@ def build_batch_native(records, klength, canon, W, stroi=(), first_ordinal=0, wa
             colv = np.arange(n, dtype=np.uint32)
         else:
             colv = np.fromiter(map(col.__getitem__, names), dtype=np.uint32, count=n)
-        tg = np.zeros(n, dtype=np.uint8)                          # panfeed.py:90
-        if stroi:
-            for x in stroi:
-                if x in col:
-                    tg[names.index(x)] = 1
+        if stroi:                                                 # panfeed.py:90 (`strain in stroi`, one look-up per strain)
+            tg = np.fromiter(map(stroi_set.__contains__, names), dtype=np.uint8, count=n)
+        else:
+            tg = np.zeros(n, dtype=np.uint8)
         any_target = any_target or bool(tg.any())
         if int(counts.min(initial=1)) == 1 and int(counts.max(initial=1)) == 1:
             col_parts.append(colv); tgt_parts.append(tg); strain_parts.append(np.arange(n, dtype=np.uint32))
@@ -355,6 +402,11 @@ def build_batch_native(records, klength, canon, W, stroi=(), first_ordinal=0, wa
         ci = int(seq_cluster[q])
         return ci, cl_names[ci][int(a_strain[q])], flat_s[q]
 
+    def resolve(t_seq):
+        ci = seq_cluster[t_seq]
+        st = a_strain[t_seq]
+        return ci, [cl_names[c][a] for c, a in zip(ci.tolist(), st.tolist())], [flat_s[q] for q in t_seq.tolist()]
+
     pin = _lib.PackIn(len(cl_nstr), nseq, C.cast(a_seq.ctypes.data, C.POINTER(C.c_char_p)),
                       C.cast(a_comp.ctypes.data, C.POINTER(C.c_char_p)), a_len.ctypes.data, a_col.ctypes.data,
                       a_tgt.ctypes.data if any_target else None, a_off.ctypes.data, k, int(bool(canon)), W,
@@ -363,7 +415,7 @@ def build_batch_native(records, klength, canon, W, stroi=(), first_ordinal=0, wa
     try:
         _lib.check(L.pf_pack_records(C.byref(pin), C.byref(handle)))
         try:
-            _fill_from_packed(L, hb, handle, len(cl_nstr), seq_ref)
+            _fill_from_packed(L, hb, handle, len(cl_nstr), seq_ref, resolve)
         finally:
             L.pf_packed_free(handle)
     finally:

@@ -983,3 +983,82 @@ def test_buffer_slack_is_not_required():
         assert ei.value.status == _lib.ERR_OOM
     finally:
         _lib.check(L.pf_debug_limit_alloc(0, None))
+
+
+def _device_kmers_tsv(eng, records, chunk=None):
+    """submit `records` as one batch and have the GPU write the kmers.tsv rows (pf_render_kmers_tsv_device)"""
+    from panfeed_amd.packing import build_batch_native
+    hb = build_batch_native(records, eng.k, eng.canon, eng.W, stroi=eng.stroi, first_ordinal=eng.next_ordinal)
+    eng.next_ordinal += len(records)
+    eng.submit_host_batch(hb)
+    dt = eng.render_targets_device(hb)
+    if chunk is None:
+        return bytes(dt).decode(), hb
+    parts = [bytes(b) for b in dt.chunks(chunk)]          # (a block is only valid until the next one is asked for)
+    assert all(len(p) <= chunk for p in parts) and sum(map(len, parts)) == len(dt)
+    return b"".join(parts).decode(), hb
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c["opts"]["stroi"] and not c["opts"]["multiple_files"]],
+                         ids=lambda c: c["name"])
+def test_golden_kmers_tsv_written_on_the_device(case):
+    """H6 (panfeed.py:90-107): the positional rows written by kt_text_kernel -- pure-ACGT target sequences on the GPU,
+    sequences with another letter by the host renderer, spliced in place -- against the reference's kmers.tsv"""
+    o = case["opts"]
+    ms = max(32, (len(case["all_strains"]) + 31) // 32 * 32)
+    eng = _engine(o, ms)
+    text, hb = _device_kmers_tsv(eng, case_records(case))
+    hk, _, _ = _headers(case)
+    assert hk + text == case["expect"]["kmers.tsv"]
+    eng.close()
+
+
+@pytest.mark.parametrize("k,canon,n_rate", [(31, True, 0.0), (31, True, 0.05), (21, False, 0.02), (65, True, 0.01), (126, False, 0.0)])
+def test_kmers_tsv_device_equals_host_renderer(k, canon, n_rate):
+    """every strain a target (BASELINE configs[4]'s second pass in small): both strands, paralogs, flanks that make
+    gene_start negative, 'N's (host-rendered sequences between device-rendered ones), two rows per window in
+    non-canonical mode, blocks handed out in small pieces; device text == host renderer's text == the oracle's"""
+    from panfeed_amd import synth
+    from panfeed_amd.engine import Engine
+    S = 70
+    cl = synth.generate(6, S, first=77, flank=40, mean_len=300, min_len=40, max_len=900, n_rate=n_rate,
+                        paralog_rate=0.05, shuffle_columns=3)
+    recs = [c.record() for c in cl]
+    stroi = set(cl[0].names)
+    eng = Engine(klength=k, canon=canon, max_strains=96, stroi=stroi)
+    text, hb = _device_kmers_tsv(eng, recs, chunk=100_000)
+    host = eng._render_targets(hb, hb.targets)
+    assert text == host
+    (ek, _, _), _ = _oracle_texts(recs, stroi=stroi, klength=k, canon=canon)
+    assert text == ek
+    # through the batched driver (run_batches renders target rows on the device)
+    eng2 = Engine(klength=k, canon=canon, max_strains=96, stroi=stroi)
+    outs = list(eng2.run_stream(recs, batch_clusters=4, device_text=True))
+    assert b"".join(bytes(o.kmers_tsv) if not isinstance(o.kmers_tsv, str) else o.kmers_tsv.encode() for o in outs).decode() == ek
+    eng.close(); eng2.close()
+
+
+def test_kmers_tsv_device_long_names_and_large_coordinates():
+    """rows too long for the kernel's tile (a 300-character contig name) fall to the host renderer; 13-digit coordinates
+    and negative ones go through the device's integer formatting"""
+    from panfeed_amd.classes import Seqinfo
+    from panfeed_amd.engine import Engine
+    rng = np.random.default_rng(5)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+
+    def seq(n):
+        s = bytes(rng.choice(list(b"ACGT"), n)).decode()
+        return s, s.encode().translate(comp).decode()
+    gs = {}
+    s1, c1 = seq(120); s2, c2 = seq(90); s3, c3 = seq(150); s4, c4 = seq(64)
+    gs["strainA"] = [Seqinfo(s1, c1, "geneA", "contig" + "x" * 300, 10, 130, 1, 0)]
+    gs["strainB"] = [Seqinfo(s2, c2, "geneB", "ctg2", 9_999_999_999_950, 10_000_000_000_040, -1, 7)]
+    gs["strainC"] = [Seqinfo(s3, c3, "geneC", "ctg3", -40, 110, 1, 135), Seqinfo(s4, c4, "geneC2", "ctg3", 3, 67, -1, 2)]
+    rec = (gs, "grpX", np.array([1, 1, 1], dtype=np.int64))
+    for canon in (True, False):
+        eng = Engine(klength=31, canon=canon, max_strains=32, stroi={"strainA", "strainB", "strainC"})
+        text, hb = _device_kmers_tsv(eng, [rec])
+        assert text == eng._render_targets(hb, hb.targets)
+        (ek, _, _), _ = _oracle_texts([rec], stroi={"strainA", "strainB", "strainC"}, klength=31, canon=canon)
+        assert text == ek
+        eng.close()
