@@ -1047,7 +1047,7 @@ def test_kmers_tsv_device_long_names_and_large_coordinates():
     comp = bytes.maketrans(b"ACGT", b"TGCA")
 
     def seq(n):
-        s = bytes(rng.choice(list(b"ACGT"), n)).decode()
+        s = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), n).tobytes().decode()
         return s, s.encode().translate(comp).decode()
     gs = {}
     s1, c1 = seq(120); s2, c2 = seq(90); s3, c3 = seq(150); s4, c4 = seq(64)
