@@ -495,6 +495,20 @@ def end_to_end(args, local):
     return out
 
 
+def start_heartbeat(period=60.0):
+    """one line on stderr every minute while the run lasts: the oracle sample, the synthetic input of a 25 000 x 5 000
+    workload and the CRC of a 37 GB text each take minutes in silence, and a silent run reads as a hung one"""
+    import threading
+    t_begin = time.time()
+
+    def beat():
+        while True:
+            time.sleep(period)
+            sys.stderr.write(f"bench.py: running, {time.time() - t_begin:.0f} s\n")
+            sys.stderr.flush()
+    threading.Thread(target=beat, name="bench-heartbeat", daemon=True).start()
+
+
 def main():
     args = parse()
     env_world = os.environ.get("WORLD_SIZE")
@@ -503,6 +517,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(env_world or "1")
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if rank == 0:
+        start_heartbeat()
     if args.gpus is not None and args.gpus != world:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); nothing was run\n")
         sys.exit(2)

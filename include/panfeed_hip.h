@@ -388,6 +388,23 @@ typedef struct {
 } pf_records_view_t;
 
 int pf_pangenome_open(const pf_pangenome_opts* opts, pf_pangenome** out);
+/* The same reader with the genomes going to the device AS THE FILES ARE READ (one pass over the input instead of
+ * pf_pangenome_open's read + upper-casing copy and pf_genomes_upload's second copy): every file is read straight into
+ * pinned memory, its GFF lines parsed there (input.py:274-332), its contigs measured without copying a base, and a kernel
+ * de-wraps, upper-cases and packs the letters to 2 bits per base in the context's genome store while other files are
+ * still being read.  Contig text stays on the host only for contigs with a letter other than A/C/G/T and for target
+ * strains (what iter_gene_clusters cuts out of text, input.py:427-452).  The reader comes back in by-reference mode
+ * (as after pf_pangenome_contigs / pf_genomes_upload / pf_pangenome_set_store); pf_pangenome_contigs is refused on it.
+ * PF_ERR_CAPACITY: the store's estimate (half a byte per byte of input) did not hold -- contigs of a few letters each;
+ * use pf_pangenome_open + pf_genomes_upload. */
+int pf_pangenome_open_device(const pf_pangenome_opts* opts, pf_ctx* ctx, pf_pangenome** out);
+/* The same with the context asked for when the first genome needs it (get_ctx(user), called once, from one of the reader's
+ * threads): the caller may still be creating it while the reader parses the presence/absence table. */
+int pf_pangenome_open_device_cb(const pf_pangenome_opts* opts, pf_ctx* (*get_ctx)(void*), void* user, pf_pangenome** out);
+/* Test hook: the reader side of pf_pangenome_open_device without a device -- blocks of ordinary memory, the store filled
+ * on the host by the kernel's addressing (letter j of a contig = byte text_off + j + (j / width) * eol of its block).
+ * *store (pf_free_text) holds *nwords words; the reader is in by-reference mode. */
+int pf_debug_open_hostsink(const pf_pangenome_opts* opts, pf_pangenome** out, uint64_t** store, uint64_t* nwords);
 void pf_pangenome_close(pf_pangenome* p);
 /* The same on a thread of its own: returns at once, the reader's memory (tables, features, gigabytes of contigs) is
  * given back in the background.  For a caller that has finished its run. */

@@ -140,7 +140,7 @@ EXPORTS = ["pf_last_error", "pf_version", "pf_device_count", "pf_create", "pf_de
            "pf_dev_upload", "pf_dev_download", "pf_synth_expand", "pf_pack_acgt", "pf_b64_digest",
            "pf_render_kmers_to_hashes", "pf_render_hashes_to_patterns", "pf_render_kmers_tsv", "pf_render_kmers_tsv_device", "pf_device_text_chunk", "pf_free_text",
            "pf_pack_records", "pf_packed_view", "pf_packed_free",
-           "pf_pangenome_open", "pf_pangenome_close", "pf_pangenome_info", "pf_pangenome_strain",
+           "pf_pangenome_open", "pf_pangenome_open_device", "pf_pangenome_open_device_cb", "pf_debug_open_hostsink", "pf_pangenome_close", "pf_pangenome_info", "pf_pangenome_strain",
            "pf_pangenome_take_log", "pf_pangenome_next", "pf_records_free", "pf_pangenome_contigs",
            "pf_pangenome_set_store", "pf_genomes_upload", "pf_genomes_clear", "pf_submit_gather", "pf_gzip_members", "pf_render_device",
            "pf_render_device_ex", "pf_render_pattern_rows", "pf_pangenome_weights", "pf_pangenome_set_range",
@@ -148,6 +148,7 @@ EXPORTS = ["pf_last_error", "pf_version", "pf_device_count", "pf_create", "pf_de
            "pf_py_str_addresses", "pf_pangenome_close_async", "pf_py_seqinfo_columns", "pf_py_release"]
 
 RENDER_NO_PATTERN_ROWS = 1
+GET_CTX = C.CFUNCTYPE(C.c_void_p, C.c_void_p)     # pf_pangenome_open_device_cb: the context, when the first genome needs it
 ERR_ARG, ERR_OOM, ERR_HIP, ERR_CAPACITY, ERR_STATE = -1, -2, -3, -4, -5
 
 _lib = None
@@ -222,6 +223,10 @@ def _load_locked():
     L.pf_packed_free.argtypes = [C.c_void_p]
     L.pf_packed_free.restype = None
     L.pf_pangenome_open.argtypes = [C.POINTER(PangenomeOpts), C.POINTER(C.c_void_p)]
+    L.pf_pangenome_open_device.argtypes = [C.POINTER(PangenomeOpts), C.c_void_p, C.POINTER(C.c_void_p)]
+    L.pf_pangenome_open_device_cb.argtypes = [C.POINTER(PangenomeOpts), GET_CTX, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.pf_debug_open_hostsink.argtypes = [C.POINTER(PangenomeOpts), C.POINTER(C.c_void_p), C.POINTER(C.POINTER(C.c_uint64)),
+                                         C.POINTER(C.c_uint64)]
     L.pf_pangenome_close.argtypes = [C.c_void_p]
     L.pf_pangenome_close.restype = None
     L.pf_pangenome_close_async.argtypes = [C.c_void_p]

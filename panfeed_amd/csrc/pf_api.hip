@@ -10,7 +10,11 @@
 // pattern-counter read-back of the last pass and the end of the batch.
 #include "pf_kernels.h"
 #include "../../include/panfeed_hip.h"
+#include "pf_ingest.h"
 
+#include <sys/stat.h>
+#include <condition_variable>
+#include <mutex>
 #include <algorithm>
 #include <cmath>
 #include <chrono>
@@ -2606,6 +2610,257 @@ int pf_submit_gather(pf_ctx* c, const pf_batch* b, const pf_gather* g, pf_result
     const int rc = pf_submit(c, b, r);
     c->pending_gather = nullptr;
     return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// One-pass ingest: the reader's sink (pf_ingest.h).  A ring of blocks, each a pinned host block with a device twin: a reader
+// thread read()s a genome's file straight into a pinned block, parses the GFF lines there, measures the contigs without
+// copying a base, and gives the block back with one piece per contig; the block goes to its twin (one copy over PCIe) and
+// genome_pack_text_kernel de-wraps, upper-cases and packs the pieces into the genome store, while other threads are still
+// reading other files.  The host never touches a base of a pure-A/C/G/T contig: rounds 1-4 made three passes over every
+// genome on the host (read, upper-casing copy into contig strings, copy into pinned blocks) before the same pack.
+namespace {
+struct IngestSlot {
+    char* pin = nullptr; size_t cap = 0;
+    bool own = false;         // its blocks are its own (a file larger than the ring's slots), not parts of the ring's two blocks
+    DevBuf dev, dpieces;
+    pf::TextPiece* pin_pieces = nullptr; size_t pieces_cap = 0;
+    hipEvent_t ev = nullptr;
+    bool held = false;        // a reader thread is filling it
+    bool inflight = false;    // its copy / kernel may not have finished (ev)
+};
+struct Ingest {
+    pf_ctx* c = nullptr;
+    const pf_pangenome_opts* o = nullptr;
+    pf_ctx* (*get_ctx)(void*) = nullptr;
+    void* user = nullptr;
+    std::once_flag once;
+    bool setup_ok = false;
+    char* ring_pin = nullptr;
+    DevBuf ring_dev;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<IngestSlot> slots;
+    uint64_t store_cap = 0;
+    std::atomic<uint64_t> store_used{0};
+    std::string err;
+    int rc = PF_OK;
+    uint64_t bytes_up = 0;
+    int failed(int code, const std::string& m) { if (rc == PF_OK) { rc = code; err = m; } return code; }   // (caller holds mu)
+};
+int ingest_ready(Ingest* I);
+int ingest_acquire(void* self, size_t bytes, char** host, uint32_t* slot) {
+    Ingest* I = (Ingest*)self;
+    if (ingest_ready(I) != PF_OK) return I->rc != PF_OK ? I->rc : PF_ERR_STATE;
+    if (hipSetDevice(I->c->device) != hipSuccess) return PF_ERR_HIP;
+    std::unique_lock<std::mutex> lk(I->mu);
+    for (;;) {
+        if (I->rc != PF_OK) return I->rc;
+        int pick = -1, waitable = -1;
+        for (size_t i = 0; i < I->slots.size(); i++) {
+            IngestSlot& s = I->slots[i];
+            if (s.held) continue;
+            if (s.inflight && hipEventQuery(s.ev) == hipSuccess) s.inflight = false;
+            if (!s.inflight) { if (pick < 0 || (s.cap >= bytes && I->slots[pick].cap < bytes)) pick = (int)i; }
+            else if (waitable < 0) waitable = (int)i;
+        }
+        if (pick >= 0) {
+            IngestSlot& s = I->slots[pick];
+            s.held = true;
+            if (s.cap < bytes) {
+                lk.unlock();                                   // (the slot is ours: nobody else looks at it while it is held)
+                if (s.pin && s.own) { (void)hipHostUnregister(s.pin); free(s.pin); }
+                if (!s.own) { s.dev.p = nullptr; s.dev.cap = 0; s.dev.view = false; }     // (a part of the ring's block: not ours to free)
+                s.pin = nullptr; s.cap = 0; s.own = true;
+                const size_t want = bytes + bytes / 4 + 4096;
+                bool ok = posix_memalign((void**)&s.pin, 4096, want) == 0 && s.pin;
+                if (ok && hipHostRegister(s.pin, want, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); free(s.pin); s.pin = nullptr; ok = false; }
+                ok = ok && s.dev.ensure(want) == PF_OK;
+                lk.lock();
+                if (!ok) { s.held = false; I->cv.notify_all(); return I->failed(PF_ERR_OOM, "no pinned / device block of " + std::to_string(want) + " bytes for a genome's text"); }
+                s.cap = want;
+            }
+            *host = s.pin; *slot = (uint32_t)pick;
+            return PF_OK;
+        }
+        if (waitable >= 0) {                                    // every free block is still on its way to the device
+            hipEvent_t ev = I->slots[waitable].ev;
+            lk.unlock();
+            (void)hipEventSynchronize(ev);
+            lk.lock();
+            continue;
+        }
+        I->cv.wait(lk);
+    }
+}
+uint64_t ingest_claim(void* self, uint64_t nwords) {
+    Ingest* I = (Ingest*)self;
+    if (ingest_ready(I) != PF_OK) return UINT64_MAX;
+    const uint64_t at = I->store_used.fetch_add(nwords);
+    return at + nwords <= I->store_cap ? at : UINT64_MAX;
+}
+int ingest_submit(void* self, uint32_t slot, size_t text_bytes, const pf_ingest_piece* pieces, uint32_t n) {
+    Ingest* I = (Ingest*)self;
+    IngestSlot& s = I->slots[slot];
+    std::unique_lock<std::mutex> lk(I->mu);
+    auto done = [&](int rc) { s.held = false; I->cv.notify_all(); return rc; };
+    if (!n || !text_bytes || I->rc != PF_OK) return done(I->rc);
+    if (hipSetDevice(I->c->device) != hipSuccess) return done(I->failed(PF_ERR_HIP, "hipSetDevice failed"));
+    // the pieces travel behind the text in the same block when there is room (one copy instead of two per file)
+    const size_t tail = (text_bytes + 63) & ~(size_t)63;
+    const bool inline_pieces = tail + (size_t)n * sizeof(pf::TextPiece) <= s.cap;
+    pf::TextPiece* const pcs = inline_pieces ? reinterpret_cast<pf::TextPiece*>(s.pin + tail) : nullptr;
+    if (!inline_pieces && n > s.pieces_cap) {
+        if (s.pin_pieces) (void)hipHostFree(s.pin_pieces);
+        s.pin_pieces = nullptr; s.pieces_cap = 0;
+        const size_t want = (size_t)n + n / 2 + 64;
+        if (hipHostMalloc((void**)&s.pin_pieces, want * sizeof(pf::TextPiece), hipHostMallocDefault) != hipSuccess)
+            return done(I->failed(PF_ERR_OOM, "hipHostMalloc failed (ingest pieces)"));
+        s.pieces_cap = want;
+    }
+    uint64_t lo = text_bytes, blocks = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        pf::TextPiece& t = (inline_pieces ? pcs : s.pin_pieces)[i];
+        t.text_off = pieces[i].text_off; t.dst_word = pieces[i].dst_word; t.nbases = (uint32_t)pieces[i].nbases;
+        t.nwords = (uint32_t)(2 * ((pieces[i].nbases + 63) / 64) + 4);
+        t.width = pieces[i].width; t.eol = pieces[i].eol; t.block0 = (uint32_t)blocks; t.pad = 0;
+        blocks += (t.nwords + 255) / 256;
+        lo = std::min<uint64_t>(lo, pieces[i].text_off);
+        // the last letter's byte must lie inside the block
+        const uint64_t lines = pieces[i].width && pieces[i].nbases ? (pieces[i].nbases - 1) / pieces[i].width : 0;
+        if (pieces[i].text_off + pieces[i].nbases + lines * pieces[i].eol > text_bytes || pieces[i].dst_word + t.nwords > I->store_cap)
+            return done(I->failed(PF_ERR_STATE, "ingest: a contig's letters lie outside its block"));
+    }
+    if (blocks > 0x7FFFFFFFull) return done(I->failed(PF_ERR_CAPACITY, "ingest: too many words in one file"));
+    lo &= ~(uint64_t)63;
+    hipStream_t st = I->c->stream;
+    const pf::TextPiece* dpcs;
+    if (getenv("PF_DEBUG_INGEST_SKIP_UPLOAD")) return done(PF_OK);        // (timing experiment: the reader alone; nothing reaches the store)
+    if (inline_pieces) {
+        if (hipMemcpyAsync((char*)s.dev.p + lo, s.pin + lo, tail + (size_t)n * sizeof(pf::TextPiece) - lo, hipMemcpyHostToDevice, st) != hipSuccess)
+            return done(I->failed(PF_ERR_HIP, "ingest: upload of a genome's text failed"));
+        dpcs = reinterpret_cast<const pf::TextPiece*>((char*)s.dev.p + tail);
+    } else {
+        if (s.dpieces.ensure((size_t)n * sizeof(pf::TextPiece)) != PF_OK) return done(I->failed(PF_ERR_OOM, "device block for ingest pieces"));
+        if (hipMemcpyAsync((char*)s.dev.p + lo, s.pin + lo, text_bytes - lo, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(s.dpieces.p, s.pin_pieces, (size_t)n * sizeof(pf::TextPiece), hipMemcpyHostToDevice, st) != hipSuccess)
+            return done(I->failed(PF_ERR_HIP, "ingest: upload of a genome's text failed"));
+        dpcs = (const pf::TextPiece*)s.dpieces.p;
+    }
+    hipLaunchKernelGGL(pf::genome_pack_text_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, (const uint8_t*)s.dev.p,
+                       dpcs, n, I->c->g_store.as<uint64_t>());
+    if (hipGetLastError() != hipSuccess || hipEventRecord(s.ev, st) != hipSuccess) return done(I->failed(PF_ERR_HIP, "genome_pack_text_kernel launch failed"));
+    s.inflight = true;
+    I->bytes_up += text_bytes - lo;
+    return done(PF_OK);
+}
+}  // namespace
+
+namespace {
+// what the first callback of the reader sets up (the context may still be in the making while the reader parses the table:
+// it is asked for here, when the first genome needs it): the store, the events, the ring's two blocks
+int ingest_setup(Ingest* I) {
+    const pf_pangenome_opts* o = I->o;
+    pf_ctx* c = I->get_ctx ? I->get_ctx(I->user) : nullptr;
+    if (!c) return fail(PF_ERR_ARG, "pf_pangenome_open_device: no context");
+    I->c = c;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    // the store's room: 2 bits per letter, and 2 * ceil(len / 64) + 4 words per contig -- the letters are at most the files'
+    // bytes; half a byte of store per byte of text covers contigs down to ~200 letters on average (smaller ones: the
+    // claim fails, PF_ERR_CAPACITY, and the caller takes pf_pangenome_open + pf_genomes_upload)
+    uint64_t text_bytes = 0;
+    size_t biggest = 0;
+    for (uint32_t i = 0; i < o->n_genomes; i++) {
+        const char* path = (o->fasta_paths && o->fasta_paths[i]) ? o->fasta_paths[i] : (o->gff_paths ? o->gff_paths[i] : nullptr);
+        struct stat st;
+        if (path && ::stat(path, &st) == 0 && S_ISREG(st.st_mode)) { text_bytes += (uint64_t)st.st_size; biggest = std::max<size_t>(biggest, (size_t)st.st_size); }
+        else text_bytes += 64ull << 20;
+    }
+    I->store_cap = text_bytes / 16 + (8ull << 20);            // words
+    c->g_store.release();
+    c->g_words = 0;
+    PFCHK(c->g_store.ensure((size_t)I->store_cap * 8));
+    const unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+    I->slots.resize(std::max<size_t>(4, std::min<size_t>(2 * (size_t)nt, (size_t)o->n_genomes + 1)));
+    for (auto& s : I->slots)
+        if (hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) return fail(PF_ERR_HIP, "hipEventCreate failed");
+    // the ring's blocks: ONE page-locked allocation and ONE device allocation, cut into slots that hold the largest file (an
+    // allocation per slot was 2 x 32 calls into the driver, one after the other, in front of the first upload).  Ordinary
+    // memory, page-locked where it lies (hipHostRegister): the reader only COPIES the FASTA text into these blocks -- it
+    // parses in its threads' own buffers.
+    const size_t slot_bytes = (std::min<size_t>(biggest, 256u << 20) + 64 + (64u << 10) + 4095) & ~(size_t)4095;   // (+ room for the pieces)
+    const size_t total = slot_bytes * I->slots.size();
+    if (posix_memalign((void**)&I->ring_pin, 4096, total) == 0 && I->ring_pin) {
+        if (hipHostRegister(I->ring_pin, total, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); free(I->ring_pin); I->ring_pin = nullptr; }
+    } else I->ring_pin = nullptr;
+    if (I->ring_pin && I->ring_dev.ensure(total) == PF_OK) {
+        for (size_t i = 0; i < I->slots.size(); i++) {
+            IngestSlot& s = I->slots[i];
+            s.pin = I->ring_pin + i * slot_bytes; s.cap = slot_bytes; s.own = false;
+            s.dev.p = (char*)I->ring_dev.p + i * slot_bytes; s.dev.cap = 0; s.dev.view = true;
+        }
+    } else if (I->ring_pin) { (void)hipHostUnregister(I->ring_pin); free(I->ring_pin); I->ring_pin = nullptr; I->ring_dev.release(); }   // (slots then allocate their own)
+    return PF_OK;
+}
+// every callback starts here: PF_OK once the set-up has succeeded (it runs once, on whichever reader thread comes first)
+int ingest_ready(Ingest* I) {
+    std::call_once(I->once, [I] {
+        const int rc = ingest_setup(I);
+        if (rc != PF_OK) { std::lock_guard<std::mutex> g(I->mu); I->failed(rc, pf_last_error()); }
+        I->setup_ok = rc == PF_OK;
+    });
+    return I->setup_ok ? PF_OK : (I->rc != PF_OK ? I->rc : PF_ERR_STATE);
+}
+}  // namespace
+
+int pf_pangenome_open_device_cb(const pf_pangenome_opts* o, pf_ctx* (*get_ctx)(void*), void* user, pf_pangenome** out) {
+    if (!o || !get_ctx || !out) return fail(PF_ERR_ARG, "pf_pangenome_open_device: null argument");
+    *out = nullptr;
+    Ingest I;
+    I.o = o; I.get_ctx = get_ctx; I.user = user;
+    const bool dbg = getenv("PF_DEBUG_TIMING") != nullptr;
+    auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!dbg) return;
+        auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[open_device] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - T0).count());
+        T0 = t;
+    };
+    pf_pangenome* P = nullptr;
+    pf_ingest_sink sink{&I, ingest_acquire, ingest_claim, ingest_submit};
+    int rc = pf_pangenome_open_sink(o, &sink, &P);           // (its error text is this thread's: the reader sets it here)
+    if (I.rc != PF_OK) rc = fail(I.rc, "%s", I.err.c_str());
+    lap("reader (table, files -> pieces)");
+    if (rc == PF_OK && ingest_ready(&I) != PF_OK) rc = fail(I.rc != PF_OK ? I.rc : PF_ERR_STATE, "%s", I.err.c_str());   // (a pangenome without a genome)
+    pf_ctx* c = I.c;
+    if (c) {
+        (void)hipSetDevice(c->device);
+        if (hipStreamSynchronize(c->stream) != hipSuccess && rc == PF_OK) rc = fail(PF_ERR_HIP, "the genomes' upload failed");
+    }
+    lap("last uploads");
+    if (I.ring_pin) { (void)hipHostUnregister(I.ring_pin); free(I.ring_pin); }
+    I.ring_dev.release();
+    for (auto& s : I.slots) {
+        if (s.pin && s.own) { (void)hipHostUnregister(s.pin); free(s.pin); }
+        if (!s.own) { s.dev.p = nullptr; s.dev.cap = 0; s.dev.view = false; }
+        if (s.pin_pieces) (void)hipHostFree(s.pin_pieces);
+        if (s.ev) (void)hipEventDestroy(s.ev);
+        s.dev.release(); s.dpieces.release();
+    }
+    if (rc != PF_OK) {
+        if (P) pf_pangenome_close(P);
+        if (c) c->g_store.release();
+        return rc;
+    }
+    c->g_words = std::min<uint64_t>(I.store_used.load(), I.store_cap);
+    *out = P;
+    return PF_OK;
+}
+
+int pf_pangenome_open_device(const pf_pangenome_opts* o, pf_ctx* c, pf_pangenome** out) {
+    if (!c) return fail(PF_ERR_ARG, "pf_pangenome_open_device: null context");
+    return pf_pangenome_open_device_cb(o, [](void* u) { return (pf_ctx*)u; }, c, out);
 }
 
 int pf_genomes_clear(pf_ctx* c) {

@@ -9,7 +9,9 @@
 // is restated from its documented behaviour (record name = header up to the first whitespace, newline-free
 // sequence, sequence_always_upper, Python slice clipping, `-seq` = reverse complement with the IUPAC table below).
 #include "../../include/panfeed_hip.h"
+#include "pf_ingest.h"
 
+#include <immintrin.h>
 #include <algorithm>
 #include <atomic>
 #include <fcntl.h>
@@ -20,6 +22,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <memory>
 #include <mutex>
 #include <sstream>
 #include <string>
@@ -38,10 +41,50 @@ struct Contig;
 struct Feature { std::string id, chrom; long long start, end; int strand; const Contig* ctg = nullptr; };
 
 struct Contig {
-    std::string seq;                 // upper case
+    std::string seq;                 // upper case; with pf_pangenome_open_device only where text is needed (has_text)
     std::vector<uint32_t> bad;       // positions of bytes other than A/C/G/T, ascending
-    uint64_t word_off = 0;           // in the device genome store (pf_pangenome_set_store)
+    uint64_t word_off = 0;           // in the device genome store (pf_pangenome_set_store / the ingest sink)
+    uint64_t len = 0;                // letters
+    bool has_text = true;            // seq is the whole contig; false: only `spans` (what the reader will cut out of text)
+    struct Span { uint64_t start; std::string text; };
+    std::vector<Span> spans;         // ascending, disjoint
 };
+
+// contig[a:b] as text: from the whole contig, or from the span that was kept for it
+inline bool contig_text(const Contig& c, long long a, long long b, std::string& out) {
+    if (c.has_text) { out = c.seq.substr((size_t)a, (size_t)(b - a)); return true; }
+    if (b <= a) { out.clear(); return true; }
+    auto it = std::upper_bound(c.spans.begin(), c.spans.end(), (uint64_t)a, [](uint64_t v, const Contig::Span& s) { return v < s.start; });
+    if (it == c.spans.begin()) return false;
+    --it;
+    if ((uint64_t)b > it->start + it->text.size()) return false;
+    out = it->text.substr((size_t)((uint64_t)a - it->start), (size_t)(b - a));
+    return true;
+}
+
+// contig[a:b] iter_gene_clusters cuts for a feature (input.py:413-446), with Python's slice clipping: the half-open range of
+// letters, and the coordinates the Seqinfo reports
+struct SliceOf { long long a, b, seq_start, seq_end, offset; };
+inline SliceOf slice_of(const Feature& f, long long up, long long down, bool dsc, long long n) {
+    SliceOf r;
+    const long long offset = (f.strand > 0 && f.start - 1 - up < 0) ? f.start - 1 : up;        // :415-418
+    const long long offset_d = (f.strand < 0 && f.start - 1 - down < 0) ? f.start - 1 : down;  // :421-424
+    long long a, b;
+    if (!dsc) {                                   // :427-436
+        if (f.strand > 0) { a = f.start - 1 - offset; b = f.end + offset_d; r.seq_start = f.start - offset; r.seq_end = f.end + offset_d; }
+        else { a = f.start - 1 - offset_d; b = f.end + offset; r.seq_start = f.start - offset_d; r.seq_end = f.end + offset; }
+    } else {                                         // :437-446
+        if (f.strand > 0) { a = f.start - 1 - offset; b = f.start + offset_d; r.seq_start = f.start - offset; r.seq_end = f.start + offset_d; }
+        else { a = f.end - 1 - offset_d; b = f.end + offset; r.seq_start = f.end - offset_d; r.seq_end = f.end + offset; }
+    }
+    // Python slice clipping of contig[a:b]
+    if (a < 0) a = std::max(0LL, a + n);
+    if (b < 0) b = std::max(0LL, b + n);
+    a = std::min(a, n); b = std::min(b, n);
+    if (b < a) b = a;
+    r.a = a; r.b = b; r.offset = offset;
+    return r;
+}
 
 struct Genome {
     std::unordered_map<std::string, Contig> contigs;            // name -> sequence
@@ -106,6 +149,7 @@ void parse_fasta(const char* p, const char* end, Genome& g) {
             // looked for only in a stretch that holds one (a genome is ~all A/C/G/T: this loop is what opening a
             // pangenome spends its time in)
             const size_t o = cur->seq.size(), n = (size_t)(e - p);
+            cur->len = o + n;
             cur->seq.resize(o + n);
             char* dst = &cur->seq[o];
             const unsigned char* src = (const unsigned char*)p;
@@ -124,6 +168,283 @@ void parse_fasta(const char* p, const char* end, Genome& g) {
         }
         p = nl ? nl + 1 : end;
     }
+}
+
+// ---- one-pass ingest (pf_pangenome_open_device): where a record's letters lie, without copying one -----------------------
+// every byte of [p, p + n) one of A C G T a c g t?
+__attribute__((target("avx2"))) static bool all_acgt_avx2(const unsigned char* p, size_t n) {
+    const __m256i lower = _mm256_set1_epi8(0x20), a = _mm256_set1_epi8('a'), c = _mm256_set1_epi8('c'), g = _mm256_set1_epi8('g'),
+                  t = _mm256_set1_epi8('t');
+    size_t i = 0;
+    for (; i + 32 <= n; i += 32) {
+        const __m256i x = _mm256_or_si256(_mm256_loadu_si256((const __m256i*)(p + i)), lower);
+        const __m256i ok = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(x, a), _mm256_cmpeq_epi8(x, c)),
+                                           _mm256_or_si256(_mm256_cmpeq_epi8(x, g), _mm256_cmpeq_epi8(x, t)));
+        if ((uint32_t)_mm256_movemask_epi8(ok) != 0xFFFFFFFFu) return false;
+    }
+    unsigned bad = 0;
+    for (; i < n; i++) bad |= g_fasta.bad[p[i]];
+    return !bad;
+}
+static bool all_acgt(const unsigned char* p, size_t n) {
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) return all_acgt_avx2(p, n);
+    unsigned bad = 0;
+    for (size_t i = 0; i < n; i++) bad |= g_fasta.bad[p[i]];
+    return !bad;
+}
+
+// One vector pass over a record's bytes: how many '\n' and '\r' it holds, and where the bytes lie that are neither a line
+// end nor one of A C G T a c g t (offsets from p, ascending -- a genome has few).
+__attribute__((target("avx2"))) static void scan_region_avx2(const unsigned char* p, size_t n, size_t* n_nl, size_t* n_cr,
+                                                             std::vector<uint32_t>& other) {
+    const __m256i lower = _mm256_set1_epi8(0x20), a = _mm256_set1_epi8('a'), c = _mm256_set1_epi8('c'), g = _mm256_set1_epi8('g'),
+                  t = _mm256_set1_epi8('t'), nl = _mm256_set1_epi8('\n'), cr = _mm256_set1_epi8('\r');
+    size_t i = 0, cnl = 0, ccr = 0;
+    for (; i + 32 <= n; i += 32) {
+        const __m256i v = _mm256_loadu_si256((const __m256i*)(p + i));
+        const __m256i x = _mm256_or_si256(v, lower);
+        const __m256i let = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(x, a), _mm256_cmpeq_epi8(x, c)),
+                                            _mm256_or_si256(_mm256_cmpeq_epi8(x, g), _mm256_cmpeq_epi8(x, t)));
+        const uint32_t m_nl = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, nl));
+        const uint32_t m_cr = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, cr));
+        uint32_t rest = ~((uint32_t)_mm256_movemask_epi8(let) | m_nl | m_cr);
+        while (rest) { other.push_back((uint32_t)(i + (size_t)__builtin_ctz(rest))); rest &= rest - 1; }
+        cnl += (size_t)__builtin_popcount(m_nl); ccr += (size_t)__builtin_popcount(m_cr);
+    }
+    for (; i < n; i++) {
+        const unsigned char ch = p[i];
+        if (ch == '\n') cnl++;
+        else if (ch == '\r') ccr++;
+        else if (g_fasta.bad[ch]) other.push_back((uint32_t)i);
+    }
+    *n_nl = cnl; *n_cr = ccr;
+}
+// The common record -- every line but the last `width` letters and one line end ("\n" or "\r\n") -- recognised in ONE vector
+// pass over its bytes plus one look per line at where the line ends must be; `other` receives the LETTER positions (line
+// ends taken out) of what is not A/C/G/T.  Anything else (lines of other lengths, blank lines) is left to the exact
+// line-by-line walk.
+static bool fast_uniform(const char* b, const char* e, uint64_t* nbases, uint32_t* width, uint32_t* eol, std::vector<uint32_t>& other) {
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    other.clear();
+    if (!avx2 || b >= e || (size_t)(e - b) >= 0xFFFFFF00u) return false;
+    const char* nl = (const char*)memchr(b, '\n', (size_t)(e - b));
+    size_t n_nl = 0, n_cr = 0;
+    scan_region_avx2((const unsigned char*)b, (size_t)(e - b), &n_nl, &n_cr, other);
+    if (!nl) {                                          // one line, no line end
+        if (n_cr) return false;
+        *nbases = (uint64_t)(e - b); *width = (uint32_t)(e - b); *eol = 1;
+        return true;
+    }
+    const size_t gap = (nl > b && nl[-1] == '\r') ? 2 : 1;
+    const size_t w = (size_t)(nl - b) + 1 - gap;
+    if (!w) return false;
+    const size_t stride = w + gap, body = (size_t)(e - b), n_full = body / stride, rem = body - n_full * stride;
+    // the line ends where they must be ...
+    for (size_t k = 0; k < n_full; k++) {
+        const char* q = b + k * stride + w;
+        if (gap == 2 ? (q[0] != '\r' || q[1] != '\n') : q[0] != '\n') return false;
+    }
+    // ... and nowhere else: the last, shorter line may carry one line end of its own
+    size_t last = rem, tail_nl = 0, tail_cr = 0;
+    if (rem) {
+        const char* q = b + n_full * stride;
+        if (q[rem - 1] == '\n') { last--; tail_nl = 1; if (gap == 2) { if (last && q[last - 1] == '\r') { last--; tail_cr = 1; } else return false; } }
+    }
+    if (n_nl != n_full + tail_nl || n_cr != (gap == 2 ? n_full : 0) + tail_cr) return false;
+    *nbases = (uint64_t)n_full * w + last; *width = (uint32_t)w; *eol = (uint32_t)gap;
+    for (auto& o : other) o = (uint32_t)(o - (o / stride) * gap);          // byte offset -> letter position
+    return true;
+}
+
+// The FASTA text [p, end) of one genome, lying in a block the sink gave (`block` = its first byte): contigs are named and
+// measured as parse_fasta names and measures them (header up to the first whitespace; the lines joined, a line's trailing
+// '\r's dropped; a repeated name keeps its first record), but their letters stay where they are -- a contig becomes one
+// piece {first letter, letters, letters per line, bytes between lines}.  A record whose lines are not wrapped evenly (every
+// line but the last of one length and one line end) is joined in place first.  Text is built, as parse_fasta builds it,
+// only for contigs with a letter other than A/C/G/T (the reader cuts such sequences out of text) and, with want_text, for
+// all of a target strain's.
+bool scan_fasta(char* block, char* p, char* end, Genome& g, bool want_text, pf_ingest_sink* sink,
+                std::vector<pf_ingest_piece>& pieces, long long up, long long down, bool dsc) {
+    // the genome's features by contig: which stretches of a contig with other letters the reader will ask for as text
+    std::unordered_map<std::string, std::vector<const Feature*>> by_chrom;
+    for (auto& fv : g.features) by_chrom[fv.second.chrom].push_back(&fv.second);
+    const std::string* cur_name = nullptr;
+    std::vector<uint32_t> other;
+    Contig* cur = nullptr;
+    char* rec_begin = nullptr;            // first byte behind the current record's header line
+    auto finish = [&](char* rec_end) -> bool {
+        if (!cur) return true;
+        // ---- the record's lines: letters, wrapping, other letters
+        uint64_t nbases = 0;
+        uint32_t width = 0, eol = 1;
+        bool started = false, ragged = false, prev_full = true, blank_after = false, bad = false;
+        char* first = rec_begin;
+        const bool quick = fast_uniform(rec_begin, rec_end, &nbases, &width, &eol, other);
+        if (quick && !other.empty() && !want_text) {
+            // Other letters in an evenly wrapped record: their positions, and text ONLY for the slices the reader will cut
+            // around them (a feature's contig[a:b] that holds one: it goes to the packer as text) -- not the whole contig.
+            if (nbases >= 0xFFFFFF00ull) { g.error = "a contig is too long for 32-bit coordinates"; return false; }
+            cur->len = nbases;
+            cur->has_text = false;
+            cur->bad = other;
+            std::vector<std::pair<uint64_t, uint64_t>> need;
+            auto fit = by_chrom.find(*cur_name);
+            if (fit != by_chrom.end())
+                for (const Feature* f : fit->second) {
+                    const SliceOf so = slice_of(*f, up, down, dsc, (long long)nbases);
+                    if (so.b <= so.a) continue;
+                    auto it = std::lower_bound(cur->bad.begin(), cur->bad.end(), (uint32_t)so.a);
+                    if (it != cur->bad.end() && (long long)*it < so.b) need.emplace_back((uint64_t)so.a, (uint64_t)so.b);
+                }
+            std::sort(need.begin(), need.end());
+            const size_t stride = (size_t)width + eol;
+            for (size_t i = 0; i < need.size();) {
+                uint64_t s0 = need[i].first, s1 = need[i].second;
+                size_t j = i + 1;
+                while (j < need.size() && need[j].first <= s1) { s1 = std::max(s1, need[j].second); j++; }
+                Contig::Span sp;
+                sp.start = s0;
+                sp.text.resize((size_t)(s1 - s0));
+                for (uint64_t q = s0; q < s1;) {                   // line by line: letters [q, end of its line or s1)
+                    const uint64_t line = q / width, col = q - line * width;
+                    const uint64_t take = std::min<uint64_t>(s1 - q, width - col);
+                    const unsigned char* src = (const unsigned char*)rec_begin + line * stride + col;
+                    char* dst = &sp.text[(size_t)(q - s0)];
+                    for (uint64_t z = 0; z < take; z++) dst[z] = (char)g_fasta.up[src[z]];
+                    q += take;
+                }
+                cur->spans.push_back(std::move(sp));
+                i = j;
+            }
+            const uint64_t nwords = 2 * ((nbases + 63) / 64) + 4;
+            const uint64_t w0 = sink->claim_words(sink->self, nwords);
+            if (w0 == UINT64_MAX) { g.error = "\x01genome store full"; return false; }
+            cur->word_off = w0;
+            pf_ingest_piece pc{};
+            pc.text_off = (uint64_t)(rec_begin - block); pc.nbases = nbases; pc.dst_word = w0; pc.width = nbases ? width : 0; pc.eol = eol;
+            pieces.push_back(pc);
+            return true;
+        }
+        if (quick && !other.empty()) bad = true;
+        for (char* q = rec_begin; !quick && q < rec_end;) {
+            char* nl = (char*)memchr(q, '\n', rec_end - q);
+            char* le = nl ? nl : rec_end;
+            char* e = le;
+            while (e > q && e[-1] == '\r') e--;
+            const size_t L = (size_t)(e - q);
+            const size_t gap = (size_t)((nl ? nl + 1 : rec_end) - e);
+            if (L) {
+                if (blank_after) ragged = true;
+                if (!started) { started = true; first = q; width = (uint32_t)std::min<size_t>(L, 0xFFFFFFFFu); eol = (uint32_t)gap; prev_full = true; if (L > 0xFFFFFFF0u) ragged = true; }
+                else if (!prev_full || L > width) ragged = true;
+                prev_full = L == width && gap == eol;
+                nbases += L;
+                if (!bad && !all_acgt((const unsigned char*)q, L)) bad = true;
+            } else if (started) {
+                blank_after = true;
+            }
+            q = nl ? nl + 1 : rec_end;
+        }
+        cur->len = nbases;
+        cur->has_text = want_text || bad;
+        if (cur->has_text) {
+            // (parse_fasta's loop over this record's lines: upper-cased text + the positions of the other letters)
+            Genome tmp;
+            std::string hdr = ">x\n";
+            auto ins = tmp.contigs.emplace("x", Contig());
+            Contig* c2 = &ins.first->second;
+            (void)hdr;
+            c2->seq.reserve((size_t)nbases);
+            for (char* q = rec_begin; q < rec_end;) {
+                char* nl = (char*)memchr(q, '\n', rec_end - q);
+                char* e = nl ? nl : rec_end;
+                while (e > q && e[-1] == '\r') e--;
+                const size_t o = c2->seq.size(), n = (size_t)(e - q);
+                c2->seq.resize(o + n);
+                for (size_t i2 = 0; i2 < n; i2++) {
+                    const unsigned char ch = (unsigned char)q[i2];
+                    c2->seq[o + i2] = (char)g_fasta.up[ch];
+                    if (g_fasta.bad[ch]) c2->bad.push_back((uint32_t)(o + i2));
+                }
+                q = nl ? nl + 1 : rec_end;
+            }
+            cur->seq.swap(c2->seq);
+            cur->bad.swap(c2->bad);
+        }
+        if (nbases >= 0xFFFFFF00ull) { g.error = "a contig is too long for 32-bit coordinates"; return false; }
+        if (ragged) {                     // join the lines in place: the letters then lie back to back from `first` on
+            char* dst = first;
+            for (char* q = first; q < rec_end;) {
+                char* nl = (char*)memchr(q, '\n', rec_end - q);
+                char* e = nl ? nl : rec_end;
+                while (e > q && e[-1] == '\r') e--;
+                const size_t L = (size_t)(e - q);
+                if (L && dst != q) memmove(dst, q, L);
+                dst += L;
+                q = nl ? nl + 1 : rec_end;
+            }
+            width = 0;
+        }
+        if (!nbases) width = 0;
+        const uint64_t nwords = 2 * ((nbases + 63) / 64) + 4;
+        const uint64_t w0 = sink->claim_words(sink->self, nwords);
+        if (w0 == UINT64_MAX) { g.error = "\x01genome store full"; return false; }
+        cur->word_off = w0;
+        pf_ingest_piece pc{};
+        pc.text_off = (uint64_t)(first - block); pc.nbases = nbases; pc.dst_word = w0; pc.width = width; pc.eol = eol;
+        pieces.push_back(pc);
+        return true;
+    };
+    while (p < end) {
+        char* nl = (char*)memchr(p, '\n', end - p);
+        char* le = nl ? nl : end;
+        if (p < le && *p == '>') {
+            if (!finish(p)) return false;
+            char* e = le;
+            while (e > p && e[-1] == '\r') e--;
+            char* q = p + 1;
+            while (q < e && !is_space(*q)) q++;
+            std::string name(p + 1, q);
+            auto ins = g.contigs.emplace(name, Contig());
+            cur = ins.second ? &ins.first->second : nullptr;      // a repeated name keeps its first record
+            cur_name = &ins.first->first;
+            rec_begin = nl ? nl + 1 : end;
+            // the record runs to the next header line: the next '>' that stands at the start of a line
+            p = rec_begin;
+            while (p < end) {
+                char* gt = (char*)memchr(p, '>', end - p);
+                if (!gt) { p = end; break; }
+                if (gt == rec_begin || gt[-1] == '\n') { p = gt; break; }
+                p = gt + 1;
+            }
+            continue;
+        }
+        p = nl ? nl + 1 : end;            // (text in front of the first header: nobody's)
+    }
+    return finish(end);
+}
+
+// a whole file into `buf` (a thread's own buffer, kept from file to file: no allocation, no page faults after the first
+// files): *n bytes
+bool read_file_buf(const std::string& path, std::vector<char>& buf, size_t* n, std::string& err) {
+    int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) { err = "cannot read " + path; return false; }
+    struct stat st;
+    size_t want = 1u << 16;
+    if (::fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) want = (size_t)st.st_size;
+    if (buf.size() < want + 64) buf.resize(want + want / 4 + 4096);
+    size_t have = 0;
+    for (;;) {
+        if (buf.size() - have < 64) buf.resize(buf.size() * 2);
+        const ssize_t r = ::read(fd, buf.data() + have, buf.size() - have);
+        if (r < 0) { ::close(fd); err = "cannot read " + path; return false; }
+        if (r == 0) break;
+        have += (size_t)r;
+    }
+    ::close(fd);
+    *n = have;
+    return true;
 }
 
 // Python int(str): optional surrounding whitespace, a sign, decimal digits with single underscores between them
@@ -172,9 +493,9 @@ std::string py_repr(const std::string& s) {
 
 // input.py:274-332 (feature_types = {'CDS'}).  Fields are looked at where they lie in the file's text: a line becomes
 // strings only where the reference's result needs one (the feature's ID and contig; a warning's text).
-void parse_gff(const std::string& text, const std::string& file_name, Genome& g) {
-    const char* p = text.data();
-    const char* end = p + text.size();
+void parse_gff(const char* text, size_t text_bytes, const std::string& file_name, Genome& g) {
+    const char* p = text;
+    const char* end = p + text_bytes;
     while (p < end) {
         const char* nl = (const char*)memchr(p, '\n', end - p);
         const char* le = nl ? nl + 1 : end;                      // the line keeps its newline, as in `for line in gff`
@@ -387,23 +708,8 @@ void build_row(const pf_pangenome* P, size_t row, RowOut& R) {
                     if (P->raise_missing) { R.error = "Could not find chromosome " + f.chrom + " in " + strain; return; }
                 } else {
                     const Contig& ctg = *f.ctg;
-                    const long long up = P->up, down = P->down;
-                    const long long offset = (f.strand > 0 && f.start - 1 - up < 0) ? f.start - 1 : up;        // :415-418
-                    const long long offset_d = (f.strand < 0 && f.start - 1 - down < 0) ? f.start - 1 : down;  // :421-424
-                    long long a, b, seq_start, seq_end;
-                    if (!P->dsc) {                                   // :427-436
-                        if (f.strand > 0) { a = f.start - 1 - offset; b = f.end + offset_d; seq_start = f.start - offset; seq_end = f.end + offset_d; }
-                        else { a = f.start - 1 - offset_d; b = f.end + offset; seq_start = f.start - offset_d; seq_end = f.end + offset; }
-                    } else {                                         // :437-446
-                        if (f.strand > 0) { a = f.start - 1 - offset; b = f.start + offset_d; seq_start = f.start - offset; seq_end = f.start + offset_d; }
-                        else { a = f.end - 1 - offset_d; b = f.end + offset; seq_start = f.end - offset_d; seq_end = f.end + offset; }
-                    }
-                    // Python slice clipping of contig[a:b]
-                    const long long n = (long long)ctg.seq.size();
-                    if (a < 0) a = std::max(0LL, a + n);
-                    if (b < 0) b = std::max(0LL, b + n);
-                    a = std::min(a, n); b = std::min(b, n);
-                    if (b < a) b = a;
+                    const SliceOf so = slice_of(f, P->up, P->down, P->dsc, (long long)ctg.len);
+                    const long long a = so.a, b = so.b, seq_start = so.seq_start, seq_end = so.seq_end, offset = so.offset;
                     // resident genomes: a pure-ACGT range of a non-target strain goes by reference
                     bool ref = P->by_ref && !is_target;
                     if (ref) {
@@ -415,7 +721,8 @@ void build_row(const pf_pangenome* P, size_t row, RowOut& R) {
                         R.seq_src_off.push_back(ctg.word_off); R.seq_src_start.push_back((uint32_t)a);
                         R.seq_flags.push_back(1u | (f.strand < 0 ? 2u : 0u));
                     } else {
-                        std::string seq = ctg.seq.substr((size_t)a, (size_t)(b - a));
+                        std::string seq;
+                        if (!contig_text(ctg, a, b, seq)) { R.error = "internal: text of contig " + f.chrom + " of " + strain + " was not kept"; return; }
                         if (f.strand < 0) {                          // -sequences[...]: reverse complement
                             std::reverse(seq.begin(), seq.end());
                             for (auto& ch : seq) ch = (char)g_comp.t[(unsigned char)ch];
@@ -463,7 +770,9 @@ Closers& closers() { static Closers c; return c; }
 
 extern "C" {
 
-int pf_pangenome_open(const pf_pangenome_opts* o, pf_pangenome** out) {
+}  // extern "C"
+namespace {
+int open_impl(const pf_pangenome_opts* o, pf_ingest_sink* sink, pf_pangenome** out) {
     if (!o || !out || !o->presence_absence_csv) return in_fail(PF_ERR_ARG, "pf_pangenome_open: null argument");
     *out = nullptr;
     closers().join_all();              // a reader still being torn down in the background: its memory first
@@ -558,11 +867,61 @@ int pf_pangenome_open(const pf_pangenome_opts* o, pf_pangenome** out) {
         th.emplace_back([&, t] {
             for (uint32_t i = t; i < o->n_genomes; i += nt) {
                 Genome& g = gs[i];
+                if (sink) {
+                    // ---- one pass: the file's text into a block of the sink, GFF lines parsed where they lie, the contigs'
+                    // letters left where they lie (scan_fasta) and handed on as pieces
+                    auto T0 = std::chrono::steady_clock::now();
+                    const bool want_text = P->targets.count(o->genome_names[i]) != 0;
+                    const bool separate = o->fasta_paths && o->fasta_paths[i];
+                    // The file is read into THIS THREAD's buffer, parsed and measured there, and only the FASTA text is
+                    // copied on into the sink's (page-locked) block: the CPU reads page-locked memory -- the driver's own
+                    // or registered -- ten times slower than ordinary memory on this platform (GFF lines parsed in a
+                    // pinned block: 18 thread-seconds against 1.5), and a buffer kept from file to file is in the caches.
+                    static thread_local std::vector<char> tbuf;
+                    size_t nb = 0;
+                    char *fa0 = nullptr, *fa1 = nullptr;
+                    if (separate) {
+                        std::string text;
+                        if (!read_file(o->gff_paths[i], text)) { g.error = std::string("cannot read ") + o->gff_paths[i]; continue; }
+                        parse_gff(text.data(), text.size(), o->gff_paths[i], g);
+                        if (!read_file_buf(o->fasta_paths[i], tbuf, &nb, g.error)) continue;
+                        fa0 = tbuf.data(); fa1 = tbuf.data() + nb;
+                    } else {
+                        if (!read_file_buf(o->gff_paths[i], tbuf, &nb, g.error)) continue;
+                        auto T1 = std::chrono::steady_clock::now();
+                        parse_gff(tbuf.data(), nb, o->gff_paths[i], g);
+                        dbg_ns[0] += (T1 - T0).count(); dbg_ns[1] += (std::chrono::steady_clock::now() - T1).count();
+                        // open(gff).read().split("##FASTA")[1]   (input.py:103-108)
+                        char* a = (char*)memmem(tbuf.data(), nb, "##FASTA", 7);
+                        if (!a) { g.error = std::string("no ##FASTA section in ") + o->gff_paths[i]; continue; }
+                        a += 7;
+                        char* b = (char*)memmem(a, (size_t)(tbuf.data() + nb - a), "##FASTA", 7);
+                        fa0 = a; fa1 = b ? b : tbuf.data() + nb;
+                    }
+                    auto T2 = std::chrono::steady_clock::now();
+                    std::vector<pf_ingest_piece> pieces;
+                    if (!scan_fasta(fa0, fa0, fa1, g, want_text, sink, pieces, P->up, P->down, P->dsc)) continue;   // (offsets relative to the FASTA text)
+                    dbg_ns[2] += (std::chrono::steady_clock::now() - T2).count();
+                    auto T3 = std::chrono::steady_clock::now();
+                    if (!pieces.empty()) {
+                        char* blk = nullptr; uint32_t slot = 0;
+                        const size_t fb = (size_t)(fa1 - fa0);
+                        if (sink->acquire(sink->self, fb + 64, &blk, &slot) != PF_OK) { g.error = "\x01no block for a genome's text"; continue; }
+                        memcpy(blk, fa0, fb);
+                        if (sink->submit(sink->self, slot, fb, pieces.data(), (uint32_t)pieces.size()) != PF_OK) { g.error = "\x01the genome store's upload failed"; continue; }
+                    }
+                    dbg_ns[3] += (std::chrono::steady_clock::now() - T3).count();
+                    for (auto& fv : g.features) {
+                        auto cit = g.contigs.find(fv.second.chrom);
+                        fv.second.ctg = cit == g.contigs.end() ? nullptr : &cit->second;
+                    }
+                    continue;
+                }
                 std::string text;
                 auto T0 = std::chrono::steady_clock::now();
                 if (!read_file(o->gff_paths[i], text)) { g.error = std::string("cannot read ") + o->gff_paths[i]; continue; }
                 auto T1 = std::chrono::steady_clock::now();
-                parse_gff(text, o->gff_paths[i], g);
+                parse_gff(text.data(), text.size(), o->gff_paths[i], g);
                 auto T2 = std::chrono::steady_clock::now();
                 dbg_ns[0] += (T1 - T0).count(); dbg_ns[1] += (T2 - T1).count();
                 if (o->fasta_paths && o->fasta_paths[i]) {
@@ -589,11 +948,17 @@ int pf_pangenome_open(const pf_pangenome_opts* o, pf_pangenome** out) {
     for (auto& x : th) x.join();
     if (getenv("PF_DEBUG_TIMING")) {
         auto TB = std::chrono::steady_clock::now();
-        fprintf(stderr, "[open] genomes wall %.3f s; thread-seconds: read %.3f gff %.3f fasta %.3f\n", (TB - TA).count() / 1e9,
-                dbg_ns[0] / 1e9, dbg_ns[1] / 1e9, dbg_ns[2] / 1e9);
+        fprintf(stderr, "[open] genomes wall %.3f s; thread-seconds: read %.3f gff %.3f fasta %.3f to-sink %.3f\n", (TB - TA).count() / 1e9,
+                dbg_ns[0] / 1e9, dbg_ns[1] / 1e9, dbg_ns[2] / 1e9, dbg_ns[3] / 1e9);
     }
     for (uint32_t i = 0; i < o->n_genomes; i++) {
-        if (!gs[i].error.empty()) { std::string e = gs[i].error; delete P; return in_fail(PF_ERR_ARG, e); }
+        if (!gs[i].error.empty()) {
+            std::string e = gs[i].error;
+            delete P;
+            // (\x01: not the input's fault -- the sink ran out of room: the caller may take the two-step way)
+            if (e[0] == '\x01') return in_fail(PF_ERR_CAPACITY, e.substr(1));
+            return in_fail(PF_ERR_ARG, e);
+        }
         P->log += gs[i].warnings;
         P->genomes.emplace(o->genome_names[i], std::move(gs[i]));
     }
@@ -609,7 +974,77 @@ int pf_pangenome_open(const pf_pangenome_opts* o, pf_pangenome** out) {
         P->log += "There are " + std::to_string(missing) + " strains present in the pangenome table but not in the GFF directory\n";
         if (P->raise_missing) { delete P; return in_fail(PF_ERR_ARG, "Missing " + std::to_string(missing) + " from the GFF directory"); }
     }
+    if (sink) P->by_ref = true;            // the genomes are in the device's store: sequences go by reference from the start
     *out = P;
+    return PF_OK;
+}
+}  // namespace
+
+int pf_pangenome_open_sink(const void* opts, pf_ingest_sink* sink, pf_pangenome** out) {
+    if (!sink || !sink->acquire || !sink->claim_words || !sink->submit) return in_fail(PF_ERR_ARG, "pf_pangenome_open_sink: null sink");
+    return open_impl((const pf_pangenome_opts*)opts, sink, out);
+}
+
+extern "C" {
+
+int pf_pangenome_open(const pf_pangenome_opts* o, pf_pangenome** out) { return open_impl(o, nullptr, out); }
+
+// Test hook: pf_pangenome_open_device's reader side WITHOUT a device -- the sink is ordinary memory and the store is
+// filled on the host by the addressing genome_pack_text_kernel uses (letter j = byte text_off + j + (j / width) * eol), so
+// that what scan_fasta makes of a FASTA (names, lengths, wrapping, joined-in-place records, kept text) can be checked in
+// the CPU test suite.  *store is malloc'd (pf_free_text), *nwords its used words.
+int pf_debug_open_hostsink(const pf_pangenome_opts* o, pf_pangenome** out, uint64_t** store, uint64_t* nwords) {
+    if (!o || !out || !store || !nwords) return in_fail(PF_ERR_ARG, "pf_debug_open_hostsink: null argument");
+    struct Host {
+        std::mutex mu;
+        std::vector<std::unique_ptr<char[]>> blocks;
+        std::vector<uint64_t> words;
+        std::atomic<uint64_t> used{0};
+    } H;
+    uint64_t text_bytes = 0;
+    for (uint32_t i = 0; i < o->n_genomes; i++) {
+        const char* path = (o->fasta_paths && o->fasta_paths[i]) ? o->fasta_paths[i] : o->gff_paths[i];
+        struct stat st;
+        if (path && ::stat(path, &st) == 0) text_bytes += (uint64_t)st.st_size;
+    }
+    H.words.assign((size_t)(text_bytes / 4 + 4096), 0);
+    pf_ingest_sink sink{};
+    sink.self = &H;
+    sink.acquire = [](void* self, size_t bytes, char** host, uint32_t* slot) -> int {
+        Host* h = (Host*)self;
+        std::lock_guard<std::mutex> g(h->mu);
+        h->blocks.emplace_back(new char[bytes]);
+        *host = h->blocks.back().get(); *slot = (uint32_t)(h->blocks.size() - 1);
+        return PF_OK;
+    };
+    sink.claim_words = [](void* self, uint64_t n) -> uint64_t {
+        Host* h = (Host*)self;
+        const uint64_t at = h->used.fetch_add(n);
+        return at + n <= h->words.size() ? at : UINT64_MAX;
+    };
+    sink.submit = [](void* self, uint32_t slot, size_t text_bytes2, const pf_ingest_piece* pieces, uint32_t n) -> int {
+        Host* h = (Host*)self;
+        const unsigned char* text;
+        { std::lock_guard<std::mutex> g(h->mu); text = (const unsigned char*)h->blocks[slot].get(); }
+        if (getenv("PF_DEBUG_INGEST_SKIP_UPLOAD")) return PF_OK;       // (timing experiment: the reader alone)
+        for (uint32_t i = 0; i < n; i++) {
+            const pf_ingest_piece& pc = pieces[i];
+            for (uint64_t j = 0; j < pc.nbases; j++) {
+                const uint64_t at = pc.text_off + j + (pc.width ? (j / pc.width) * pc.eol : 0);
+                if (at >= text_bytes2) return PF_ERR_STATE;
+                const unsigned ch = text[at];
+                h->words[pc.dst_word + j / 32] |= (uint64_t)(((ch >> 1) ^ (ch >> 2)) & 3u) << (62 - 2 * (j & 31));
+            }
+        }
+        return PF_OK;
+    };
+    const int rc = open_impl(o, &sink, out);
+    if (rc != PF_OK) return rc;
+    const uint64_t n = std::min<uint64_t>(H.used.load(), H.words.size());
+    uint64_t* w = (uint64_t*)malloc((size_t)std::max<uint64_t>(n, 1) * 8);
+    if (!w) { pf_pangenome_close(*out); *out = nullptr; return in_fail(PF_ERR_OOM, "malloc failed"); }
+    memcpy(w, H.words.data(), (size_t)n * 8);
+    *store = w; *nwords = n;
     return PF_OK;
 }
 
@@ -833,7 +1268,10 @@ int pf_pangenome_contigs(pf_pangenome* P, uint32_t* n, const char* const** ascii
             std::sort(cn.begin(), cn.end());
             for (auto& c : cn) P->flat.push_back(&g.contigs.find(c)->second);
         }
-        for (Contig* c : P->flat) { P->flat_ptr.push_back(c->seq.data()); P->flat_len.push_back(c->seq.size()); }
+        for (Contig* c : P->flat) {
+            if (!c->has_text && c->len) return in_fail(PF_ERR_STATE, "pf_pangenome_contigs: this reader's genomes went to the device as it was opened");
+            P->flat_ptr.push_back(c->seq.data()); P->flat_len.push_back(c->seq.size());
+        }
     }
     *n = (uint32_t)P->flat.size();
     *ascii = P->flat_ptr.data();

@@ -4835,6 +4835,41 @@ __global__ __launch_bounds__(256) void genome_pack_kernel(const uint8_t* ascii, 
     store[pc.dst_word + w] = out;
 }
 
+// One-pass ingest (pf_pangenome_open_device): a contig's letters as they lie in the FASTA text -- wrapped at `width` letters
+// with `eol` bytes between lines, upper or lower case -- to 2 bits per base.  Letter j is byte text_off + j + (j / width) * eol.
+struct TextPiece {
+    uint64_t text_off;       // byte offset of the contig's first letter in the block
+    uint64_t dst_word;       // first word of the contig in the store
+    uint32_t nbases;
+    uint32_t nwords;         // words to write: ceil(nbases / 32) plus the contig's zero padding
+    uint32_t width, eol;     // width 0: not wrapped
+    uint32_t block0;         // first 256-thread block of the piece
+    uint32_t pad;
+};
+__global__ __launch_bounds__(256) void genome_pack_text_kernel(const uint8_t* text, const TextPiece* pieces, uint32_t npieces,
+                                                               uint64_t* store) {
+    uint32_t a = 0, b = npieces;                         // last piece with block0 <= blockIdx.x
+    while (b - a > 1) { const uint32_t m = (a + b) >> 1; if (pieces[m].block0 <= blockIdx.x) a = m; else b = m; }
+    const TextPiece pc = pieces[a];
+    const uint32_t w = (blockIdx.x - pc.block0) * 256 + threadIdx.x;
+    if (w >= pc.nwords) return;
+    uint64_t out = 0;
+    const uint64_t j0 = (uint64_t)w * 32;
+    if (j0 < pc.nbases) {
+        const uint32_t nb = (uint32_t)min((uint64_t)32, pc.nbases - j0);
+        uint64_t at = pc.text_off + j0;
+        uint32_t col = 0, width = pc.width ? pc.width : 0xFFFFFFFFu;
+        if (pc.width) { const uint64_t line = j0 / pc.width; at += line * pc.eol; col = (uint32_t)(j0 - line * pc.width); }
+        for (uint32_t q = 0; q < nb; q++) {
+            const uint32_t ch = text[at];
+            out |= (uint64_t)(((ch >> 1) ^ (ch >> 2)) & 3u) << (62 - 2 * q);      // A/a 0, C/c 1, G/g 2, T/t 3
+            at++;
+            if (++col == width) { col = 0; at += pc.eol; }
+        }
+    }
+    store[pc.dst_word + w] = out;
+}
+
 struct GatherParams {
     const uint64_t* store;        // genome store
     const uint64_t* literal;      // packed words the host prepared itself (sequences with non-ACGT bases, target strains)

@@ -394,7 +394,8 @@ class Engine:
                 for ci, metas in by_cl.items():
                     kt_by_cluster[ci].append(self._render_targets(hb, metas))
             else:
-                kt_by_cluster[0].append(self._render_targets(hb, hb.targets))
+                # written by the GPU (kt_text_kernel); sequences with a letter outside A/C/G/T by the host renderer, in place
+                kt_by_cluster[0].append(bytes(self.render_targets_device(hb)).decode())
         if self.multiple_files:
             for ci in range(C_):
                 out.per_cluster.append((hb.idx[ci], "".join(kt_by_cluster[ci]), kh_parts[ci],

@@ -59,7 +59,12 @@ class Pangenome:
 
     def __init__(self, presence_absence, gffdir, fastadir=None, upstream=0, downstream=0,
                  downstream_start_codon=False, targets=(), genes=None, genome_names=None, gff_paths=None,
-                 fasta_paths=None, raise_missing=False):
+                 fasta_paths=None, raise_missing=False, engine=None, debug_hostsink=False):
+        """engine: open with the genomes going to that engine's GPU as the files are read (pf_pangenome_open_device: one
+        pass over the input; the reader is resident from the start and keeps contig text only where text is needed).
+        When the device store's size estimate does not hold (PF_ERR_CAPACITY: contigs of a few letters each) the reader
+        is opened the two-step way and made resident.  `engine` may be a callable that returns the engine: it is called
+        when the first genome needs the context (the caller may be creating it while the table is parsed)."""
         self.L = _lib.load()
         if genome_names is None:
             names, _with_fa, gffs, fastas = what_are_my_inputfiles(gffdir, fastadir)
@@ -83,13 +88,47 @@ class Pangenome:
         if genes is not None:
             o.gene_list, o.n_genes = self._keep[4], len(genes)
         self.h = C.c_void_p()
-        _lib.check(self.L.pf_pangenome_open(C.byref(o), C.byref(self.h)))
+        self.one_pass = False
+        got = {}
+
+        def engine_now():
+            if "eng" not in got:
+                got["eng"] = engine() if callable(engine) else engine
+            return got["eng"]
+        if engine is not None:
+            def get_ctx(_user):
+                try:
+                    return engine_now().ctx.value
+                except BaseException as e:       # noqa: BLE001  (no exception crosses the C frame: the open fails instead)
+                    got["err"] = e
+                    return None
+            cb = _lib.GET_CTX(get_ctx)
+            try:
+                _lib.check(self.L.pf_pangenome_open_device_cb(C.byref(o), cb, None, C.byref(self.h)))
+                self.one_pass = True
+            except _lib.PanfeedHipError as e:
+                if "err" in got:
+                    raise got["err"] from e
+                if e.status != _lib.ERR_CAPACITY:
+                    raise
+        self.store_words = None
+        if debug_hostsink:
+            # tests: the one-pass reader without a device; the store it would have filled on the GPU comes back as an array
+            st, nw = C.POINTER(C.c_uint64)(), C.c_uint64()
+            _lib.check(self.L.pf_debug_open_hostsink(C.byref(o), C.byref(self.h), C.byref(st), C.byref(nw)))
+            self.store_words = np.ctypeslib.as_array(st, shape=(max(int(nw.value), 1),))[:int(nw.value)].copy()
+            self.L.pf_free_text(C.cast(st, C.c_void_p))
+            self.one_pass = True
+        if not self.one_pass:
+            _lib.check(self.L.pf_pangenome_open(C.byref(o), C.byref(self.h)))
         info = _lib.PangenomeInfo()
         _lib.check(self.L.pf_pangenome_info(self.h, C.byref(info)))
         self.n_clusters, self.n_strains = int(info.n_clusters), int(info.n_strains)
         self.strains = [self.L.pf_pangenome_strain(self.h, i, 0).decode() for i in range(self.n_strains)]
         self.sorted_strains = [self.L.pf_pangenome_strain(self.h, i, 1).decode() for i in range(self.n_strains)]
-        self.resident = False
+        self.resident = self.one_pass
+        if engine is not None and not self.one_pass:
+            self.make_resident(engine_now())
 
     def make_resident(self, engine):
         """Upload every contig to `engine`'s GPU (2 bits per base, pf_genomes_upload) and switch the reader to

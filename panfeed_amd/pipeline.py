@@ -36,12 +36,14 @@ def _peek_n_strains(presence_absence):
 def run_files(presence_absence, gffdir, output, fastadir=None, klength=31, canon=True, consider_missing=False,
               patfilt=True, maf=0.01, upstream=0, downstream=0, downstream_start_codon=False, targets=(), genes=None,
               compress=False, multiple_files=False, batch_clusters=256, resident=True, device_text=True, device=0,
-              max_items=0, pattern_capacity=0, overlap=True):
+              max_items=0, pattern_capacity=0, overlap=True, one_pass=True):
     """One directory of outputs (`kmers.tsv`, `kmers_to_hashes.tsv`, `hashes_to_patterns.tsv`, `.gz` under
     `compress`; under `multiple_files` one such directory per gene cluster, `<output>/<cluster>/`, the pattern set
     starting empty in each: `panfeed.py:35-43,153-167`) from a panaroo table and a directory (or file of files) of GFFs.  Option names and meaning follow
     the reference's (`__main__.py:86-186`); `patfilt` is what `pattern_hasher` receives (`--no-filter` inverted,
-    `__main__.py:283-297`).  Returns a dict of counters."""
+    `__main__.py:283-297`).  one_pass (with resident): the genomes go to the GPU as their files are read
+    (pf_pangenome_open_device) instead of being read into host strings first and uploaded afterwards.
+    Returns a dict of counters."""
     import time as _time
     t_start = _time.perf_counter()
     if os.path.isdir(output):                       # the reference refuses an existing directory (input.py:213-216)
@@ -73,18 +75,45 @@ def run_files(presence_absence, gffdir, output, fastadir=None, klength=31, canon
             early["err"] = e
         early["s"] = _time.perf_counter() - t0
     et = None
-    if n_peek:
+    pg = None
+    if n_peek and resident and one_pass:
+        # one pass over the input: the genomes go into the context's store as their files are read; the context is made on
+        # its thread while the reader parses the table and is asked for when the first genome needs it
         et = threading.Thread(target=early_engine, name="panfeed-context")
         et.start()
-    try:
-        pg = Pangenome(presence_absence, gffdir, fastadir, upstream, downstream, downstream_start_codon, targets=targets,
-                       genes=genes)
-    except BaseException:
-        if et is not None:
+
+        def engine_when_needed():
+            et.join()
+            if "err" in early:
+                raise early["err"]
+            return early["eng"]
+        try:
+            pg = Pangenome(presence_absence, gffdir, fastadir, upstream, downstream, downstream_start_codon,
+                           targets=targets, genes=genes, engine=engine_when_needed)
+        except BaseException:
             et.join()
             if "eng" in early:
                 early["eng"].close()
-        raise
+            raise
+        et.join()
+        if "eng" in early and early["eng"].max_strains < pg.n_strains:       # (the header was not what the reader made of it: the classic way)
+            pg.close()
+            early.pop("eng").close()
+            pg = None
+        et = None
+    if pg is None:
+        if n_peek:
+            et = threading.Thread(target=early_engine, name="panfeed-context")
+            et.start()
+        try:
+            pg = Pangenome(presence_absence, gffdir, fastadir, upstream, downstream, downstream_start_codon, targets=targets,
+                           genes=genes)
+        except BaseException:
+            if et is not None:
+                et.join()
+                if "eng" in early:
+                    early["eng"].close()
+            raise
     eng = None
     uploader = None
     stats = {"clusters": 0, "instances": 0, "kept_kmers": 0, "patterns": 0, "device_ms": 0.0, "bytes": 0}
@@ -93,6 +122,7 @@ def run_files(presence_absence, gffdir, output, fastadir=None, klength=31, canon
         t0 = _time.perf_counter()
         if et is not None:
             et.join()
+        if et is not None or pg.resident:
             eng = early.get("eng")
             if eng is not None and eng.max_strains < pg.n_strains:        # (the header was not what the reader made of it)
                 eng.close()
@@ -104,14 +134,15 @@ def run_files(presence_absence, gffdir, output, fastadir=None, klength=31, canon
         t0 = _time.perf_counter()
         upload_err = []
         stages["genome_upload_s"] = 0.0
-        if resident:
+        stages["one_pass_ingest"] = bool(pg.one_pass)
+        if resident and not pg.resident:
             # The genome store's layout follows from the contig lengths: the reader switches to by-reference records at
             # once and the packer thread starts on the first batches while the contigs go up on a thread of their own
             # (the library packs them to 2 bits per base on the device); the first pf_submit waits for that thread.
             if not overlap:
                 pg.make_resident(eng)
                 stages["genome_upload_s"] = _time.perf_counter() - t0
-        if resident and overlap:
+        if resident and overlap and not pg.resident:
             pg.assign_store()
 
             def upload():

@@ -140,9 +140,10 @@ def test_run_files_pipeline(tmp_path, compress, resident, device_text):
     assert rd("kmers.tsv") == KMERS_TSV_HEADER + ek
 
 
-def test_run_files_serial_start_up_writes_the_same_files(tmp_path):
-    """run_files' overlapped start-up (context made while the reader opens, genomes uploaded while the packer starts:
-    the store's layout comes from the contig lengths alone) against the serial one: the same three files"""
+def test_run_files_start_ups_write_the_same_files(tmp_path):
+    """run_files' three start-ups -- one pass (the genomes go to the GPU as their files are read,
+    pf_pangenome_open_device), two steps overlapped (context made while the reader opens, genomes uploaded while the packer
+    starts: the store's layout comes from the contig lengths alone), two steps in series -- write the same three files"""
     import os
     from panfeed_amd import synth
     from panfeed_amd.pipeline import run_files
@@ -150,14 +151,55 @@ def test_run_files_serial_start_up_writes_the_same_files(tmp_path):
     src = tmp_path / "in"
     csvp, _gffs, _fas = synth.write_pangenome(str(src), cl, workers=2)
     texts = {}
-    for overlap in (True, False):
-        out = str(tmp_path / f"out_{overlap}")
-        st = run_files(csvp, str(src / "gffs"), out, klength=21, upstream=10, downstream=10, batch_clusters=9, overlap=overlap)
-        assert st["clusters"] == 40
-        if overlap:
+    for one_pass, overlap in ((True, True), (False, True), (False, False)):
+        out = str(tmp_path / f"out_{one_pass}_{overlap}")
+        st = run_files(csvp, str(src / "gffs"), out, klength=21, upstream=10, downstream=10, batch_clusters=9, overlap=overlap,
+                       one_pass=one_pass)
+        assert st["clusters"] == 40 and st["stages"]["one_pass_ingest"] == one_pass
+        if overlap and not one_pass:
             assert "first_submit_wait_s" in st["stages"] and st["stages"]["genome_upload_s"] > 0
-        texts[overlap] = {f: open(os.path.join(out, f)).read() for f in sorted(os.listdir(out))}
-    assert texts[True] == texts[False] and len(texts[True]) == 3
+        texts[(one_pass, overlap)] = {f: open(os.path.join(out, f)).read() for f in sorted(os.listdir(out))}
+    assert texts[(True, True)] == texts[(False, True)] == texts[(False, False)] and len(texts[(True, True)]) == 3
+
+
+@pytest.mark.parametrize("style", ["crlf", "ragged", "lower", "oneline", "trailing"])
+def test_one_pass_ingest_of_awkward_fasta(tmp_path, style):
+    """genome_pack_text_kernel on FASTA that is not wrapped the usual way (CRLF, lines of any length with blank ones
+    between, lower case, one line without a final newline, blank lines and a repeated record at the end), a target strain
+    (its text stays on the host), 'N's, flanks over contig ends: files -> three files against the oracle over the restated
+    records of the same files, and against the two-step start-up"""
+    import os
+    from oracle import input_restatement as ir
+    from oracle import oracle as po
+    from panfeed_amd import synth
+    from panfeed_amd.engine import KMERS_TO_HASHES_HEADER, KMERS_TSV_HEADER, hashes_to_patterns_header
+    from panfeed_amd.pipeline import run_files
+    from test_native_input import _mangle_fasta
+    rng = np.random.default_rng(9)
+    cl = synth.generate(24, 20, first=40, flank=0, mean_len=280, min_len=50, max_len=800, n_rate=0.05, paralog_rate=0.08)
+    names = cl[0].names
+    src = tmp_path / "in"
+    csvp, gffs, fas = synth.write_pangenome(str(src), cl, separate_fasta_for=(names[2],), lower_rate=0.0)
+    gn = sorted(gffs)
+    for n in gn:
+        _mangle_fasta(fas[n] or gffs[n], rng, style)
+    tg = (names[4],)
+    outs = {}
+    for one_pass in (True, False):
+        out = str(tmp_path / f"out_{one_pass}")
+        st = run_files(csvp, str(src / "gffs"), out, fastadir=str(src / "gffs"), klength=25, upstream=300, downstream=120,
+                       targets=tg, batch_clusters=5, one_pass=one_pass)
+        assert st["stages"]["one_pass_ingest"] == one_pass
+        outs[one_pass] = {f: open(os.path.join(out, f)).read() for f in sorted(os.listdir(out))}
+    assert outs[True] == outs[False]
+    strains, table = ir.load_table(csvp)
+    data = ir.load_genomes(gn, [gffs[n] for n in gn], [fas[n] for n in gn])
+    run = po.OracleRun(klength=25, stroi=set(tg))
+    run.feed(list(ir.iter_gene_clusters(strains, table, data, 300, 120, False)))
+    ek, ekh, ehp = run.texts()
+    assert outs[True]["kmers_to_hashes.tsv"] == KMERS_TO_HASHES_HEADER + ekh
+    assert outs[True]["hashes_to_patterns.tsv"] == hashes_to_patterns_header(strains) + ehp
+    assert outs[True]["kmers.tsv"] == KMERS_TSV_HEADER + ek
 
 
 def test_run_files_multiple_files(tmp_path):

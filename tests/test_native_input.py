@@ -323,3 +323,131 @@ def test_native_reader_equals_reference_goldens(name, tmp_path):
     else:
         assert raised is not None and e["raises"] in raised
     assert _as_json(got) == e["records"]
+
+
+def _mangle_fasta(path, rng, style):
+    """re-wrap the FASTA of a GFF (or FASTA) file without changing a letter's meaning: what parse_fasta -- and pyfaidx --
+    make of the file stays the same"""
+    raw = open(path, "rb").read()
+    cut = raw.find(b"##FASTA")
+    head, fa = (raw[:cut + 8], raw[cut + 8:]) if cut >= 0 else (b"", raw)
+    recs, name, chunks = [], None, []
+    for line in fa.split(b"\n"):
+        if line.startswith(b">"):
+            if name is not None:
+                recs.append((name, b"".join(chunks)))
+            name, chunks = line, []
+        elif name is not None:
+            chunks.append(line.rstrip(b"\r"))
+    if name is not None:
+        recs.append((name, b"".join(chunks)))
+    out = [head]
+    eol = b"\r\n" if style == "crlf" else b"\n"
+    for i, (hdr, seq) in enumerate(recs):
+        out.append(hdr + (b" description with spaces" if style == "ragged" else b"") + eol)
+        if style == "ragged":
+            at = 0
+            while at < len(seq):
+                n = int(rng.integers(1, 97))
+                out.append(seq[at:at + n] + eol)
+                at += n
+                if rng.random() < 0.1:
+                    out.append(eol)                                   # a blank line inside a record
+        elif style == "lower":
+            s2 = bytearray(seq)
+            for _ in range(3):
+                a = int(rng.integers(0, max(len(s2), 1)))
+                s2[a:a + 40] = bytes(s2[a:a + 40]).lower()
+            for at in range(0, len(s2), 70):
+                out.append(bytes(s2[at:at + 70]) + eol)
+        elif style == "oneline":
+            out.append(seq + eol)
+        else:
+            w = 80 if style == "crlf" else 60
+            for at in range(0, len(seq), w):
+                out.append(seq[at:at + w] + eol)
+            if style == "trailing":
+                out.append(eol + eol)
+        if style == "ragged" and i == 0:
+            out.append(b">emptyrecord" + eol)                           # a record without a letter
+    if recs and style in ("ragged", "trailing"):
+        out.append(recs[0][0] + eol + b"ACGTACGTNNACGT" + eol)          # a repeated name: the first record stays
+    blob = b"".join(out)
+    if style == "oneline":
+        blob = blob.rstrip(b"\n")                                       # no newline at the end of the file
+    open(path, "wb").write(blob)
+
+
+def _decode_store(words, word_off, start, n):
+    """n letters from base `start` of the contig whose words begin at word_off (2 bits per base, first base in bits 63:62)"""
+    j = np.arange(start, start + n, dtype=np.uint64)
+    w = words[(np.uint64(word_off) + (j >> np.uint64(5))).astype(np.int64)]
+    code = (w >> (np.uint64(62) - np.uint64(2) * (j & np.uint64(31)))) & np.uint64(3)
+    return np.frombuffer(b"ACGT", dtype=np.uint8)[code.astype(np.int64)].tobytes()
+
+
+@pytest.mark.parametrize("style", ["plain", "crlf", "ragged", "lower", "oneline", "trailing"])
+def test_one_pass_reader_describes_the_same_input(tmp_path, style):
+    """pf_pangenome_open_device's reader side (scan_fasta through the host sink): contigs measured where their letters lie
+    -- evenly wrapped, CRLF, lines of any length with blank ones between (joined in place), lower case, one line without a
+    newline at the end of the file, blank lines at the end, a repeated contig name, a record without letters -- and packed
+    by the kernel's addressing.  The by-reference batches must rebuild, word for word, the packed buffer the text-mode
+    reader makes of the UNMANGLED files; everything else equal; text kept exactly for 'N'-carrying contigs and the target
+    strain."""
+    import ctypes as C
+    from panfeed_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(3)
+    cl = synth.generate(14, 9, first=500, flank=0, mean_len=260, min_len=40, max_len=700, n_rate=0.08, paralog_rate=0.1)
+    names = cl[0].names
+    csvp, gffs, fas = synth.write_pangenome(str(tmp_path), cl, separate_fasta_for=(names[3],), missing_gene_rate=0.0,
+                                            lower_rate=0.0)
+    gn = sorted(gffs)
+    p = dict(csv=csvp, names=names, genomes=gn, gff=[gffs[n] for n in gn], fasta=[fas[n] for n in gn])
+    k, W = 21, 1
+    tg = (names[1],)
+    with _open(p, 30, 20, targets=tg) as pg:
+        text = list(pg.batches(k, True, W, max_clusters=5))
+    if style != "plain":
+        for n in gn:
+            _mangle_fasta(fas[n] or gffs[n], rng, style)
+        with _open(p, 30, 20, targets=tg) as pg:                        # (parse_fasta on the mangled files: the same input)
+            again = list(pg.batches(k, True, W, max_clusters=5))
+        assert all(np.array_equal(a.packed, b.packed) and np.array_equal(a.seg_len, b.seg_len) for a, b in zip(text, again))
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    with _open(p, 30, 20, targets=tg, debug_hostsink=True) as pg:
+        assert pg.resident and pg.one_pass
+        store = pg.store_words
+        refd = list(pg.batches(k, True, W, max_clusters=5))
+        with pytest.raises(_lib.PanfeedHipError):                       # its contigs are not text any more
+            n, ptrs, lens = C.c_uint32(), C.POINTER(C.c_char_p)(), C.POINTER(C.c_uint64)()
+            _lib.check(L.pf_pangenome_contigs(pg.h, C.byref(n), C.byref(ptrs), C.byref(lens)))
+    assert len(text) == len(refd)
+    n_ref = n_rev = n_lit = 0
+    for a, b in zip(text, refd):
+        for f in ("seg_word_off", "seg_len", "seg_sample", "seg_ord_base", "seg_strand_off", "cluster_seg_off",
+                  "extra_cluster", "extra_ord", "extra_bits", "cluster_nstrains", "cluster_npresab", "cluster_presab"):
+            assert np.array_equal(getattr(a, f), getattr(b, f)), f
+        assert a.extra_keys == b.extra_keys and a.n_instances == b.n_instances
+        assert [(x.cluster, x.strain, x.seq, x.segs, x.ambig) for x in a.targets] == \
+               [(y.cluster, y.strain, y.seq, y.segs, y.ambig) for y in b.targets]
+        assert b.n_words_dev == len(a.packed)
+        rebuilt = np.zeros(b.n_words_dev, dtype=np.uint64)
+        for s in range(len(b.seg_len)):
+            ln, wo = int(b.seg_len[s]), int(b.seg_word_off[s])
+            nw = 2 * ((ln + 63) // 64)
+            fl, so, st = int(b.gather_src_flags[s]), int(b.gather_src_off[s]), int(b.gather_src_start[s])
+            if fl & 1:
+                rebuilt[wo:wo + nw] = b.packed[so:so + nw]
+                n_lit += 1
+                continue
+            seq = _decode_store(store, so, st, ln)
+            if fl & 2:
+                seq = seq[::-1].translate(comp)
+                n_rev += 1
+            buf = (C.c_uint64 * max(nw, 1))()
+            assert L.pf_pack_acgt(seq, ln, buf) == nw
+            rebuilt[wo:wo + nw] = np.ctypeslib.as_array(buf)[:nw]
+            n_ref += 1
+        assert np.array_equal(rebuilt, a.packed)
+    assert n_ref > 60 and n_rev > 15 and n_lit > 8
