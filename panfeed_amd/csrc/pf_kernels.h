@@ -37,6 +37,16 @@ __device__ unsigned long long pf_prof[64];
 #define PF_PROF_BEGIN() do { } while (0)
 #define PF_PROF_STAMP(k) do { } while (0)
 #endif
+// timing experiments (never shipped): -DPF_KO_FINISH=n, n = 0 .. 4, makes finish_kernel return behind its phase n (0 set-up +
+// sample sets, 1 mask table, 2 row evaluation, 3 ordinal bitmaps, 4 prefix counts) -- nothing has been claimed or written by
+// then, the later passes find empty clusters; n = 7 keeps every phase but gives every pattern the id 0 without touching the
+// run-global table (no pattern is made: MD5 has nothing to do).  A return behind phase 5 or 6 would leave claimed slots
+// unpublished / rows unwritten for the kernels behind it: not offered.  profiles/r05/experiment_finish_knockout.txt
+#ifdef PF_KO_FINISH
+#define PF_KO_FINISH_AT(n) do { if ((n) == PF_KO_FINISH && (n) <= 4) return; } while (0)
+#else
+#define PF_KO_FINISH_AT(n) do { } while (0)
+#endif
 
 constexpr uint32_t SCAN_THREADS = 1024;
 constexpr uint32_t SCAN_WAVES = SCAN_THREADS / 64;
@@ -1289,6 +1299,10 @@ void cluster_dedup_kernel(DedupParams p) {
                               dedup_word_hash(x.y, dedup_salt_lo(2 * j + 1), dedup_salt_hi(2 * j + 1));
                 }
             }
+#if defined(PF_KO_DEDUP) && PF_KO_DEDUP >= 2
+            if (acc[0] == 0x123456789ull) sh_bad = 1;            // (timing experiment: loads + hash only)
+            continue;
+#endif
             // claim: lane 0 of the group finds or opens the hash group
 #pragma unroll
             for (int u = 0; u < (int)DEDUP_U; u++) {
@@ -1353,6 +1367,9 @@ void cluster_dedup_kernel(DedupParams p) {
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
+#if defined(PF_KO_DEDUP) && PF_KO_DEDUP >= 1
+            continue;                                            // (timing experiment: no exact compare)
+#endif
             // compare: every other segment of the group against the pool (or against the first one's global words)
 #pragma unroll
             for (int u = 0; u < (int)DEDUP_U; u++) {
@@ -3259,6 +3276,7 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
         }
     }
     PF_PROF_STAMP(0);
+    PF_KO_FINISH_AT(0);
     // phase A: distinct allele masks
     for (uint32_t q = 0; q < nparts; q++) {
     set_part(q);
@@ -3295,6 +3313,7 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
     }
     __syncthreads();
     PF_PROF_STAMP(1);
+    PF_KO_FINISH_AT(1);
     const uint32_t npresent = sh_npres;
     const uint32_t n_eff = p.consider_missing ? npresent : nstr;               // panfeed.py:191 / :196
     const uint32_t lo = p.maf_lo[n_eff], hi = p.maf_hi[n_eff];
@@ -3462,6 +3481,7 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
     }
     __syncthreads();
     PF_PROF_STAMP(2);
+    PF_KO_FINISH_AT(2);
     // phase C: ordinal bitmaps, lowest ordinal per mask.  Slots whose mask did not fit the table (rare) are left to
     // a second, plain loop so that the batched one stays small.
     bool saw_untabled = false;
@@ -3515,6 +3535,7 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
     }
     __syncthreads();
     PF_PROF_STAMP(3);
+    PF_KO_FINISH_AT(3);
     // prefix popcounts over the bitmap words
     uint32_t tot_o, tot_k;
     {
@@ -3539,6 +3560,7 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
     if (tid == 0) at_count = 0;      // from here on: number of pattern-table slots this workgroup claims
     __syncthreads();
     PF_PROF_STAMP(4);
+    PF_KO_FINISH_AT(4);
     const uint32_t half_o = DW > 2048 ? sh_half_o : 0, half_k = DW > 2048 ? sh_half_k : 0;
     auto rank_of = [&](uint32_t o) -> uint32_t {
         return pocc[o >> 5] + __popc(occ[o >> 5] & ((1u << (o & 31)) - 1)) + (DW > 2048 && (o >> 5) >= 2048 ? half_o : 0u);
@@ -3593,13 +3615,18 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
         }
         if (e_state < 0) at_pid[tid] = 0xFFFFFFFFu;
     }
+#if defined(PF_KO_FINISH) && PF_KO_FINISH == 7
+    if (e_state == 0) e_pid = 0;                                   // (timing experiment: no run-global table)
+#else
     if (e_state == 0) {
         e_state = pattern_find_or_claim(p.pt, e_lo, e_hi, &e_gslot, &e_pid);
         if (e_state == 3) e_state = 0;                             // table full: e_pid = PID_NONE, the batch is re-run
         if (e_state == 1) e_newidx = atomicAdd(&at_count, 1u);     // at_count: claims of this workgroup (reused)
     }
+#endif
     __syncthreads();
     PF_PROF_STAMP(5);
+    PF_KO_FINISH_AT(5);
     if (tid == 0) {
         const uint32_t nnew = at_count;
         uint32_t base = 0;
@@ -3619,8 +3646,10 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
     if (e_state == 2) {
         e_pid = pattern_insert_lower(p.pt, e_lo, e_hi, e_fs, &lowered);
     } else if (e_state >= 0 && e_pid < p.pt.pool) {
+#if !(defined(PF_KO_FINISH) && PF_KO_FINISH == 7)
         const uint64_t old = atomicMin((unsigned long long*)&p.pt.first_seen[e_pid], (unsigned long long)e_fs);
         lowered = old > e_fs;
+#endif
     }
     if (e_state >= 0) {
         if (is_row_entry) {
@@ -3639,6 +3668,7 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
     }
     __syncthreads();
     PF_PROF_STAMP(6);
+    PF_KO_FINISH_AT(6);
     const uint64_t obase = sh_base - p.out_base;
     // rows of the patterns whose first_seen this workgroup lowered (at_minord is free by now: the list of their
     // mask-table positions)
