@@ -72,9 +72,12 @@ typedef struct {
 /* Opt-in: the work items of a batch's simple clusters (at most 64 distinct sequences, one key partition, a fused finish
    class) are laid out by three small kernels right behind the dedup pass, and the host reads a 40-byte summary before it
    launches their scan (the reference's hand-off is a queue, __main__.py:39-52), building only the rest of the batch from
-   the per-cluster records.  Same output.  Off by default: measured on MI355X it saves a small batch 0.02-0.03 ms of 2.6
-   and costs a 50 000-cluster batch 0.2 ms of 15 (two scan launches per part instead of one heaviest-first launch; the
-   host's work was hidden behind the other part's kernels already) -- DESIGN.md section 6. */
+   the per-cluster records.  Same output.  What it is for: batches of a few thousand SIMPLE clusters that go through in one
+   part, where the host's work lies on the critical path -- configs[1] (5 000 x 200) 1.337 -> 1.30 ms a pass, a rank's
+   share of configs[3] (6 250 clusters) 2.53 -> 2.51 (profiles/r05/device_plan_ab_small_batches.txt).  Not the default: a
+   50 000-cluster batch hides the host's work behind its other part's kernels (14.98 -> 15.18 ms with the plan), and in a
+   batch that mixes simple clusters with many-allele ones the planned clusters' finish kernels run in front of the general
+   path instead of beside it (the second stream). */
 #define PF_FLAG_DEVICE_PLAN 8u
 
 /*

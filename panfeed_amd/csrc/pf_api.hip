@@ -1877,25 +1877,35 @@ int submit_once(pf_ctx* c, const pf_batch* b, const pf_gather* gth, pf_result* c
         mp.pat_nan = c->o.consider_missing ? c->pat_nan.as<uint32_t>() : nullptr;
         mp.pat_n = c->pat_n.as<uint32_t>(); mp.pat_md5 = c->pat_md5.as<uint8_t>();
         mp.pid0 = c->pid0; mp.pid1 = pid1; mp.W = W; mp.range = nullptr;
-        // int64 rows (the clusters' own rows) are listed by the float pass and hashed by a second, small one
-        PFCHK(c->md5_list.ensure(((size_t)C + 2) * 4));
-        HIPCHK(hipMemsetAsync(c->md5_list.p, 0, 4, c->stream));
-        mp.int_list = c->md5_list.as<uint32_t>();
+        // int64 rows are the clusters' own rows: the int pass goes by cluster (cl_pattern) and runs BESIDE the float pass, on
+        // the side stream, instead of behind it
+        mp.cluster_pattern = c->cl_pattern.as<uint32_t>(); mp.n_clusters = C;
         PFCHK(mark_begin(c, 5));
-        // (one workgroup per CU -- one wave per SIMD -- already runs this kernel at 0.93 of its full-grid speed: 3.21 against
-        // 2.99 ms, profiles/r03/md5_occupancy_experiment.txt; it is a chain of dependent integer instructions)
-        const dim3 g_float((pid1 - c->pid0 + pf::MD5_THREADS - 1) / pf::MD5_THREADS);
+        // A small launch is spread over the chip: the float pass's workgroups (four waves, one per SIMD) number a few per
+        // CU, and the dispatcher fills CUs with up to eight before it moves on -- a SIMD gets through its rows at one rate
+        // however many waves share it, so the pass took as long as the FULLEST SIMD (a rank's share of configs[3]: 5 waves
+        // per SIMD on average, 8 on two thirds of the CUs, none on the rest).  Dynamic LDS the kernel never touches caps the
+        // workgroups per CU at what an even spread needs.
+        const uint32_t n_float = (pid1 - c->pid0 + pf::MD5_THREADS - 1) / pf::MD5_THREADS;
+        const uint32_t per_cu = (n_float + (uint32_t)c->n_cu - 1) / (uint32_t)c->n_cu;
+        uint32_t lds_cap = 0;
+        if (per_cu < 8) lds_cap = std::min<uint32_t>(64u << 10, ((160u << 10) / std::max(per_cu, 1u)) & ~1023u);
+        const dim3 g_float(n_float);
         const dim3 g_int(std::min<uint32_t>((C + pf::MD5_THREADS - 1) / pf::MD5_THREADS, 1024u));
+        HIPCHK(hipEventRecord(c->ev_fork, c->stream));
+        HIPCHK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
         if (mp.pat_nan) {
-            hipLaunchKernelGGL((pf::md5_kernel<true, true>), g_float, dim3(pf::MD5_THREADS), 0, c->stream, mp);
+            hipLaunchKernelGGL((pf::md5_kernel<false, true>), g_int, dim3(pf::MD5_THREADS), 0, c->side, mp);
             HIPCHK(hipGetLastError());
-            hipLaunchKernelGGL((pf::md5_kernel<false, true>), g_int, dim3(pf::MD5_THREADS), 0, c->stream, mp);
+            hipLaunchKernelGGL((pf::md5_kernel<true, true>), g_float, dim3(pf::MD5_THREADS), lds_cap, c->stream, mp);
         } else {
-            hipLaunchKernelGGL((pf::md5_kernel<true, false>), g_float, dim3(pf::MD5_THREADS), 0, c->stream, mp);
+            hipLaunchKernelGGL((pf::md5_kernel<false, false>), g_int, dim3(pf::MD5_THREADS), 0, c->side, mp);
             HIPCHK(hipGetLastError());
-            hipLaunchKernelGGL((pf::md5_kernel<false, false>), g_int, dim3(pf::MD5_THREADS), 0, c->stream, mp);
+            hipLaunchKernelGGL((pf::md5_kernel<true, false>), g_float, dim3(pf::MD5_THREADS), lds_cap, c->stream, mp);
         }
         HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(c->ev_join, c->side));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
         PFCHK(mark_end(c));
     }
     c->n_patterns = pid1;

@@ -4068,7 +4068,8 @@ __device__ __forceinline__ void md5_block(uint32_t st[4], const uint32_t m[16]) 
 struct Md5Params {
     const uint32_t* pat_bits; const uint32_t* pat_nan; const uint32_t* pat_n;
     uint8_t* pat_md5;
-    uint32_t* int_list;      // [0] = count, [1..] = pattern ids of int64 rows (cluster rows) met by the float pass
+    const uint32_t* cluster_pattern;   // [n_clusters] the int pass: the clusters' own rows are the int64 rows
+    uint32_t n_clusters;
     const uint32_t* range;   // device: {first id, one past the last id} of this launch, or null:
     uint32_t pid0, pid1, W;  // ... the range given here
 };
@@ -4082,21 +4083,23 @@ constexpr uint32_t MD5_THREADS = 256;
 // HAS_NAN: a NaN mask exists (--consider-missing-cluster); compiled apart, the common case pays nothing for it.
 // Vector-issue bound: 310 instructions per block at the ~4 cycles per wave-instruction this mix of 2- and 4-cycle
 // operations sustains on a SIMD (tools/micro/valu_chain.hip: 4.05 with one to eight waves, one to four chains per wave).
+// The int pass goes by cluster (its rows are the clusters' own: cluster_pattern[c], hashed by whichever cluster names a new
+// one -- clusters with the same row write the same digest), so it does not wait for the float pass: the two run side by
+// side on two streams (round 5: listed by the float pass, the int rows were a second launch behind it -- one wave's chain of
+// 126 blocks, 66 us, with the chip empty).
 template <bool FLOAT_ROWS, bool HAS_NAN>
 __global__ __launch_bounds__(MD5_THREADS) void md5_kernel(Md5Params p) {
     // rows blockIdx.x * 256 + tid, + gridDim.x * 256, ... of the id range (the grid is sized before the range is known)
     const uint32_t r0 = FLOAT_ROWS ? (p.range ? p.range[0] : p.pid0) : 0;
-    const uint32_t r1 = FLOAT_ROWS ? (p.range ? p.range[1] : p.pid1) : p.int_list[0];
+    const uint32_t r1 = FLOAT_ROWS ? (p.range ? p.range[1] : p.pid1) : p.n_clusters;
     const uint32_t W = p.W;
     for (uint64_t base = (uint64_t)r0 + (uint64_t)blockIdx.x * MD5_THREADS; base < r1; base += (uint64_t)gridDim.x * MD5_THREADS) {
         const uint32_t idx = (uint32_t)base + threadIdx.x;
         if (idx >= r1) continue;
-        const uint32_t pid = FLOAT_ROWS ? idx : p.int_list[1 + idx];
+        const uint32_t pid = FLOAT_ROWS ? idx : p.cluster_pattern[idx];
+        if (!FLOAT_ROWS && (pid < p.pid0 || pid >= p.pid1)) continue;      // a row of an earlier batch (hashed then), or none
         const uint32_t nk = p.pat_n[pid];
-        if (FLOAT_ROWS && (nk >> 31)) {                       // an int64 row: left to the second pass
-            p.int_list[1 + atomicAdd(&p.int_list[0], 1u)] = pid;
-            continue;
-        }
+        if (FLOAT_ROWS == ((nk >> 31) != 0)) continue;        // an int64 row is the int pass's, a float64 row the float pass's
         const uint32_t n = nk & 0x7FFFFFFFu;
         const uint32_t* rb = p.pat_bits + (size_t)pid * W;
         const uint32_t* rn = HAS_NAN ? p.pat_nan + (size_t)pid * W : nullptr;

@@ -3,7 +3,7 @@
 # to be copied into profiles/ROUND/.  (The headline's bench line, kernel stats and PMC passes: tools/profile_round.sh.)
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-R=${1:-r04}; OUT=gpurun_out/${R}_extra
+R=${1:-r05}; OUT=gpurun_out/${R}_extra
 if [ "${2:-all}" != "b" ]; then
 rm -rf $OUT && mkdir -p $OUT
 F="--no-every-copy-leg --no-n-leg --no-e2e-leg"

@@ -3,7 +3,7 @@
 # usage (GPU box): bash tools/d150_profile.sh [ROUND] -> gpurun_out/ROUND_d150/, to be copied into profiles/ROUND/
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-R=${1:-r04}; OUT=gpurun_out/${R}_d150
+R=${1:-r05}; OUT=gpurun_out/${R}_d150
 rm -rf $OUT && mkdir -p $OUT
 SQ="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES"
 for M in star tree; do

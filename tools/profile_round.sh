@@ -1,11 +1,11 @@
 # bench line + rocprofv3 kernel stats + PMC passes (HBM bytes, SQ counters) of the default bench command.
 # usage (on a GPU box): PF_COMMIT=<git rev-parse --short HEAD, taken where .git is> bash tools/profile_round.sh [--prof-only] [ROUND] ;
-# results under gpurun_out/ROUND/ (default r04), to be
+# results under gpurun_out/ROUND/ (default r05), to be
 # copied into profiles/ROUND/
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 PROF_ONLY=0; if [ "$1" = "--prof-only" ]; then PROF_ONLY=1; shift; fi
-OUT=gpurun_out/${1:-r04}
+OUT=gpurun_out/${1:-r05}
 rm -rf $OUT && mkdir -p $OUT
 B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-every-copy-leg --no-n-leg --no-e2e-leg"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- $B > $OUT/stats.log 2>&1
