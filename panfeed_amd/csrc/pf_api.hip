@@ -8,6 +8,7 @@
 //   through in two parts so that the host builds a part's items while the GPU is on the other.
 // Everything is stream-ordered on one HIP stream; the host syncs are the dedup results per part, the overflow / cursor /
 // pattern-counter read-back of the last pass and the end of the batch.
+#include "pf_host.h"
 #include "pf_kernels.h"
 #include "../../include/panfeed_hip.h"
 #include "pf_ingest.h"
@@ -527,8 +528,7 @@ int launch_scan(pf_ctx* c, const pf::ScanParams& sp, uint32_t n) {
 namespace {
 template <class F>
 void parallel_for(uint64_t n, F f) {
-    unsigned nt = std::thread::hardware_concurrency();
-    nt = std::max(1u, std::min(nt, 32u));
+    const unsigned nt = pf_host_threads(32u);
     if (n < 4096 || nt == 1) { f(0, n); return; }
     std::vector<std::thread> th;
     const uint64_t chunk = (n + nt - 1) / nt;
@@ -2791,7 +2791,7 @@ int ingest_setup(Ingest* I) {
     c->g_store.release();
     c->g_words = 0;
     PFCHK(c->g_store.ensure((size_t)I->store_cap * 8));
-    const unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+    const unsigned nt = pf_host_threads(32u);
     I->slots.resize(std::max<size_t>(4, std::min<size_t>(2 * (size_t)nt, (size_t)o->n_genomes + 1)));
     for (auto& s : I->slots)
         if (hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) return fail(PF_ERR_HIP, "hipEventCreate failed");

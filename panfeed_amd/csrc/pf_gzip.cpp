@@ -5,6 +5,7 @@
 // TSV of a large run.  Here a block of text is cut into chunks at line ends, every chunk is deflated (level 9 by
 // default) as its own gzip member on its own thread, and the members are concatenated: a multi-member gzip file
 // (RFC 1952 section 2.2), which gzip / zcat / Python's gzip / pandas read back as the same text.
+#include "pf_host.h"
 #include "../../include/panfeed_hip.h"
 
 #include <zlib.h>
@@ -56,7 +57,7 @@ extern "C" int pf_gzip_members(const char* data, uint64_t n, int level, uint64_t
         }
     };
     if (chunk_bytes >= (1ull << 31)) { pf_set_error_("pf_gzip_members: chunk_bytes must stay below 2 GiB"); return PF_ERR_ARG; }
-    unsigned nt = (unsigned)std::min<size_t>(std::max(1u, std::min(std::thread::hardware_concurrency(), 64u)), std::max<size_t>(nchunk, 1));
+    unsigned nt = (unsigned)std::min<size_t>(pf_host_threads(64u), std::max<size_t>(nchunk, 1));
     std::vector<std::thread> th;
     for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
     work();

@@ -8,6 +8,7 @@
 // PARITY UNPINNED at the pyfaidx boundary: pyfaidx is not in /root/reference and not installed; what it would return
 // is restated from its documented behaviour (record name = header up to the first whitespace, newline-free
 // sequence, sequence_always_upper, Python slice clipping, `-seq` = reverse complement with the IUPAC table below).
+#include "pf_host.h"
 #include "../../include/panfeed_hip.h"
 #include "pf_ingest.h"
 
@@ -825,7 +826,7 @@ int open_impl(const pf_pangenome_opts* o, pf_ingest_sink* sink, pf_pangenome** o
         std::vector<std::string> names(nrec);
         std::vector<std::vector<std::string>> cells(nrec);
         std::vector<uint8_t> blank(nrec, 0);
-        unsigned ntc = std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+        unsigned ntc = pf_host_threads(32u);
         if (nrec < 64) ntc = 1;
         std::atomic<size_t> nextrec{0};
         auto work = [&] {
@@ -861,7 +862,7 @@ int open_impl(const pf_pangenome_opts* o, pf_ingest_sink* sink, pf_pangenome** o
     std::vector<Genome> gs(o->n_genomes);
     std::atomic<long long> dbg_ns[4] = {};
     auto TA = std::chrono::steady_clock::now();
-    unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+    unsigned nt = pf_host_threads(32u);
     std::vector<std::thread> th;
     for (unsigned t = 0; t < nt; t++)
         th.emplace_back([&, t] {
@@ -1057,7 +1058,7 @@ void pf_pangenome_close(pf_pangenome* P) {
     gs.reserve(P->genomes.size());
     for (auto& kv : P->genomes) gs.push_back(&kv.second);
     const size_t ng = gs.size(), nr = P->cells.size();
-    unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+    unsigned nt = pf_host_threads(32u);
     if (ng + nr < 64) nt = 1;
     std::atomic<size_t> next{0};
     auto work = [&] {
@@ -1144,7 +1145,7 @@ int pf_pangenome_next(pf_pangenome* P, uint32_t max_clusters, pf_records** out, 
         t0 = t;
     };
     {
-        unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+        unsigned nt = pf_host_threads(32u);
         if (made < 4) nt = 1;
         std::atomic<uint32_t> next{0};
         std::vector<std::thread> th;

@@ -2,6 +2,10 @@
 // segment arrays of include/panfeed_hip.h, plus the slow path for windows that contain a non-ACGT base
 // (grouped with the reference's own string semantics, /root/reference/panfeed/panfeed.py:64-88).
 // No GPU involved; panfeed_amd/packing.py holds the same logic in numpy and tests compare the two array for array.
+#include "pf_host.h"
+#include <sched.h>
+#include <cstdio>
+#include <mutex>
 #include "../../include/panfeed_hip.h"
 
 #include <algorithm>
@@ -291,7 +295,7 @@ int pf_pack_records(const pf_pack_in* in, pf_packed** out) {
     const uint32_t C = in->n_clusters;
     std::vector<ClusterOut> outs(C);
     const auto T_0 = std::chrono::steady_clock::now();
-    unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+    unsigned nt = pf_host_threads(32u);
     if (C < 8) nt = 1;
     {
         std::vector<std::thread> th;
@@ -468,3 +472,33 @@ int pf_py_release(void** held, uint64_t n, const pf_py_api* api) {
 }
 
 }  // extern "C"
+
+// ---- pf_host.h ------------------------------------------------------------------------------------------------------------
+static unsigned usable_cpus() {
+    unsigned n = std::thread::hardware_concurrency();
+    if (!n) n = 1;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) {
+        const int a = CPU_COUNT(&set);
+        if (a > 0) n = std::min<unsigned>(n, (unsigned)a);
+    }
+    // cgroup v2: "<quota|max> <period>"; v1: two files
+    long long quota = -1, period = 0;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = {0};
+        if (fscanf(f, "%31s %lld", q, &period) == 2 && q[0] != 'm') quota = atoll(q);
+        fclose(f);
+    } else {
+        if (FILE* fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(fq, "%lld", &quota) != 1) quota = -1; fclose(fq); }
+        if (FILE* fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(fp, "%lld", &period) != 1) period = 0; fclose(fp); }
+    }
+    // twice the quota: the sections that use this are bound by memory latency as much as by instructions (the reader's
+    // 8 M look-ups in per-genome hash maps: 0.50 s with 32 threads on a 16-CPU quota, 0.65 s with 16), and more threads
+    // than CPUs keep more misses in flight; what the bound prevents is 32 threads on a 2-CPU quota
+    if (quota > 0 && period > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, 2 * ((quota + period - 1) / period)));
+    return std::max(1u, n);
+}
+unsigned pf_host_threads(unsigned cap) {
+    static const unsigned n = usable_cpus();
+    return std::max(1u, std::min(n, cap));
+}
