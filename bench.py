@@ -467,10 +467,21 @@ def end_to_end(args, local):
             setup = time.time() - t0
             del cl
             od = os.path.join(scratch, "out")
-            t0 = time.time()
-            st = run_files(csvp, os.path.join(scratch, "gffs"), od, klength=k, upstream=up, downstream=up, batch_clusters=256,
-                           device_text=True, device=local)
-            dt = time.time() - t0
+            # The run twice, both reported: the first one of a process pays for things a pangenome run pays once per
+            # MACHINE rather than once per run (the input files' pages entering this process's NUMA neighbourhood, the first
+            # use of the ingest kernels and of page-locked registration: 2.0 - 2.4 s against 0.9 - 1.2 s in every A/B of
+            # round 5); `seconds` is the second run, `first_run_seconds` the first.  The reader of a run gives its memory
+            # back on a thread of its own and the next open waits for it: joined (2 s) before the clock starts.
+            dts = []
+            for rep in range(2):
+                if rep:
+                    shutil.rmtree(od, ignore_errors=True)
+                    time.sleep(2.0)
+                t0 = time.time()
+                st = run_files(csvp, os.path.join(scratch, "gffs"), od, klength=k, upstream=up, downstream=up, batch_clusters=256,
+                               device_text=True, device=local)
+                dts.append(time.time() - t0)
+            dt = dts[-1]
             assert st["instances"] == ninst, (st["instances"], ninst)
             fbytes = sum(os.path.getsize(os.path.join(od, f)) for f in os.listdir(od))
             stg = st["stages"]
@@ -480,6 +491,7 @@ def end_to_end(args, local):
                      "the text stage (text_s: device text + its copy to the host)": stg.get("text_s", 0.0)}
             out["files_to_files_device_text_long"] = {
                 "clusters": n_long, "setup_write_inputs_s": setup, "input_bytes": in_bytes, "seconds": dt, "inst_per_s": ninst / dt,
+                "first_run_seconds": dts[0], "first_run_inst_per_s": ninst / dts[0],
                 "output_bytes": fbytes, "output_GBps": fbytes / dt / 1e9, "input_GBps": in_bytes / dt / 1e9, "instances": ninst,
                 "kept_kmers": st["kept_kmers"], "patterns": st["patterns"],
                 "gpu_busy_share": stg.get("device_ms", 0.0) / 1e3 / dt,

@@ -243,14 +243,69 @@ class Pangenome:
 
     def batches(self, klength, canon, W, max_clusters=256, want_strand=True, first_ordinal=0, with_names=False):
         """HostBatch per `max_clusters` rows of the table, packed by the library straight from the reader's buffers.
-        with_names: also fill hb.sorted_strains / hb.presab (Python lists per cluster; nothing on the GPU path reads them)."""
-        L = self.L
+        with_names: also fill hb.sorted_strains / hb.presab (Python lists per cluster; nothing on the GPU path reads them).
+        (The reader runs up to three blocks of rows ahead of what has been yielded: a generator that is dropped before its
+        end leaves the reader further down the table than its last batch -- `set_range` rewinds it.)"""
         k = int(klength)
         ordinal = int(first_ordinal)
+        # Two stages on two threads: the reader cuts the next rows' records (pf_pangenome_next: 8 M gene look-ups per
+        # 8 000 x 1 000 pangenome, bound by memory latency, a serial merge at its end) while this thread packs the rows
+        # before them (pf_pack_records + the arrays' way into the HostBatch).  Both stages belong to the run's critical
+        # path -- the GPU waits for the packer -- and neither fills the host on its own.
+        import queue
+        import threading
+        q = queue.Queue(maxsize=2)
+        stop = threading.Event()
+
+        def reader():
+            try:
+                while not stop.is_set():
+                    got = self.next_records(max_clusters)
+                    sent = False
+                    while not stop.is_set() and not sent:
+                        try:
+                            q.put(got, timeout=0.1)
+                            sent = True
+                        except queue.Full:
+                            pass
+                    if not sent:                            # (the consumer went away: the block in hand goes back)
+                        if got is not None:
+                            self.free_records(got[0])
+                        return
+                    if got is None:
+                        return
+            except BaseException as e:      # noqa: BLE001  (handed to the consumer)
+                q.put(e)
+        rt = threading.Thread(target=reader, name="panfeed-reader")
+        rt.start()
+        try:
+            yield from self._batches_from(q, k, canon, W, want_strand, ordinal, with_names)
+        finally:
+            stop.set()
+            while rt.is_alive():                                # drain what the reader still hands over
+                try:
+                    got = q.get(timeout=0.05)
+                    if isinstance(got, tuple):
+                        self.free_records(got[0])
+                except queue.Empty:
+                    pass
+            rt.join()
+            while True:
+                try:
+                    got = q.get_nowait()
+                    if isinstance(got, tuple):
+                        self.free_records(got[0])
+                except queue.Empty:
+                    break
+
+    def _batches_from(self, q, k, canon, W, want_strand, ordinal, with_names):
+        L = self.L
         while True:
-            got = self.next_records(max_clusters)
+            got = q.get()
             if got is None:
                 return
+            if isinstance(got, BaseException):
+                raise got
             h, v = got
             try:
                 nc = int(v.n_clusters)
