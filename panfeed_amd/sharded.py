@@ -225,19 +225,40 @@ def run_files_sharded(presence_absence, gffdir, output, rank, world, dist=None, 
     if rank == 0:
         os.makedirs(output)
     _barrier(dist, device)
-    pg = Pangenome(presence_absence, gffdir, fastadir, upstream, downstream, downstream_start_codon, targets=targets,
-                   genes=genes)
-    eng = None
+    def make_engine(n_strains):
+        return Engine(klength=klength, canon=canon, consider_missing=consider_missing, patfilt=patfilt, maf=maf,
+                      multiple_files=multiple_files, max_strains=max(32, (n_strains + 31) // 32 * 32),
+                      stroi=set(targets), device=gpu,
+                      # the same rule as pipeline.run_files (a cluster that needs more makes the library re-make its scratch)
+                      max_items=max_items or max(512, 2 * int(batch_clusters)), pattern_capacity=pattern_capacity)
+    # every rank reads every genome (a cluster's sequences come from all of them): with resident genomes the files go to
+    # the rank's GPU as they are read (pf_pangenome_open_device), as in pipeline.run_files; the context is made first, from
+    # the table's header line
+    from .pipeline import _peek_n_strains
+    eng = pg = None
+    n_peek = _peek_n_strains(presence_absence) if resident else 0
+    if n_peek:
+        eng = make_engine(n_peek)
+        try:
+            pg = Pangenome(presence_absence, gffdir, fastadir, upstream, downstream, downstream_start_codon, targets=targets,
+                           genes=genes, engine=eng)
+        except BaseException:
+            eng.close()
+            raise
+        if eng.max_strains < pg.n_strains:               # (the header was not what the reader made of it)
+            pg.close()
+            eng.close()
+            eng = pg = None
+    if pg is None:
+        pg = Pangenome(presence_absence, gffdir, fastadir, upstream, downstream, downstream_start_codon, targets=targets,
+                       genes=genes)
     try:
         w = pg.weights()
         start, stop = shard_range(len(w), rank, world, w)
         pg.set_range(start, stop - start)
-        eng = Engine(klength=klength, canon=canon, consider_missing=consider_missing, patfilt=patfilt, maf=maf,
-                     multiple_files=multiple_files, max_strains=max(32, (pg.n_strains + 31) // 32 * 32),
-                     stroi=set(targets), device=gpu,
-                     # the same rule as pipeline.run_files (a cluster that needs more makes the library re-make its scratch)
-                     max_items=max_items or max(512, 2 * int(batch_clusters)), pattern_capacity=pattern_capacity)
-        if resident:
+        if eng is None:
+            eng = make_engine(pg.n_strains)
+        if resident and not pg.resident:
             pg.make_resident(eng)
         eng.next_ordinal = start
         batches = eng.run_pangenome(pg, batch_clusters=batch_clusters, device_text=device_text,
