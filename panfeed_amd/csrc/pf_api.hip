@@ -2792,7 +2792,10 @@ int ingest_setup(Ingest* I) {
     c->g_words = 0;
     PFCHK(c->g_store.ensure((size_t)I->store_cap * 8));
     const unsigned nt = pf_host_threads(32u);
-    I->slots.resize(std::max<size_t>(4, std::min<size_t>(2 * (size_t)nt, (size_t)o->n_genomes + 1)));
+    // (a slot is held for one memcpy and handed to the copy engine, which empties it in a fifth of a millisecond: half as many
+    // slots as reader threads, plus a few, are never all busy -- and 64 slots of 10 MB were 0.6 GB to allocate and page-lock
+    // in front of the first upload)
+    I->slots.resize(std::max<size_t>(4, std::min<size_t>((size_t)nt / 2 + 4, (size_t)o->n_genomes + 1)));
     for (auto& s : I->slots)
         if (hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) return fail(PF_ERR_HIP, "hipEventCreate failed");
     // the ring's blocks: ONE page-locked allocation and ONE device allocation, cut into slots that hold the largest file (an
