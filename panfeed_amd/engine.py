@@ -230,16 +230,18 @@ class Engine:
         return self.run_batches(host_batches(), prefetch, device_text, defer_patterns=defer_patterns)
 
     def run_pangenome(self, pangenome, batch_clusters=256, prefetch=2, device_text=False, defer_patterns=False,
-                      before_first_submit=None):
+                      before_first_submit=None, targets_sink=None):
         """run_stream fed by the native reader (native_input.Pangenome): table rows -> records -> packed batches
         without leaving the library, then the GPU; yields BatchOutput in table order."""
         if tuple(sorted(pangenome.targets)) != tuple(sorted(self.stroi or ())):
             raise ValueError("the pangenome reader and the engine were given different target strains")
         return self.run_batches(pangenome.batches(self.k, self.canon, self.W, max_clusters=batch_clusters,
                                                   first_ordinal=self.next_ordinal), prefetch, device_text,
-                                defer_patterns=defer_patterns, before_first_submit=before_first_submit)
+                                defer_patterns=defer_patterns, before_first_submit=before_first_submit,
+                                targets_sink=targets_sink)
 
-    def run_batches(self, host_batches, prefetch=2, device_text=False, defer_patterns=False, before_first_submit=None):
+    def run_batches(self, host_batches, prefetch=2, device_text=False, defer_patterns=False, before_first_submit=None,
+                    targets_sink=None):
         """GPU over an iterator of HostBatch, the next ones being prepared on one host thread meanwhile.
         device_text: kmers_to_hashes / hashes_to_patterns of a batch without target-strain rows come back as
         memoryviews of text the GPU wrote (render_device; valid until the batch after the next one has been rendered)
@@ -247,7 +249,11 @@ class Engine:
         defer_patterns: leave hashes_to_patterns empty -- a rank of a sharded run renders its pattern rows after the
         run-global merge (`render_pattern_rows`).
         before_first_submit: called once, right before the first pf_submit (pipeline.run_files joins the thread that
-        uploads the genomes there: the packer has been at work on the first batches meanwhile)."""
+        uploads the genomes there: the packer has been at work on the first batches meanwhile).
+        targets_sink (with device_text): called with every block of a batch's kmers.tsv rows as it leaves the device
+        (a bytes-like view, valid during the call) instead of the rows being gathered into `out.kmers_tsv` -- with every
+        strain a target a batch's rows are tens of gigabytes (BASELINE configs[4]'s second pass: 256 clusters x 5 000
+        samples = 150 GB), which no host buffer should hold; `out.stats["kmers_tsv_streamed"]` says how many bytes went."""
         from concurrent.futures import ThreadPoolExecutor
         import time as _time
         it = iter(host_batches)
@@ -297,14 +303,26 @@ class Engine:
                     out.kmers_to_hashes, out.hashes_to_patterns = texts
                     # target strains: their rows written by the GPU too (the next submit reuses the device's text
                     # block, so the rows come over now)
-                    out.kmers_tsv = bytes(self.render_targets_device(hb)) if hb.n_targets else b""
-                    out.stats = {"clusters": int(hb.n_clusters), "instances": int(hb.n_instances),
+                    streamed = 0
+                    if hb.n_targets and targets_sink is not None:
+                        for blk in self.render_targets_device(hb).chunks():
+                            targets_sink(blk)
+                            streamed += len(blk)
+                        out.kmers_tsv = b""
+                    else:
+                        out.kmers_tsv = bytes(self.render_targets_device(hb)) if hb.n_targets else b""
+                    out.stats = {"clusters": int(hb.n_clusters), "instances": int(hb.n_instances), "kmers_tsv_streamed": streamed,
                                  "device_instances": int(res.n_instances), "unique_kmers": int(res.n_unique),
                                  "kept_kmers": int(res.n_kept), "new_patterns": int(res.n_new_patterns),
                                  "patterns": self.pattern_count()}
                     out.timing = self.timing()
                 else:
                     out = self._render(hb, self.fetch(), defer_patterns)
+                    if targets_sink is not None and out.kmers_tsv and not self.multiple_files:
+                        # (the rows of this batch must not overtake, or be overtaken by, the streamed rows of its neighbours)
+                        out.stats["kmers_tsv_streamed"] = len(out.kmers_tsv)
+                        targets_sink(out.kmers_tsv)
+                        out.kmers_tsv = ""
                 st["text_s"] += _time.perf_counter() - t1
                 st["device_ms"] += out.timing.get("total_ms", 0.0)
                 yield out

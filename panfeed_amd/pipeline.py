@@ -227,8 +227,11 @@ def run_files(presence_absence, gffdir, output, fastadir=None, klength=31, canon
         wt = threading.Thread(target=writer, name="panfeed-writer")
         wt.start()
         try:
+            # (target strains' rows go to kmers.tsv block by block as they leave the device, from this thread: the file is
+            # the writer thread's only when a batch's rows come as one object -- the host renderers' path)
+            sink = (lambda blk: put(kmer_stroi, blk)) if (device_text and not multiple_files) else None
             batches = eng.run_pangenome(pg, batch_clusters=batch_clusters, device_text=device_text,
-                                        before_first_submit=wait_for_genomes)
+                                        before_first_submit=wait_for_genomes, targets_sink=sink)
             while True:
                 slots.acquire()
                 o = next(batches, None)
@@ -239,7 +242,8 @@ def run_files(presence_absence, gffdir, output, fastadir=None, klength=31, canon
                 stats["kept_kmers"] += o.stats.get("kept_kmers", 0)
                 stats["patterns"] = o.stats.get("patterns", stats["patterns"])
                 stats["device_ms"] += o.timing.get("total_ms", 0.0)
-                stats["bytes"] += len(o.kmers_tsv) + len(o.kmers_to_hashes) + len(o.hashes_to_patterns)
+                stats["bytes"] += (len(o.kmers_tsv) + len(o.kmers_to_hashes) + len(o.hashes_to_patterns) +
+                                   o.stats.get("kmers_tsv_streamed", 0))
                 q.put(o)
         finally:
             q.put(None)
