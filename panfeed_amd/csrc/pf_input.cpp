@@ -1270,7 +1270,10 @@ int pf_pangenome_contigs(pf_pangenome* P, uint32_t* n, const char* const** ascii
             for (auto& c : cn) P->flat.push_back(&g.contigs.find(c)->second);
         }
         for (Contig* c : P->flat) {
-            if (!c->has_text && c->len) return in_fail(PF_ERR_STATE, "pf_pangenome_contigs: this reader's genomes went to the device as it was opened");
+            if (!c->has_text && c->len) {
+                P->flat.clear(); P->flat_ptr.clear(); P->flat_len.clear();       // (a second call fails the same way)
+                return in_fail(PF_ERR_STATE, "pf_pangenome_contigs: this reader's genomes went to the device as it was opened");
+            }
             P->flat_ptr.push_back(c->seq.data()); P->flat_len.push_back(c->seq.size());
         }
     }
