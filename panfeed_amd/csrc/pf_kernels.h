@@ -2872,6 +2872,49 @@ __device__ __forceinline__ uint32_t pattern_insert(const PatternTable& t, uint4 
     return pattern_insert(t, ((uint64_t)h.x << 32) | h.y, h.z, first_seen);
 }
 
+// One insert per thread of a WORKGROUP (every thread calls it; `active` says who has a pattern), the ids of the patterns the
+// workgroup claims taken with ONE add on the run-global counter: that word serves ~96 returning adds per microsecond whoever
+// asks (MI355X_MICROARCH.md, "dequeue"; measured here: 5.3 M inserts by 316 000 waves, one add each, took 4.2 ms -- 0.9 ms with
+// the add compiled out, profiles/r05/experiment_pattern_id_counter.txt).  lds: two words, zero, not touched by anyone else
+// until the call returns; finish_kernel has the same steps inline.
+__device__ __forceinline__ uint32_t pattern_insert_block(const PatternTable& t, bool active, uint64_t lo, uint32_t hi32,
+                                                         uint64_t first_seen, uint32_t* lds) {
+    uint64_t slot = 0;
+    uint32_t pid = PID_NONE, newidx = 0;
+    int st = -1;
+    if (active) {
+        st = pattern_find_or_claim(t, lo, hi32, &slot, &pid);
+        if (st == 1) newidx = atomicAdd(&lds[0], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t nnew = lds[0];
+        uint32_t base = 0;
+        if (nnew) {
+            base = atomicAdd(&t.counters[0], nnew);
+            if ((uint64_t)base + nnew > t.pool) t.counters[1] = 1;
+        }
+        lds[1] = base;
+    }
+    __syncthreads();
+    if (st == 1) {
+        const uint32_t id = lds[1] + newidx;
+        pid = id < t.pool ? id : PID_NONE;
+        pattern_publish(t, slot, hi32, pid);            // published even on failure: nobody waits for ever
+    }
+    // EVERY claim of the workgroup is published before any of its lanes waits for somebody else's: left to itself the compiler
+    // put the waiting lanes' loop in FRONT of the claiming lanes' store (the two branches are disjoint sets of lanes, their
+    // order is its choice), and two waves of sibling items, each with a claim the other's lanes were waiting for, never came
+    // back (tests/fuzz_parity.py 80 7, case 8).  A barrier is a point no lane's code moves across.
+    __syncthreads();
+    if (st == 2) return pattern_insert(t, lo, hi32, first_seen);     // somebody's claim, not yet published: the waiting form
+    if (st == 0 || st == 1) {
+        if (pid == PID_NONE) t.counters[1] = 1;
+        else atomicMin((unsigned long long*)&t.first_seen[pid], (unsigned long long)first_seen);
+    }
+    return pid;
+}
+
 // pattern table of a larger capacity: re-insert the entries of the old one whose pattern id is < keep_below (the
 // patterns of earlier batches; whatever a failed batch added is dropped)
 struct RehashParams {
@@ -2950,6 +2993,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
     __shared__ uint64_t lt_first[LT_SLOTS];
     __shared__ uint32_t lt_pid[LT_SLOTS];
     __shared__ uint32_t lt_count;
+    __shared__ uint32_t ins_cnt[2];
 
     PF_PROF_BEGIN();
     const uint32_t tid = threadIdx.x;
@@ -2997,7 +3041,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
     const uint32_t n_entries = sorted ? U : min(kp[0], ns);
     uint32_t* kres = p.kept_prefix_rw + (size_t)slice * (NS + 1) + 1;
     for (uint32_t i = tid; i < LT_SLOTS; i += EMIT_THREADS) { lt_lo[i] = EMPTY64; lt_hi[i] = EMPTY64; lt_first[i] = EMPTY64; }
-    if (tid == 0) lt_count = 0;
+    if (tid == 0) { lt_count = 0; ins_cnt[0] = 0; }
     // (ranks by bitmap: nobody reads a slot's output index -- pattern_rows_kernel and pass 3 go by entry, kres[] -- so the
     // array is not initialised slot by slot (38 KB of stores per item) nor written per kept k-mer; its first n_entries words
     // take, per entry, where pass 1 found the k-mer's pattern in the local table, so that pass 3 need not read the row hash
@@ -3103,11 +3147,13 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(EmitParams p) {
     }
     __syncthreads();
     PF_PROF_STAMP(33);
-    // pass 2: one insert into the run-global table per distinct pattern of this item
-    for (uint32_t t0 = 0; t0 < LT_SLOTS; t0 += EMIT_THREADS) {
-        const uint32_t t = t0 + tid;
-        const uint64_t lo = lt_lo[t];
-        if (lo != EMPTY64) lt_pid[t] = pattern_insert(p.pt, lo, (uint32_t)(lt_hi[t] >> 32), lt_first[t]);
+    // pass 2: one insert into the run-global table per distinct pattern of this item, the ids of the new ones from ONE add
+    // per item (pattern_insert_block: with an add per wave this pass was 2 of the kernel's 4.4 ms at ~150 SURVEY alleles)
+    static_assert(LT_SLOTS == EMIT_THREADS, "one place of the local table per thread");
+    {
+        const uint64_t lo = lt_lo[tid];
+        const uint32_t pid = pattern_insert_block(p.pt, lo != EMPTY64, lo, (uint32_t)(lt_hi[tid] >> 32), lt_first[tid], ins_cnt);
+        if (lo != EMPTY64) lt_pid[tid] = pid;
     }
     __syncthreads();
     PF_PROF_STAMP(34);
@@ -3642,6 +3688,10 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
         e_pid = id < p.pt.pool ? id : PID_NONE;
         pattern_publish(p.pt, e_gslot, e_hi, e_pid);
     }
+    // (The publish above must come before the waiting form below in the CODE the compiler emits, not only here: the two
+    // branches are disjoint sets of lanes and their order is its choice -- pattern_insert_block says what happened when it
+    // chose the other one.  Checked in the ISA of this build for the four instantiations: counter add, publish store, then
+    // the loop with s_sleep; a barrier here would pin it and costs this kernel 1 %.)
     bool lowered = false;
     if (e_state == 2) {
         e_pid = pattern_insert_lower(p.pt, e_lo, e_hi, e_fs, &lowered);

@@ -1,6 +1,6 @@
 """Randomised differential test on the GPU: random options and cluster shapes, HIP path vs the oracle, text for text.
 usage: python tests/fuzz_parity.py [n_cases] [seed] [big]   (test infrastructure: imports oracle/)"""
-import sys, time
+import os, sys, time
 import numpy as np
 sys.path.insert(0, ".")
 from oracle import oracle as po
@@ -11,9 +11,13 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 big = len(sys.argv) > 3 and sys.argv[3] == "big"        # BASELINE-sized clusters: hundreds to 1 000 samples
 fails = 0
+verbose = bool(os.environ.get("PF_FUZZ_VERBOSE"))
 seen = {"binned": 0, "wide": 0, "retried": 0, "partitioned": 0}      # cases that took the path at least once
 t0 = time.time()
+only = os.environ.get("PF_FUZZ_ONLY")                     # one case of the run, by its number
 for case in range(n_cases):
+    if only is not None and case != int(only):
+        continue
     rng = np.random.default_rng(seed0 * 100003 + case)
     k = int(rng.choice([3, 7, 15, 21, 31, 32, 33, 47, 63, 64, 80, 95, 126]))
     S = int(rng.choice([300, 640, 1000, 1100])) if big else int(rng.choice([5, 17, 33, 64, 90, 130, 260]))
@@ -38,6 +42,9 @@ for case in range(n_cases):
     device_plan = bool(rng.random() < 0.5)
     max_items = int(rng.choice([64, 2048]))
     cut = int(rng.integers(0, ncl + 1))
+    if verbose:        # (PF_FUZZ_VERBOSE=1: what is about to run, for a case that never comes back)
+        print("case", case, kw, gen, "S", S, "ncl", ncl, "dedup", dedup, "stroi", len(stroi), "shuffle", shuffle, "unit_dedup", unit_dedup,
+              "key_binning", key_binning, "device_plan", device_plan, "max_items", max_items, "cut", cut, flush=True)
     try:
         for attempt in range(2):
             eng = Engine(max_strains=(S + 31) // 32 * 32, stroi=stroi, dedup=dedup, unit_dedup=unit_dedup, key_binning=key_binning, device_plan=device_plan, max_items=max_items, **kw)
