@@ -1989,9 +1989,15 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         if (p.multiple_files) { s.h2 ^= (uint32_t)ordinal; s.h3 ^= (uint32_t)(ordinal >> 32); }
         uint32_t cnt = 0;
         bool eq = true;
-        for (uint32_t ch = 0; ch < nchunks; ch += 4) {
-            uint32_t wv[4] = {0, 0, 0, 0};
-            if (from_mask) {
+        auto fold = [&](uint32_t ch, const uint32_t (&wv)[4]) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (ch + j < nchunks) { cnt += __popc(wv[j]); eq = eq && (wv[j] == presab[ch + j]); }
+            mm3_block(s, wv[0], wv[1], wv[2], wv[3]);
+        };
+        if (from_mask) {
+            for (uint32_t ch = 0; ch < nchunks; ch += 4) {
+                uint32_t wv[4] = {0, 0, 0, 0};
                 uint64_t t = amask;
                 while (t) {
                     const uint32_t d = __ffsll((unsigned long long)t) - 1;
@@ -1999,17 +2005,28 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
                     const uint4 m = *reinterpret_cast<const uint4*>(&M[d * Wp + ch]);
                     wv[0] |= m.x; wv[1] |= m.y; wv[2] |= m.z; wv[3] |= m.w;
                 }
-            } else {
+                fold(ch, wv);
+            }
+        } else {
+            // (sixteen chunk words of the slot asked for at a time, NS words apart in the scan's dump: the hash is a chain, the
+            // loads need not be -- four at a time a row of 1 000 samples was eight trips to memory one after the other)
+            for (uint32_t ch0 = 0; ch0 < nchunks; ch0 += 16) {
+                uint32_t w16[16];
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t cc = ch + j;
-                    if (cc < nchunks && ((cmask[cc >> 5] >> (cc & 31)) & 1)) wv[j] = cb[(size_t)cc * NS + i];
+                for (uint32_t j = 0; j < 16; j++) w16[j] = cb[(size_t)min(ch0 + j, nchunks - 1) * NS + i];
+#pragma unroll
+                for (uint32_t j = 0; j < 16; j++) {
+                    asm volatile("" : "+v"(w16[j]));
+                    const uint32_t cc = ch0 + j;
+                    if (!(cc < nchunks && ((cmask[cc >> 5] >> (cc & 31)) & 1))) w16[j] = 0;
+                }
+#pragma unroll
+                for (uint32_t q = 0; q < 4; q++) {
+                    if (ch0 + 4 * q >= nchunks) break;
+                    const uint32_t wv[4] = {w16[4 * q], w16[4 * q + 1], w16[4 * q + 2], w16[4 * q + 3]};
+                    fold(ch0 + 4 * q, wv);
                 }
             }
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (ch + j < nchunks) { cnt += __popc(wv[j]); eq = eq && (wv[j] == presab[ch + j]); }
-            mm3_block(s, wv[0], wv[1], wv[2], wv[3]);
         }
         if (p.consider_missing) {
             // NaN where clusterpresab == 0 (panfeed.py:19): the image depends on presab too
@@ -2158,13 +2175,23 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
             if (p.multiple_files) { st.h2 ^= (uint32_t)ordinal; st.h3 ^= (uint32_t)(ordinal >> 32); }
             uint32_t cnt = 0;
             bool eq = true;
-            for (uint32_t ch = 0; ch < nchunks; ch += 4) {
-                const uint4 v = *reinterpret_cast<const uint4*>(row + ch);
-                const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+            // (four 16-byte pieces of the row asked for at a time: the hash is a chain, the loads need not be -- piece by piece
+            // a row of 1 000 samples was eight trips to L2 one after the other per mask, 40 at 5 000)
+            for (uint32_t ch0 = 0; ch0 < nchunks; ch0 += 16) {
+                uint4 vq[4];
 #pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (ch + j < nchunks) { cnt += __popc(wv[j]); eq = eq && (wv[j] == presab[ch + j]); }
-                mm3_block(st, wv[0], wv[1], wv[2], wv[3]);
+                for (uint32_t q = 0; q < 4; q++)
+                    vq[q] = *reinterpret_cast<const uint4*>(row + min(ch0 + 4 * q, RW - 4));
+#pragma unroll
+                for (uint32_t q = 0; q < 4; q++) {
+                    const uint32_t ch = ch0 + 4 * q;
+                    if (ch >= nchunks) break;
+                    const uint32_t wv[4] = {vq[q].x, vq[q].y, vq[q].z, vq[q].w};
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (ch + j < nchunks) { cnt += __popc(wv[j]); eq = eq && (wv[j] == presab[ch + j]); }
+                    mm3_block(st, wv[0], wv[1], wv[2], wv[3]);
+                }
             }
             if (p.consider_missing) {
                 for (uint32_t ch = 0; ch < nchunks; ch += 4) {
