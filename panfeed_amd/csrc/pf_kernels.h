@@ -3715,10 +3715,10 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
         e_pid = id < p.pt.pool ? id : PID_NONE;
         pattern_publish(p.pt, e_gslot, e_hi, e_pid);
     }
-    // (The publish above must come before the waiting form below in the CODE the compiler emits, not only here: the two
+    // The publish above must come before the waiting form below in the CODE the compiler emits, not only here: the two
     // branches are disjoint sets of lanes and their order is its choice -- pattern_insert_block says what happened when it
-    // chose the other one.  Checked in the ISA of this build for the four instantiations: counter add, publish store, then
-    // the loop with s_sleep; a barrier here would pin it and costs this kernel 1 %.)
+    // chose the other one.  The barrier pins it (measured: no cost, finish_kernel 3.91 ms with and without).
+    __syncthreads();
     bool lowered = false;
     if (e_state == 2) {
         e_pid = pattern_insert_lower(p.pt, e_lo, e_hi, e_fs, &lowered);
@@ -3982,25 +3982,51 @@ __global__ __launch_bounds__(PR_THREADS) void pattern_rows_kernel(PatRowsParams 
         if (tid == 0) l_count = 0;
         __syncthreads();
         // PR_LIST / stride rounds fit the list even if every thread appends in every round
-        for (uint32_t r8 = 0; r8 < PR_LIST / PR_THREADS && round < rounds_total; r8++, round++) {
-            const uint32_t i = round * stride + tid;
-            uint32_t slot = 0xFFFFFFFFu, kept_before = 0;
-            if (i < total) {
-                // emit_kernel left the output index of every kept entry (sorted position / slot)
-                const uint32_t kb = sorted ? sout[i] : kres[i];
-                if (kb != 0xFFFFFFFFu) { slot = (uint32_t)sp[i]; kept_before = kb; }
-            }
-            if (slot != 0xFFFFFFFFu) {
-                const uint64_t o = obase + kept_before;
-                if (o < p.out_cap) {
-                    const uint32_t pid = p.out_pid[o];
-                    if (pid < p.pool && p.pat_first_seen[pid] == p.out_first[o]) {
-                        const uint32_t at = atomicAdd(&l_count, 1u);
-                        if (at < PR_LIST) { l_slot[at] = slot; l_pid[at] = pid; }
-                    }
-                }
+        // (the rounds of one list fill, four at most, side by side: each entry is a chain of three trips to memory -- output
+        // index, pattern id + the k-mer's first_seen, the pattern's first_seen -- and round after round that was twelve)
+        constexpr uint32_t PRR = PR_LIST / PR_THREADS;
+        static_assert(PRR * PR_THREADS == PR_LIST, "whole rounds per list fill");
+        const uint32_t nr = min(PRR, rounds_total - round);
+        uint32_t kb_[PRR], sl_[PRR], pid_[PRR];
+        uint64_t of_[PRR], pf_[PRR];
+        const uint32_t tclamp = total - 1;                       // (total > 0 here: rounds_total > 0)
+#pragma unroll
+        for (uint32_t r = 0; r < PRR; r++) {
+            const uint32_t i = min((round + r) * stride + tid, tclamp);
+            // emit_kernel left the output index of every kept entry (sorted position / slot)
+            kb_[r] = sorted ? sout[i] : kres[i];
+            sl_[r] = (uint32_t)sp[i];
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < PRR; r++) {
+            asm volatile("" : "+v"(kb_[r])); asm volatile("" : "+v"(sl_[r]));
+            const uint32_t i = (round + r) * stride + tid;
+            if (!(r < nr && i < total)) kb_[r] = 0xFFFFFFFFu;
+        }
+        bool ok_[PRR];
+#pragma unroll
+        for (uint32_t r = 0; r < PRR; r++) {
+            const uint64_t o = obase + kb_[r];
+            ok_[r] = kb_[r] != 0xFFFFFFFFu && o < p.out_cap;
+            const uint64_t oc = ok_[r] ? o : 0;                  // (an arena holds at least one entry)
+            pid_[r] = p.out_pid[oc];                             // (unconditional: the loads of the four rounds go out together)
+            of_[r] = p.out_first[oc];
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < PRR; r++) {
+            asm volatile("" : "+v"(pid_[r]));
+            if (!ok_[r]) pid_[r] = 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < PRR; r++) pf_[r] = p.pat_first_seen[min(pid_[r], p.pool - 1)];
+#pragma unroll
+        for (uint32_t r = 0; r < PRR; r++) {
+            if (pid_[r] < p.pool && pf_[r] == of_[r]) {
+                const uint32_t at = atomicAdd(&l_count, 1u);
+                if (at < PR_LIST) { l_slot[at] = sl_[r]; l_pid[at] = pid_[r]; }
             }
         }
+        round += nr;
         __syncthreads();
         const uint32_t cnt = min(l_count, PR_LIST);
         for (uint32_t e = wave; e < cnt; e += nwaves) {
