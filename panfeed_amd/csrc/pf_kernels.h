@@ -1906,6 +1906,11 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
     constexpr uint16_t SINGLE_TAG = 0x8000u;             // slot_tag: SINGLE_TAG | distinct index
     __shared__ uint4 single_hash[SINGLE_MAX];
     __shared__ uint32_t single_keep[SINGLE_MAX / 32];
+    // ... and the slots of several bits of such an item, listed by step A's first pass for its dense second one (the list lies
+    // where the round's row hashes will: at_hash is written behind step A only)
+    __shared__ uint32_t ml_count;
+    constexpr uint32_t ML_CAP = AT_SLOTS * sizeof(uint4) / sizeof(uint16_t);
+    uint16_t* const mlist = reinterpret_cast<uint16_t*>(at_hash);
 
     PF_PROF_BEGIN();
     const uint32_t tid = threadIdx.x;
@@ -2237,7 +2242,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
         }
         for (;;) {
             for (uint32_t t = tid; t < AT_SLOTS; t += ROWS_THREADS) at_key[t] = 0;
-            if (tid == 0) { at_count = 0; sh_more = 0; }
+            if (tid == 0) { at_count = 0; sh_more = 0; ml_count = 0; }
             __syncthreads();
             PF_PROF_STAMP(55);
             // A: every waiting slot finds its mask in the table (hash, then word for word against the entry's copy) or
@@ -2247,6 +2252,66 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
             // slots are asked for at a time where a mask is eight words at most, of two up to sixteen words.)
             auto step_a = [&](auto nbc) {
                 constexpr uint32_t NWA = decltype(nbc)::value * MWB, U = NWA == MWB ? 4 : NWA == 2 * MWB ? 2 : 1;
+                // slot i's mask (words w) into the round's table: its entry's number becomes the slot's tag
+                auto resolve = [&](uint32_t i, const uint32_t (&w)[NWA]) {
+                    uint64_t a1 = 0x9E3779B97F4A7C15ull, a2 = 0xC2B2AE3D27D4EB4Full;
+#pragma unroll
+                    for (uint32_t j = 0; j < NWA; j++) {              // sums of word x odd constant of its place
+                        const uint32_t kj = (2 * j + 1) * 0x9E3779B1u;
+                        a1 += (uint64_t)w[j] * (kj | 1u);
+                        a2 += (uint64_t)w[j] * (((kj >> 9) | (kj << 23)) | 1u);
+                    }
+                    const uint64_t hsh = mix64(a1 ^ ((a2 << 32) | (a2 >> 32)));
+                    uint64_t h50 = hsh >> 14;
+                    if (!h50) h50 = 1;
+                    uint32_t a = (uint32_t)(hsh & (AT_SLOTS - 1));
+                    uint32_t tag = WIDE_PENDING, probes = 0, spins = 0;
+                    bool done = false;
+                    while (!done) {
+                        uint64_t cur = __hip_atomic_load(&at_key[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (cur == 0) {
+                            if (__hip_atomic_load(&at_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= cap) {
+                                done = true;                                     // full: next round
+                            } else {
+                                cur = atomicCAS((unsigned long long*)&at_key[a], 0ull, (unsigned long long)((h50 << 14) | ENT_BUSY));
+                                if (cur == 0) {
+                                    const uint32_t e = atomicAdd(&at_count, 1u);
+                                    if (e >= cap) {
+                                        __hip_atomic_store(&at_key[a], (h50 << 14) | ENT_DEAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    } else {
+#pragma unroll
+                                        for (uint32_t j = 0; j < NWA; j++)
+                                            if (j < nmw) tabw[e * nmw + j] = w[j];
+                                        __hip_atomic_store(&at_key[a], (h50 << 14) | e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                        tag = e;
+                                    }
+                                    done = true;
+                                }
+                            }
+                        }
+                        if (!done) {                                             // cur: somebody's entry
+                            const uint32_t st = (uint32_t)cur & 0x3FFFu;
+                            uint32_t adv = 1;
+                            if ((cur >> 14) == h50) {
+                                if (st == ENT_BUSY) { adv = 0; spins++; }        // look again on the next trip
+                                else if (st == ENT_DEAD) done = true;
+                                else {
+                                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                                    uint32_t diff = 0;
+#pragma unroll
+                                    for (uint32_t j = 0; j < NWA; j++)
+                                        if (j < nmw) diff |= tabw[st * nmw + j] ^ w[j];
+                                    if (!diff) { tag = st; done = true; }
+                                }
+                            }
+                            a = (a + adv) & (AT_SLOTS - 1);
+                            probes += adv;
+                            if (probes >= AT_SLOTS || spins >= 4096u) done = true;   // (gives up for this round; never met)
+                        }
+                    }
+                    if (tag == WIDE_PENDING) sh_more = 1;
+                    else slot_tag[i] = (uint16_t)tag;
+                };
                 for (uint32_t i0 = tid; i0 < ns; i0 += U * ROWS_THREADS) {
                     uint32_t wu[U][NWA], ou[U];
                     bool pend[U], any = false;
@@ -2290,63 +2355,31 @@ __global__ __launch_bounds__(ROWS_THREADS) void rows_kernel(RowsParams p) {
                             for (uint32_t j = 0; j < NWA; j++) { pc += __popc(w[j]); if (w[j]) at = 32u * j + (uint32_t)__ffs((int)w[j]) - 1u; }
                             if (pc == 1) { slot_tag[i] = (uint16_t)(SINGLE_TAG | at); continue; }
                         }
-                        uint64_t a1 = 0x9E3779B97F4A7C15ull, a2 = 0xC2B2AE3D27D4EB4Full;
-#pragma unroll
-                        for (uint32_t j = 0; j < NWA; j++) {              // sums of word x odd constant of its place
-                            const uint32_t kj = (2 * j + 1) * 0x9E3779B1u;
-                            a1 += (uint64_t)w[j] * (kj | 1u);
-                            a2 += (uint64_t)w[j] * (((kj >> 9) | (kj << 23)) | 1u);
+                        if (singles) {
+                            // (a slot of several bits: on the list, looked at by a dense pass below -- here the hash and
+                            // the walk through the table ran with the one or two lanes of a wave that had such a slot,
+                            // ten times per wave: 40 000 of this kernel's 155 000 cycles per item at ~150 SURVEY alleles)
+                            const uint32_t q = atomicAdd(&ml_count, 1u);
+                            if (q < ML_CAP) { mlist[q] = (uint16_t)i; continue; }
                         }
-                        const uint64_t hsh = mix64(a1 ^ ((a2 << 32) | (a2 >> 32)));
-                        uint64_t h50 = hsh >> 14;
-                        if (!h50) h50 = 1;
-                        uint32_t a = (uint32_t)(hsh & (AT_SLOTS - 1));
-                        uint32_t tag = WIDE_PENDING, probes = 0, spins = 0;
-                        bool done = false;
-                        while (!done) {
-                            uint64_t cur = __hip_atomic_load(&at_key[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (cur == 0) {
-                                if (__hip_atomic_load(&at_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= cap) {
-                                    done = true;                                     // full: next round
-                                } else {
-                                    cur = atomicCAS((unsigned long long*)&at_key[a], 0ull, (unsigned long long)((h50 << 14) | ENT_BUSY));
-                                    if (cur == 0) {
-                                        const uint32_t e = atomicAdd(&at_count, 1u);
-                                        if (e >= cap) {
-                                            __hip_atomic_store(&at_key[a], (h50 << 14) | ENT_DEAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                        } else {
+                        resolve(i, w);
+                    }
+                }
+                if (singles) {
+                    // the listed slots, 64 to a wave and trip: words in, mask into the table
+                    __syncthreads();
+                    const uint32_t nl = min(ml_count, ML_CAP);
+                    for (uint32_t q = tid; q < nl; q += ROWS_THREADS) {
+                        const uint32_t i = mlist[q];
+                        uint32_t w[NWA];
 #pragma unroll
-                                            for (uint32_t j = 0; j < NWA; j++)
-                                                if (j < nmw) tabw[e * nmw + j] = w[j];
-                                            __hip_atomic_store(&at_key[a], (h50 << 14) | e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                            tag = e;
-                                        }
-                                        done = true;
-                                    }
-                                }
-                            }
-                            if (!done) {                                             // cur: somebody's entry
-                                const uint32_t st = (uint32_t)cur & 0x3FFFu;
-                                uint32_t adv = 1;
-                                if ((cur >> 14) == h50) {
-                                    if (st == ENT_BUSY) { adv = 0; spins++; }        // look again on the next trip
-                                    else if (st == ENT_DEAD) done = true;
-                                    else {
-                                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                                        uint32_t diff = 0;
+                        for (uint32_t j = 0; j < NWA; j++) w[j] = cb[min(j, nmw - 1) * NS + i];
 #pragma unroll
-                                        for (uint32_t j = 0; j < NWA; j++)
-                                            if (j < nmw) diff |= tabw[st * nmw + j] ^ w[j];
-                                        if (!diff) { tag = st; done = true; }
-                                    }
-                                }
-                                a = (a + adv) & (AT_SLOTS - 1);
-                                probes += adv;
-                                if (probes >= AT_SLOTS || spins >= 4096u) done = true;   // (gives up for this round; never met)
-                            }
+                        for (uint32_t j = 0; j < NWA; j++) {
+                            asm volatile("" : "+v"(w[j]));
+                            if (!(j < nmw && ((cm0 >> j) & 1))) w[j] = 0;
                         }
-                        if (tag == WIDE_PENDING) sh_more = 1;
-                        else slot_tag[i] = (uint16_t)tag;
+                        resolve(i, w);
                     }
                 }
             };
@@ -3274,6 +3307,15 @@ struct FinishParams {
 // MULTI: the work item is the first of several key partitions of the cluster; the slot loops run over all of
 // them (the mask table, ordinal bitmaps and M are per cluster anyway) and slot tags are looked up again instead
 // of being kept per slot.
+// (finish_kernel's stamps are off unless -DPF_PROF_FINISH is given too: with them the kernel faults on batches of thousands of
+// clusters -- round 5, cause not found, the stamps themselves index nothing -- and took the whole profiling build with it; its
+// phases have knock-out builds instead, PF_KO_FINISH)
+#if defined(PF_PROF) && !defined(PF_PROF_FINISH)
+#undef PF_PROF_BEGIN
+#undef PF_PROF_STAMP
+#define PF_PROF_BEGIN() do { } while (0)
+#define PF_PROF_STAMP(k) do { } while (0)
+#endif
 template <class CFG, bool MULTI>
 __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void finish_kernel(FinishParams p) {
     constexpr uint32_t T = CFG::THREADS, DW = CFG::DW, AT = CFG::AT;
@@ -3853,6 +3895,13 @@ __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8,
 // ---------------------------------------------------------------------------------------------
 // pattern_rows_kernel: the k-mer (or cluster row) that holds a pattern's first_seen writes its row
 // ---------------------------------------------------------------------------------------------
+#if defined(PF_PROF) && !defined(PF_PROF_FINISH)
+#undef PF_PROF_BEGIN
+#undef PF_PROF_STAMP
+#define PF_PROF_BEGIN() uint64_t prof_t_ = __builtin_readcyclecounter()
+#define PF_PROF_STAMP(k) do { if (threadIdx.x == 0) { const uint64_t n_ = __builtin_readcyclecounter(); \
+    atomicAdd(&pf_prof[k], (unsigned long long)(n_ - prof_t_)); prof_t_ = n_; } } while (0)
+#endif
 struct PatRowsParams {
     const uint32_t* item_cluster; const uint32_t* item_scratch; const uint32_t* item_unique;
     const uint32_t* item_nslots; const uint32_t* item_is_extra;
