@@ -25,8 +25,9 @@ if [ "${2:-all}" = "b" ] || [ "${2:-all}" = "all" ]; then
 mkdir -p $OUT
 # randomised differential runs against the oracle (tests/fuzz_parity.py): small and BASELINE-sized clusters
 (timeout -k 10 400 python tests/fuzz_parity.py 1000 301 | tail -1; timeout -k 10 400 python tests/fuzz_parity.py 200 302 big | tail -1) > $OUT/fuzz_parity_runs.txt 2>&1
-# (the -DPF_PROF phase-stamp build is not run any more: it faulted on the headline shape in round 5, cause not found; the knock-out
-# builds of tools/ab_bench.sh -- -DPF_KO_DEDUP, -DPF_KO_FINISH -- take its place: profiles/r05/experiment_*_knockout.txt)
+# (the -DPF_PROF phase-stamp build: tools/phase_prof.py, by hand -- finish_kernel's stamps are off in it since round 5, where they made
+# the kernel fault on large batches; its phases have the knock-out builds of tools/ab_bench.sh, -DPF_KO_FINISH, and the dedup pass
+# -DPF_KO_DEDUP: profiles/r05/experiment_*_knockout.txt)
 # end to end at 2 000 clusters (2.4 GB of GFF input)
 timeout -k 10 500 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-every-copy-leg --no-n-leg --e2e-clusters 2000 --e2e-long-clusters 0 > $OUT/bench_e2e_2000.json 2> $OUT/e2e.err
 ls -la $OUT

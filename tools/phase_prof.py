@@ -1,6 +1,8 @@
-"""Cycles per phase inside the fused kernels (PF_PROF build).  On the GPU box:
-    PF_PROF=1 python -c "import __graft_entry__ as g; g.build(force=True)" && python tools/phase_prof.py [clusters [mean_alleles star|tree]]
-then rebuild without PF_PROF."""
+"""Cycles per phase inside kmer_scan_kernel, rows_kernel and emit_kernel (PF_PROF build; finish_kernel's stamps are off unless
+-DPF_PROF_FINISH is given too -- with them it faults on batches of thousands of clusters).  Here:
+    bash tools/ab_bench.sh build prof "-DPF_PROF"
+and on the GPU box, with ab/prof.so copied over panfeed_amd/libpanfeed_hip.so for the run:
+    python tools/phase_prof.py [clusters [mean_alleles star|tree]]"""
 import ctypes as C
 import sys
 
