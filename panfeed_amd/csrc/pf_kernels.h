@@ -404,6 +404,9 @@ __device__ __forceinline__ bool scan_unit(uint64_t* keys, uint32_t* ord, uint32_
 // and go through the insert loop 64 at a time.
 template <int KW>
 struct ScanQueue { Key<KW> key; uint32_t ord, bit; };
+template <>
+struct ScanQueue<1> { Key<1> key; uint32_t ord, bit, home; };   // home: the bucket the entry's walk through the table starts at
+                                                                 // (one-word keys only: the wider kernels have no register for it)
 
 constexpr uint32_t M_WQ_WORDS = 16;            // 64 lane numbers per wave
 
@@ -411,9 +414,10 @@ template <int KW>
 __device__ __forceinline__ bool queue_flush(uint64_t* keys, uint32_t* ord, uint32_t* bits, uint32_t* misc, uint32_t NS,
                                             uint32_t ns, uint32_t limit, uint32_t lane, ScanQueue<KW>& pq, uint32_t& pn) {
     if (!pn) return false;                                           // (uniform)
-    const uint32_t nhome = KW == 1 ? ns / SCAN_BUCKET : ns;
-    const uint32_t h = key_hash<KW>(pq.key);
-    const bool over = table_update<KW>(keys, ord, bits, misc, NS, ns, limit, lane < pn, pq.key, __umulhi(h, nhome), pq.ord, pq.bit);
+    uint32_t home;
+    if constexpr (KW == 1) home = pq.home;
+    else home = __umulhi(key_hash<KW>(pq.key), ns);
+    const bool over = table_update<KW>(keys, ord, bits, misc, NS, ns, limit, lane < pn, pq.key, home, pq.ord, pq.bit);
     pn = 0;
     return __any(over);
 }
@@ -421,7 +425,7 @@ __device__ __forceinline__ bool queue_flush(uint64_t* keys, uint32_t* ord, uint3
 template <int KW>
 __device__ __forceinline__ bool queue_push(uint64_t* keys, uint32_t* ord, uint32_t* bits, uint32_t* misc, uint32_t NS,
                                            uint32_t ns, uint32_t limit, uint32_t lane, uint8_t* wq, ScanQueue<KW>& pq,
-                                           uint32_t& pn, bool mine, const Key<KW>& key, uint32_t myord, uint32_t bit) {
+                                           uint32_t& pn, bool mine, const Key<KW>& key, uint32_t home, uint32_t myord, uint32_t bit) {
     const uint64_t mm = __ballot(mine);
     if (!mm) return false;                                           // (uniform)
     const uint32_t m = (uint32_t)__popcll(mm);
@@ -443,6 +447,10 @@ __device__ __forceinline__ bool queue_push(uint64_t* keys, uint32_t* ord, uint32
     }
     const uint32_t o = (uint32_t)__shfl((int)myord, (int)src), b = (uint32_t)__shfl((int)bit, (int)src);
     if (take) { pq.ord = o; pq.bit = b; }
+    if constexpr (KW == 1) {
+        const uint32_t hm = (uint32_t)__shfl((int)home, (int)src);
+        if (take) pq.home = hm;
+    }
     pn += m;
     return over;
 }
@@ -457,20 +465,94 @@ __device__ __forceinline__ bool scan_unit_queued(uint64_t* keys, uint32_t* ord, 
     const bool valid = pos < ninst;
     Key<KW> fwd, rc;
     const bool rc_smaller = window_keys<KW>(k, lane, cw, fwd, rc);
+    const uint32_t nhome = KW == 1 ? ns / SCAN_BUCKET : ns;
     if (CANON) {
         Key<KW> key = rc_smaller ? rc : fwd;          // specseq <= revspecseq -> forward (panfeed.py:70)
         const uint32_t h = key_hash<KW>(key);
         const bool mine = valid && (((h & 0xFFFFu) * nparts) >> 16) == part;
-        return queue_push<KW>(keys, ord, bits, misc, NS, ns, limit, lane, wq, pq, pn, mine, key, ordb + pos, bit);
+        return queue_push<KW>(keys, ord, bits, misc, NS, ns, limit, lane, wq, pq, pn, mine, key, __umulhi(h, nhome), ordb + pos, bit);
     } else {
         uint32_t h = key_hash<KW>(fwd);
         bool mine = valid && (((h & 0xFFFFu) * nparts) >> 16) == part;
-        bool over = queue_push<KW>(keys, ord, bits, misc, NS, ns, limit, lane, wq, pq, pn, mine, fwd, 2 * (ordb + pos), bit);
+        bool over = queue_push<KW>(keys, ord, bits, misc, NS, ns, limit, lane, wq, pq, pn, mine, fwd, __umulhi(h, nhome), 2 * (ordb + pos), bit);
         h = key_hash<KW>(rc);
         mine = valid && (((h & 0xFFFFu) * nparts) >> 16) == part;
-        over |= queue_push<KW>(keys, ord, bits, misc, NS, ns, limit, lane, wq, pq, pn, mine, rc, 2 * (ordb + pos) + 1, bit);
+        over |= queue_push<KW>(keys, ord, bits, misc, NS, ns, limit, lane, wq, pq, pn, mine, rc, __umulhi(h, nhome), 2 * (ordb + pos) + 1, bit);
         return over;
     }
+}
+
+// ONE look at a one-word key's bucket (`bucket`: its home, or where an earlier look left off): the key is found or takes the
+// first empty slot -- ordinal, presence bits and the table's key count follow -- or the lane is left over (true), to look at
+// `next` later: the same bucket when it lost a race for the slot, the following one when the bucket is full of other keys.
+__device__ __forceinline__ bool table_first_trip(uint64_t* keys, uint32_t* ord, uint32_t* bits, uint32_t* misc, uint32_t ns,
+                                                 uint32_t limit, bool active, const Key<1>& key, uint32_t bucket, uint32_t myord,
+                                                 uint32_t bit, bool& over, uint32_t& next) {
+    const uint32_t nb = ns / SCAN_BUCKET;
+    ulonglong2 kk[SCAN_BUCKET / 2];
+#pragma unroll
+    for (uint32_t j = 0; j < SCAN_BUCKET / 2; j++) kk[j] = *reinterpret_cast<const ulonglong2*>(&keys[SCAN_BUCKET * bucket + 2 * j]);
+    bool hit = false, emp = false;
+    uint32_t ih = 0, ie = 0;
+#pragma unroll
+    for (int j = SCAN_BUCKET / 2 - 1; j >= 0; j--) {             // downwards: the lowest index wins
+        if (kk[j].y == key.w[0]) { hit = true; ih = 2 * j + 1; }
+        if (kk[j].x == key.w[0]) { hit = true; ih = 2 * j; }
+        if (kk[j].y == EMPTY64) { emp = true; ie = 2 * j + 1; }
+        if (kk[j].x == EMPTY64) { emp = true; ie = 2 * j; }
+    }
+    const uint32_t cand = SCAN_BUCKET * bucket + (hit ? ih : ie);
+    bool got = active && hit, inserted = false;
+    if (active && !hit && emp) {
+        const uint64_t cur = atomicCAS((unsigned long long*)&keys[cand], (unsigned long long)EMPTY64, (unsigned long long)key.w[0]);
+        inserted = cur == EMPTY64;
+        got = inserted || cur == key.w[0];
+    }
+    if (got) {
+        atomicMin(&ord[cand], myord);
+        atomicOr(&bits[cand], bit);
+        if (inserted) {
+            const uint32_t c = atomicAdd(&misc[0], 1u);
+            if (c + 1 > limit) { misc[1] = 1; over = true; }   // overflow: the cluster is re-run with more partitions
+        }
+    }
+    next = emp ? bucket : (bucket + 1 == nb ? 0 : bucket + 1);
+    return active && !got;
+}
+
+// One-word keys, an item that is its cluster's only key partition: the table's insert loop runs as long as the slowest of a
+// unit's 64 lanes, and the trips after the first serve the few lanes that found their home bucket full or lost a race for a
+// slot -- 0.9 of the scan's 4.1 ms on the headline workload (one trip per unit and the rest dropped, timing only: 3.22 ms).
+// Here a unit makes exactly ONE trip; the lanes it leaves unplaced join the wave's queue (the one key partitions use) and go
+// through the full loop 64 at a time.  Order does not matter to what the table ends up holding (smallest ordinal, OR of bits).
+template <bool CANON>
+__device__ __forceinline__ bool scan_unit_deferred(uint64_t* keys, uint32_t* ord, uint32_t* bits, uint32_t* misc, uint32_t NS,
+                                                   uint32_t ns, uint32_t limit, uint32_t k, uint32_t lane,
+                                                   const uint64_t (&cw)[2], uint32_t u, uint32_t ninst, uint32_t ordb, uint32_t bit,
+                                                   uint8_t* wq, ScanQueue<1>& pq, uint32_t& pn) {
+    const uint32_t pos = (u << 6) + lane;
+    const bool valid = pos < ninst;
+    Key<1> fwd, rc;
+    const bool rc_smaller = window_keys<1>(k, lane, cw, fwd, rc);
+    const uint32_t nb = ns / SCAN_BUCKET;
+    auto first_trip = [&](bool active, const Key<1>& key, uint32_t myord, bool& over, uint32_t& next) -> bool {
+        return table_first_trip(keys, ord, bits, misc, ns, limit, active, key, __umulhi(key_hash<1>(key), nb), myord, bit, over, next);
+    };
+    bool over = false;
+    if (CANON) {
+        const Key<1> key = rc_smaller ? rc : fwd;          // specseq <= revspecseq -> forward (panfeed.py:70)
+        uint32_t next;
+        const bool left = first_trip(valid, key, ordb + pos, over, next);
+        over |= queue_push<1>(keys, ord, bits, misc, NS, ns, limit, lane, wq, pq, pn, left, key, next, ordb + pos, bit);
+    } else {
+        // forward then reverse complement, both inserted (panfeed.py:82-88)
+        uint32_t next;
+        bool left = first_trip(valid, fwd, 2 * (ordb + pos), over, next);
+        over |= queue_push<1>(keys, ord, bits, misc, NS, ns, limit, lane, wq, pq, pn, left, fwd, next, 2 * (ordb + pos), bit);
+        left = first_trip(valid, rc, 2 * (ordb + pos) + 1, over, next);
+        over |= queue_push<1>(keys, ord, bits, misc, NS, ns, limit, lane, wq, pq, pn, left, rc, next, 2 * (ordb + pos) + 1, bit);
+    }
+    return __any(over);
 }
 
 // chunkmask word 0 is accumulated by thread 0
@@ -641,6 +723,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
                 uint32_t no, nb;
                 load(en < e1 ? en : e, nkey, no, nb);      // unconditional: one request in flight across the table work
                 const uint32_t h = key_hash<KW>(key);
+                // (one look per entry and the leftovers through the wave's queue, as scan_unit_deferred has it, was measured here
+                // too: nothing, 6.5 - 6.7 ms of binning + scan either way at ~150 SURVEY alleles)
                 const bool over = table_update<KW>(keys, ord, bits, misc, NS, ns, limit, e + lane < e1, key, __umulhi(h, nhome), eo, eb);
                 if (__any(over)) {
                     if (lane == 0) atomicMin(&misc[M_PROG], (e - qbeg) >> 6);
@@ -729,6 +813,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
                 // one of several key partitions (one- and two-word keys: the wider kernels have no registers to spare):
                 // this wave's kept windows are queued and inserted 64 at a time
                 const bool queued = KW <= 2 && nparts > 1;
+                const bool deferred = KW == 1 && nparts == 1;       // (a unit makes one trip to the table; stragglers queue up)
                 ScanQueue<KW> pq{};
                 uint32_t pn = 0;
                 uint8_t* const wq = reinterpret_cast<uint8_t*>(misc + M_WQ + wave * M_WQ_WORDS);
@@ -760,10 +845,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
                     // LDS round trip in front of every unit (looking every fourth unit was measured too: slower, 4.36 ->
                     // 4.55 ms) -- so after the limit trips every wave finishes at most the unit it is in:
                     // 16 waves x 64 lanes x 2 keys < INSERT_SLACK.
-                    const bool over = queued
-                        ? scan_unit_queued<KW, CANON>(keys, ord, bits, misc, NS, ns, limit, k, lane, part, nparts, cw, u, ninst,
-                                                      ordb, bit, wq, pq, pn)
-                        : scan_unit<KW, CANON>(keys, ord, bits, misc, NS, ns, limit, k, lane, part, nparts, cw, u, ninst, ordb, bit);
+                    bool over;
+                    if constexpr (KW == 1) {
+                        over = deferred ? scan_unit_deferred<CANON>(keys, ord, bits, misc, NS, ns, limit, k, lane, cw, u, ninst, ordb, bit, wq, pq, pn)
+                                        : scan_unit_queued<KW, CANON>(keys, ord, bits, misc, NS, ns, limit, k, lane, part, nparts, cw, u, ninst,
+                                                                      ordb, bit, wq, pq, pn);
+                    } else {
+                        over = queued
+                            ? scan_unit_queued<KW, CANON>(keys, ord, bits, misc, NS, ns, limit, k, lane, part, nparts, cw, u, ninst,
+                                                          ordb, bit, wq, pq, pn)
+                            : scan_unit<KW, CANON>(keys, ord, bits, misc, NS, ns, limit, k, lane, part, nparts, cw, u, ninst, ordb, bit);
+                    }
                     if (over) {
                         if (lane == 0) atomicMin(&misc[M_PROG], ubefore + g);
                         stopped = true;
@@ -775,7 +867,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void kmer_scan_kernel(ScanParams p) {
                     g = gn;
                 }
                 // what is still queued belongs to this chunk's words: in before they are flushed
-                if (queued && !stopped && queue_flush<KW>(keys, ord, bits, misc, NS, ns, limit, lane, pq, pn)) {
+                if ((queued || deferred) && !stopped && queue_flush<KW>(keys, ord, bits, misc, NS, ns, limit, lane, pq, pn)) {
                     if (lane == 0) atomicMin(&misc[M_PROG], ubefore + gend - 1);
                 }
             }
