@@ -3399,14 +3399,19 @@ struct FinishParams {
 // MULTI: the work item is the first of several key partitions of the cluster; the slot loops run over all of
 // them (the mask table, ordinal bitmaps and M are per cluster anyway) and slot tags are looked up again instead
 // of being kept per slot.
-// (finish_kernel's stamps are off unless -DPF_PROF_FINISH is given too: with them the kernel faults on batches of thousands of
-// clusters -- round 5, cause not found, the stamps themselves index nothing -- and took the whole profiling build with it; its
-// phases have knock-out builds instead, PF_KO_FINISH)
+// (finish_kernel's stamps are off unless -DPF_PROF_FINISH is given too: all together they make the kernel fault on batches of
+// thousands of clusters -- round 5; the stamps index nothing, what changes is the register allocation of a kernel that spills
+// 110 - 175 SGPRs -- and took the whole profiling build with them.  In two halves they work: -DPF_PROF_FINISH_MASK=0x0F, then
+// =0xF0 (profiles/r05/phase_profile_finish_headline.txt); the phases also have knock-out builds, PF_KO_FINISH)
 #if defined(PF_PROF) && !defined(PF_PROF_FINISH)
 #undef PF_PROF_BEGIN
 #undef PF_PROF_STAMP
 #define PF_PROF_BEGIN() do { } while (0)
 #define PF_PROF_STAMP(k) do { } while (0)
+#elif defined(PF_PROF) && defined(PF_PROF_FINISH_MASK)
+#undef PF_PROF_STAMP
+#define PF_PROF_STAMP(k) do { if (((PF_PROF_FINISH_MASK >> (k)) & 1) && threadIdx.x == 0) { const uint64_t n_ = __builtin_readcyclecounter(); \
+    atomicAdd(&pf_prof[k], (unsigned long long)(n_ - prof_t_)); prof_t_ = n_; } } while (0)
 #endif
 template <class CFG, bool MULTI>
 __global__ __launch_bounds__(CFG::THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void finish_kernel(FinishParams p) {
